@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory from the REAL reference.
+
+Run in the build container only (it imports /root/reference, which does not
+exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It drives the unmodified reference classes
+  losses.scene_flow_projection.{flow_by_depth, scene_flow_projection_slack,
+                                unproject_ptcld, BackwardWarp}
+  networks.sceneflow_field.SceneFlowFieldNet
+  models.scene_flow_motion_field.Model.{_predict_on_batch,_calc_loss,_opt_reg,
+                                        forward_sf_net*,disp_loss}
+on small seeded inputs and stores inputs + outputs (+ autograd gradients) as
+.npz.  The Model methods are called on an instance created with
+`Model.__new__` whose depth net is a stub returning fixed leaf depth maps, so
+no checkpoint, torch.hub or logger is needed; every line of arithmetic that
+runs is the reference's own.
+
+Nothing here is product code and nothing in the repo imports this file.
+"""
+
+import os
+import sys
+from functools import partial
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, 'dynamic-video-depth_amd'))
+
+from dvd_hip import synthetic  # noqa: E402  (pure-torch input generator, no HIP needed)
+
+
+def np_dict(d, prefix=''):
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            out[prefix + k] = v.detach().cpu().numpy()
+    return out
+
+
+def ref_modules():
+    from losses.scene_flow_projection import (flow_by_depth, scene_flow_projection_slack,
+                                              unproject_ptcld, BackwardWarp)
+    from networks.sceneflow_field import SceneFlowFieldNet
+    return flow_by_depth, scene_flow_projection_slack, unproject_ptcld, BackwardWarp, SceneFlowFieldNet
+
+
+CAM_KEYS = ('R_1', 'R_2', 'R_1_T', 'R_2_T', 't_1', 't_2', 'K', 'K_inv')
+
+
+def case_geometry(name, B, H, W, gap, behind, seed):
+    fbd, slack, unproj, bwarp, _ = ref_modules()
+    batch = synthetic.make_batch(B, H, W, gap=gap, seed=seed, behind_camera_pairs=behind, with_images=False)
+    d1, d2 = synthetic.make_depths(B, H, W, seed=seed + 1, far_depth_frac=0.02)
+    sf = synthetic.make_scene_flow(B, H, W, seed=seed + 2)
+    cams = {k: batch[k] for k in CAM_KEYS}
+    d1r = d1.clone().requires_grad_(True)
+    d2r = d2.clone().requires_grad_(True)
+    sfr = sf.clone().requires_grad_(True)
+    st = fbd()(d1r, d2r, batch['flow_1_2'], **cams)
+    sflow = sfr.permute(0, 2, 3, 1)[..., None, :]
+    dy = slack()(d1r, d2r, batch['flow_1_2'], batch['flow_2_1'], sflow_1_2=sflow, sflow_2_1=sflow, **cams)
+    out = {}
+    out.update(np_dict({k: batch[k] for k in CAM_KEYS + ('flow_1_2', 'mask_2')}, 'in_'))
+    out['in_depth_1'] = d1.numpy()
+    out['in_depth_2'] = d2.numpy()
+    out['in_sf_1_2'] = sf.numpy()
+    out.update(np_dict(st, 'fbd_'))
+    out.update(np_dict(dy, 'slack_'))
+    # fixed upstream gradients -> gradients of the module outputs (operator-level backward check)
+    g = torch.Generator().manual_seed(seed + 3)
+    up = {}
+    total = 0
+    for key, t in list(st.items()) + [('s_' + k, v) for k, v in dy.items()]:
+        if not t.requires_grad or key in ('s_depth_1', 's_depth_2', 's_scenef_1_2'):
+            continue
+        u = torch.randn(t.shape, generator=g)
+        up[key] = u
+        total = total + (t * u).sum()
+    total.backward()
+    out.update(np_dict(up, 'up_'))
+    out['g_depth_1'] = d1r.grad.numpy()
+    out['g_depth_2'] = d2r.grad.numpy()
+    out['g_sf_1_2'] = sfr.grad.numpy()
+    # stand-alone unproject + BackwardWarp
+    out['unproject_global_p1'] = unproj()(d1, batch['R_1'], batch['t_1'], batch['K_inv']).numpy()
+    out['bwarp_depth_2'] = bwarp()(d2, batch['flow_1_2']).numpy()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: v.shape for k, v in out.items() if k.startswith('slack_')})
+
+
+def case_mlp(name, B, H, W, seed):
+    *_, Net = ref_modules()
+    torch.manual_seed(seed)
+    net = Net(net_width=256, n_layers=4, time_dependent=True, N_freq_xyz=16, N_freq_t=16)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight.data, a=0.2, mode='fan_in')
+            torch.nn.init.normal_(m.bias.data, 0.0, 0.05)   # non-zero so bias paths are exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    x = (torch.randn(B, 3, H, W, generator=g) * 2.0).requires_grad_(True)
+    t = torch.rand(B, 1, 1, 1, generator=g).expand(B, 1, H, W).contiguous()
+    y = net(x, t)
+    up = torch.randn(y.shape, generator=g)
+    (y * up).sum().backward()
+    out = {'in_x': x.detach().numpy(), 'in_t': t.numpy(), 'out_y': y.detach().numpy(), 'up_y': up.numpy(),
+           'g_x': x.grad.numpy()}
+    for k, v in net.state_dict().items():
+        out['sd_' + k] = v.numpy()
+    for k, p in net.named_parameters():
+        out['gsd_' + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name)
+
+
+def _fake_model(opt, batch, d1, d2, net):
+    """A reference Model instance without NetInterface/loggers/checkpoints."""
+    import inspect
+    from models.scene_flow_motion_field import Model
+    from losses.scene_flow_projection import flow_by_depth, scene_flow_projection_slack
+    m = Model.__new__(Model)
+    m.opt = opt
+    m._input = SimpleNamespace(**batch)
+    lookup = {id(batch['img_1']): d1, id(batch['img_2']): d2}
+    m.net_depth = lambda img, *a: lookup[id(img)]
+    m.net_sceneflow = net
+    m.L1_crit = partial(F.l1_loss, reduction='none')
+    m.L2_crit = partial(F.mse_loss, reduction='none')
+    m.warp = scene_flow_projection_slack()
+    m.depth_flow = flow_by_depth()
+    m.warp_args = [a for a in inspect.getfullargspec(m.warp.forward).args[1:] if hasattr(m._input, a)]
+    m.flow_args = [a for a in inspect.getfullargspec(m.depth_flow.forward).args[1:] if hasattr(m._input, a)]
+    return m
+
+
+def case_step(name, B, H, W, gap, behind, seed, warm, **opt_over):
+    """Real _predict_on_batch + _calc_loss (+ _opt_reg) on leaf depths."""
+    *_, Net = ref_modules()
+    o = dict(midas=True, use_disp=True, use_disp_ratio=False, time_dependent=True, use_cnn=False,
+             flow_mul=1.0, disp_mul=1.0, acc_mul=1.0, sf_mag_div=100.0, interp_steps=5,
+             warm_reg=False, weight_steps=False, use_motion_seg=False, n_freq_xyz=16, n_freq_t=16)
+    o.update(opt_over)
+    opt = SimpleNamespace(**o)
+    torch.manual_seed(seed)
+    net = Net(net_width=256, n_layers=4, time_dependent=True, N_freq_xyz=16, N_freq_t=16)
+    for mod in net.modules():
+        if isinstance(mod, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(mod.weight.data, a=0.2, mode='fan_in')
+            torch.nn.init.normal_(mod.bias.data, 0.0, 0.02)
+    batch = synthetic.make_batch(B, H, W, gap=gap, seed=seed, behind_camera_pairs=behind)
+    d1, d2 = synthetic.make_depths(B, H, W, seed=seed + 1, far_depth_frac=0.02)
+    d1 = d1.requires_grad_(True)
+    d2 = d2.requires_grad_(True)
+    model = _fake_model(opt, batch, d1, d2, net)
+    model.warm = warm
+    pred = model._predict_on_batch()
+    loss, loss_data = model._calc_loss(pred)
+    do_reg = opt.interp_steps > 0 and (not warm or opt.warm_reg) and opt.acc_mul > 0
+    if do_reg:
+        loss.backward(retain_graph=True)
+        acc = model._opt_reg(pred, steps=opt.interp_steps)
+    else:
+        loss.backward()
+        acc = 0.0
+    out = np_dict({k: v for k, v in batch.items() if k not in ('img_1', 'img_2')}, 'in_')
+    out['in_depth_1'] = d1.detach().numpy()
+    out['in_depth_2'] = d2.detach().numpy()
+    out['opt_keys'] = np.array(sorted(o.keys()))
+    out['opt_vals'] = np.array([float(o[k]) for k in sorted(o.keys())])
+    out['warm'] = np.array(int(warm))
+    out['steps'] = np.array(model.steps)
+    for k, v in net.state_dict().items():
+        out['sd_' + k] = v.numpy()
+    for k, p in net.named_parameters():
+        out['gsd_' + k] = p.grad.numpy()
+    out['g_depth_1'] = d1.grad.numpy()
+    out['g_depth_2'] = (d2.grad if d2.grad is not None else torch.zeros_like(d2)).numpy()
+    for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss'):
+        out['loss_' + k] = np.array(loss_data[k], dtype=np.float64)
+    out['loss_acc_reg'] = np.array(acc, dtype=np.float64)
+    for k in ('dflow_1_2', 'p1_camera_2', 'warped_p2_camera_2', 'sf_1_2', 'global_p1', 'sf_by_dep_1_2',
+              'staticflow_1_2', 'depth_image_1_2', 'depth_warp_1_2', 'sf_loss_pp'):
+        out['pred_' + k] = pred[k].detach().numpy()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: float(out['loss_' + k]) for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg')})
+
+
+def main():
+    torch.set_num_threads(4)
+    case_geometry('geom_b2_24x32', B=2, H=24, W=32, gap=1, behind=0, seed=11)
+    case_geometry('geom_b3_16x40_behind', B=3, H=16, W=40, gap=2, behind=1, seed=23)
+    case_mlp('mlp_b2_8x16', B=2, H=8, W=16, seed=5)
+    case_step('step_b2_24x32_full', B=2, H=24, W=32, gap=1, behind=0, seed=31, warm=False)
+    case_step('step_b2_24x32_warm', B=2, H=24, W=32, gap=2, behind=0, seed=37, warm=True)
+    case_step('step_b3_16x40_behind_gap2', B=3, H=16, W=40, gap=2, behind=1, seed=41, warm=False)
+    case_step('step_b2_16x24_sfloss', B=2, H=16, W=24, gap=1, behind=0, seed=43, warm=False, use_disp=False)
+    case_step('step_b2_16x24_ratio', B=2, H=16, W=24, gap=1, behind=0, seed=47, warm=False,
+              use_disp=False, use_disp_ratio=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,94 @@
+"""The CPU oracle must reproduce the fixtures generated from the real
+reference (tests/golden/make_golden.py) -- this is what pins the oracle.
+
+Same host + same torch build => the restatement runs the same ATen kernels in
+the same order and is bit-identical; across hosts (the GPU box may dispatch a
+different CPU capability) we allow a few ulp on floats and still demand
+bit-exact index masks.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import CAM_KEYS, golden_batch, golden_mlp_sd, golden_opt, load_golden, t
+from oracle import geometry as G
+from oracle import losses as L
+from oracle import sceneflow_mlp as M
+
+TIGHT = dict(rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize('name', ['geom_b2_24x32', 'geom_b3_16x40_behind'])
+def test_geometry_surfaces(name):
+    gd = load_golden(name)
+    cams = {k: t(gd['in_' + k]) for k in CAM_KEYS}
+    d1, d2, flow = t(gd['in_depth_1']), t(gd['in_depth_2']), t(gd['in_flow_1_2'])
+    sf = t(gd['in_sf_1_2'])
+    st = G.static_reprojection(d1, d2, flow, **cams)
+    for k in ('dflow_1_2', 'sf_by_depth', 'warped_global_p2', 'global_p1'):
+        np.testing.assert_allclose(st[k].numpy(), gd['fbd_' + k], **TIGHT, err_msg=k)
+    sflow = sf.permute(0, 2, 3, 1)[..., None, :]
+    dy = G.dynamic_reprojection(d1, d2, flow, -flow, sflow_1_2=sflow, sflow_2_1=sflow, **cams)
+    for k in ('dflow_1_2', 'depth_image_1_2', 'depth_warp_1_2', 'global_p1', 'staticflow_1_2', 'p1_camera_2',
+              'warped_p2_camera_2'):
+        np.testing.assert_allclose(dy[k].numpy(), gd['slack_' + k], **TIGHT, err_msg=k)
+    # index masks, bit exact: behind-camera pixels are exactly those with zero predicted flow
+    behind = dy['_behind'][..., 0, 0].numpy()
+    gold_behind = (gd['slack_depth_image_1_2'][:, 0] < 1e-3)
+    assert np.array_equal(behind, gold_behind)
+    if 'behind' in name:
+        assert behind.any() and not behind.all()
+    np.testing.assert_allclose(G.unproject(d1, cams['R_1'], cams['t_1'], cams['K_inv']).numpy(),
+                               gd['unproject_global_p1'], **TIGHT)
+    grid = G.pixel_grid(d1.shape[2], d1.shape[3])
+    np.testing.assert_allclose(G.flow_sample(d2, flow, grid).numpy(), gd['bwarp_depth_2'], **TIGHT)
+
+
+def test_mlp_forward_backward():
+    gd = load_golden('mlp_b2_8x16')
+    sd = {k: v.requires_grad_(True) for k, v in golden_mlp_sd(gd).items()}
+    x = t(gd['in_x']).requires_grad_(True)
+    y = M.mlp_forward(sd, x, t(gd['in_t']))
+    np.testing.assert_allclose(y.detach().numpy(), gd['out_y'], rtol=1e-5, atol=1e-6)
+    (y * t(gd['up_y'])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), gd['g_x'], rtol=1e-4, atol=1e-6)
+    for k, v in sd.items():
+        g = gd['gsd_' + k]
+        np.testing.assert_allclose(v.grad.numpy(), g, rtol=1e-4, atol=1e-5 * np.abs(g).max(), err_msg=k)
+
+
+def test_mlp_init_statistics():
+    sd = M.init_params(seed=0)
+    dims = M.layer_dims()
+    assert dims == [132, 256, 256, 256, 256, 256, 3]
+    assert sum(v.numel() for v in sd.values()) == 297987
+    w = sd['convs.1.conv.weight']
+    assert abs(float(w.std()) - (2.0 / (1 + 0.04)) ** 0.5 / 16.0) < 2e-3
+
+
+@pytest.mark.parametrize('name', ['step_b2_24x32_full', 'step_b2_24x32_warm', 'step_b3_16x40_behind_gap2',
+                                  'step_b2_16x24_sfloss', 'step_b2_16x24_ratio'])
+def test_step_losses_and_grads(name):
+    gd = load_golden(name)
+    opt = golden_opt(gd)
+    warm = bool(gd['warm'])
+    batch = golden_batch(gd)
+    sd = golden_mlp_sd(gd)
+    out = L.warp_loss_with_leaf_depths(opt, warm, sd, batch, t(gd['in_depth_1']), t(gd['in_depth_2']))
+    assert out['pred']['_steps'] == int(gd['steps'])
+    for k in ('flow_loss_1_2', 'disp_loss_1_2', 'sf_loss'):
+        np.testing.assert_allclose(float(out['parts'][k]), float(gd['loss_' + k]), rtol=1e-6, err_msg=k)
+    np.testing.assert_allclose(float(out['loss']), float(gd['loss_loss']), rtol=1e-6)
+    np.testing.assert_allclose(float(out['acc_reg']), float(gd['loss_acc_reg']), rtol=1e-5, atol=1e-9)
+    for k in ('dflow_1_2', 'p1_camera_2', 'warped_p2_camera_2', 'sf_1_2', 'global_p1', 'sf_by_dep_1_2'):
+        np.testing.assert_allclose(out['pred'][k].detach().numpy(), gd['pred_' + k], rtol=1e-5, atol=1e-5, err_msg=k)
+    for k in ('g_depth_1', 'g_depth_2'):
+        g = gd[k]
+        np.testing.assert_allclose(out[k].numpy(), g, rtol=1e-4, atol=1e-6 * max(1.0, np.abs(g).max()), err_msg=k)
+    for k, v in out['g_mlp'].items():
+        g = gd['gsd_' + k]
+        np.testing.assert_allclose(v.numpy(), g, rtol=1e-3, atol=1e-5 * np.abs(g).max(), err_msg=k)
+    # valid-pixel mask is bit exact
+    m_gold = (gd['in_mask_2'][..., 0, 0] * (gd['in_depth_1'][:, 0] < 100) *
+              (gd['pred_warped_p2_camera_2'][..., 0, 2] < 100)).astype(np.float32)
+    assert np.array_equal(out['occ'][..., 0].numpy(), m_gold)
