@@ -1,0 +1,84 @@
+"""ctypes binding of libdvd_hip.so (the C ABI in include/dvd_hip.h).
+
+No torch types cross the boundary: tensors are passed as raw device pointers
+(`tensor.data_ptr()`), shapes as ints, the stream as the hipStream_t handle of
+torch's current stream.  A missing library is a hard error (no CPU fallback).
+"""
+import ctypes
+import os
+import threading
+
+from . import build as _build
+
+c_float_p = ctypes.c_void_p   # device pointers travel as void*
+c_size_t = ctypes.c_size_t
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+
+DVD_OK, DVD_EINVAL, DVD_EHIP, DVD_ENOSPC = 0, -1, -2, -3
+ABI_VERSION = 1
+
+
+class Cameras(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ('R_1', 'R_2', 'R_1_T', 'R_2_T', 't_1', 't_2', 'K', 'K_inv')]
+
+
+class WarpCfg(ctypes.Structure):
+    _fields_ = [('B', c_int), ('H', c_int), ('W', c_int), ('midas_mask', c_int), ('crit_l2', c_int),
+                ('disp_mode', c_int), ('loss_on_sf', c_int), ('flow_mul', c_float), ('disp_mul', c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/dvd_hip.h
+SIGNATURES = {
+    'dvd_abi_version': (c_int, []),
+    'dvd_last_error': (ctypes.c_char_p, []),
+    'dvd_device_cu_count': (c_int, []),
+    'dvd_unproject_fwd': (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    'dvd_unproject_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_int, c_void_p]),
+    'dvd_warp_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'dvd_warp_loss_fused': (c_int, [ctypes.POINTER(WarpCfg)] + [c_void_p] * 5 + [ctypes.POINTER(Cameras),
+                                                                               c_void_p, c_size_t] +
+                            [c_void_p] * 4 + [c_void_p]),
+    'dvd_warp_loss_fwd': (c_int, [ctypes.POINTER(WarpCfg)] + [c_void_p] * 5 + [ctypes.POINTER(Cameras), c_void_p,
+                                                                             c_size_t, c_void_p, c_void_p]),
+    'dvd_loss_finalize': (c_int, [ctypes.POINTER(WarpCfg), c_void_p, c_void_p, c_void_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def library_path():
+    return os.environ.get('DVD_HIP_LIB', _build.lib_path())
+
+
+def load():
+    """Load (once) and type the library.  Raises RuntimeError if it is absent:
+    build it with `python -m dvd_hip.build` (or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError('libdvd_hip.so not found at %s -- run `python -m dvd_hip.build`; '
+                               'dvd_hip has no CPU fallback' % path)
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dvd_abi_version() != ABI_VERSION:
+            raise RuntimeError('libdvd_hip.so ABI %d != binding %d' % (lib.dvd_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != DVD_OK:
+        msg = load().dvd_last_error()
+        raise RuntimeError('%s failed (%d): %s' % (what, status, (msg or b'').decode('utf-8', 'replace')))

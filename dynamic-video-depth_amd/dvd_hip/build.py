@@ -1,0 +1,85 @@
+"""Builds libdvd_hip.so (gfx950) in-tree with hipcc.
+
+    python -m dvd_hip.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects and the library live under
+dvd_hip/lib/ (git-ignored; they travel to the GPU box with the tree).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(ROOT, 'include')
+LIBDIR = os.path.join(HERE, 'lib')
+LIBNAME = 'libdvd_hip.so'
+ARCH = 'gfx950'
+
+# (source, extra flags).  The geometry kernels reproduce the reference's fp32
+# operation order, so the compiler must not contract a*b+c behind our back.
+SOURCES = [
+    ('core.hip', []),
+    ('unproject.hip', ['-ffp-contract=off']),
+    ('warp_loss.hip', ['-ffp-contract=off']),
+]
+COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
+          '-I' + INCLUDE, '-I' + CSRC]
+
+
+def lib_path():
+    return os.path.join(LIBDIR, LIBNAME)
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return 'hipcc'
+
+
+def _digest(paths, flags):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(flags).encode())
+    return h.hexdigest()
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP translation unit and link the shared library.
+    Returns the library path.  Re-uses objects whose sources did not change."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')]
+    headers.append(os.path.join(INCLUDE, 'dvd_hip.h'))
+    objs, relink = [], force or not os.path.exists(lib_path())
+    for src, extra in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
+        stamp = obj + '.sha'
+        dig = _digest([sp] + headers, COMMON + extra)
+        fresh = os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig
+        if force or not fresh:
+            cmd = [_hipcc()] + COMMON + extra + ['-c', sp, '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+            with open(stamp, 'w') as f:
+                f.write(dig)
+            relink = True
+        objs.append(obj)
+    if relink:
+        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', lib_path()]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return lib_path()
+
+
+if __name__ == '__main__':
+    print(build_library(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,139 @@
+"""Tensor-level wrappers over the C ABI (include/dvd_hip.h).
+
+These functions only validate, allocate outputs with torch (so the caching
+allocator owns every buffer) and enqueue the HIP kernels on torch's current
+stream.  They never touch tensor contents on the host and never fall back to
+PyTorch arithmetic: a tensor that is not on a GPU is an error.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+CAM_KEYS = ('R_1', 'R_2', 'R_1_T', 'R_2_T', 't_1', 't_2', 'K', 'K_inv')
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev32(t, name):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise RuntimeError('%s must be a GPU tensor (dvd_hip has no CPU path)' % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError('%s must be float32, got %s' % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def pack_cameras(cams):
+    """dict of the eight camera tensors ([B,1,1,3,3] / [B,1,1,1,3] or flat)
+    -> (ctypes struct, list of tensors kept alive)."""
+    keep, st = [], _lib.Cameras()
+    for k in CAM_KEYS:
+        t = _dev32(cams[k], k)
+        keep.append(t)
+        setattr(st, k, t.data_ptr())
+    return st, keep
+
+
+def warp_cfg(B, H, W, midas_mask=True, crit_l2=False, disp_mode=1, loss_on_sf=False, flow_mul=1.0, disp_mul=1.0):
+    return _lib.WarpCfg(int(B), int(H), int(W), int(bool(midas_mask)), int(bool(crit_l2)), int(disp_mode),
+                        int(bool(loss_on_sf)), float(flow_mul), float(disp_mul))
+
+
+def unproject(depth, R, t, K_inv, planar=True):
+    """depth [B,1,H,W] -> world points, [B,3,H,W] (planar) or [B,H,W,1,3]."""
+    depth = _dev32(depth, 'depth')
+    R, t, K_inv = _dev32(R, 'R'), _dev32(t, 't'), _dev32(K_inv, 'K_inv')
+    B, _, H, W = depth.shape
+    out = torch.empty((B, 3, H, W) if planar else (B, H, W, 1, 3), device=depth.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.dvd_unproject_fwd(_p(depth), _p(R), _p(t), _p(K_inv), _p(out), int(planar), B, H, W, _stream()),
+               'dvd_unproject_fwd')
+    return out
+
+
+def unproject_backward(g_points, planar, R, K_inv, scale=None, out=None, accumulate=False):
+    """g_depth (+)= scale * ((g_points @ R^T) . ray);  scale: 1-element GPU tensor or None."""
+    g_points = _dev32(g_points, 'g_points')
+    R, K_inv = _dev32(R, 'R'), _dev32(K_inv, 'K_inv')
+    if planar:
+        B, _, H, W = g_points.shape
+    else:
+        B, H, W = g_points.shape[:3]
+    if out is None:
+        if accumulate:
+            raise RuntimeError('accumulate=True needs an output tensor')
+        out = torch.empty((B, 1, H, W), device=g_points.device, dtype=torch.float32)
+    out = _dev32(out, 'g_depth')
+    lib = _lib.load()
+    _lib.check(lib.dvd_unproject_bwd(_p(g_points), int(planar), _p(R), _p(K_inv), _p(scale), _p(out),
+                                     int(bool(accumulate)), B, H, W, _stream()), 'dvd_unproject_bwd')
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = ws
+    return ws
+
+
+def warp_loss_fused(cfg, depth_1, depth_2, flow_1_2, mask_2, sf_1_2, cams, grads=True, out=None):
+    """One launch: the four un-normalised loss sums and, if grads, the
+    un-normalised gradients w.r.t. depth_1, depth_2 and the scene flow.
+
+    mask_2: [B,H,W] (or [B,H,W,1,1]); sf_1_2: planar [B,3,H,W].
+    Returns (sums[4], g_depth_1, g_depth_2, g_sf) -- gradients None if not grads.
+    `out` may pass pre-allocated (sums, g_depth_1, g_depth_2, g_sf) to avoid allocation.
+    """
+    depth_1, depth_2 = _dev32(depth_1, 'depth_1'), _dev32(depth_2, 'depth_2')
+    flow_1_2, mask_2, sf_1_2 = _dev32(flow_1_2, 'flow_1_2'), _dev32(mask_2, 'mask_2'), _dev32(sf_1_2, 'sf_1_2')
+    B, H, W = cfg.B, cfg.H, cfg.W
+    if depth_1.numel() != B * H * W or depth_2.numel() != B * H * W or mask_2.numel() != B * H * W:
+        raise RuntimeError('warp_loss_fused: depth/mask shape does not match cfg %dx%dx%d' % (B, H, W))
+    if flow_1_2.numel() != 2 * B * H * W or sf_1_2.numel() != 3 * B * H * W:
+        raise RuntimeError('warp_loss_fused: flow / scene-flow shape mismatch')
+    cst, keep = pack_cameras(cams)
+    dev = depth_1.device
+    lib = _lib.load()
+    nws = lib.dvd_warp_loss_workspace_bytes(B, H, W)
+    ws = _workspace(nws, dev)
+    if out is not None:
+        sums, g1, g2, gs = out
+    else:
+        sums = torch.empty(4, device=dev, dtype=torch.float32)
+        g1 = torch.empty_like(depth_1) if grads else None
+        g2 = torch.empty_like(depth_2) if grads else None
+        gs = torch.empty_like(sf_1_2) if grads else None
+    if grads:
+        st = lib.dvd_warp_loss_fused(ctypes.byref(cfg), _p(depth_1), _p(depth_2), _p(flow_1_2), _p(mask_2),
+                                     _p(sf_1_2), ctypes.byref(cst), _p(ws), ws.numel(), _p(sums), _p(g1), _p(g2),
+                                     _p(gs), _stream())
+        _lib.check(st, 'dvd_warp_loss_fused')
+    else:
+        st = lib.dvd_warp_loss_fwd(ctypes.byref(cfg), _p(depth_1), _p(depth_2), _p(flow_1_2), _p(mask_2),
+                                   _p(sf_1_2), ctypes.byref(cst), _p(ws), ws.numel(), _p(sums), _stream())
+        _lib.check(st, 'dvd_warp_loss_fwd')
+    del keep
+    return sums, g1, g2, gs
+
+
+def loss_finalize(cfg, sums, out=None):
+    """scalars[8]: [0]=1/(S0+1e-8) [1]=loss [2]=flow [3]=disp [4]=sf [5]=S0."""
+    sums = _dev32(sums, 'sums')
+    if out is None:
+        out = torch.empty(8, device=sums.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.dvd_loss_finalize(ctypes.byref(cfg), _p(sums), _p(out), _stream()), 'dvd_loss_finalize')
+    return out

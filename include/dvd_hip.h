@@ -1,0 +1,124 @@
+/*
+ * dvd_hip.h -- C ABI of libdvd_hip.so, the MI355X (gfx950) kernels behind the
+ * dynamic-video-depth test-time-optimisation inner loop.
+ *
+ * The reference (google/dynamic-video-depth) has NO native boundary: its
+ * operator API is Python classes.  Each entry point below therefore names the
+ * reference Python interface it replaces (file:line under /root/reference) and
+ * is what the host-side mirror in dynamic-video-depth_amd/dvd_hip binds with
+ * ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless noted;
+ *     the caller (PyTorch's caching allocator) owns all memory, the library
+ *     never allocates or frees; scratch is passed in (`*_workspace_bytes`).
+ *   - all work is enqueued on `stream` (a hipStream_t) and returns at once.
+ *   - return value: DVD_OK or a negative dvd_status; text via dvd_last_error()
+ *     (thread local).  Nothing throws across the ABI.
+ *   - tensors: depth [B,1,H,W]; flow [B,H,W,2] (x then y, pixels);
+ *     mask [B,H,W]; scene flow / world points planar [B,3,H,W] unless a
+ *     `*_interleaved` ([B,H,W,3]) variant is named; camera blocks as in the
+ *     reference data files: row-vector convention, matrices stored transposed,
+ *     each [B,3,3] or [B,3] (SURVEY.md section 8 header;
+ *     scripts/preprocess/davis/generate_sequence_midas.py:69-76).
+ */
+#ifndef DVD_HIP_H
+#define DVD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVD_ABI_VERSION 1
+
+typedef void* dvd_stream_t; /* hipStream_t */
+
+typedef enum dvd_status {
+  DVD_OK = 0,
+  DVD_EINVAL = -1, /* bad shape / null pointer / unsupported option */
+  DVD_EHIP = -2,   /* a HIP runtime call failed; see dvd_last_error() */
+  DVD_ENOSPC = -3  /* workspace too small */
+} dvd_status;
+
+int dvd_abi_version(void);
+const char* dvd_last_error(void);
+/* Static properties the host needs for sizing (CU count etc.). */
+int dvd_device_cu_count(void);
+
+/* Camera block of a batch of frame pairs (the eight tensors the reference
+ * forwards take by name: losses/scene_flow_projection.py:114,222). */
+typedef struct dvd_cameras {
+  const float* R_1;   /* [B,3,3] cam1->world, stored transposed   */
+  const float* R_2;   /* [B,3,3] cam2->world, stored transposed   */
+  const float* R_1_T; /* [B,3,3] world->cam1                       */
+  const float* R_2_T; /* [B,3,3] world->cam2                       */
+  const float* t_1;   /* [B,3] camera centre 1 (world)             */
+  const float* t_2;   /* [B,3]                                     */
+  const float* K;     /* [B,3,3] intrinsics^T                      */
+  const float* K_inv; /* [B,3,3] (intrinsics^-1)^T                 */
+} dvd_cameras;
+
+/* ------------------------------------------------------------------------
+ * unproject: depth -> world points.
+ * Replaces unproject_ptcld.forward (losses/scene_flow_projection.py:54-67)
+ * and the `global_p1` half of flow_by_depth.forward (:127-131).
+ * out_planar != 0: [B,3,H,W] (what the scene-flow MLP consumes,
+ * models/scene_flow_motion_field.py:245); else [B,H,W,3].
+ * bwd: g_depth (+)= (g_points @ R_1^T) . ray ;  accumulate != 0 adds. */
+int dvd_unproject_fwd(const float* depth, const float* R, const float* t, const float* K_inv,
+                      float* points, int out_planar, int B, int H, int W, dvd_stream_t stream);
+int dvd_unproject_bwd(const float* g_points, int planar, const float* R, const float* K_inv,
+                      const float* scale_or_null, float* g_depth, int accumulate,
+                      int B, int H, int W, dvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused warp + reprojection + masked losses, forward AND backward in one
+ * launch (the HBM-bound kernel of BASELINE.json).
+ * Replaces, for the training step, the chain
+ *   flow_by_depth.forward            losses/scene_flow_projection.py:114-153
+ *   scene_flow_projection_slack.fwd  losses/scene_flow_projection.py:222-278
+ *   F.grid_sample (bilinear, border) losses/scene_flow_projection.py:112,220
+ *   Model._calc_loss / disp_loss     models/scene_flow_motion_field.py:140-150,285-324
+ * and their autograd backward.
+ *
+ * sums[0..3] (device) receive  S0=sum m, S1=sum m*flow_err, S2=sum m*disp_err,
+ * S3=sum m*sf_err  (un-normalised; deterministic two-stage reduction).
+ * Gradients are written UN-NORMALISED, i.e. as if the loss were
+ *   flow_mul*S1 + disp_mul*(use_disp ? S2 : S3);
+ * the global 1/(S0+1e-8) (after the data-parallel all-reduce of the sums,
+ * SURVEY.md section 8e) is applied by the consumers through a device scalar
+ * (dvd_loss_finalize writes it).  g_depth_2 is zeroed inside the call and
+ * accumulated with hardware fp32 atomics (bilinear scatter). */
+typedef struct dvd_warp_cfg {
+  int B, H, W;
+  int midas_mask;  /* 1: m *= [depth_1<100]*[W2.z<100]   (model:286-289)        */
+  int crit_l2;     /* 1: squared flow error (warm phase, model:291), 0: L1      */
+  int disp_mode;   /* 0:|z1-z2|  1:use_disp  2:use_disp_ratio  (model:140-150)  */
+  int loss_on_sf;  /* 1: second loss term is sf_loss (not use_disp, model:310)  */
+  float flow_mul;  /* already multiplied by `steps` when --weight_steps         */
+  float disp_mul;
+} dvd_warp_cfg;
+
+size_t dvd_warp_loss_workspace_bytes(int B, int H, int W);
+int dvd_warp_loss_fused(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth_2,
+                        const float* flow_1_2, const float* mask_2, const float* sf_1_2,
+                        const dvd_cameras* cams, void* workspace, size_t workspace_bytes,
+                        float* sums /*[4]*/, float* g_depth_1, float* g_depth_2, float* g_sf_1_2,
+                        dvd_stream_t stream);
+/* Forward only (validation / logging): same sums, no gradients. */
+int dvd_warp_loss_fwd(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth_2,
+                      const float* flow_1_2, const float* mask_2, const float* sf_1_2,
+                      const dvd_cameras* cams, void* workspace, size_t workspace_bytes,
+                      float* sums, dvd_stream_t stream);
+/* scalars[0]=1/(S0+1e-8) [1]=loss [2]=flow_loss [3]=disp_loss [4]=sf_loss
+ * [5]=S0; reads sums after the caller's (optional) all-reduce. */
+int dvd_loss_finalize(const dvd_warp_cfg* cfg, const float* sums, float* scalars /*[8]*/,
+                      dvd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVD_HIP_H */

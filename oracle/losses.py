@@ -155,3 +155,34 @@ def warp_loss_with_leaf_depths(opt, warm, sd_mlp, batch, depth_1, depth_2, with_
     out['g_depth_2'] = d2.grad if d2.grad is not None else torch.zeros_like(d2)
     out['g_mlp'] = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sd.items()}
     return out
+
+
+def warp_loss_leaf_sf(opt, warm, batch, depth_1, depth_2, sf_1_2, need_grads=True):
+    """The warp+loss operator in isolation: scene flow is a leaf [B,3,H,W]
+    (no MLP), exactly the contract of dvd_warp_loss_fused.  Returns the four
+    un-normalised sums, the normalised losses and autograd gradients of the
+    *normalised* loss w.r.t. depth_1, depth_2, sf_1_2."""
+    d1 = depth_1.detach().clone().requires_grad_(need_grads)
+    d2 = depth_2.detach().clone().requires_grad_(need_grads)
+    sf = sf_1_2.detach().clone().requires_grad_(need_grads)
+    cams = {k: batch[k] for k in ('R_1', 'R_2', 'R_1_T', 'R_2_T', 't_1', 't_2', 'K', 'K_inv')}
+    st = G.static_reprojection(d1, d2, batch['flow_1_2'], **cams)
+    sflow = sf.permute(0, 2, 3, 1)[..., None, :]
+    dyn = G.dynamic_reprojection(d1, d2, batch['flow_1_2'], batch['flow_2_1'], sflow_1_2=sflow,
+                                 sflow_2_1=sflow, **cams)
+    loss, parts, occ = masked_losses(opt, warm, batch['mask_2'], batch['flow_1_2'], dyn['depth_1'],
+                                     dyn['dflow_1_2'], dyn['p1_camera_2'], dyn['warped_p2_camera_2'],
+                                     st['sf_by_depth'], sf)
+    out = {'loss': loss.detach(), 'parts': {k: v.detach() for k, v in parts.items()}, 'occ': occ.detach(),
+           'behind': dyn['_behind'].detach(), 'dyn': dyn, 'static': st}
+    S0 = parts['mask_sum'].detach()
+    den = S0 + 1e-8
+    out['sums'] = torch.stack([S0, parts['flow_loss_1_2'].detach() * den, parts['disp_loss_1_2'].detach() * den,
+                               parts['sf_loss'].detach() * den])
+    if need_grads:
+        loss.backward()
+        z = torch.zeros_like
+        out['g_depth_1'] = d1.grad if d1.grad is not None else z(d1)
+        out['g_depth_2'] = d2.grad if d2.grad is not None else z(d2)
+        out['g_sf'] = sf.grad if sf.grad is not None else z(sf)
+    return out
