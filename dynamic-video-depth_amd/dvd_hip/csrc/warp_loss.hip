@@ -25,6 +25,8 @@
 // index masks [depth_1<100], [W2.z<100], [I.z<1e-3] and the tap indices are
 // bit-identical to PyTorch's CPU path.  Build with -ffp-contract=off.
 
+#include <stdlib.h>
+
 #include "dvd_common.h"
 
 namespace dvd {
@@ -43,6 +45,7 @@ struct WarpArgs {
   const float* __restrict__ K;
   const float* __restrict__ Ki;
   float* __restrict__ partial;
+  float* sums;
   float* __restrict__ g_d1;
   float* g_d2;
   float* __restrict__ g_sf;
@@ -102,8 +105,11 @@ __device__ __forceinline__ float2 load_pair(const float* p) {
   return r;
 }
 
-template <bool GRADS>
-__device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, int b, int y, int x,
+// `IO` supplies the frame-2 depth taps and takes the depth_2 gradient taps:
+//   io.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse)   (out-of-image taps -> 0)
+//   io.scatter(o_n, x0, y0, in_e, in_s, t_nw, t_ne, t_sw, t_se)
+template <bool GRADS, class IO>
+__device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, int y, int x,
                                       float d1, float fx, float fy, float mk, float s0, float s1,
                                       float s2, float acc[4], float& g_d1_out, float g_s_out[3]) {
   const float xf = (float)x, yf = (float)y;
@@ -126,28 +132,9 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, int b, in
   const float w_nw = ws * we, w_ne = ws * ww, w_sw = wn * we, w_se = wn * ww;
   const int x0 = (int)x0f, y0 = (int)y0f;
   const bool in_e = (x0 + 1) < a.W, in_s = (y0 + 1) < a.H;  // x0,y0 are always in range
-  const float* d2b = a.d2 + (size_t)b * a.HW;
   const int o_n = y0 * a.W + x0;
-  const int o_s = o_n + a.W;
   float dnw, dne, dsw, dse;
-  if (in_e) {
-    const float2 pn = load_pair(d2b + o_n);
-    dnw = pn.x;
-    dne = pn.y;
-    if (in_s) {
-      const float2 ps = load_pair(d2b + o_s);
-      dsw = ps.x;
-      dse = ps.y;
-    } else {
-      dsw = 0.0f;
-      dse = 0.0f;
-    }
-  } else {
-    dnw = d2b[o_n];
-    dne = 0.0f;
-    dsw = in_s ? d2b[o_s] : 0.0f;
-    dse = 0.0f;
-  }
+  io.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
   // rays of the four tap pixels (same expression as for the own pixel)
   float rn0[2], rn1[2], rn2[2], rs0[2], rs1[2], rs2[2];
   const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
@@ -267,14 +254,47 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, int b, in
   rowvec_mat3_T(gG0, gG1, gG2, c.R2, h0, h1, h2);
   h2 += gW2z;
   if (h0 != 0.0f || h1 != 0.0f || h2 != 0.0f) {
-    float* gb = a.g_d2 + (size_t)b * a.HW;
-    const float t_nw = w_nw * (h0 * rn0[0] + h1 * rn1[0] + h2 * rn2[0]);
-    unsafeAtomicAdd(gb + o_n, t_nw);
-    if (in_e) unsafeAtomicAdd(gb + o_n + 1, w_ne * (h0 * rn0[1] + h1 * rn1[1] + h2 * rn2[1]));
-    if (in_s) unsafeAtomicAdd(gb + o_s, w_sw * (h0 * rs0[0] + h1 * rs1[0] + h2 * rs2[0]));
-    if (in_se) unsafeAtomicAdd(gb + o_s + 1, w_se * (h0 * rs0[1] + h1 * rs1[1] + h2 * rs2[1]));
+    io.scatter(o_n, x0, y0, in_e, in_s, w_nw * (h0 * rn0[0] + h1 * rn1[0] + h2 * rn2[0]),
+               w_ne * (h0 * rn0[1] + h1 * rn1[1] + h2 * rn2[1]), w_sw * (h0 * rs0[0] + h1 * rs1[0] + h2 * rs2[0]),
+               w_se * (h0 * rs0[1] + h1 * rs1[1] + h2 * rs2[1]));
   }
 }
+
+// ---- IO policy 1: straight to global memory (gather via L1/L2, hardware fp32 atomics).
+struct DirectIO {
+  const float* d2b;
+  float* gb;
+  int W;
+  __device__ __forceinline__ void fetch(int o_n, int, int, bool in_e, bool in_s, float& dnw, float& dne,
+                                        float& dsw, float& dse) const {
+    const int o_s = o_n + W;
+    if (in_e) {
+      const float2 pn = load_pair(d2b + o_n);
+      dnw = pn.x;
+      dne = pn.y;
+      if (in_s) {
+        const float2 ps = load_pair(d2b + o_s);
+        dsw = ps.x;
+        dse = ps.y;
+      } else {
+        dsw = 0.0f;
+        dse = 0.0f;
+      }
+    } else {
+      dnw = d2b[o_n];
+      dne = 0.0f;
+      dsw = in_s ? d2b[o_s] : 0.0f;
+      dse = 0.0f;
+    }
+  }
+  __device__ __forceinline__ void scatter(int o_n, int, int, bool in_e, bool in_s, float tnw, float tne,
+                                          float tsw, float tse) const {
+    unsafeAtomicAdd(gb + o_n, tnw);
+    if (in_e) unsafeAtomicAdd(gb + o_n + 1, tne);
+    if (in_s) unsafeAtomicAdd(gb + o_n + W, tsw);
+    if (in_e && in_s) unsafeAtomicAdd(gb + o_n + W + 1, tse);
+  }
+};
 
 template <int PX, bool GRADS>
 __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
@@ -310,11 +330,12 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
     const int y = p0 / a.W;
     const int x = p0 - y * a.W;  // PX divides W, so the PX pixels share the row
     float gd1[PX], gs[PX][3];
+    DirectIO io{a.d2 + (size_t)b * a.HW, a.g_d2 + (size_t)b * a.HW, a.W};
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
       gd1[i] = 0.0f;
       gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
-      pixel<GRADS>(a, c, b, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
+      pixel<GRADS>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
                    gd1[i], gs[i]);
     }
     if (GRADS) {
@@ -347,6 +368,269 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
   if (threadIdx.x < 4) {
     const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     a.partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Tiled variant (the production path).
+//
+// Global fp32 atomics run at only ~9e10 lane-ops/s on MI355X (measured: the
+// direct kernel above spends 1.7 of its 1.9 ms in them at 48x384x672), and the
+// per-lane gathers of depth_2 are TA-bound.  So a block owns a TW x TH tile of
+// one pair and keeps two LDS windows that extend the tile by R pixels:
+//   win  : depth_2 values, filled with coalesced 16-byte loads; the bilinear
+//          taps are read from it (ds_read2_b32);
+//   accw : depth_2-gradient accumulator (ds_add_f32).
+// At the end the accumulator window is stored, coalesced, to the tile's slab
+// in the workspace; `combine_slabs_kernel` then sums, in a fixed order, the
+// <= 4 slabs that cover each pixel and writes g_depth_2 once with plain
+// stores: no global atomics, no memset of g_depth_2.  Taps that fall outside
+// the window (|flow| > R) stay correct: they are gathered from global memory
+// and their gradient goes to an overflow list applied after the combine.
+// Blocks are numbered so that each XCD receives a contiguous run of tiles
+// (neighbouring tiles share depth_2 halo lines in that XCD's L2).
+
+struct Overflow {
+  unsigned* count;
+  int2* rec;
+  unsigned cap;
+};
+
+template <int WW, int WH>
+struct TileIO {
+  const float* d2b;  // depth_2 of this pair
+  float* win;        // LDS [WH][WW]
+  float* accw;       // LDS [WH][WW]
+  int W, wx0, wy0, pair_base;
+  Overflow ovf;
+  __device__ __forceinline__ bool inside(int x0, int y0) const {
+    const int lx = x0 - wx0, ly = y0 - wy0;
+    return (lx >= 0) && (lx + 1 < WW) && (ly >= 0) && (ly + 1 < WH);
+  }
+  __device__ __forceinline__ void fetch(int o_n, int x0, int y0, bool in_e, bool in_s, float& dnw, float& dne,
+                                        float& dsw, float& dse) const {
+    if (inside(x0, y0)) {
+      // window cells outside the image hold 0, exactly what ATen's masked gather returns
+      const float* p = win + (y0 - wy0) * WW + (x0 - wx0);
+      dnw = p[0];
+      dne = p[1];
+      dsw = p[WW];
+      dse = p[WW + 1];
+    } else {
+      DirectIO g{d2b, nullptr, W};
+      g.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
+    }
+  }
+  __device__ __forceinline__ void spill(int idx, float v) const {
+    const unsigned i = atomicAdd(ovf.count, 1u);
+    if (i < ovf.cap) ovf.rec[i] = make_int2(pair_base + idx, __float_as_int(v));
+  }
+  __device__ __forceinline__ void scatter(int o_n, int x0, int y0, bool in_e, bool in_s, float tnw, float tne,
+                                          float tsw, float tse) const {
+    if (inside(x0, y0)) {
+      float* p = accw + (y0 - wy0) * WW + (x0 - wx0);
+      atomicAdd(p, tnw);  // ds_add_f32
+      if (in_e) atomicAdd(p + 1, tne);
+      if (in_s) atomicAdd(p + WW, tsw);
+      if (in_e && in_s) atomicAdd(p + WW + 1, tse);
+    } else {
+      spill(o_n, tnw);
+      if (in_e) spill(o_n + 1, tne);
+      if (in_s) spill(o_n + W, tsw);
+      if (in_e && in_s) spill(o_n + W + 1, tse);
+    }
+  }
+};
+
+struct TileArgs {
+  float* slabs;
+  Overflow ovf;
+  int ntx, nty;
+};
+
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
+  // dispatcher places block b on XCD b % 8 (speed only, never correctness)
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int TW, int TH, int R, int NT, bool GRADS>
+__global__ __launch_bounds__(NT) void warp_loss_tiled_kernel(const WarpArgs a, const TileArgs ta) {
+  constexpr int WW = TW + 2 * R + 4;  // multiple of 4: window rows are float4-aligned
+  constexpr int WH = TH + 2 * R + 1;
+  constexpr int QW = TW / 4;
+  static_assert(R % 4 == 0 && TW % 4 == 0, "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* win = smem;
+  float* accw = smem + WW * WH;
+
+  const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tiles = ta.ntx * ta.nty;
+  const int b = logical / tiles;
+  const int t = logical - b * tiles;
+  const int tj = t / ta.ntx, ti = t - tj * ta.ntx;
+  const int tx0 = ti * TW, ty0 = tj * TH;
+  const int wx0 = tx0 - R, wy0 = ty0 - R;
+  Cam c;
+  load_cam(a, b, c);
+  const float* d2b = a.d2 + (size_t)b * a.HW;
+
+  // ---- phase 0: fill the depth_2 window, clear the accumulator
+  const bool w4 = (a.W & 3) == 0;
+  for (int i = threadIdx.x; i < (WW / 4) * WH; i += NT) {
+    const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
+    const int iy = wy0 + wy, ixx = wx0 + wx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < a.H) {
+      if (w4) {
+        if (ixx >= 0 && ixx < a.W) v = *reinterpret_cast<const float4*>(d2b + (size_t)iy * a.W + ixx);
+      } else {
+        const float* row = d2b + (size_t)iy * a.W;
+        if (ixx >= 0 && ixx < a.W) v.x = row[ixx];
+        if (ixx + 1 >= 0 && ixx + 1 < a.W) v.y = row[ixx + 1];
+        if (ixx + 2 >= 0 && ixx + 2 < a.W) v.z = row[ixx + 2];
+        if (ixx + 3 >= 0 && ixx + 3 < a.W) v.w = row[ixx + 3];
+      }
+    }
+    *reinterpret_cast<float4*>(win + wy * WW + wx) = v;
+    if (GRADS) *reinterpret_cast<float4*>(accw + wy * WW + wx) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, ta.ovf};
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  // ---- phase 1: the tile's pixels, 4 per thread per step
+  for (int q = threadIdx.x; q < QW * TH; q += NT) {
+    const int ly = q / QW, lx = (q - ly * QW) * 4;
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y >= a.H || x >= a.W) continue;
+    const int p0 = y * a.W + x;
+    const size_t base = (size_t)b * a.HW + p0;
+    const float* sfb = a.sf + (size_t)b * 3 * a.HW + p0;
+    float d1[4], mk[4], fl[8], s0[4], s1[4], s2[4];
+    const int nvalid = (a.W - x) < 4 ? (a.W - x) : 4;
+    if (w4) {
+      *reinterpret_cast<float4*>(d1) = *reinterpret_cast<const float4*>(a.d1 + base);
+      *reinterpret_cast<float4*>(mk) = *reinterpret_cast<const float4*>(a.mask + base);
+      *reinterpret_cast<float4*>(fl) = *reinterpret_cast<const float4*>(a.flow + 2 * base);
+      *reinterpret_cast<float4*>(fl + 4) = *reinterpret_cast<const float4*>(a.flow + 2 * base + 4);
+      *reinterpret_cast<float4*>(s0) = *reinterpret_cast<const float4*>(sfb);
+      *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(sfb + a.HW);
+      *reinterpret_cast<float4*>(s2) = *reinterpret_cast<const float4*>(sfb + 2 * a.HW);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = i < nvalid;
+        d1[i] = ok ? a.d1[base + i] : 1.0f;
+        mk[i] = ok ? a.mask[base + i] : 0.0f;
+        fl[2 * i] = ok ? a.flow[2 * (base + i)] : 0.0f;
+        fl[2 * i + 1] = ok ? a.flow[2 * (base + i) + 1] : 0.0f;
+        s0[i] = ok ? sfb[i] : 0.0f;
+        s1[i] = ok ? sfb[a.HW + i] : 0.0f;
+        s2[i] = ok ? sfb[2 * a.HW + i] : 0.0f;
+      }
+    }
+    float gd1[4], gs[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gd1[i] = 0.0f;
+      gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
+      if (i < nvalid)
+        pixel<GRADS>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc, gd1[i],
+                     gs[i]);
+    }
+    if (GRADS) {
+      float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
+      if (w4) {
+        *reinterpret_cast<float4*>(a.g_d1 + base) = make_float4(gd1[0], gd1[1], gd1[2], gd1[3]);
+        *reinterpret_cast<float4*>(gsb) = make_float4(gs[0][0], gs[1][0], gs[2][0], gs[3][0]);
+        *reinterpret_cast<float4*>(gsb + a.HW) = make_float4(gs[0][1], gs[1][1], gs[2][1], gs[3][1]);
+        *reinterpret_cast<float4*>(gsb + 2 * a.HW) = make_float4(gs[0][2], gs[1][2], gs[2][2], gs[3][2]);
+      } else {
+        for (int i = 0; i < nvalid; ++i) {
+          a.g_d1[base + i] = gd1[i];
+          gsb[i] = gs[i][0];
+          gsb[a.HW + i] = gs[i][1];
+          gsb[2 * a.HW + i] = gs[i][2];
+        }
+      }
+    }
+  }
+  // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
+  __syncthreads();
+  if (GRADS) {
+    float* slab = ta.slabs + (size_t)logical * (WW * WH);
+    for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT)
+      reinterpret_cast<float4*>(slab)[i] = reinterpret_cast<const float4*>(accw)[i];
+  }
+  float* red = win;  // window no longer needed
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) red[wave * 4 + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.0f;
+    for (int w = 0; w < NT / 64; ++w) v += red[w * 4 + threadIdx.x];
+    a.partial[(size_t)logical * 4 + threadIdx.x] = v;
+  }
+}
+
+// g_depth_2[b,y,x] = sum over the tiles whose window covers (x,y), fixed order.
+template <int TW, int TH, int R>
+__global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ slabs,
+                                                            float* __restrict__ g_d2, int H, int W, int ntx,
+                                                            int nty, int total_quads) {
+  constexpr int WW = TW + 2 * R + 4;
+  constexpr int WH = TH + 2 * R + 1;
+  static_assert(2 * R + 4 <= TW && 2 * R + 1 <= TH, "only adjacent tiles may overlap a pixel");
+  const int qid = blockIdx.x * 256 + threadIdx.x;
+  if (qid >= total_quads) return;
+  const int qpr = (W + 3) >> 2;  // quads per row
+  const int row = qid / qpr;
+  const int x = (qid - row * qpr) * 4;
+  const int b = row / H, y = row - b * H;
+  const int ti = x / TW, tj = y / TH;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int dj = -1; dj <= 1; ++dj) {
+    const int j = tj + dj;
+    const int wy = y - (j * TH - R);
+    if (j < 0 || j >= nty || wy < 0 || wy >= WH) continue;
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+      const int i = ti + di;
+      const int wx = x - (i * TW - R);
+      if (i < 0 || i >= ntx || wx < 0 || wx + 3 >= WW) continue;
+      const float4 v =
+          *reinterpret_cast<const float4*>(slabs + ((size_t)(b * nty + j) * ntx + i) * (WW * WH) + wy * WW + wx);
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+  }
+  float* dst = g_d2 + ((size_t)b * H + y) * W + x;
+  if ((W & 3) == 0) {
+    *reinterpret_cast<float4*>(dst) = s;
+  } else {
+    dst[0] = s.x;
+    if (x + 1 < W) dst[1] = s.y;
+    if (x + 2 < W) dst[2] = s.z;
+    if (x + 3 < W) dst[3] = s.w;
+  }
+}
+
+__global__ __launch_bounds__(256) void apply_overflow_kernel(const unsigned* __restrict__ count,
+                                                             const int2* __restrict__ rec, unsigned cap,
+                                                             float* g_d2) {
+  unsigned n = *count;
+  if (n > cap) n = cap;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int2 r = rec[i];
+    unsafeAtomicAdd(g_d2 + r.x, __int_as_float(r.y));
   }
 }
 
@@ -393,6 +677,106 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float flow_
 
 static int blocks_x(int HW, int px) { return (HW + 256 * px - 1) / (256 * px); }
 
+// ---- tile selection -----------------------------------------------------------------
+constexpr int kR = 8;  // LDS window halo: taps within |flow| <= 8 px stay on chip
+struct TileShape {
+  int tw, th, nt;
+};
+static const TileShape kShapes[] = {{96, 64, 512}, {64, 64, 512}, {128, 32, 512}, {64, 32, 256}};
+constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// Least padded area wins; ties go to the earlier (larger) shape.  DVD_WARP_TILE=<index> overrides.
+static int choose_shape(int H, int W) {
+  const int forced = env_int("DVD_WARP_TILE", -1);
+  if (forced >= 0 && forced < kNumShapes) return forced;
+  int best = 0;
+  long long best_area = -1;
+  for (int i = 0; i < kNumShapes; ++i) {
+    const long long ntx = (W + kShapes[i].tw - 1) / kShapes[i].tw, nty = (H + kShapes[i].th - 1) / kShapes[i].th;
+    const long long area = ntx * kShapes[i].tw * nty * kShapes[i].th;
+    if (best_area < 0 || area < best_area) {
+      best_area = area;
+      best = i;
+    }
+  }
+  return best;
+}
+
+struct Plan {
+  int shape, ntx, nty, ww, wh;
+  size_t n_partials, off_count, off_slabs, off_ovf, ovf_cap, total;
+};
+
+static Plan make_plan(int B, int H, int W) {
+  Plan p;
+  p.shape = choose_shape(H, W);
+  const TileShape& t = kShapes[p.shape];
+  p.ntx = (W + t.tw - 1) / t.tw;
+  p.nty = (H + t.th - 1) / t.th;
+  p.ww = t.tw + 2 * kR + 4;
+  p.wh = t.th + 2 * kR + 1;
+  const size_t tiles = (size_t)p.ntx * p.nty * B;
+  const size_t direct_blocks = (size_t)blocks_x(H * W, 1) * B;
+  p.n_partials = tiles > direct_blocks ? tiles : direct_blocks;
+  size_t off = p.n_partials * 4 * sizeof(float);
+  off = (off + 255) & ~(size_t)255;
+  p.off_count = off;
+  off += 256;
+  p.off_slabs = off;
+  off += tiles * (size_t)p.ww * p.wh * sizeof(float);
+  off = (off + 255) & ~(size_t)255;
+  p.off_ovf = off;
+  p.ovf_cap = (size_t)4 * B * H * W;  // every tap of every pixel: the list can never overflow
+  off += p.ovf_cap * sizeof(int2);
+  p.total = off;
+  return p;
+}
+
+template <int TW, int TH, int NT>
+static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, hipStream_t stream) {
+  constexpr int WW = TW + 2 * kR + 4, WH = TH + 2 * kR + 1;
+  TileArgs ta;
+  ta.slabs = reinterpret_cast<float*>(ws + p.off_slabs);
+  ta.ovf.count = reinterpret_cast<unsigned*>(ws + p.off_count);
+  ta.ovf.rec = reinterpret_cast<int2*>(ws + p.off_ovf);
+  ta.ovf.cap = (unsigned)(p.ovf_cap > 0xffffffffULL ? 0xffffffffULL : p.ovf_cap);
+  ta.ntx = p.ntx;
+  ta.nty = p.nty;
+  const int nblocks = p.ntx * p.nty * a.B;
+  const size_t lds = (size_t)WW * WH * sizeof(float) * 2;
+  if (grads) DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, sizeof(unsigned), stream));
+  if (grads) {
+    auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, true>;
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);
+  } else {
+    auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, false>;
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);
+  }
+  DVD_LAUNCH_OK();
+  if (grads) {
+    const int qpr = (a.W + 3) / 4;
+    const int total_quads = qpr * a.H * a.B;
+    hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, stream,
+                       ta.slabs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads);
+    DVD_LAUNCH_OK();
+    hipLaunchKernelGGL(apply_overflow_kernel, dim3(64), dim3(256), 0, stream, ta.ovf.count, ta.ovf.rec, ta.ovf.cap,
+                       a.g_d2);
+    DVD_LAUNCH_OK();
+  }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, a.partial, nblocks, a.sums);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
 static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth_2, const float* flow_1_2,
                const float* mask_2, const float* sf_1_2, const dvd_cameras* cams, void* workspace,
                size_t workspace_bytes, float* sums, float* g_depth_1, float* g_depth_2, float* g_sf_1_2,
@@ -408,12 +792,13 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
   DVD_REQUIRE(cfg->disp_mode >= 0 && cfg->disp_mode <= 2, "warp_loss: disp_mode %d", cfg->disp_mode);
   if (grads) DVD_REQUIRE(g_depth_1 && g_depth_2 && g_sf_1_2, "warp_loss: null gradient pointer");
   const int HW = cfg->H * cfg->W;
-  DVD_REQUIRE((long long)cfg->B * HW * 3 < (1LL << 40), "warp_loss: tensor too large");
-  const size_t need = dvd_warp_loss_workspace_bytes(cfg->B, cfg->H, cfg->W);
-  if (workspace_bytes < need) {
-    set_error("warp_loss: workspace %zu < %zu bytes", workspace_bytes, need);
+  DVD_REQUIRE((long long)cfg->B * HW * 3 < (1LL << 31), "warp_loss: tensor too large for 32-bit indexing");
+  const Plan plan = make_plan(cfg->B, cfg->H, cfg->W);
+  if (workspace_bytes < plan.total) {
+    set_error("warp_loss: workspace %zu < %zu bytes", workspace_bytes, plan.total);
     return DVD_ENOSPC;
   }
+  DVD_REQUIRE(((uintptr_t)workspace & 255) == 0, "warp_loss: workspace must be 256-byte aligned");
   WarpArgs a;
   a.d1 = depth_1;
   a.d2 = depth_2;
@@ -428,6 +813,7 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
   a.K = cams->K;
   a.Ki = cams->K_inv;
   a.partial = static_cast<float*>(workspace);
+  a.sums = sums;
   a.g_d1 = g_depth_1;
   a.g_d2 = g_depth_2;
   a.g_sf = g_sf_1_2;
@@ -445,29 +831,43 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
   a.half_h = (float)((cfg->H - 1) / 2.0);
   a.wmax = (float)(cfg->W - 1);
   a.hmax = (float)(cfg->H - 1);
-  const bool vec4 = (cfg->W % 4 == 0) && (((uintptr_t)depth_1 | (uintptr_t)flow_1_2 | (uintptr_t)mask_2 |
-                                            (uintptr_t)sf_1_2 | (uintptr_t)g_depth_1 | (uintptr_t)g_sf_1_2) %
-                                               16 ==
-                                           0);
-  const int px = vec4 ? 4 : 1;
-  const int nbx = blocks_x(HW, px);
-  dim3 grid(nbx, cfg->B), block(256);
-  if (grads) DVD_HIP_OK(hipMemsetAsync(g_depth_2, 0, (size_t)cfg->B * HW * sizeof(float), stream));
-  if (grads) {
-    if (vec4)
-      hipLaunchKernelGGL((warp_loss_kernel<4, true>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((warp_loss_kernel<1, true>), grid, block, 0, stream, a);
-  } else {
-    if (vec4)
-      hipLaunchKernelGGL((warp_loss_kernel<4, false>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((warp_loss_kernel<1, false>), grid, block, 0, stream, a);
+  const bool all16 = (((uintptr_t)depth_1 | (uintptr_t)depth_2 | (uintptr_t)flow_1_2 | (uintptr_t)mask_2 |
+                       (uintptr_t)sf_1_2 | (uintptr_t)g_depth_1 | (uintptr_t)g_depth_2 | (uintptr_t)g_sf_1_2) &
+                      15) == 0;
+  DVD_REQUIRE(all16, "warp_loss: tensors must be 16-byte aligned");
+  if (env_int("DVD_WARP_DIRECT", 0)) {
+    // reference variant: global gathers + hardware atomics (kept for A/B runs and as a second implementation)
+    const bool vec4 = (cfg->W % 4 == 0);
+    const int nbx = blocks_x(HW, vec4 ? 4 : 1);
+    dim3 grid(nbx, cfg->B), block(256);
+    if (grads) DVD_HIP_OK(hipMemsetAsync(g_depth_2, 0, (size_t)cfg->B * HW * sizeof(float), stream));
+    if (grads) {
+      if (vec4)
+        hipLaunchKernelGGL((warp_loss_kernel<4, true>), grid, block, 0, stream, a);
+      else
+        hipLaunchKernelGGL((warp_loss_kernel<1, true>), grid, block, 0, stream, a);
+    } else {
+      if (vec4)
+        hipLaunchKernelGGL((warp_loss_kernel<4, false>), grid, block, 0, stream, a);
+      else
+        hipLaunchKernelGGL((warp_loss_kernel<1, false>), grid, block, 0, stream, a);
+    }
+    DVD_LAUNCH_OK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, a.partial, nbx * cfg->B, sums);
+    DVD_LAUNCH_OK();
+    return DVD_OK;
   }
-  DVD_LAUNCH_OK();
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, a.partial, nbx * cfg->B, sums);
-  DVD_LAUNCH_OK();
-  return DVD_OK;
+  char* ws = static_cast<char*>(workspace);
+  switch (plan.shape) {
+    case 0:
+      return launch_tiled<96, 64, 512>(a, plan, ws, grads, stream);
+    case 1:
+      return launch_tiled<64, 64, 512>(a, plan, ws, grads, stream);
+    case 2:
+      return launch_tiled<128, 32, 512>(a, plan, ws, grads, stream);
+    default:
+      return launch_tiled<64, 32, 256>(a, plan, ws, grads, stream);
+  }
 }
 
 }  // namespace dvd
@@ -476,8 +876,8 @@ extern "C" {
 
 size_t dvd_warp_loss_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  // one float4 per block; sized for the scalar (PX=1) tiling, the larger of the two
-  return (size_t)dvd::blocks_x(H * W, 1) * (size_t)B * 4 * sizeof(float);
+  // block partial sums + overflow counter + per-tile accumulator slabs + overflow list
+  return dvd::make_plan(B, H, W).total;
 }
 
 int dvd_warp_loss_fused(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth_2,

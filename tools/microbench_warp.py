@@ -23,10 +23,18 @@ def main():
     ap.add_argument('--W', type=int, default=672)
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--fwd_only', action='store_true')
+    ap.add_argument('--direct', action='store_true', help='global-atomics reference variant')
+    ap.add_argument('--tile', type=int, default=-1, help='force tile shape index')
+    ap.add_argument('--flow_sigma', type=float, default=3.0)
     ap.add_argument('--smooth_flow', action='store_true', help='constant flow per pair instead of iid noise')
     a = ap.parse_args()
     B, H, W = a.B, a.H, a.W
+    if a.direct:
+        os.environ['DVD_WARP_DIRECT'] = '1'
+    if a.tile >= 0:
+        os.environ['DVD_WARP_TILE'] = str(a.tile)
     batch = synthetic.make_batch(B, H, W, device='cuda', with_images=False)
+    batch['flow_1_2'] = batch['flow_1_2'] * (a.flow_sigma / 3.0)
     if a.smooth_flow:
         batch['flow_1_2'] = batch['flow_1_2'][:, :1, :1].expand(B, H, W, 2).contiguous()
     d1, d2 = synthetic.make_depths(B, H, W, device='cuda')
@@ -50,7 +58,7 @@ def main():
     print(json.dumps({'kernel': 'warp_loss_fused' if grads else 'warp_loss_fwd', 'B': B, 'H': H, 'W': W,
                       'ms_per_call_incl_memset_and_reduce': ms, 'algorithmic_bytes': bytes_alg,
                       'GBps': bytes_alg / ms / 1e6, 'frac_of_8TBps': bytes_alg / ms / 1e6 / 8000.0,
-                      'smooth_flow': a.smooth_flow}))
+                      'smooth_flow': a.smooth_flow, 'direct': a.direct, 'tile': a.tile, 'flow_sigma': a.flow_sigma}))
 
 
 if __name__ == '__main__':
