@@ -108,12 +108,27 @@ __device__ __forceinline__ float2 load_pair(const float* p) {
 // `IO` supplies the frame-2 depth taps and takes the depth_2 gradient taps:
 //   io.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse)   (out-of-image taps -> 0)
 //   io.scatter(o_n, x0, y0, in_e, in_s, t_nw, t_ne, t_sw, t_se)
-template <bool GRADS, class IO>
+//
+// The arithmetic is split in two classes:
+//   EXACT  -- everything that decides an index or a mask (tap indices, I.z < 1e-3,
+//             W2.z < 100) follows the reference's fp32 rounding sequence: separate
+//             multiplies/adds in torch's matmul order, IEEE division, the mul+3*fma
+//             bilinear of ATen.  (The file is built with -ffp-contract=off.)
+//   FAST   -- quantities only compared within a tolerance (sf_by_depth, the disparity
+//             error, the whole backward) use explicit FMAs, v_rcp_f32 and the affine
+//             structure of the tap rays, which cuts the VALU work per pixel by ~2x.
+// SHIPPED=true folds the flag set of experiments/davis/train_sequence.sh
+// (--midas --use_disp) at compile time; false reads the flags from the config.
+#define DVD_FMA __builtin_fmaf
+template <bool GRADS, bool SHIPPED, class IO>
 __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, int y, int x,
                                       float d1, float fx, float fy, float mk, float s0, float s1,
                                       float s2, float acc[4], float& g_d1_out, float g_s_out[3]) {
+  const bool midas_mask = SHIPPED ? true : (a.midas_mask != 0);
+  const int disp_mode = SHIPPED ? 1 : a.disp_mode;
+  const bool loss_on_sf = SHIPPED ? false : (a.loss_on_sf != 0);
   const float xf = (float)x, yf = (float)y;
-  // --- frame-1 point: ray = (x,y,1) @ K_inv ; p1c = d1*ray ; P1 = p1c@R1 + t1
+  // --- EXACT: ray = (x,y,1) @ K_inv ; p1c = d1*ray ; P1 = p1c@R1 + t1
   float r0, r1, r2;
   rowvec_mat3(xf, yf, 1.0f, c.Ki, r0, r1, r2);
   const float pc0 = d1 * r0, pc1 = d1 * r1, pc2 = d1 * r2;
@@ -123,7 +138,7 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
   P1 = P1 + c.t1[1];
   P2 = P2 + c.t1[2];
 
-  // --- bilinear taps of frame 2 at (x,y)+flow
+  // --- EXACT: bilinear taps of frame 2 at (x,y)+flow
   const float ix = sample_coord(xf, fx, a.half_w, a.wmax);
   const float iy = sample_coord(yf, fy, a.half_h, a.hmax);
   const float x0f = floorf(ix), y0f = floorf(iy);
@@ -133,130 +148,118 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
   const int x0 = (int)x0f, y0 = (int)y0f;
   const bool in_e = (x0 + 1) < a.W, in_s = (y0 + 1) < a.H;  // x0,y0 are always in range
   const int o_n = y0 * a.W + x0;
-  float dnw, dne, dsw, dse;
+  float dnw, dne, dsw, dse;  // 0 for out-of-image taps, like ATen's masked gather
   io.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
-  // rays of the four tap pixels (same expression as for the own pixel)
-  float rn0[2], rn1[2], rn2[2], rs0[2], rs1[2], rs2[2];
+  // EXACT: z of the camera-2 points at the taps, W2.z = warped_p2_camera_2.z
   const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
-  rowvec_mat3(x0f, y0f, 1.0f, c.Ki, rn0[0], rn1[0], rn2[0]);
-  rowvec_mat3(x1f, y0f, 1.0f, c.Ki, rn0[1], rn1[1], rn2[1]);
-  rowvec_mat3(x0f, y1f, 1.0f, c.Ki, rs0[0], rs1[0], rs2[0]);
-  rowvec_mat3(x1f, y1f, 1.0f, c.Ki, rs0[1], rs1[1], rs2[1]);
-  // camera-2 points at the taps (0 for out-of-image taps, like ATen's masked gather)
-  const float cnw0 = dnw * rn0[0], cnw1 = dnw * rn1[0], cnw2 = dnw * rn2[0];
-  const float cne0 = in_e ? dne * rn0[1] : 0.0f, cne1 = in_e ? dne * rn1[1] : 0.0f,
-              cne2 = in_e ? dne * rn2[1] : 0.0f;
-  const float csw0 = in_s ? dsw * rs0[0] : 0.0f, csw1 = in_s ? dsw * rs1[0] : 0.0f,
-              csw2 = in_s ? dsw * rs2[0] : 0.0f;
-  const bool in_se = in_e && in_s;
-  const float cse0 = in_se ? dse * rs0[1] : 0.0f, cse1 = in_se ? dse * rs1[1] : 0.0f,
-              cse2 = in_se ? dse * rs2[1] : 0.0f;
-  // W2 = warped_p2_camera_2 ; only z feeds masks/loss, x,y are not needed here
-  const float W2z = bilinear(cnw2, cne2, csw2, cse2, w_nw, w_ne, w_sw, w_se);
-  // warped world point of frame 2 (for sf_by_depth)
-  float gnw0, gnw1, gnw2, gne0, gne1, gne2, gsw0, gsw1, gsw2, gse0, gse1, gse2;
-  rowvec_mat3(cnw0, cnw1, cnw2, c.R2, gnw0, gnw1, gnw2);
-  gnw0 += c.t2[0];
-  gnw1 += c.t2[1];
-  gnw2 += c.t2[2];
-  rowvec_mat3(cne0, cne1, cne2, c.R2, gne0, gne1, gne2);
-  gne0 = in_e ? gne0 + c.t2[0] : 0.0f;
-  gne1 = in_e ? gne1 + c.t2[1] : 0.0f;
-  gne2 = in_e ? gne2 + c.t2[2] : 0.0f;
-  rowvec_mat3(csw0, csw1, csw2, c.R2, gsw0, gsw1, gsw2);
-  gsw0 = in_s ? gsw0 + c.t2[0] : 0.0f;
-  gsw1 = in_s ? gsw1 + c.t2[1] : 0.0f;
-  gsw2 = in_s ? gsw2 + c.t2[2] : 0.0f;
-  rowvec_mat3(cse0, cse1, cse2, c.R2, gse0, gse1, gse2);
-  gse0 = in_se ? gse0 + c.t2[0] : 0.0f;
-  gse1 = in_se ? gse1 + c.t2[1] : 0.0f;
-  gse2 = in_se ? gse2 + c.t2[2] : 0.0f;
-  const float G0 = bilinear(gnw0, gne0, gsw0, gse0, w_nw, w_ne, w_sw, w_se);
-  const float G1 = bilinear(gnw1, gne1, gsw1, gse1, w_nw, w_ne, w_sw, w_se);
-  const float G2 = bilinear(gnw2, gne2, gsw2, gse2, w_nw, w_ne, w_sw, w_se);
-  const float sb0 = G0 - P0, sb1 = G1 - P1, sb2 = G2 - P2;  // sf_by_depth
+  const float zn0 = (x0f * c.Ki[2] + y0f * c.Ki[5]) + c.Ki[8];
+  const float zn1 = (x1f * c.Ki[2] + y0f * c.Ki[5]) + c.Ki[8];
+  const float zs0 = (x0f * c.Ki[2] + y1f * c.Ki[5]) + c.Ki[8];
+  const float zs1 = (x1f * c.Ki[2] + y1f * c.Ki[5]) + c.Ki[8];
+  const float W2z = bilinear(dnw * zn0, dne * zn1, dsw * zs0, dse * zs1, w_nw, w_ne, w_sw, w_se);
 
-  // --- dynamic reprojection: Q = (P1 + s - t2) @ R2T ; I = Q @ K
+  // --- EXACT: dynamic reprojection  Q = (P1 + s - t2) @ R2T ; I = Q @ K
   const float A0 = (P0 + s0) - c.t2[0], A1 = (P1 + s1) - c.t2[1], A2 = (P2 + s2) - c.t2[2];
   float Q0, Q1, Q2, I0, I1, I2;
   rowvec_mat3(A0, A1, A2, c.R2T, Q0, Q1, Q2);
   rowvec_mat3(Q0, Q1, Q2, c.K, I0, I1, I2);
   const float den = I2 + 1e-8f;
   const bool behind = I2 < 1e-3f;
-  const float u = behind ? xf : I0 / den;
+  const float u = behind ? xf : I0 / den;  // IEEE divides: sign(dflow - flow) must match the reference
   const float v = behind ? yf : I1 / den;
   const float ex = (u - xf) - fx, ey = (v - yf) - fy;  // dflow - flow
 
-  // --- mask and per-pixel errors
+  // --- FAST: warped world point of frame 2, G = sum_k w_k (d2_k ray_k @ R2 + t2), via
+  //     ray(x0+i, y0+j) = ray(x0,y0) + i*Ki[0,:] + j*Ki[1,:]
+  const float q0 = DVD_FMA(x0f, c.Ki[0], DVD_FMA(y0f, c.Ki[3], c.Ki[6]));
+  const float q1 = DVD_FMA(x0f, c.Ki[1], DVD_FMA(y0f, c.Ki[4], c.Ki[7]));
+  const float q2 = DVD_FMA(x0f, c.Ki[2], DVD_FMA(y0f, c.Ki[5], c.Ki[8]));
+  const float a_nw = w_nw * dnw, a_ne = w_ne * dne, a_sw = w_sw * dsw, a_se = w_se * dse;
+  const float sE = a_ne + a_se, sS = a_sw + a_se, sA = (a_nw + a_ne) + sS;
+  const float V0 = DVD_FMA(q0, sA, DVD_FMA(c.Ki[0], sE, c.Ki[3] * sS));
+  const float V1 = DVD_FMA(q1, sA, DVD_FMA(c.Ki[1], sE, c.Ki[4] * sS));
+  const float V2 = DVD_FMA(q2, sA, DVD_FMA(c.Ki[2], sE, c.Ki[5] * sS));
+  const float G0 = DVD_FMA(V0, c.R2[0], DVD_FMA(V1, c.R2[3], DVD_FMA(V2, c.R2[6], c.t2[0])));
+  const float G1 = DVD_FMA(V0, c.R2[1], DVD_FMA(V1, c.R2[4], DVD_FMA(V2, c.R2[7], c.t2[1])));
+  const float G2 = DVD_FMA(V0, c.R2[2], DVD_FMA(V1, c.R2[5], DVD_FMA(V2, c.R2[8], c.t2[2])));
+  const float f0 = (G0 - P0) - s0, f1 = (G1 - P1) - s1, f2 = (G2 - P2) - s2;  // sf_by_depth - sf
+
+  // --- mask (EXACT) and per-pixel errors
   float m = mk;
-  if (a.midas_mask) {
+  if (midas_mask) {
     m = ((d1 < 100.0f) ? 1.0f : 0.0f) * m;
     m = ((W2z < 100.0f) ? 1.0f : 0.0f) * m;
   }
   const float flow_err = a.crit_l2 ? (ex * ex + ey * ey) : (fabsf(ex) + fabsf(ey));
-  float disp_err, ca = 0.0f, cb = 0.0f, ediff = 0.0f;
-  if (a.disp_mode == 1) {
-    ca = fmaxf(Q2, 1e-3f);
-    cb = fmaxf(W2z, 1e-3f);
-    ediff = (1.0f / ca) - (1.0f / cb);
+  float disp_err, rca = 0.0f, rcb = 0.0f, ediff = 0.0f;
+  if (disp_mode == 1) {
+    rca = __builtin_amdgcn_rcpf(fmaxf(Q2, 1e-3f));
+    rcb = __builtin_amdgcn_rcpf(fmaxf(W2z, 1e-3f));
+    ediff = rca - rcb;
     disp_err = 100.0f * fabsf(ediff);
-  } else if (a.disp_mode == 2) {
-    ca = fmaxf(Q2, 1e-3f);
-    cb = fmaxf(W2z, 1e-3f);
-    disp_err = fmaxf(ca, cb) / fminf(ca, cb) - 1.0f;
+  } else if (disp_mode == 2) {
+    const float ca = fmaxf(Q2, 1e-3f), cb = fmaxf(W2z, 1e-3f);
+    disp_err = fmaxf(ca, cb) * __builtin_amdgcn_rcpf(fminf(ca, cb)) - 1.0f;
   } else {
     disp_err = fabsf(Q2 - W2z);
   }
-  const float f0 = sb0 - s0, f1 = sb1 - s1, f2 = sb2 - s2;
   const float sf_err = fabsf(f0) + fabsf(f1) + fabsf(f2);
   acc[0] += m;
-  acc[1] += m * flow_err;
-  acc[2] += m * disp_err;
-  acc[3] += m * sf_err;
+  acc[1] = DVD_FMA(m, flow_err, acc[1]);
+  acc[2] = DVD_FMA(m, disp_err, acc[2]);
+  acc[3] = DVD_FMA(m, sf_err, acc[3]);
 
   if (!GRADS) return;
-  // ------------------------------ backward (un-normalised) ----------------
+  // ------------------------------ FAST: backward (un-normalised) ----------
   float gQ0 = 0.0f, gQ1 = 0.0f, gQ2 = 0.0f;
   const float fm = a.flow_mul * m;
   if (!behind && fm != 0.0f) {
     const float gu = a.crit_l2 ? fm * 2.0f * ex : fm * sgn(ex);
     const float gv = a.crit_l2 ? fm * 2.0f * ey : fm * sgn(ey);
-    const float gI0 = gu / den, gI1 = gv / den;
-    const float gI2 = -(gu * u + gv * v) / den;
-    rowvec_mat3_T(gI0, gI1, gI2, c.K, gQ0, gQ1, gQ2);
+    const float rden = __builtin_amdgcn_rcpf(den);
+    const float gI0 = gu * rden, gI1 = gv * rden;
+    const float gI2 = -DVD_FMA(gu, u, gv * v) * rden;
+    gQ0 = DVD_FMA(gI0, c.K[0], DVD_FMA(gI1, c.K[1], gI2 * c.K[2]));
+    gQ1 = DVD_FMA(gI0, c.K[3], DVD_FMA(gI1, c.K[4], gI2 * c.K[5]));
+    gQ2 = DVD_FMA(gI0, c.K[6], DVD_FMA(gI1, c.K[7], gI2 * c.K[8]));
   }
-  float gW2z = 0.0f;  // d loss / d W2.z
+  float gW2z = 0.0f;                         // d loss / d W2.z
   float gG0 = 0.0f, gG1 = 0.0f, gG2 = 0.0f;  // d loss / d warped world point
   const float dm = a.disp_mul * m;
-  if (!a.loss_on_sf) {
-    if (a.disp_mode == 1 && dm != 0.0f) {
+  if (!loss_on_sf) {
+    if (disp_mode == 1 && dm != 0.0f) {
       const float ge = dm * 100.0f * sgn(ediff);
-      if (Q2 >= 1e-3f) gQ2 += -ge / (ca * ca);
-      if (W2z >= 1e-3f) gW2z = ge / (cb * cb);
+      if (Q2 >= 1e-3f) gQ2 = DVD_FMA(-ge, rca * rca, gQ2);
+      if (W2z >= 1e-3f) gW2z = ge * (rcb * rcb);
     }
   } else if (dm != 0.0f) {
     gG0 = dm * sgn(f0);
     gG1 = dm * sgn(f1);
     gG2 = dm * sgn(f2);
   }
-  float gA0, gA1, gA2;
-  rowvec_mat3_T(gQ0, gQ1, gQ2, c.R2T, gA0, gA1, gA2);
-  // scene flow enters A (+) and, in sf-loss mode, the error term (-)
-  g_s_out[0] = gA0 - gG0;
-  g_s_out[1] = gA1 - gG1;
-  g_s_out[2] = gA2 - gG2;
-  // P1 enters A (+) and sf_by_depth (-)
-  float gp0, gp1, gp2;
-  rowvec_mat3_T(gA0 - gG0, gA1 - gG1, gA2 - gG2, c.R1, gp0, gp1, gp2);
-  g_d1_out = gp0 * r0 + gp1 * r1 + gp2 * r2;
-  // depth_2 taps: d(W2)/d(d2_k) = w_k * ray_k ; d(G)/d(d2_k) = w_k * ray_k @ R2
-  float h0, h1, h2;
-  rowvec_mat3_T(gG0, gG1, gG2, c.R2, h0, h1, h2);
-  h2 += gW2z;
+  // scene flow enters A (+) and, in sf-loss mode, the error term (-); so does P1
+  const float gA0 = DVD_FMA(gQ0, c.R2T[0], DVD_FMA(gQ1, c.R2T[1], gQ2 * c.R2T[2])) - gG0;
+  const float gA1 = DVD_FMA(gQ0, c.R2T[3], DVD_FMA(gQ1, c.R2T[4], gQ2 * c.R2T[5])) - gG1;
+  const float gA2 = DVD_FMA(gQ0, c.R2T[6], DVD_FMA(gQ1, c.R2T[7], gQ2 * c.R2T[8])) - gG2;
+  g_s_out[0] = gA0;
+  g_s_out[1] = gA1;
+  g_s_out[2] = gA2;
+  const float gp0 = DVD_FMA(gA0, c.R1[0], DVD_FMA(gA1, c.R1[1], gA2 * c.R1[2]));
+  const float gp1 = DVD_FMA(gA0, c.R1[3], DVD_FMA(gA1, c.R1[4], gA2 * c.R1[5]));
+  const float gp2 = DVD_FMA(gA0, c.R1[6], DVD_FMA(gA1, c.R1[7], gA2 * c.R1[8]));
+  g_d1_out = DVD_FMA(gp0, r0, DVD_FMA(gp1, r1, gp2 * r2));
+  // depth_2 taps: d/d(d2_k) = w_k * (h . ray_k),  h = gG @ R2^T + (0,0,gW2z)
+  float h0 = 0.0f, h1 = 0.0f, h2 = gW2z;
+  if (loss_on_sf) {
+    h0 = DVD_FMA(gG0, c.R2[0], DVD_FMA(gG1, c.R2[1], gG2 * c.R2[2]));
+    h1 = DVD_FMA(gG0, c.R2[3], DVD_FMA(gG1, c.R2[4], gG2 * c.R2[5]));
+    h2 += DVD_FMA(gG0, c.R2[6], DVD_FMA(gG1, c.R2[7], gG2 * c.R2[8]));
+  }
   if (h0 != 0.0f || h1 != 0.0f || h2 != 0.0f) {
-    io.scatter(o_n, x0, y0, in_e, in_s, w_nw * (h0 * rn0[0] + h1 * rn1[0] + h2 * rn2[0]),
-               w_ne * (h0 * rn0[1] + h1 * rn1[1] + h2 * rn2[1]), w_sw * (h0 * rs0[0] + h1 * rs1[0] + h2 * rs2[0]),
-               w_se * (h0 * rs0[1] + h1 * rs1[1] + h2 * rs2[1]));
+    const float hb = DVD_FMA(h0, q0, DVD_FMA(h1, q1, h2 * q2));
+    const float hx = DVD_FMA(h0, c.Ki[0], DVD_FMA(h1, c.Ki[1], h2 * c.Ki[2]));
+    const float hy = DVD_FMA(h0, c.Ki[3], DVD_FMA(h1, c.Ki[4], h2 * c.Ki[5]));
+    io.scatter(o_n, x0, y0, in_e, in_s, w_nw * hb, w_ne * (hb + hx), w_sw * (hb + hy), w_se * ((hb + hx) + hy));
   }
 }
 
@@ -335,8 +338,8 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
     for (int i = 0; i < PX; ++i) {
       gd1[i] = 0.0f;
       gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
-      pixel<GRADS>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
-                   gd1[i], gs[i]);
+      pixel<GRADS, false>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
+                          gd1[i], gs[i]);
     }
     if (GRADS) {
       float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
@@ -454,8 +457,8 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int TW, int TH, int R, int NT, bool GRADS>
-__global__ __launch_bounds__(NT) void warp_loss_tiled_kernel(const WarpArgs a, const TileArgs ta) {
+template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED>
+__global__ __launch_bounds__(NT, 4) void warp_loss_tiled_kernel(const WarpArgs a, const TileArgs ta) {
   constexpr int WW = TW + 2 * R + 4;  // multiple of 4: window rows are float4-aligned
   constexpr int WH = TH + 2 * R + 1;
   constexpr int QW = TW / 4;
@@ -473,6 +476,16 @@ __global__ __launch_bounds__(NT) void warp_loss_tiled_kernel(const WarpArgs a, c
   const int wx0 = tx0 - R, wy0 = ty0 - R;
   Cam c;
   load_cam(a, b, c);
+  // The 51 camera scalars are wave-uniform; left alone they all land in SGPRs and push the
+  // kernel past the 102-SGPR file (hundreds of v_readlane spill reloads).  Pin the three
+  // matrices used mostly by the FMA-heavy parts into VGPRs instead.
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    asm volatile("" : "+v"(c.R1[i]));
+    asm volatile("" : "+v"(c.R2[i]));
+    asm volatile("" : "+v"(c.K[i]));
+    asm volatile("" : "+v"(c.R2T[i]));
+  }
   const float* d2b = a.d2 + (size_t)b * a.HW;
 
   // ---- phase 0: fill the depth_2 window, clear the accumulator
@@ -536,8 +549,8 @@ __global__ __launch_bounds__(NT) void warp_loss_tiled_kernel(const WarpArgs a, c
       gd1[i] = 0.0f;
       gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
       if (i < nvalid)
-        pixel<GRADS>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc, gd1[i],
-                     gs[i]);
+        pixel<GRADS, SHIPPED>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
+                              gd1[i], gs[i]);
     }
     if (GRADS) {
       float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
@@ -750,17 +763,26 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   const int nblocks = p.ntx * p.nty * a.B;
   const size_t lds = (size_t)WW * WH * sizeof(float) * 2;
   if (grads) DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, sizeof(unsigned), stream));
+  const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
+#define DVD_TILED_LAUNCH(G, S)                                                                            \
+  do {                                                                                                    \
+    auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, G, S>;                                                \
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                      \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+    hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);                                   \
+  } while (0)
   if (grads) {
-    auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, true>;
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);
+    if (shipped)
+      DVD_TILED_LAUNCH(true, true);
+    else
+      DVD_TILED_LAUNCH(true, false);
   } else {
-    auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, false>;
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-    hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);
+    if (shipped)
+      DVD_TILED_LAUNCH(false, true);
+    else
+      DVD_TILED_LAUNCH(false, false);
   }
+#undef DVD_TILED_LAUNCH
   DVD_LAUNCH_OK();
   if (grads) {
     const int qpr = (a.W + 3) / 4;
