@@ -223,20 +223,23 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
     gQ1 = DVD_FMA(gI0, c.K[3], DVD_FMA(gI1, c.K[4], gI2 * c.K[5]));
     gQ2 = DVD_FMA(gI0, c.K[6], DVD_FMA(gI1, c.K[7], gI2 * c.K[8]));
   }
-  float gW2z = 0.0f;                         // d loss / d W2.z
-  float gG0 = 0.0f, gG1 = 0.0f, gG2 = 0.0f;  // d loss / d warped world point
-  const float dm = a.disp_mul * m;
+  // The second loss term only reaches depth_2 through W2.z / G, both linear in disp_mul:
+  // keep those two in units of disp_mul (`u*`), the IO policy multiplies it back.
+  float uW2z = 0.0f;                         // d loss / d W2.z        / disp_mul
+  float uG0 = 0.0f, uG1 = 0.0f, uG2 = 0.0f;  // d loss / d warped point / disp_mul
+  const float dm = a.disp_mul;
   if (!loss_on_sf) {
-    if (disp_mode == 1 && dm != 0.0f) {
-      const float ge = dm * 100.0f * sgn(ediff);
-      if (Q2 >= 1e-3f) gQ2 = DVD_FMA(-ge, rca * rca, gQ2);
-      if (W2z >= 1e-3f) gW2z = ge * (rcb * rcb);
+    if (disp_mode == 1 && m != 0.0f) {
+      const float ue = m * 100.0f * sgn(ediff);
+      if (Q2 >= 1e-3f) gQ2 = DVD_FMA(-ue * dm, rca * rca, gQ2);
+      if (W2z >= 1e-3f) uW2z = ue * (rcb * rcb);
     }
-  } else if (dm != 0.0f) {
-    gG0 = dm * sgn(f0);
-    gG1 = dm * sgn(f1);
-    gG2 = dm * sgn(f2);
+  } else if (m != 0.0f) {
+    uG0 = m * sgn(f0);
+    uG1 = m * sgn(f1);
+    uG2 = m * sgn(f2);
   }
+  const float gG0 = dm * uG0, gG1 = dm * uG1, gG2 = dm * uG2;
   // scene flow enters A (+) and, in sf-loss mode, the error term (-); so does P1
   const float gA0 = DVD_FMA(gQ0, c.R2T[0], DVD_FMA(gQ1, c.R2T[1], gQ2 * c.R2T[2])) - gG0;
   const float gA1 = DVD_FMA(gQ0, c.R2T[3], DVD_FMA(gQ1, c.R2T[4], gQ2 * c.R2T[5])) - gG1;
@@ -248,12 +251,12 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
   const float gp1 = DVD_FMA(gA0, c.R1[3], DVD_FMA(gA1, c.R1[4], gA2 * c.R1[5]));
   const float gp2 = DVD_FMA(gA0, c.R1[6], DVD_FMA(gA1, c.R1[7], gA2 * c.R1[8]));
   g_d1_out = DVD_FMA(gp0, r0, DVD_FMA(gp1, r1, gp2 * r2));
-  // depth_2 taps: d/d(d2_k) = w_k * (h . ray_k),  h = gG @ R2^T + (0,0,gW2z)
-  float h0 = 0.0f, h1 = 0.0f, h2 = gW2z;
+  // depth_2 taps (units of disp_mul): d/d(d2_k) = w_k * (h . ray_k),  h = uG @ R2^T + (0,0,uW2z)
+  float h0 = 0.0f, h1 = 0.0f, h2 = uW2z;
   if (loss_on_sf) {
-    h0 = DVD_FMA(gG0, c.R2[0], DVD_FMA(gG1, c.R2[1], gG2 * c.R2[2]));
-    h1 = DVD_FMA(gG0, c.R2[3], DVD_FMA(gG1, c.R2[4], gG2 * c.R2[5]));
-    h2 += DVD_FMA(gG0, c.R2[6], DVD_FMA(gG1, c.R2[7], gG2 * c.R2[8]));
+    h0 = DVD_FMA(uG0, c.R2[0], DVD_FMA(uG1, c.R2[1], uG2 * c.R2[2]));
+    h1 = DVD_FMA(uG0, c.R2[3], DVD_FMA(uG1, c.R2[4], uG2 * c.R2[5]));
+    h2 += DVD_FMA(uG0, c.R2[6], DVD_FMA(uG1, c.R2[7], uG2 * c.R2[8]));
   }
   if (h0 != 0.0f || h1 != 0.0f || h2 != 0.0f) {
     const float hb = DVD_FMA(h0, q0, DVD_FMA(h1, q1, h2 * q2));
@@ -268,6 +271,7 @@ struct DirectIO {
   const float* d2b;
   float* gb;
   int W;
+  float unit;
   __device__ __forceinline__ void fetch(int o_n, int, int, bool in_e, bool in_s, float& dnw, float& dne,
                                         float& dsw, float& dse) const {
     const int o_s = o_n + W;
@@ -292,10 +296,10 @@ struct DirectIO {
   }
   __device__ __forceinline__ void scatter(int o_n, int, int, bool in_e, bool in_s, float tnw, float tne,
                                           float tsw, float tse) const {
-    unsafeAtomicAdd(gb + o_n, tnw);
-    if (in_e) unsafeAtomicAdd(gb + o_n + 1, tne);
-    if (in_s) unsafeAtomicAdd(gb + o_n + W, tsw);
-    if (in_e && in_s) unsafeAtomicAdd(gb + o_n + W + 1, tse);
+    unsafeAtomicAdd(gb + o_n, tnw * unit);
+    if (in_e) unsafeAtomicAdd(gb + o_n + 1, tne * unit);
+    if (in_s) unsafeAtomicAdd(gb + o_n + W, tsw * unit);
+    if (in_e && in_s) unsafeAtomicAdd(gb + o_n + W + 1, tse * unit);
   }
 };
 
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
     const int y = p0 / a.W;
     const int x = p0 - y * a.W;  // PX divides W, so the PX pixels share the row
     float gd1[PX], gs[PX][3];
-    DirectIO io{a.d2 + (size_t)b * a.HW, a.g_d2 + (size_t)b * a.HW, a.W};
+    DirectIO io{a.d2 + (size_t)b * a.HW, a.g_d2 + (size_t)b * a.HW, a.W, a.disp_mul};
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
       gd1[i] = 0.0f;
@@ -399,12 +403,22 @@ struct Overflow {
   unsigned cap;
 };
 
+// LDS accumulation is 64-bit fixed point (Q31.32): ds_add_u64 sustains ~6.5 lane-ops/clk/CU
+// on gfx950 while ds_add_f32 manages 0.38 (tools/ubench/lds_atomics.hip), and integer adds
+// commute, so g_depth_2 is bitwise reproducible.  Taps are accumulated in units of the loss
+// multiplier (see `unit` in pixel()), which keeps the magnitudes O(100/depth^2) whatever the
+// multipliers are; |value| >= 2^30 goes to the overflow list as a float.
+constexpr float kFixScale = 4294967296.0f;          // 2^32
+constexpr float kFixInv = 1.0f / 4294967296.0f;
+constexpr float kFixMax = 1073741824.0f;            // 2^30
+
 template <int WW, int WH>
 struct TileIO {
-  const float* d2b;  // depth_2 of this pair
-  float* win;        // LDS [WH][WW]
-  float* accw;       // LDS [WH][WW]
+  const float* d2b;          // depth_2 of this pair
+  float* win;                // LDS [WH][WW]
+  unsigned long long* accw;  // LDS [WH][WW], Q31.32
   int W, wx0, wy0, pair_base;
+  float unit;                // accumulated values are multiplied by this at the end
   Overflow ovf;
   __device__ __forceinline__ bool inside(int x0, int y0) const {
     const int lx = x0 - wx0, ly = y0 - wy0;
@@ -420,22 +434,28 @@ struct TileIO {
       dsw = p[WW];
       dse = p[WW + 1];
     } else {
-      DirectIO g{d2b, nullptr, W};
+      DirectIO g{d2b, nullptr, W, 1.0f};
       g.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
     }
   }
   __device__ __forceinline__ void spill(int idx, float v) const {
     const unsigned i = atomicAdd(ovf.count, 1u);
-    if (i < ovf.cap) ovf.rec[i] = make_int2(pair_base + idx, __float_as_int(v));
+    if (i < ovf.cap) ovf.rec[i] = make_int2(pair_base + idx, __float_as_int(v * unit));
+  }
+  __device__ __forceinline__ void add_fixed(unsigned long long* p, int idx, float v) const {
+    if (fabsf(v) < kFixMax)
+      atomicAdd(p, (unsigned long long)(long long)(v * kFixScale));  // ds_add_u64
+    else
+      spill(idx, v);
   }
   __device__ __forceinline__ void scatter(int o_n, int x0, int y0, bool in_e, bool in_s, float tnw, float tne,
                                           float tsw, float tse) const {
     if (inside(x0, y0)) {
-      float* p = accw + (y0 - wy0) * WW + (x0 - wx0);
-      atomicAdd(p, tnw);  // ds_add_f32
-      if (in_e) atomicAdd(p + 1, tne);
-      if (in_s) atomicAdd(p + WW, tsw);
-      if (in_e && in_s) atomicAdd(p + WW + 1, tse);
+      unsigned long long* p = accw + (y0 - wy0) * WW + (x0 - wx0);
+      add_fixed(p, o_n, tnw);
+      if (in_e) add_fixed(p + 1, o_n + 1, tne);
+      if (in_s) add_fixed(p + WW, o_n + W, tsw);
+      if (in_e && in_s) add_fixed(p + WW + 1, o_n + W + 1, tse);
     } else {
       spill(o_n, tnw);
       if (in_e) spill(o_n + 1, tne);
@@ -464,8 +484,8 @@ __global__ __launch_bounds__(NT, 4) void warp_loss_tiled_kernel(const WarpArgs a
   constexpr int QW = TW / 4;
   static_assert(R % 4 == 0 && TW % 4 == 0, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* win = smem;
-  float* accw = smem + WW * WH;
+  unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);  // [WH][WW] u64 first (8-byte aligned)
+  float* win = smem + 2 * WW * WH;
 
   const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int tiles = ta.ntx * ta.nty;
@@ -506,11 +526,15 @@ __global__ __launch_bounds__(NT, 4) void warp_loss_tiled_kernel(const WarpArgs a
       }
     }
     *reinterpret_cast<float4*>(win + wy * WW + wx) = v;
-    if (GRADS) *reinterpret_cast<float4*>(accw + wy * WW + wx) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (GRADS) {
+      uint4* z = reinterpret_cast<uint4*>(accw + wy * WW + wx);
+      z[0] = make_uint4(0u, 0u, 0u, 0u);
+      z[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
   __syncthreads();
 
-  TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, ta.ovf};
+  TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, a.disp_mul, ta.ovf};
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   // ---- phase 1: the tile's pixels, 4 per thread per step
   for (int q = threadIdx.x; q < QW * TH; q += NT) {
@@ -573,8 +597,13 @@ __global__ __launch_bounds__(NT, 4) void warp_loss_tiled_kernel(const WarpArgs a
   __syncthreads();
   if (GRADS) {
     float* slab = ta.slabs + (size_t)logical * (WW * WH);
-    for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT)
-      reinterpret_cast<float4*>(slab)[i] = reinterpret_cast<const float4*>(accw)[i];
+    const float back = kFixInv * a.disp_mul;
+    for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
+      const longlong2 lo = reinterpret_cast<const longlong2*>(accw)[2 * i];
+      const longlong2 hi = reinterpret_cast<const longlong2*>(accw)[2 * i + 1];
+      reinterpret_cast<float4*>(slab)[i] =
+          make_float4((float)lo.x * back, (float)lo.y * back, (float)hi.x * back, (float)hi.y * back);
+    }
   }
   float* red = win;  // window no longer needed
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -695,7 +724,7 @@ constexpr int kR = 8;  // LDS window halo: taps within |flow| <= 8 px stay on ch
 struct TileShape {
   int tw, th, nt;
 };
-static const TileShape kShapes[] = {{96, 64, 512}, {64, 64, 512}, {128, 32, 512}, {64, 32, 256}};
+static const TileShape kShapes[] = {{96, 32, 512}, {64, 48, 512}, {128, 32, 512}, {64, 32, 256}};
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 static int env_int(const char* name, int dflt) {
@@ -761,7 +790,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.ntx = p.ntx;
   ta.nty = p.nty;
   const int nblocks = p.ntx * p.nty * a.B;
-  const size_t lds = (size_t)WW * WH * sizeof(float) * 2;
+  const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
   if (grads) DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, sizeof(unsigned), stream));
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
 #define DVD_TILED_LAUNCH(G, S)                                                                            \
@@ -882,9 +911,9 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
   char* ws = static_cast<char*>(workspace);
   switch (plan.shape) {
     case 0:
-      return launch_tiled<96, 64, 512>(a, plan, ws, grads, stream);
+      return launch_tiled<96, 32, 512>(a, plan, ws, grads, stream);
     case 1:
-      return launch_tiled<64, 64, 512>(a, plan, ws, grads, stream);
+      return launch_tiled<64, 48, 512>(a, plan, ws, grads, stream);
     case 2:
       return launch_tiled<128, 32, 512>(a, plan, ws, grads, stream);
     default:
