@@ -53,6 +53,7 @@ struct WarpArgs {
   int midas_mask, crit_l2, disp_mode, loss_on_sf;
   float flow_mul, disp_mul;
   float half_w, half_h, wmax, hmax;
+  int ablate;  // DVD_WARP_ABLATE bit mask, timing experiments only (1: no scatter, 2: no g stores, 4: no slab flush)
 };
 
 struct Cam {
@@ -258,7 +259,7 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
     h1 = DVD_FMA(uG0, c.R2[3], DVD_FMA(uG1, c.R2[4], uG2 * c.R2[5]));
     h2 += DVD_FMA(uG0, c.R2[6], DVD_FMA(uG1, c.R2[7], uG2 * c.R2[8]));
   }
-  if (h0 != 0.0f || h1 != 0.0f || h2 != 0.0f) {
+  if ((h0 != 0.0f || h1 != 0.0f || h2 != 0.0f) && !(a.ablate & 1)) {
     const float hb = DVD_FMA(h0, q0, DVD_FMA(h1, q1, h2 * q2));
     const float hx = DVD_FMA(h0, c.Ki[0], DVD_FMA(h1, c.Ki[1], h2 * c.Ki[2]));
     const float hy = DVD_FMA(h0, c.Ki[3], DVD_FMA(h1, c.Ki[4], h2 * c.Ki[5]));
@@ -477,8 +478,17 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+constexpr int tile_lds_bytes(int tw, int th, int r) { return (tw + 2 * r + 4) * (th + 2 * r + 1) * 12; }
+constexpr int tile_blocks_per_cu(int tw, int th, int r) { return 163840 / tile_lds_bytes(tw, th, r); }
+// Measured on MI355X: this kernel is latency bound and its time falls steeply with resident
+// waves (12 -> 16 waves/CU: 335 -> 233 us at 48x384x672), so take 4 waves/SIMD (128 VGPRs)
+// whenever the LDS footprint admits it.
+constexpr int tile_waves_per_simd(int tw, int th, int r, int nt) {
+  return (tile_blocks_per_cu(tw, th, r) * nt + 255) / 256 > 4 ? 4 : (tile_blocks_per_cu(tw, th, r) * nt + 255) / 256;
+}
+
 template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED>
-__global__ __launch_bounds__(NT, 4) void warp_loss_tiled_kernel(const WarpArgs a, const TileArgs ta) {
+__global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_loss_tiled_kernel(const WarpArgs a, const TileArgs ta) {
   constexpr int WW = TW + 2 * R + 4;  // multiple of 4: window rows are float4-aligned
   constexpr int WH = TH + 2 * R + 1;
   constexpr int QW = TW / 4;
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(NT, 4) void warp_loss_tiled_kernel(const WarpArgs a
         pixel<GRADS, SHIPPED>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
                               gd1[i], gs[i]);
     }
-    if (GRADS) {
+    if (GRADS && !(a.ablate & 2)) {
       float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
       if (w4) {
         *reinterpret_cast<float4*>(a.g_d1 + base) = make_float4(gd1[0], gd1[1], gd1[2], gd1[3]);
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(NT, 4) void warp_loss_tiled_kernel(const WarpArgs a
   }
   // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
   __syncthreads();
-  if (GRADS) {
+  if (GRADS && !(a.ablate & 4)) {
     float* slab = ta.slabs + (size_t)logical * (WW * WH);
     const float back = kFixInv * a.disp_mul;
     for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
@@ -677,11 +687,11 @@ __global__ __launch_bounds__(256) void apply_overflow_kernel(const unsigned* __r
 }
 
 // Second stage: fixed-order sum of the per-block partials (deterministic).
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int n,
-                                                              float* __restrict__ sums) {
-  __shared__ double sh[256][4];
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int n,
+                                                               float* __restrict__ sums) {
+  __shared__ double sh[1024][4];
   double acc[4] = {0, 0, 0, 0};
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += 1024) {
     const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)i * 4);
     acc[0] += v.x;
     acc[1] += v.y;
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 #pragma unroll
   for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] = acc[k];
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = 512; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + s][k];
@@ -724,7 +734,7 @@ constexpr int kR = 8;  // LDS window halo: taps within |flow| <= 8 px stay on ch
 struct TileShape {
   int tw, th, nt;
 };
-static const TileShape kShapes[] = {{96, 32, 512}, {64, 48, 512}, {128, 32, 512}, {64, 32, 256}};
+static const TileShape kShapes[] = {{96, 32, 512}, {64, 48, 512}, {64, 32, 512}, {64, 32, 256}};
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 static int env_int(const char* name, int dflt) {
@@ -823,7 +833,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
                        a.g_d2);
     DVD_LAUNCH_OK();
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, a.partial, nblocks, a.sums);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nblocks, a.sums);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -882,6 +892,7 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
   a.half_h = (float)((cfg->H - 1) / 2.0);
   a.wmax = (float)(cfg->W - 1);
   a.hmax = (float)(cfg->H - 1);
+  a.ablate = env_int("DVD_WARP_ABLATE", 0);
   const bool all16 = (((uintptr_t)depth_1 | (uintptr_t)depth_2 | (uintptr_t)flow_1_2 | (uintptr_t)mask_2 |
                        (uintptr_t)sf_1_2 | (uintptr_t)g_depth_1 | (uintptr_t)g_depth_2 | (uintptr_t)g_sf_1_2) &
                       15) == 0;
@@ -904,7 +915,7 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
         hipLaunchKernelGGL((warp_loss_kernel<1, false>), grid, block, 0, stream, a);
     }
     DVD_LAUNCH_OK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, a.partial, nbx * cfg->B, sums);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nbx * cfg->B, sums);
     DVD_LAUNCH_OK();
     return DVD_OK;
   }
@@ -915,7 +926,7 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
     case 1:
       return launch_tiled<64, 48, 512>(a, plan, ws, grads, stream);
     case 2:
-      return launch_tiled<128, 32, 512>(a, plan, ws, grads, stream);
+      return launch_tiled<64, 32, 512>(a, plan, ws, grads, stream);
     default:
       return launch_tiled<64, 32, 256>(a, plan, ws, grads, stream);
   }
