@@ -29,6 +29,15 @@ class WarpCfg(ctypes.Structure):
                 ('disp_mode', c_int), ('loss_on_sf', c_int), ('flow_mul', c_float), ('disp_mul', c_float)]
 
 
+class MlpDesc(ctypes.Structure):
+    _fields_ = [('n_freq_xyz', c_int), ('n_freq_t', c_int), ('time_dependent', c_int), ('freqs_xyz', c_void_p),
+                ('freqs_t', c_void_p)]
+
+
+c_longlong = ctypes.c_longlong
+PtrArr6 = c_void_p * 6
+PtrArr5 = c_void_p * 5
+
 # name -> (restype, argtypes); must list every symbol declared in include/dvd_hip.h
 SIGNATURES = {
     'dvd_abi_version': (c_int, []),
@@ -44,6 +53,19 @@ SIGNATURES = {
     'dvd_warp_loss_fwd': (c_int, [ctypes.POINTER(WarpCfg)] + [c_void_p] * 5 + [ctypes.POINTER(Cameras), c_void_p,
                                                                              c_size_t, c_void_p, c_void_p]),
     'dvd_loss_finalize': (c_int, [ctypes.POINTER(WarpCfg), c_void_p, c_void_p, c_void_p]),
+    'dvd_sf_mlp_in_channels': (c_int, [ctypes.POINTER(MlpDesc)]),
+    'dvd_sf_mlp_packed_bytes': (c_size_t, [ctypes.POINTER(MlpDesc)]),
+    'dvd_sf_mlp_stash_bytes': (c_size_t, [ctypes.POINTER(MlpDesc), c_longlong]),
+    'dvd_sf_mlp_gstash_bytes': (c_size_t, [c_longlong]),
+    'dvd_sf_mlp_pack': (c_int, [ctypes.POINTER(MlpDesc), ctypes.POINTER(PtrArr6), ctypes.POINTER(PtrArr6), c_void_p,
+                                c_void_p]),
+    'dvd_sf_mlp_fwd': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_void_p, c_float, c_float, c_longlong,
+                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'dvd_sf_mlp_bwd_dx': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p,
+                                  c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p]),
+    'dvd_sf_mlp_bwd_dw': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_longlong, ctypes.POINTER(PtrArr5),
+                                  ctypes.POINTER(PtrArr5), c_void_p]),
 }
 
 _lock = threading.Lock()

@@ -24,6 +24,7 @@ SOURCES = [
     ('core.hip', []),
     ('unproject.hip', ['-ffp-contract=off']),
     ('warp_loss.hip', ['-ffp-contract=off']),
+    ('sf_mlp.hip', []),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

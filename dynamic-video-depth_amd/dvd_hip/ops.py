@@ -137,3 +137,102 @@ def loss_finalize(cfg, sums, out=None):
     lib = _lib.load()
     _lib.check(lib.dvd_loss_finalize(ctypes.byref(cfg), _p(sums), _p(out), _stream()), 'dvd_loss_finalize')
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# scene-flow field MLP
+
+
+def embed_frequencies(n_freq):
+    """PeriodicEmbed(max_freq=N, N_freq=N).freqs, exactly as the reference builds them
+    (torch.linspace(1, N + 1, N), networks/blocks.py:24)."""
+    return torch.linspace(1, n_freq + 1, steps=n_freq)
+
+
+class SceneFlowMLPKernels(object):
+    """Host-side handle of the fused MLP kernels for one network configuration:
+    owns the frequency tables, the packed-weight buffer and the scratch stashes."""
+
+    def __init__(self, device, n_freq_xyz=16, n_freq_t=16, time_dependent=True):
+        if torch.device(device).type != 'cuda':
+            raise RuntimeError('SceneFlowMLPKernels needs a GPU device (dvd_hip has no CPU path)')
+        self.device = torch.device(device)
+        self.n_freq_xyz, self.n_freq_t, self.time_dependent = int(n_freq_xyz), int(n_freq_t), bool(time_dependent)
+        self.fx = embed_frequencies(self.n_freq_xyz).to(self.device) if self.n_freq_xyz > 0 else None
+        self.ft = embed_frequencies(self.n_freq_t).to(self.device) if (self.time_dependent and self.n_freq_t > 0) else None
+        self.desc = _lib.MlpDesc(self.n_freq_xyz, self.n_freq_t, int(self.time_dependent),
+                                 self.fx.data_ptr() if self.fx is not None else 0,
+                                 self.ft.data_ptr() if self.ft is not None else 0)
+        lib = _lib.load()
+        self.c_in = lib.dvd_sf_mlp_in_channels(ctypes.byref(self.desc))
+        self.packed = torch.empty(lib.dvd_sf_mlp_packed_bytes(ctypes.byref(self.desc)) // 4, device=self.device,
+                                  dtype=torch.float32)
+
+    # -- sizes
+    def stash_floats(self, n_pix):
+        return _lib.load().dvd_sf_mlp_stash_bytes(ctypes.byref(self.desc), int(n_pix)) // 4
+
+    def gstash_floats(self, n_pix):
+        return _lib.load().dvd_sf_mlp_gstash_bytes(int(n_pix)) // 4
+
+    def new_stash(self, n_pix):
+        return torch.empty(self.stash_floats(n_pix), device=self.device, dtype=torch.float32)
+
+    def new_gstash(self, n_pix):
+        return torch.empty(self.gstash_floats(n_pix), device=self.device, dtype=torch.float32)
+
+    # -- kernels
+    def pack(self, weights, biases):
+        """weights: six tensors [out,in,1,1] (or [out,in]); biases: six [out]."""
+        ws = [_dev32(w.detach(), 'weight') for w in weights]
+        bs = [_dev32(b.detach(), 'bias') for b in biases]
+        if len(ws) != 6 or len(bs) != 6:
+            raise RuntimeError('the fused MLP has exactly 6 conv layers (n_layers=4)')
+        dims = [self.c_in] + [256] * 5
+        for i, w in enumerate(ws):
+            o = 256 if i < 5 else 3
+            if w.numel() != o * dims[i] or bs[i].numel() != o:
+                raise RuntimeError('layer %d: expected weight %dx%d, got %s' % (i, o, dims[i], tuple(w.shape)))
+        W = _lib.PtrArr6(*[w.data_ptr() for w in ws])
+        Bp = _lib.PtrArr6(*[b.data_ptr() for b in bs])
+        lib = _lib.load()
+        _lib.check(lib.dvd_sf_mlp_pack(ctypes.byref(self.desc), ctypes.byref(W), ctypes.byref(Bp), _p(self.packed),
+                                       _stream()), 'dvd_sf_mlp_pack')
+
+    def forward(self, p, t, t_offset=0.0, out_scale=1.0, sf_out=None, p_next=None, acc=None, stash=None):
+        p = _dev32(p, 'p')
+        B, C, H, W = p.shape
+        if C != 3:
+            raise RuntimeError('p must be [B,3,H,W]')
+        if self.time_dependent:
+            if t is None:
+                raise ValueError('time dependent scene-flow field needs t')
+            t = _dev32(t, 't')
+            if t.numel() != B * H * W:
+                raise RuntimeError('t must be [B,1,H,W]')
+        n_pix = B * H * W
+        if stash is not None and stash.numel() < self.stash_floats(n_pix):
+            raise RuntimeError('stash too small')
+        lib = _lib.load()
+        _lib.check(lib.dvd_sf_mlp_fwd(ctypes.byref(self.desc), _p(self.packed), _p(p),
+                                      _p(t) if self.time_dependent else ctypes.c_void_p(0), float(t_offset),
+                                      float(out_scale), n_pix, H * W, _p(sf_out), _p(p_next), _p(acc), _p(stash),
+                                      _stream()), 'dvd_sf_mlp_fwd')
+
+    def backward_dx(self, stash, out_scale, g_out1, g_p, gstash, gW5, gb5, shape, gscale=1.0, scale_ptr=None,
+                    g_out2=None, g_p_add=None):
+        B, H, W = shape
+        n_pix = B * H * W
+        lib = _lib.load()
+        _lib.check(lib.dvd_sf_mlp_bwd_dx(ctypes.byref(self.desc), _p(self.packed), _p(stash), float(out_scale),
+                                         _p(g_out1), float(gscale), _p(scale_ptr), _p(g_out2), _p(g_p_add), n_pix,
+                                         H * W, _p(g_p), _p(gstash), _p(gW5), _p(gb5), _stream()),
+                   'dvd_sf_mlp_bwd_dx')
+
+    def backward_dw(self, stash, gstash, n_pix, gW, gb):
+        """Accumulates into gW[0..4] ([256,in]) and gb[0..4] ([256])."""
+        W = _lib.PtrArr5(*[g.data_ptr() for g in gW])
+        Bp = _lib.PtrArr5(*[g.data_ptr() for g in gb])
+        lib = _lib.load()
+        _lib.check(lib.dvd_sf_mlp_bwd_dw(ctypes.byref(self.desc), _p(stash), _p(gstash), int(n_pix), ctypes.byref(W),
+                                         ctypes.byref(Bp), _stream()), 'dvd_sf_mlp_bwd_dw')

@@ -118,6 +118,57 @@ int dvd_warp_loss_fwd(const dvd_warp_cfg* cfg, const float* depth_1, const float
 int dvd_loss_finalize(const dvd_warp_cfg* cfg, const float* sums, float* scalars /*[8]*/,
                       dvd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Scene-flow field MLP (fused, fp32 MFMA).
+ * Replaces SceneFlowFieldNet.forward (networks/sceneflow_field.py:43-53):
+ *   PeriodicEmbed of t and xyz (networks/blocks.py:19-34), 1x1 conv C_in->256,
+ *   4 x (256->256), each + LeakyReLU(0.2), then 256->3 (blocks.py:50-102),
+ * the division by sf_mag_div and one Euler step of
+ * Model.forward_sf_net_multi_step (models/scene_flow_motion_field.py:346-367),
+ * and their autograd backward.  Width 256 / 4 hidden layers are what the
+ * reference Model builds (scene_flow_motion_field.py:107).
+ *
+ * Pixels are processed in tiles of 64; `n_pix` = B*H*W, p/sf tensors are planar
+ * [B,3,H,W] (pix_per_img = H*W), t is [B,1,H,W].
+ * Weights are the reference state_dict tensors convs.{0..5}.conv.{weight,bias}
+ * (weight [out,in] row-major); dvd_sf_mlp_pack re-orders them into MFMA
+ * fragment order (both orientations) inside `packed`.
+ * `stash` (forward, optional) receives the embedding and the five hidden
+ * activations, 5.53 KB per pixel; the backward kernels consume it. */
+typedef struct dvd_mlp_desc {
+  int n_freq_xyz;      /* 16 */
+  int n_freq_t;        /* 16; ignored if !time_dependent */
+  int time_dependent;  /* 1: input = [embed(t), embed(xyz)] */
+  const float* freqs_xyz; /* device [n_freq_xyz] = linspace(1, n+1, n) as torch computes it */
+  const float* freqs_t;   /* device [n_freq_t] */
+} dvd_mlp_desc;
+
+int dvd_sf_mlp_in_channels(const dvd_mlp_desc* d);             /* 132 for the shipped config */
+size_t dvd_sf_mlp_packed_bytes(const dvd_mlp_desc* d);
+size_t dvd_sf_mlp_stash_bytes(const dvd_mlp_desc* d, long long n_pix);
+size_t dvd_sf_mlp_gstash_bytes(long long n_pix);
+int dvd_sf_mlp_pack(const dvd_mlp_desc* d, const float* const W[6], const float* const b[6],
+                    void* packed, dvd_stream_t stream);
+/* sf = MLP(p, t + t_offset) * out_scale;  optional fused Euler bookkeeping:
+ * p_next = p + sf (may alias nothing), acc (in/out) += sf.  Any of sf_out,
+ * p_next, acc may be null. */
+int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, const float* t,
+                   float t_offset, float out_scale, long long n_pix, int pix_per_img,
+                   float* sf_out, float* p_next, float* acc, void* stash, dvd_stream_t stream);
+/* Backward w.r.t. the input points and all pre-activations:
+ *   g_out = gscale * (scale_ptr ? *scale_ptr : 1) * g_out1 + (g_out2 ? g_out2 : 0)
+ *   g_p   = J^T (out_scale * g_out)  + (g_p_add ? g_p_add : 0)
+ * writes the pre-activation gradients of layers 0..4 to `gstash` and
+ * ACCUMULATES the last layer's dW (gW5 [3,256]) and db (gb5 [3]) with atomics. */
+int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* stash, float out_scale,
+                      const float* g_out1, float gscale, const float* scale_ptr, const float* g_out2,
+                      const float* g_p_add, long long n_pix, int pix_per_img, float* g_p, void* gstash,
+                      float* gW5, float* gb5, dvd_stream_t stream);
+/* dW_l += G_l . H_{l-1}^T and db_l += rowsum(G_l) for l = 0..4 (accumulating, atomics),
+ * gW[l] in the reference layout [out,in]. */
+int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, const void* gstash, long long n_pix,
+                      float* const gW[5], float* const gb[5], dvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""Parity of the fused scene-flow MLP kernels (through the C ABI) with the
+golden fixture generated from the real reference network and with the oracle.
+Tolerances (fp32 MFMA = exact fp32 FMA chains vs MKL sgemm accumulation order):
+  forward           rtol 1e-4, atol 1e-6
+  d/dx              rtol 1e-3 of max|g|
+  weight/bias grads rtol 1e-3 of per-tensor max|g|
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden_mlp_sd, load_golden, t
+from oracle import sceneflow_mlp as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _net_from_sd(sd, time_dependent=True):
+    from dvd_hip.networks.sceneflow_field import SceneFlowFieldNet
+    net = SceneFlowFieldNet(net_width=256, n_layers=4, time_dependent=time_dependent, N_freq_xyz=16, N_freq_t=16)
+    missing = net.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net.cuda()
+
+
+def _close(got, want, rel, name):
+    want = np.asarray(want)
+    got = np.asarray(got).reshape(want.shape)
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want).max() / scale
+    assert err <= rel, '%s: max err / max|ref| = %.3e > %.1e' % (name, err, rel)
+
+
+def test_state_dict_keys_match_reference():
+    gd = load_golden('mlp_b2_8x16')
+    from dvd_hip.networks.sceneflow_field import SceneFlowFieldNet
+    net = SceneFlowFieldNet(net_width=256, n_layers=4, time_dependent=True, N_freq_xyz=16, N_freq_t=16)
+    assert sorted(net.state_dict().keys()) == sorted(k[3:] for k in gd if k.startswith('sd_'))
+
+
+def test_module_forward_backward_vs_golden():
+    gd = load_golden('mlp_b2_8x16')
+    net = _net_from_sd(golden_mlp_sd(gd))
+    x = t(gd['in_x']).cuda().requires_grad_(True)
+    tt = t(gd['in_t']).cuda()
+    y = net(x, tt)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), gd['out_y'], rtol=1e-4, atol=2e-6)
+    (y * t(gd['up_y']).cuda()).sum().backward()
+    _close(x.grad.cpu().numpy(), gd['g_x'], 1e-3, 'g_x')
+    for k, p in net.named_parameters():
+        _close(p.grad.cpu().numpy(), gd['gsd_' + k], 1e-3, k)
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 8, 8), (2, 24, 40), (3, 17, 23)])
+def test_forward_backward_vs_oracle_ragged(B, H, W):
+    """Sizes that are not multiples of the 64-pixel tile, tiles straddling images."""
+    sd = M.init_params(seed=3)
+    g = torch.Generator().manual_seed(B * 100 + W)
+    for k in sd:
+        if k.endswith('bias'):
+            sd[k] = 0.05 * torch.randn(sd[k].shape, generator=g)
+    x = 3.0 * torch.randn(B, 3, H, W, generator=g)
+    tt = torch.rand(B, 1, 1, 1, generator=g).expand(B, 1, H, W).contiguous()
+    up = torch.randn(B, 3, H, W, generator=g)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = M.mlp_forward(sdr, xr, tt)
+    (yr * up).sum().backward()
+    net = _net_from_sd(sd)
+    xg = x.cuda().requires_grad_(True)
+    yg = net(xg, tt.cuda())
+    (yg * up.cuda()).sum().backward()
+    np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=2e-6)
+    _close(xg.grad.cpu().numpy(), xr.grad.numpy(), 1e-3, 'g_x')
+    for k, p in net.named_parameters():
+        _close(p.grad.cpu().numpy(), sdr[k].grad.numpy(), 1e-3, k)
+
+
+def test_euler_steps_fused_bookkeeping():
+    """p_next / acc outputs of the forward kernel reproduce forward_sf_net_multi_step."""
+    from dvd_hip import ops
+    sd = M.init_params(seed=9)
+    B, H, W, steps, dt, div = 2, 16, 24, 3, 0.01, 100.0
+    g = torch.Generator().manual_seed(1)
+    p = 2.0 * torch.randn(B, 3, H, W, generator=g)
+    ts = torch.rand(B, 1, 1, 1, generator=g).expand(B, 1, H, W).contiguous()
+    want = M.sf_multi_step(sd, p, ts, dt, steps, div)
+    k = ops.SceneFlowMLPKernels('cuda', 16, 16, True)
+    k.pack([sd['convs.%d.conv.weight' % i].cuda() for i in range(6)], [sd['convs.%d.conv.bias' % i].cuda() for i in range(6)])
+    acc = torch.zeros(B, 3, H, W, device='cuda')
+    cur = p.cuda()
+    tg = ts.cuda()
+    for i in range(steps):
+        nxt = torch.empty_like(cur)
+        k.forward(cur, tg, t_offset=i * dt, out_scale=1.0 / div, p_next=nxt, acc=acc)
+        cur = nxt
+    np.testing.assert_allclose(acc.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_unsupported_configuration_is_refused():
+    from dvd_hip.networks.sceneflow_field import SceneFlowFieldNet
+    with pytest.raises(NotImplementedError):
+        SceneFlowFieldNet(net_width=128, n_layers=4, N_freq_xyz=16, N_freq_t=16)
