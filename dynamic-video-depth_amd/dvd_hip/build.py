@@ -25,6 +25,7 @@ SOURCES = [
     ('unproject.hip', ['-ffp-contract=off']),
     ('warp_loss.hip', ['-ffp-contract=off']),
     ('sf_mlp.hip', []),
+    ('elementwise.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

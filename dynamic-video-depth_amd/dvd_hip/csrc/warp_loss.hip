@@ -896,7 +896,7 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
   const bool all16 = (((uintptr_t)depth_1 | (uintptr_t)depth_2 | (uintptr_t)flow_1_2 | (uintptr_t)mask_2 |
                        (uintptr_t)sf_1_2 | (uintptr_t)g_depth_1 | (uintptr_t)g_depth_2 | (uintptr_t)g_sf_1_2) &
                       15) == 0;
-  DVD_REQUIRE(all16, "warp_loss: tensors must be 16-byte aligned");
+  DVD_REQUIRE(all16 || (cfg->W & 3) != 0, "warp_loss: tensors must be 16-byte aligned when W %% 4 == 0");
   if (env_int("DVD_WARP_DIRECT", 0)) {
     // reference variant: global gathers + hardware atomics (kept for A/B runs and as a second implementation)
     const bool vec4 = (cfg->W % 4 == 0);

@@ -1,0 +1,68 @@
+"""Flat parameter / gradient / Adam-state buffers for one network.
+
+Laid out for the MI355X step: every parameter of a net becomes a view into ONE
+fp32 buffer (16-byte aligned segments), its `.grad` a view into a second one, and
+the Adam moments live in two more.  That turns the optimiser into a single fused
+HIP launch per net (dvd_adam_step) and the data-parallel exchange into a single
+RCCL all-reduce per net instead of one message per tensor (the reference
+broadcasts ~600 tensors one by one, train.py:290-292).
+"""
+import torch
+
+from . import ops, parallel
+
+
+class FlatNet(object):
+    def __init__(self, module, lr, betas, eps=1e-8):
+        self.module = module
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        params = [p for p in module.parameters()]
+        self.params = params
+        dev = params[0].device
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4        # keep every segment 16-byte aligned
+        self.offsets, self.numel = offs, n
+        self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, o in zip(params, offs):
+            seg = self.flat[o:o + p.numel()].view_as(p)
+            seg.copy_(p.data)
+            p.data = seg
+            p.grad = self.grad[o:o + p.numel()].view_as(p)
+        self.step_count = 0
+
+    def view(self, buf, p_index):
+        p, o = self.params[p_index], self.offsets[p_index]
+        return buf[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):      # autograd may have replaced .grad; re-attach
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def all_reduce_grads(self, async_op=False):
+        if async_op:
+            return parallel.all_reduce_sum_async_(self.grad)
+        parallel.all_reduce_sum_(self.grad)
+        return None
+
+    def adam_step(self, extra_grad=None, scale=1.0, scale_ptr=None):
+        """param -= Adam(scale * (*scale_ptr) * grad + extra_grad)."""
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
+                      self.betas[1], self.eps, scale=scale, scale_ptr=scale_ptr, grad2=extra_grad)
+
+    # torch.optim-compatible state for checkpoints (netinterface.py:528-536 stores optimizer.state_dict())
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(),
+                'lr': self.lr, 'betas': self.betas, 'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])

@@ -1,0 +1,247 @@
+"""Trainer base with the surface `train.py` and the loggers of the reference expect.
+
+Counterpart of /root/reference/models/netinterface.py:35-601 (`NetInterface`), reduced
+to what the test-time-optimisation loop uses: the attribute contract
+(`_nets`, `_optimizers`, `_metrics`, `input_names`, `_input`), `load_batch`,
+`train_epoch` (per-batch callbacks `on_batch_begin/end`, per-epoch
+`on_epoch_begin/end`, netinterface.py:246-360), `to/train/eval/num_parameters`, and the
+checkpoint format `{'nets': [...], 'optimizers': [...], **extra}`
+(netinterface.py:528-562).  The loggers themselves are out of scope (SURVEY.md section 2
+row 13): any object with the callback methods works; `NullLogger` is the default.
+"""
+import time
+from types import SimpleNamespace
+
+import torch
+
+from .. import parallel
+
+
+class NullLogger(object):
+    """Accepts every callback of the reference's ComposeLogger and records the last logs."""
+
+    def __init__(self):
+        self.batch_logs, self.epoch_logs = [], []
+
+    def add_logger(self, *_a, **_k):
+        pass
+
+    def get_html_logger(self):
+        return None
+
+    def set_params(self, *_a, **_k):
+        pass
+
+    def set_model(self, *_a, **_k):
+        pass
+
+    def train(self):
+        pass
+
+    def eval(self):
+        pass
+
+    def on_train_begin(self, *_a):
+        pass
+
+    def on_train_end(self, *_a):
+        pass
+
+    def on_epoch_begin(self, *_a):
+        pass
+
+    def on_epoch_end(self, epoch, log=None):
+        self.epoch_logs.append((epoch, log))
+
+    def on_batch_begin(self, *_a):
+        pass
+
+    def on_batch_end(self, i, log=None):
+        self.batch_logs.append(log)
+
+
+class _EpochMean(object):
+    """Size-weighted epoch means of the batch logs (loggers/loggers.py:88-110)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.tot, self.n = {}, 0
+
+    def add(self, log):
+        size = log.get('size', 1)
+        self.n += size
+        for k, v in log.items():
+            if k in ('batch', 'size', 'epoch') or not isinstance(v, (int, float)):
+                continue
+            self.tot[k] = self.tot.get(k, 0.0) + v * size
+
+    def get_epoch_log(self):
+        return {k: v / max(self.n, 1) for k, v in self.tot.items()}
+
+
+class NetInterface(object):
+    @classmethod
+    def add_arguments(cls, parser):
+        return parser, set()
+
+    @staticmethod
+    def preprocess(sample_loaded):
+        return sample_loaded
+
+    def __init__(self, opt, logger=None):
+        self._logger = logger if logger is not None else NullLogger()
+        self._internal_logger = _EpochMean()
+        self.opt = opt
+        self.full_logdir = getattr(opt, 'full_logdir', None)
+        if opt.optim != 'adam':
+            raise NotImplementedError('the fused HIP step implements Adam (the shipped --optim); got %s' % opt.optim)
+        self.optim_params = {'betas': (opt.adam_beta1, opt.adam_beta2)}
+        self._nets, self._optimizers, self._metrics = [], [], []
+        self._moveable_vars = []
+        self.input_names, self.gt_names, self.aux_names = [], [], []
+        self._input, self._gt, self._aux = SimpleNamespace(), SimpleNamespace(), SimpleNamespace()
+        self.device = torch.device('cpu')
+
+    def init_vars(self, add_path=True):
+        for name in self.input_names:
+            setattr(self._input, name, None)
+        for name in self.gt_names:
+            setattr(self._gt, name, None)
+
+    def init_weight(self, net=None, init_type='kaiming', init_param=0.02, a=0):
+        """Same policy as netinterface.py:55-86 for conv / linear / batch-norm modules."""
+        from torch.nn import init
+
+        def fn(m):
+            cname = m.__class__.__name__
+            if hasattr(m, 'weight') and m.weight is not None and ('Conv' in cname or 'Linear' in cname):
+                if init_type == 'normal':
+                    init.normal_(m.weight.data, 0.0, init_param)
+                elif init_type == 'xavier':
+                    init.xavier_normal_(m.weight.data, gain=init_param)
+                elif init_type == 'kaiming':
+                    init.kaiming_normal_(m.weight.data, a=a, mode='fan_in')
+                elif init_type == 'orth':
+                    init.orthogonal_(m.weight.data, gain=init_param)
+                else:
+                    raise NotImplementedError(init_type)
+                if getattr(m, 'bias', None) is not None:
+                    init.constant_(m.bias.data, 0.0)
+            elif 'BatchNorm' in cname and m.affine:
+                init.normal_(m.weight.data, 1.0, init_param)
+                init.constant_(m.bias.data, 0.0)
+        net.apply(fn)
+
+    # -- data movement -------------------------------------------------------------------
+    def load_batch(self, batch, include_gt=True):
+        for name in self.input_names:
+            if name in batch:
+                v = batch[name]
+                if torch.is_tensor(v) and v.device != self.device:
+                    v = v.to(self.device, non_blocking=True)
+                setattr(self._input, name, v)
+        if include_gt:
+            for name in self.gt_names:
+                if name in batch:
+                    setattr(self._gt, name, batch[name].to(self.device, non_blocking=True))
+
+    def to(self, device):
+        for net in self._nets:
+            net.to(device)
+        self.device = torch.device(device)
+
+    def train(self):
+        for m in self._nets:
+            m.train()
+
+    def eval(self):
+        for m in self._nets:
+            m.eval()
+
+    def num_parameters(self, return_list=False):
+        counts = [sum(p.numel() for p in net.parameters()) for net in self._nets]
+        return counts if return_list else sum(counts)
+
+    # -- checkpoints ---------------------------------------------------------------------
+    def save_state_dict(self, filepath, *, save_optimizer=False, additional_values={}):
+        sd = {'nets': [net.state_dict() for net in self._nets]}
+        if save_optimizer:
+            sd['optimizers'] = [o.state_dict() for o in self._optimizers]
+        sd.update(additional_values)
+        torch.save(sd, filepath)
+
+    def load_state_dict(self, filepath, *, load_optimizer='auto'):
+        sd = torch.load(filepath, map_location='cpu')
+        if load_optimizer == 'auto':
+            load_optimizer = 'optimizers' in sd
+        assert len(self._nets) == len(sd['nets'])
+        for net, s in zip(self._nets, sd['nets']):
+            net.load_state_dict(s)
+        if load_optimizer:
+            assert len(self._optimizers) == len(sd['optimizers'])
+            for o, s in zip(self._optimizers, sd['optimizers']):
+                o.load_state_dict(s)
+        return {k: v for k, v in sd.items() if k not in ('nets', 'optimizers')}
+
+    # -- loop ----------------------------------------------------------------------------
+    def _train_on_batch(self, epoch, batch_ind, batch):
+        raise NotImplementedError
+
+    def _vali_on_batch(self, epoch, batch_ind, batch):
+        raise NotImplementedError
+
+    def test_on_batch(self, batch_ind, batch):
+        raise NotImplementedError
+
+    def train_epoch(self, dataloader, *, dataloader_vali=None, max_batches_per_train=None, max_batches_per_vali=None,
+                    epochs=1, initial_epoch=1, verbose=1, reset_dataset=None, vali_at_start=False):
+        logger = self._logger
+        steps = len(dataloader) if hasattr(dataloader, '__len__') else None
+        if max_batches_per_train is not None:
+            steps = max_batches_per_train if steps is None else min(steps, max_batches_per_train)
+
+        def run(epoch, loader, on_batch, limit, is_train):
+            (self.train if is_train else self.eval)()
+            (logger.train if is_train else logger.eval)()
+            self._internal_logger.reset()
+            logger.on_epoch_begin(epoch)
+            t0 = time.time()
+            for i, data in enumerate(loader):
+                if limit is not None and i >= limit:
+                    break
+                data_time = time.time() - t0
+                logger.on_batch_begin(i)
+                log = on_batch(epoch, i, data)
+                if log is None:
+                    t0 = time.time()
+                    continue
+                log.update(batch=i, epoch=epoch, data_time=data_time, batch_time=time.time() - t0)
+                self._internal_logger.add(log)
+                logger.on_batch_end(i, log)
+                t0 = time.time()
+            elog = self._internal_logger.get_epoch_log()
+            if parallel.is_distributed():
+                for k in sorted(elog):
+                    v = torch.tensor(elog[k], device=self.device, dtype=torch.float64)
+                    parallel.all_reduce_sum_(v)
+                    elog[k] = float(v) / parallel.world_size()
+            logger.on_epoch_end(epoch, elog)
+            return elog
+
+        logger.set_params({'epochs': epochs + initial_epoch - 1, 'steps': steps, 'verbose': verbose})
+        logger.on_train_begin()
+        last = None
+        if vali_at_start and dataloader_vali is not None:
+            with torch.no_grad():
+                run(initial_epoch - 1, dataloader_vali, self._vali_on_batch, max_batches_per_vali, False)
+        for epoch in range(initial_epoch, initial_epoch + epochs):
+            if reset_dataset is not None:
+                reset_dataset()
+            last = run(epoch, dataloader, self._train_on_batch, steps, True)
+            if dataloader_vali is not None:
+                with torch.no_grad():
+                    run(epoch, dataloader_vali, self._vali_on_batch, max_batches_per_vali, False)
+        logger.on_train_end()
+        return last

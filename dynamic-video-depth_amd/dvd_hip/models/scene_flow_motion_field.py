@@ -1,0 +1,322 @@
+"""`--net scene_flow_motion_field` on MI355X: the per-video test-time-optimisation step.
+
+Drop-in for /root/reference/models/scene_flow_motion_field.py:32-367 (class `Model`):
+same `add_arguments` flag set (:33-67), constructor contract `Model(opt, loggers)`
+(:78-138), attributes `_nets = [net_depth, net_sceneflow]`, `_optimizers`, `_metrics`,
+`input_names`, `requires`, and `_train_on_batch(epoch, batch_ind, batch) -> batch_log`
+with the keys of :226,321-323,195.
+
+What is different is HOW a step runs.  The reference builds one autograd graph out of
+~250 ATen launches per pair; here the step is three phases over device-resident data:
+
+  1. depth nets forward WITHOUT a graph (chunks of images) -> depth_1, depth_2;
+  2. everything downstream of the depths in hand-written HIP kernels, per chunk of
+     pairs: unproject -> fused MLP (Euler steps, activations stashed) -> ONE fused
+     warp+reprojection+loss forward/backward launch -> MLP backward (dX chain, dW) ->
+     unproject backward; then the acceleration regulariser the same way.  Gradients
+     are produced UN-normalised; the batch-global 1/(sum(mask)+1e-8) is a device
+     scalar applied at the very end, after the (data-parallel) all-reduce of the five
+     loss sums, so there is no host synchronisation inside the step and N ranks
+     reproduce the single-device result on the concatenated batch;
+  3. (not in the warm-up phase) depth nets forward WITH a graph, chunk by chunk, and
+     backward from the depth gradients of phase 2 - the autograd graph of 96 MiDaS
+     forwards at 384x672 (293 GB) never exists at once; then one RCCL all-reduce per
+     net over its flat gradient buffer and one fused Adam launch per net.
+
+Depth-net convolutions run on PyTorch-ROCm/MIOpen in this round (BASELINE config 2).
+"""
+import os
+import warnings
+
+import torch
+
+from .. import configs, flat, ops, parallel
+from ..losses.scene_flow_projection import BackwardWarp, flow_by_depth, scene_flow_projection_slack, unproject_ptcld
+from ..networks.sceneflow_field import SceneFlowFieldNet
+from ..third_party.hourglass import HourglassModel_Embed
+from ..third_party.MiDaS import MidasNet
+from .netinterface import NetInterface
+
+CAM_KEYS = ops.CAM_KEYS
+
+
+class Model(NetInterface):
+    @classmethod
+    def add_arguments(cls, parser):
+        # the reference's flag set, verbatim names/defaults (scene_flow_motion_field.py:35-65)
+        f, i, s = float, int, str
+        for name, typ, default in (('l1_mul', f, 1e-4), ('disp_mul', f, 10), ('loss_type', s, 'l2'),
+                                   ('scene_lr_mul', f, 1), ('n_down', i, 3), ('sf_min_mul', f, 0),
+                                   ('sf_quantile', f, 0.5), ('static_mul', f, 1), ('flow_mul', f, 10),
+                                   ('acc_mul', f, 100), ('si_mul', f, 0), ('cos_mul', f, 0), ('warm_mul', f, 1),
+                                   ('interp_steps', i, 5), ('warm_sf', i, 0), ('n_freq_xyz', i, 16),
+                                   ('n_freq_t', i, 16), ('sf_mag_div', f, 100)):
+            parser.add_argument('--' + name, type=typ, default=default)
+        for name in ('one_way', 'weight_steps', 'static', 'motion_seg_hard', 'warm_static', 'use_disp',
+                     'use_disp_ratio', 'time_dependent', 'use_cnn', 'use_embedding', 'use_motion_seg', 'warm_reg',
+                     'midas'):
+            parser.add_argument('--' + name, action='store_true')
+        # MI355X-specific knobs (new; defaults need no tuning)
+        parser.add_argument('--mlp_stash_gb', type=float, default=48.0,
+                            help='HBM budget for the scene-flow MLP activation stashes; sets pairs per chunk')
+        parser.add_argument('--depth_chunk', type=int, default=8, help='images per depth-net forward/backward chunk')
+        return parser, set()
+
+    # ------------------------------------------------------------------------------------
+    def __init__(self, opt, loggers=None):
+        super().__init__(opt, loggers)
+        self.input_names = ['img', 'img_1', 'img_2', 'pose', 'intrinsic', 'mask_1', 'mask_2', 'R_1', 'R_1_T', 'R_2',
+                            'R_2_T', 't_1', 't_2', 'flow_1_2', 'flow_2_1', 'K', 'K_inv', 'motion_seg_1',
+                            'time_stamp_1', 'time_stamp_2', 'frame_id_1', 'frame_id_2', 'time_step']
+        self.gt_names = []
+        self.requires = list(set().union(self.input_names, self.gt_names))
+        if opt.use_cnn:
+            raise NotImplementedError('--use_cnn (FCNUnet scene-flow net) is outside the accelerated path '
+                                      '(SURVEY.md section 2 row 16)')
+        if opt.midas:
+            resize = [224, 384] if any(k in opt.dataset for k in ('real_video', 'korean', 'mctest', 'cube')) else None
+            path = configs.midas_pretrain_path if os.path.exists(configs.midas_pretrain_path) else None
+            if path is None:
+                warnings.warn('MiDaS checkpoint %s not found: random weights' % configs.midas_pretrain_path)
+            self.net_depth = MidasNet(path=path, non_negative=True, normalize_input=True, resize=resize)
+        else:
+            self.net_depth = HourglassModel_Embed(noexp=False, use_embedding=opt.use_embedding)
+            if os.path.exists(configs.depth_pretrain_path):
+                self.net_depth.net_depth.load_state_dict(torch.load(configs.depth_pretrain_path, map_location='cpu'))
+            else:
+                warnings.warn('depth checkpoint %s not found: random weights' % configs.depth_pretrain_path)
+        self.net_sceneflow = SceneFlowFieldNet(net_width=256, n_layers=4, time_dependent=opt.time_dependent,
+                                               N_freq_xyz=opt.n_freq_xyz, N_freq_t=opt.n_freq_t)
+        self.bkwarp = BackwardWarp()
+        self.unproject_points = unproject_ptcld()
+        self.global_rank = getattr(opt, 'global_rank', 0)
+        self._nets = [self.net_depth, self.net_sceneflow]
+        self._metrics = ['flow_loss_1_2', 'loss', 'disp_loss_1_2', 'data_time', 'acc_reg', 'sf_loss']
+        self.init_vars(add_path=False)
+        self.init_weight(self.net_sceneflow, 'kaiming', 0.01, a=0.2)
+        self.warp = scene_flow_projection_slack()
+        self.depth_flow = flow_by_depth()
+        self.visualizer = None
+        self._flat_depth = self._flat_sf = None     # created by .to(device)
+        self._optimizers = []
+        self._steps_cache = {}
+        self.warm = False
+
+    # flat parameter buffers + fused Adam replace the two torch.optim.Adam objects (:113-115)
+    def to(self, device):
+        super().to(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('dvd_hip Model runs on a GPU only (the reference CPU path is the oracle)')
+        betas = self.optim_params['betas']
+        self._flat_depth = flat.FlatNet(self.net_depth, self.opt.lr, betas)
+        self._flat_sf = flat.FlatNet(self.net_sceneflow, self.opt.lr * self.opt.scene_lr_mul, betas)
+        self.optimizer_depth, self.optimizer_scene = self._flat_depth, self._flat_sf
+        self._optimizers = [self._flat_depth, self._flat_sf]
+        self._sf_grad_main = torch.zeros_like(self._flat_sf.grad)
+        self._mlp = self.net_sceneflow.kernels(self.device)
+        if parallel.is_distributed():      # every rank starts from rank 0's weights (train.py:290-292)
+            parallel.broadcast_(self._flat_depth.flat)
+            parallel.broadcast_(self._flat_sf.flat)
+
+    # ------------------------------------------------------------------------------------
+    def _depth_forward(self, img, frame_ids):
+        if self.opt.midas:
+            return self.net_depth(img)
+        return self.net_depth(img, frame_ids.long() if frame_ids is not None else None)
+
+    def _depths_nograd(self, img, frame_ids):
+        out = []
+        c = max(1, int(self.opt.depth_chunk))
+        with torch.no_grad():
+            for b0 in range(0, img.shape[0], c):
+                fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
+                out.append(self._depth_forward(img[b0:b0 + c], fid))
+        return torch.cat(out, 0).contiguous()
+
+    def _depth_backward(self, img, frame_ids, g_depth):
+        c = max(1, int(self.opt.depth_chunk))
+        for b0 in range(0, img.shape[0], c):
+            fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
+            with torch.enable_grad():
+                d = self._depth_forward(img[b0:b0 + c], fid)
+            d.backward(g_depth[b0:b0 + c])
+
+    def _integer_steps(self, batch_or_input):
+        ts1, ts2 = batch_or_input['time_stamp_1'], batch_or_input['time_stamp_2']
+        step = batch_or_input['time_step']
+        key = (ts1.data_ptr(), ts2.data_ptr(), tuple(ts1.shape))
+        if key not in self._steps_cache:
+            time_step = float(step.squeeze().item()) if torch.is_tensor(step) else float(step)
+            gap = torch.mean(ts2.float() - ts1.float())
+            self._steps_cache = {key: (int((gap / time_step).round().long().item()), time_step)}
+        return self._steps_cache[key]
+
+    def _pairs_per_chunk(self, B, HW, steps, with_reg):
+        per_pair = self._mlp.stash_floats(HW) * 4 * max(steps, 2 if with_reg else 1) + self._mlp.gstash_floats(HW) * 4
+        return int(max(1, min(B, (self.opt.mlp_stash_gb * 2 ** 30) // per_pair)))
+
+    # ------------------------------------------------------------------------------------
+    def _train_on_batch(self, epoch, batch_ind, batch):
+        opt = self.opt
+        self.warm = warm = epoch <= opt.warm_sf
+        self.net_depth.eval()                        # BN statistics are never updated (:157,168 / hourglass.py:200-208)
+        for p in self.net_depth.parameters():
+            p.requires_grad = not warm
+        self._flat_sf.zero_grad()
+        self._sf_grad_main.zero_()
+        if not warm:
+            self._flat_depth.zero_grad()
+        for k, v in batch.items():                   # strip the DataLoader dimension (:177-179)
+            if type(v) != list:
+                batch[k] = v.squeeze(0)
+        steps, time_step = self._integer_steps(batch)
+        self.steps = steps
+        self.load_batch(batch)
+        inp = self._input
+        B, _, H, W = inp.img_1.shape
+        HW, dev = H * W, self.device
+        fid1 = inp.frame_id_1 if not opt.midas else None
+        fid2 = inp.frame_id_2 if not opt.midas else None
+
+        # ---- phase 1: depth maps, no autograd graph
+        depth_1 = self._depths_nograd(inp.img_1, fid1)
+        depth_2 = self._depths_nograd(inp.img_2, fid2)
+
+        # ---- phase 2: geometry + scene-flow MLP + losses, forward and backward, in HIP
+        do_reg = opt.interp_steps > 0 and (not warm or opt.warm_reg) and opt.acc_mul > 0
+        mul = steps if opt.weight_steps else 1
+        disp_mode = 1 if opt.use_disp else (2 if opt.use_disp_ratio else 0)
+        n_global = B * parallel.world_size()         # pairs in the whole (sharded) batch
+        reg_coef = opt.acc_mul / (3.0 * n_global * HW + 1e-6)
+        sums = torch.zeros(8, device=dev)            # [S0..S3, sum|sf1-sf0|, 0, 0, 0]
+        g_d1_main = torch.empty_like(depth_1)
+        g_d2_main = torch.empty_like(depth_2)
+        g_d1_reg = torch.zeros_like(depth_1) if do_reg else None
+        mlp, k = self._mlp, self._flat_sf
+        mlp.pack([p for p in self.net_sceneflow.parameter_list()[0::2]], self.net_sceneflow.parameter_list()[1::2])
+        gW_main = [k.view(self._sf_grad_main, 2 * i) for i in range(6)]
+        gb_main = [k.view(self._sf_grad_main, 2 * i + 1) for i in range(6)]
+        gW_reg = [k.view(k.grad, 2 * i) for i in range(6)]
+        gb_reg = [k.view(k.grad, 2 * i + 1) for i in range(6)]
+        inv_div = 1.0 / opt.sf_mag_div
+        Bc = self._pairs_per_chunk(B, HW, steps, do_reg)
+        mask_2 = inp.mask_2.reshape(B, H, W)
+        use_mseg = bool(opt.use_motion_seg)
+        if use_mseg:
+            raise NotImplementedError('--use_motion_seg is not wired into the fused step yet')
+        for b0 in range(0, B, Bc):
+            b1 = min(B, b0 + Bc)
+            nb = b1 - b0
+            n_pix = nb * HW
+            cams = {kk: getattr(inp, kk)[b0:b1] for kk in CAM_KEYS}
+            d1c, d2c = depth_1[b0:b1], depth_2[b0:b1]
+            ts = inp.time_stamp_1[b0:b1] if opt.time_dependent else None
+            P1 = ops.unproject(d1c, cams['R_1'], cams['t_1'], cams['K_inv'], planar=True)
+            # Euler integration of the scene flow over `steps` frames (:360-367)
+            sf_acc = torch.zeros(nb, 3, H, W, device=dev)
+            stashes, p_cur = [], P1
+            for i in range(steps):
+                st = mlp.new_stash(n_pix)
+                p_next = torch.empty_like(P1) if i + 1 < steps else None
+                mlp.forward(p_cur, ts, t_offset=i * time_step, out_scale=inv_div, p_next=p_next, acc=sf_acc, stash=st)
+                stashes.append(st)
+                p_cur = p_next
+            cfg = ops.warp_cfg(nb, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode,
+                               loss_on_sf=not opt.use_disp, flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
+            csum = torch.empty(4, device=dev)
+            g_sf = torch.empty_like(sf_acc)
+            ops.warp_loss_fused(cfg, d1c, d2c, inp.flow_1_2[b0:b1], mask_2[b0:b1], sf_acc, cams,
+                                out=(csum, g_d1_main[b0:b1], g_d2_main[b0:b1], g_sf))
+            sums[:4] += csum
+            # backward through the Euler chain: g_p_i = g_p_{i+1} + J_i^T (g_acc + g_p_{i+1})
+            gst = mlp.new_gstash(n_pix)
+            g_p = None
+            for i in reversed(range(steps)):
+                g_new = torch.empty_like(P1)
+                mlp.backward_dx(stashes[i], inv_div, g_sf, g_new, gst, gW_main[5], gb_main[5], (nb, H, W),
+                                g_out2=g_p, g_p_add=g_p)
+                mlp.backward_dw(stashes[i], gst, n_pix, gW_main[:5], gb_main[:5])
+                g_p = g_new
+            ops.unproject_backward(g_p, True, cams['R_1'], cams['K_inv'], out=g_d1_main[b0:b1], accumulate=True)
+            del stashes
+            if do_reg:       # acceleration regulariser (:326-344), P1 un-detached
+                sa, sb = mlp.new_stash(n_pix), mlp.new_stash(n_pix)
+                sf0, sf1, q = torch.empty_like(P1), torch.empty_like(P1), torch.empty_like(P1)
+                mlp.forward(P1, ts, 0.0, inv_div, sf_out=sf0, p_next=q, stash=sa)
+                mlp.forward(q, ts, time_step, inv_div, sf_out=sf1, stash=sb)
+                g1 = torch.empty_like(P1)
+                ops.acc_reg(sf0, sf1, reg_coef, g1, sums[4:5], accumulate=True)
+                g_q = torch.empty_like(P1)
+                mlp.backward_dx(sb, inv_div, g1, g_q, gst, gW_reg[5], gb_reg[5], (nb, H, W))
+                mlp.backward_dw(sb, gst, n_pix, gW_reg[:5], gb_reg[:5])
+                g_P = torch.empty_like(P1)
+                mlp.backward_dx(sa, inv_div, g1, g_P, gst, gW_reg[5], gb_reg[5], (nb, H, W), gscale=-1.0, g_out2=g_q,
+                                g_p_add=g_q)
+                mlp.backward_dw(sa, gst, n_pix, gW_reg[:5], gb_reg[:5])
+                ops.unproject_backward(g_P, True, cams['R_1'], cams['K_inv'], out=g_d1_reg[b0:b1])
+        # the batch-global normaliser: all-reduce the loss sums first
+        parallel.all_reduce_sum_(sums)
+        cfg_all = ops.warp_cfg(B, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode,
+                               loss_on_sf=not opt.use_disp, flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
+        scalars = ops.loss_finalize(cfg_all, sums)
+        inv = scalars[0:1]
+        # scene-flow MLP gradient = inv * main + reg   (flat buffers; one all-reduce)
+        ops.scale_add(k.grad, self._sf_grad_main, scale_ptr=inv, b=k.grad)
+        h_sf = k.all_reduce_grads(async_op=True)
+
+        # ---- phase 3: depth-net backward from the depth gradients
+        if not warm:
+            g_d1 = ops.scale_add(g_d1_main, g_d1_main, scale_ptr=inv, b=g_d1_reg)
+            g_d2 = ops.scale_add(g_d2_main, g_d2_main, scale_ptr=inv)
+            self._depth_backward(inp.img_1, fid1, g_d1)
+            self._depth_backward(inp.img_2, fid2, g_d2)
+            self._flat_depth.all_reduce_grads()
+            self._flat_depth.adam_step()
+        if h_sf is not None:
+            h_sf.wait()
+        k.adam_step()
+
+        host = torch.cat([scalars, sums[4:5]]).tolist()          # the only host synchronisation of the step
+        acc_reg = opt.acc_mul * host[8] / (3.0 * n_global * HW + 1e-6) if do_reg else 0
+        batch_log = {'size': opt.batch_size, 'loss': host[1], 'total_loss': host[1], 'flow_loss_1_2': host[2],
+                     'disp_loss_1_2': host[3], 'sf_loss': host[4], 'acc_reg': acc_reg}
+        self._last = {'depth_1': depth_1, 'depth_2': depth_2, 'mask_sum': host[5]}
+        return batch_log
+
+    # ------------------------------------------------------------------------------------
+    def _predict_on_batch(self, is_train=True):
+        """Inference path (is_train=False, :265-275): depth + unprojection + one MLP evaluation."""
+        if is_train:
+            raise RuntimeError('the training forward is fused into _train_on_batch')
+        inp = self._input
+        fid = inp.frame_id_1 if not self.opt.midas else None
+        depth = self._depths_nograd(inp.img, fid)
+        P = ops.unproject(depth, inp.R_1, inp.t_1, inp.K_inv, planar=True)
+        sf = torch.empty_like(P)
+        self._mlp.pack(self.net_sceneflow.parameter_list()[0::2], self.net_sceneflow.parameter_list()[1::2])
+        ts = inp.time_stamp_1 if self.opt.time_dependent else None
+        self._mlp.forward(P, ts, 0.0, 1.0 / self.opt.sf_mag_div, sf_out=sf)
+        return {'depth': depth, 'sf_1_2': sf}
+
+    @staticmethod
+    def depth2disp(depth):
+        valid = (depth > 1e-2).float()
+        return (1 / (depth + (1 - valid) * 1e-8)) * valid
+
+    def _vali_on_batch(self, epoch, batch_idx, batch):
+        """Disparity MSE against the MVS depth (models/video_base.py:72-103)."""
+        self.eval()
+        self.load_batch(batch)
+        with torch.no_grad():
+            pred = self._predict_on_batch(is_train=False)
+            gt = batch['depth_mvs'].to(self.device)
+            vali = gt > 1e-2
+            loss = torch.nn.functional.mse_loss(self.depth2disp(pred['depth']) * vali, self.depth2disp(gt) * vali).item()
+        return {'size': batch['img'].shape[0], 'loss': loss}
+
+    def test_on_batch(self, batch_ind, batch):
+        self.eval()
+        self.load_batch(batch)
+        with torch.no_grad():
+            pred = self._predict_on_batch(is_train=False)
+        return {k: v.cpu().numpy() for k, v in pred.items()}

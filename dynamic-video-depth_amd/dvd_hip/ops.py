@@ -236,3 +236,30 @@ class SceneFlowMLPKernels(object):
         lib = _lib.load()
         _lib.check(lib.dvd_sf_mlp_bwd_dw(ctypes.byref(self.desc), _p(stash), _p(gstash), int(n_pix), ctypes.byref(W),
                                          ctypes.byref(Bp), _stream()), 'dvd_sf_mlp_bwd_dw')
+
+
+# ---------------------------------------------------------------------------------------
+# elementwise helpers
+
+
+def scale_add(out, a, scale=1.0, scale_ptr=None, b=None):
+    """out = scale * (*scale_ptr) * a + b   (flat, any shape; out may alias a or b)."""
+    lib = _lib.load()
+    _lib.check(lib.dvd_scale_add(_p(out), _p(a), float(scale), _p(scale_ptr), _p(b), a.numel(), _stream()),
+               'dvd_scale_add')
+    return out
+
+
+def acc_reg(sf0, sf1, coef, g_sf1, abs_sum, accumulate=True):
+    lib = _lib.load()
+    ws = _workspace(lib.dvd_acc_reg_workspace_bytes(), sf0.device)
+    _lib.check(lib.dvd_acc_reg(_p(sf0), _p(sf1), float(coef), _p(g_sf1), _p(ws), _p(abs_sum), int(accumulate),
+                               sf0.numel(), _stream()), 'dvd_acc_reg')
+
+
+def adam_step(param, grad1, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps=1e-8, scale=1.0, scale_ptr=None,
+              grad2=None):
+    lib = _lib.load()
+    _lib.check(lib.dvd_adam_step(_p(param), _p(grad1), float(scale), _p(scale_ptr), _p(grad2), _p(exp_avg),
+                                 _p(exp_avg_sq), param.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                 int(step), _stream()), 'dvd_adam_step')

@@ -1,0 +1,75 @@
+"""Data parallelism over frame pairs: one process per GPU, RCCL over xGMI.
+
+The path shards by independent units (frame pairs) and has exactly two exchange
+steps per optimisation step:
+  1. all-reduce(sum) of the 5 loss sums [S0..S3, sum|sf1-sf0|] BEFORE gradients are
+     normalised, so that N ranks reproduce the single-device result on the
+     concatenated batch (the reference's normaliser is batch-global,
+     models/scene_flow_motion_field.py:297-306,340);
+  2. all-reduce(sum) of the gradients, as a few large flat buffers (one per
+     network): xGMI is point-to-point, so fewer / larger messages are what keeps
+     the 7 links busy; 421 MB (MiDaS) is ~5 ms on a ring, ~0.7 ms direct.
+The reference wraps its nets in DistributedDataParallel but discards the wrapped
+modules (train.py:285-287), so it never synchronises gradients; this module is new
+behaviour, not a port.  Everything degrades to a no-op when torch.distributed is not
+initialised (single GPU).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """torchrun-style initialisation (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or (dist.is_available() and dist.is_initialized()):
+        return int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # 'nccl' is RCCL on ROCm
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group(backend=backend)
+    return local
+
+
+def all_reduce_sum_(t):
+    """In-place sum over ranks (no averaging: the loss normaliser is global already)."""
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_reduce_sum_async_(t):
+    if is_distributed():
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def broadcast_(t, src=0):
+    if is_distributed():
+        dist.broadcast(t, src)
+    return t
+
+
+def shard_range(n_items, r=None, w=None):
+    """Contiguous shard [lo, hi) of n_items for rank r of w."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    base, rem = divmod(n_items, w)
+    lo = r * base + min(r, rem)
+    return lo, lo + base + (1 if r < rem else 0)

@@ -169,6 +169,24 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
 int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, const void* gstash, long long n_pix,
                       float* const gW[5], float* const gb[5], dvd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Elementwise helpers of the step.
+ * dvd_scale_add: out = scale * (scale_ptr ? *scale_ptr : 1) * a + (b ? b : 0).
+ *   Applies the late 1/(sum(mask)+1e-8) of Model._calc_loss
+ *   (models/scene_flow_motion_field.py:297-306) from a device scalar.
+ * dvd_acc_reg: the elementwise half of Model._opt_reg (:326-344):
+ *   g_sf1 = coef * sign(sf1 - sf0),  abs_sum (+)= sum |sf1 - sf0|   (coef = acc_mul/(3N+1e-6)).
+ * dvd_adam_step: torch.optim.Adam step (:113-115,212-213; betas from
+ *   options/options_train.py:84-87) on a flat buffer with grad = s*grad1 + grad2. */
+int dvd_scale_add(float* out, const float* a, float scale, const float* scale_ptr, const float* b,
+                  long long n, dvd_stream_t stream);
+size_t dvd_acc_reg_workspace_bytes(void);
+int dvd_acc_reg(const float* sf0, const float* sf1, float coef, float* g_sf1, void* workspace,
+                float* abs_sum, int accumulate, long long n, dvd_stream_t stream);
+int dvd_adam_step(float* param, const float* grad1, float scale, const float* scale_ptr,
+                  const float* grad2, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                  float beta1, float beta2, float eps, int step, dvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,6 +194,75 @@ def case_step(name, B, H, W, gap, behind, seed, warm, **opt_over):
     print('wrote', name, {k: float(out['loss_' + k]) for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg')})
 
 
+def case_full_step(name, midas, B, H, W, gap, epoch, seed):
+    """The REAL reference Model._train_on_batch (models/scene_flow_motion_field.py:152-227)
+    on CPU: depth net (hourglass, or MiDaS with the locally defined ResNeXt encoder since
+    torch.hub is unreachable) + scene-flow MLP + warp + losses + both backward passes + Adam."""
+    import tempfile
+    import unittest.mock as mock
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    import third_party.hourglass as RH
+    import third_party.midas_blocks as RB
+    import third_party.MiDaS as RM
+    import visualize.html_visualizer as HV
+    from models.scene_flow_motion_field import Model
+    from dvd_hip.third_party.MiDaS import make_resnext101_32x8d_backbone
+    o = dict(helpers.FULL_STEP_OPT)
+    o.update(midas=midas, full_logdir=tempfile.mkdtemp())
+    opt = SimpleNamespace(**o)
+
+    class _Loggers(object):
+        def add_logger(self, *a):
+            pass
+
+        def get_html_logger(self):
+            return None
+    real_load = torch.load
+    with mock.patch.object(HV, 'Pool', lambda n: None), \
+            mock.patch.object(RB, '_make_pretrained_resnext101_wsl', lambda use_pretrained: make_resnext101_32x8d_backbone()), \
+            mock.patch.object(RM.BaseModel, 'load', lambda self, path: None), \
+            mock.patch.object(torch, 'load', lambda path, *a, **k: RH.HourglassModel().state_dict()
+                              if 'pretrained_depth_ckpt' in str(path) else real_load(path, *a, **k)):
+        model = Model(opt, _Loggers())
+    helpers.seeded_fill_(model.net_depth, seed)
+    helpers.seeded_fill_(model.net_sceneflow, seed + 1)
+    if midas:
+        with torch.no_grad():
+            model.net_depth.scratch.output_conv[4].weight.mul_(30.0)
+            model.net_depth.scratch.output_conv[4].bias.fill_(2000.0)
+    model.to(torch.device('cpu'))
+    batch = synthetic.make_batch(B, H, W, gap=gap, seed=seed + 2)
+    log = model._train_on_batch(epoch, 0, helpers.loader_batch(batch))
+    out = {'B': np.array(B), 'H': np.array(H), 'W': np.array(W), 'gap': np.array(gap), 'epoch': np.array(epoch),
+           'seed': np.array(seed), 'midas': np.array(int(midas))}
+    for k, v in log.items():
+        out['log_' + k] = np.array(float(v), dtype=np.float64)
+    names, gnorm, pnorm = [], [], []
+    for prefix, net in (('depth', model.net_depth), ('sf', model.net_sceneflow)):
+        for k, p in net.named_parameters():
+            names.append(prefix + '/' + k)
+            gnorm.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+            pnorm.append(float(p.data.double().norm()))
+    out['param_names'] = np.array(names)
+    out['grad_norms'] = np.array(gnorm)
+    out['param_norms_after'] = np.array(pnorm)
+    keep = ['convs.0.conv.weight', 'convs.3.conv.bias', 'convs.5.conv.weight', 'convs.5.conv.bias']
+    for k, p in model.net_sceneflow.named_parameters():
+        if k in keep:
+            out['g_sf/' + k] = p.grad.numpy()
+            out['p_sf/' + k] = p.data.numpy()
+    dkeep = (['scratch.output_conv.4.weight', 'scratch.output_conv.2.weight', 'pretrained.layer1.0.weight',
+              'pretrained.layer4.2.bn3.weight'] if midas else
+             ['net_depth.pred_layer.weight', 'net_depth.seq.0.weight', 'net_depth.seq.1.weight'])
+    for k, p in model.net_depth.named_parameters():
+        if k in dkeep and p.grad is not None:
+            out['g_depth/' + k] = p.grad.numpy()
+            out['p_depth/' + k] = p.data.numpy()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: float(v) for k, v in log.items()})
+
+
 def main():
     torch.set_num_threads(4)
     case_geometry('geom_b2_24x32', B=2, H=24, W=32, gap=1, behind=0, seed=11)
@@ -205,6 +274,9 @@ def main():
     case_step('step_b2_16x24_sfloss', B=2, H=16, W=24, gap=1, behind=0, seed=43, warm=False, use_disp=False)
     case_step('step_b2_16x24_ratio', B=2, H=16, W=24, gap=1, behind=0, seed=47, warm=False,
               use_disp=False, use_disp_ratio=True)
+    case_full_step('fullstep_hourglass_b2_32x48_train', midas=False, B=2, H=32, W=48, gap=1, epoch=6, seed=101)
+    case_full_step('fullstep_hourglass_b2_32x48_warm', midas=False, B=2, H=32, W=48, gap=2, epoch=1, seed=103)
+    case_full_step('fullstep_midas_b1_64x96_train', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=107)
 
 
 if __name__ == '__main__':

@@ -46,3 +46,46 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def seeded_fill_(module, seed):
+    """Deterministic, architecture-independent weights: every state_dict entry is
+    drawn from a generator seeded by (seed, crc32(key)), so the reference model (in
+    tests/golden/make_golden.py) and the product model get identical values without
+    shipping 100+ MB of weights."""
+    import math
+    import zlib
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd):
+            v = sd[k]
+            if k.endswith('num_batches_tracked'):
+                continue
+            g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(k.encode()) % 1000003)
+            if k.endswith('running_var'):
+                v.copy_(0.5 + torch.rand(v.shape, generator=g))
+            elif k.endswith('running_mean'):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif v.dim() >= 2:
+                v.copy_(torch.randn(v.shape, generator=g) * (1.0 / math.sqrt(v[0].numel())))
+            elif k.endswith('weight'):
+                v.copy_(1.0 + 0.1 * torch.randn(v.shape, generator=g))
+            else:
+                v.copy_(0.05 * torch.randn(v.shape, generator=g))
+    return module
+
+
+def loader_batch(batch):
+    """Add the leading DataLoader dimension (batch_size=1) the Model strips again."""
+    out = {}
+    for k, v in batch.items():
+        out[k] = v.unsqueeze(0) if torch.is_tensor(v) else v
+    return out
+
+
+FULL_STEP_OPT = dict(
+    optim='adam', adam_beta1=0.5, adam_beta2=0.9, lr=1e-4, scene_lr_mul=10.0, dataset='davis_sequence', batch_size=1,
+    global_rank=0, vis_every_train=1, vis_at_start=False, epoch_batches=2000, vis_batches_train=0, use_cnn=False,
+    use_embedding=False, midas=False, use_disp=True, use_disp_ratio=False, time_dependent=True, flow_mul=1.0,
+    disp_mul=1.0, acc_mul=1.0, sf_mag_div=100.0, interp_steps=5, warm_reg=False, weight_steps=False,
+    use_motion_seg=False, n_freq_xyz=16, n_freq_t=16, warm_sf=5, n_down=3, mlp_stash_gb=48.0, depth_chunk=8)
