@@ -3,7 +3,8 @@ reference `Model._train_on_batch` on CPU (tests/golden/make_golden.py::case_full
 batch_log values, the norm of every parameter gradient, selected gradients element by
 element, and the parameters after the Adam step.
 
-Tolerances: losses rtol 2e-4 (fp32, different reduction order); gradient norms rtol 5e-3
+Tolerances: losses rtol 2e-4 (fp32, different reduction order); gradient norms rtol 5e-3,
+elements 2e-3 (MLP) / 2e-2 (depth net) of max|g|
 (MIOpen vs MKL-DNN convolution accumulation order; rare LeakyReLU'/ReLU' sign flips at
 pre-activations within fp32 noise of 0); parameters after the step atol 3*lr.
 """
@@ -64,7 +65,10 @@ def test_train_on_batch_matches_reference(name):
             rel = abs(got - want_g[key]) / want_g[key]
             worst = max(worst, rel)
             assert rel < 5e-3, '%s grad norm %g vs %g' % (key, got, want_g[key])
-            np.testing.assert_allclose(float(p.data.double().norm()), want_p[key], rtol=1e-5, err_msg=key)
+            # Adam's first step moves every element by ~lr*sign(g): elements whose gradient is within
+            # rounding of 0 may move the other way, so the norm is only pinned to 2*lr*sqrt(n)
+            lr = opt.lr * (opt.scene_lr_mul if prefix == 'sf' else 1.0)
+            assert abs(float(p.data.double().norm()) - want_p[key]) <= 2 * lr * p.numel() ** 0.5 + 1e-5 * want_p[key], key
     for k in [k for k in gd if k.startswith('g_sf/') or k.startswith('g_depth/')]:
         prefix, pname = k.split('/', 1)
         net = model.net_sceneflow if prefix == 'g_sf' else model.net_depth
@@ -72,8 +76,12 @@ def test_train_on_batch_matches_reference(name):
         want = gd[k]
         scale = np.abs(want).max()
         err = np.abs(p.grad.cpu().numpy() - want) / scale
-        assert (err > 2e-3).sum() <= max(2, want.size // 5000), '%s: %d elements off (worst %.2e)' % (
-            k, (err > 2e-3).sum(), err.max())
+        # scene-flow MLP: 2e-3 of max|g|.  Depth net: the stem gradient has crossed 100+ MIOpen
+        # convolutions and ReLUs evaluated in a different fp32 order than MKL-DNN (measured worst
+        # 6.6e-3 on the 7x7 stem of ResNeXt-101 with random weights) -> 2e-2.
+        tol = 2e-3 if prefix == 'g_sf' else 2e-2
+        assert (err > tol).sum() <= max(2, want.size // 5000), '%s: %d elements off (worst %.2e)' % (
+            k, (err > tol).sum(), err.max())
         after = gd[k.replace('g_', 'p_', 1)]
         lr = opt.lr * (opt.scene_lr_mul if prefix == 'g_sf' else 1.0)
         assert np.abs(p.data.cpu().numpy() - after).max() <= 3 * lr + 1e-7, k
