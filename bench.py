@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X dynamic-video-depth step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): synthetic 384x672 video, 48 frame pairs per GPU,
+MiDaS depth net (ResNeXt-101 32x8d, random init + calibrated head) + scene-flow MLP,
+non-warm phase (L1 + acceleration regulariser), gap 1, fp32.  A "step" is one
+`Model._train_on_batch`: depth nets forward, geometry + MLP + fused warp/loss forward and
+backward, depth-net backward, gradient all-reduce (N>1) and both Adam updates.  Inputs are
+resident in HBM before the timed region.
+
+Prints ONE JSON line: whole-job `value` in 48-pair iterations per second (weak scaling:
+every rank owns 48 pairs), plus
+  roofline     -- the fused warp+loss op (HBM bound), timed live with events on its stream;
+  cpu_baseline -- the CPU oracle (a port of the reference step) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'dynamic-video-depth_amd'))
+os.environ.setdefault('MIOPEN_FIND_MODE', 'FAST')
+os.environ.setdefault('MIOPEN_LOG_LEVEL', '1')
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+
+H, W, PAIRS, GAP = 384, 672, 48, 1
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+WARP_BYTES_PER_PIXEL = 52        # fused fwd+bwd, unique bytes
+
+
+def make_opt(**over):
+    from types import SimpleNamespace
+    o = dict(optim='adam', adam_beta1=0.5, adam_beta2=0.9, lr=1e-6, scene_lr_mul=1000.0, dataset='davis_sequence',
+             batch_size=1, global_rank=0, use_cnn=False, use_embedding=False, midas=True, use_disp=True,
+             use_disp_ratio=False, time_dependent=True, flow_mul=1.0, disp_mul=1.0, acc_mul=1.0, sf_mag_div=100.0,
+             interp_steps=5, warm_reg=False, weight_steps=False, use_motion_seg=False, n_freq_xyz=16, n_freq_t=16,
+             warm_sf=5, mlp_stash_gb=64.0, depth_chunk=8, full_logdir='/tmp')
+    o.update(over)
+    return SimpleNamespace(**o)
+
+
+def build_model(opt, device, seed=0):
+    import warnings
+    from dvd_hip.models.scene_flow_motion_field import Model
+    from dvd_hip.third_party.MiDaS import calibrate_head_for_random_init
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = Model(opt, None)
+    if opt.midas:
+        calibrate_head_for_random_init(model.net_depth)
+    model.to(device)
+    return model
+
+
+class WarpTimer(object):
+    """Brackets every dvd_warp_loss_fused call with events on the launch stream."""
+
+    def __init__(self):
+        from dvd_hip import ops
+        self.ops, self.orig, self.events, self.pixels, self.on = ops, ops.warp_loss_fused, [], 0, False
+
+    def __enter__(self):
+        def wrapped(cfg, *a, **k):
+            if not self.on:
+                return self.orig(cfg, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(cfg, *a, **k)
+            e1.record()
+            self.events.append((e0, e1, cfg.B * cfg.H * cfg.W))
+            return r
+        self.ops.warp_loss_fused = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.ops.warp_loss_fused = self.orig
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
+        px = sum(n for _, _, n in self.events)
+        return {'launches': len(self.events), 'avg_ms': ms / len(self.events), 'pixels_per_launch': px / len(self.events),
+                'GBps': px * WARP_BYTES_PER_PIXEL / ms / 1e6}
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle step on the host cores, on ONE pair of the same workload (the full 48-pair
+    step needs >400 GB of autograd state on the CPU path)."""
+    import copy
+    from dvd_hip import synthetic
+    from dvd_hip.third_party.MiDaS import MidasNet, calibrate_head_for_random_init
+    from oracle import sceneflow_mlp as M
+    from oracle import train_step as T
+    from oracle.losses import default_opt
+    torch.manual_seed(0)
+    net = calibrate_head_for_random_init(MidasNet(non_negative=True, normalize_input=True)).eval()
+    sd = M.init_params(seed=0)
+    opt = default_opt()
+    batch = synthetic.make_batch(1, H, W, gap=GAP, seed=1234)
+    threads = torch.get_num_threads()
+    t0 = time.time()
+    log, tim = T.train_step(opt, net, sd, batch, warm=False, lr_depth=1e-6, lr_mlp=1e-3)
+    dt = time.time() - t0
+    return {'value': (1.0 / dt) / PAIRS, 'unit': 'iters/s (48-pair steps)', 'cores': threads, 'kind': 'port',
+            'sample': '1 frame pair at %dx%d (one oracle step, %.1f s); value = pairs/s / 48' % (H, W, dt),
+            'pairs_per_s': 1.0 / dt, 'loss': log['loss']}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (48 = the BASELINE configuration)')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    a = ap.parse_args()
+
+    from dvd_hip import parallel, synthetic
+    local = parallel.init_from_env()
+    world, rank = parallel.world_size(), parallel.rank()
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (a.gpus, a.gpus))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    opt = make_opt(global_rank=rank)
+    model = build_model(opt, device, seed=0)
+    batch = synthetic.make_batch(a.pairs, H, W, gap=GAP, seed=1234, rank=rank, device=device)
+    epoch = opt.warm_sf + 1            # non-warm phase
+
+    def one_step(i):
+        return model._train_on_batch(epoch, i, synthetic.with_loader_dim(batch))
+
+    with WarpTimer() as wt:
+        for i in range(a.warmup):
+            log = one_step(i)
+        if parallel.is_distributed():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        wt.on = True
+        t0 = time.time()
+        for i in range(a.steps):
+            log = one_step(a.warmup + i)
+        torch.cuda.synchronize()
+        if parallel.is_distributed():
+            torch.distributed.barrier()
+        dt = time.time() - t0
+        warp = wt.summary()
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    if parallel.is_distributed():
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+    ms_per_step = dt / a.steps * 1e3
+    if rank != 0:
+        return
+    out = {
+        'metric': 'train iters/s (depth+sceneflow step) at 384x672, 48 pairs; warp+loss HBM GB/s',
+        'value': world * (a.pairs / float(PAIRS)) * a.steps / dt, 'unit': 'iters/s (48-pair steps, whole job)',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[1]: synthetic %dx%d, %d frame pairs per GPU, gap %d, MiDaS '
+                               '(ResNeXt-101 32x8d) depth net on PyTorch-ROCm/MIOpen + HIP scene-flow MLP + HIP fused '
+                               'warp/reprojection/loss, non-warm phase with acceleration regulariser' % (H, W, a.pairs, GAP),
+                   'pairs_per_gpu': a.pairs, 'height': H, 'width': W, 'parallelism': 'dp%d over frame pairs' % world},
+        'pairs_per_s': world * a.pairs * a.steps / dt,
+        'last_loss': log['loss'],
+    }
+    if warp is not None:
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'warp_loss_pmc.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'dvd_warp_loss_fused (tiled warp/loss kernel + slab combine + reductions)',
+                           'achieved': warp['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                           'frac': warp['GBps'] / HBM_PEAK_GBPS, 'traffic': traffic,
+                           'algorithmic_bytes_per_launch': warp['pixels_per_launch'] * WARP_BYTES_PER_PIXEL,
+                           'avg_launch_ms': warp['avg_ms'], 'launches_timed': warp['launches']}
+    if world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -98,3 +98,9 @@ def make_depths(B, H, W, seed=99, far_depth_frac=0.001, device='cpu'):
 def make_scene_flow(B, H, W, seed=7, device='cpu'):
     g = torch.Generator().manual_seed(seed)
     return (0.01 * torch.randn(B, 3, H, W, generator=g)).to(device)
+
+
+def with_loader_dim(batch):
+    """Add the leading DataLoader dimension (batch_size=1, experiments/davis/train_sequence.sh:34)
+    that Model._train_on_batch strips again (models/scene_flow_motion_field.py:177-179)."""
+    return {k: (v.unsqueeze(0) if torch.is_tensor(v) else v) for k, v in batch.items()}
