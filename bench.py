@@ -134,6 +134,8 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
+    if os.environ.get('DVD_CUDNN_BENCHMARK'):
+        torch.backends.cudnn.benchmark = True     # MIOpen find mode (experiments; the default run uses FAST immediate mode)
     opt = make_opt(global_rank=rank)
     model = build_model(opt, device, seed=0)
     batch = synthetic.make_batch(a.pairs, H, W, gap=GAP, seed=1234, rank=rank, device=device)

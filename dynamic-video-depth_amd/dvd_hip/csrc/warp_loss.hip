@@ -630,6 +630,1081 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   }
 }
 
+// ---------------------------------------------------------------------------
+// Tiled variant, second generation (the production path; DVD_WARP_V1=1 selects the kernel above).
+//
+// The first tiled kernel issues ~375 VALU + ~250 SALU instructions per pixel and runs VALU-
+// and latency-bound (233 us at 48x384x672, ~3.2 TB/s of real traffic).  This one keeps the
+// same data flow (LDS depth_2 window + Q31.32 LDS accumulator window + slab combine) and
+// the same rounding sequence, but
+//   * a thread works on TWO horizontally adjacent pixels held in float2 vectors, so the
+//     multiply/add/fma bulk becomes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (two pixels
+//     per instruction, IEEE rounding per component, so EXACT results are unchanged);
+//   * IEEE divisions are evaluated with the unscaled form of the hardware division
+//     sequence (rcp, one Newton step on the reciprocal, two fma corrections of the
+//     quotient: exactly what the compiler emits between v_div_scale and v_div_fixup, whose
+//     scaling is the identity for the operand ranges here); the reciprocal of the constant
+//     (W-1)/2, (H-1)/2 is hoisted and the one of I.z is shared between u and v;
+//   * every data-dependent branch of the per-pixel code is a select; the only divergent
+//     paths left are the two rare ones (tap outside the LDS window, fixed-point overflow);
+//   * the tile's inputs for ALL of a thread's pixels are requested before the first pixel
+//     is evaluated (the loop is fully unrolled; 14 VGPRs per pixel pair in flight).
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef DVD_WARP_PREFETCH
+#define DVD_WARP_PREFETCH 2
+#endif
+// Scheduling fence between the sections of pixel2(): without it the scheduler interleaves
+// the sections for ILP and the live set of the two-pixel arithmetic overflows 128 VGPRs.
+#ifndef DVD_WARP_FENCE
+#define DVD_WARP_FENCE 1
+#endif
+#if DVD_WARP_FENCE
+#define DVD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DVD_SCHED_FENCE() ((void)0)
+#endif
+#ifndef DVD_WARP_PIN
+#define DVD_WARP_PIN 15
+#endif
+
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f vsplat(float s) { return (v2f){s, s}; }
+
+// reciprocal refined as in the f32 division expansion: y1 = y0 + y0*(1 - b*y0)
+__device__ __forceinline__ float rcp_refined(float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, y0, 1.0f);
+  return __builtin_fmaf(e, y0, y0);
+}
+// a / b given y = rcp_refined(b): q0 = a*y, two residual corrections (correctly rounded
+// whenever the IEEE sequence needs no operand scaling, i.e. for normal-range b and a/b).
+__device__ __forceinline__ v2f div_exact(v2f a, v2f b, v2f y) {
+  v2f q = a * y;
+  v2f r = vfma(-b, q, a);
+  q = vfma(r, y, q);
+  r = vfma(-b, q, a);
+  return vfma(r, y, q);
+}
+__device__ __forceinline__ v2f sample_coord2(v2f pix, v2f fl, float half, float rhalf, float maxv) {
+  v2f g = pix + fl;
+  g = div_exact(g, vsplat(half), vsplat(rhalf));
+  g = g - 1.0f;
+  const v2f i = (g + 1.0f) * half;
+  return (v2f){fminf(maxv, fmaxf(i.x, 0.0f)), fminf(maxv, fmaxf(i.y, 0.0f))};
+}
+__device__ __forceinline__ void rowvec_mat3v(v2f v0, v2f v1, v2f v2, const float* __restrict__ M, v2f& o0,
+                                             v2f& o1, v2f& o2) {
+  o0 = (v0 * M[0] + v1 * M[3]) + v2 * M[6];
+  o1 = (v0 * M[1] + v1 * M[4]) + v2 * M[7];
+  o2 = (v0 * M[2] + v1 * M[5]) + v2 * M[8];
+}
+__device__ __forceinline__ v2f bilinear2(v2f vnw, v2f vne, v2f vsw, v2f vse, v2f wnw, v2f wne, v2f wsw, v2f wse) {
+  v2f r = vnw * wnw;
+  r = vfma(vne, wne, r);
+  r = vfma(vsw, wsw, r);
+  return vfma(vse, wse, r);
+}
+// mag * sign(x), 0 when x == 0 (v_bfi + select)
+__device__ __forceinline__ float signed_mag(float mag, float x) {
+  return (x == 0.0f) ? 0.0f : __builtin_copysignf(mag, x);
+}
+__device__ __forceinline__ v2f vabs(v2f a) { return (v2f){fabsf(a.x), fabsf(a.y)}; }
+
+// uniform base + 32-bit per-lane BYTE offset: lets the backend use the saddr+voffset addressing
+// form (no 64-bit VALU address arithmetic, one VGPR of address per lane)
+template <class T>
+__device__ __forceinline__ T ld_off(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ void st_off(float* base, unsigned byte_off, T v) {
+  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// Q31.32 from a float with |v| < 2^30: hi = floor(v), lo = (v - floor(v)) * 2^32 (both exact).
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+  const float fl = floorf(v);
+  const unsigned lo = (unsigned)((v - fl) * kFixScale);
+  const unsigned hi = (unsigned)(int)fl;
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int WW, int WH>
+struct TileIO2 {
+  const float* d2b;
+  const float* win;
+  unsigned long long* accw;
+  int W, wx0, wy0, pair_base;
+  float unit;
+  Overflow ovf;
+  __device__ __forceinline__ void spill(int idx, float v) const {
+    if (v != 0.0f) {
+      const unsigned i = atomicAdd(ovf.count, 1u);
+      if (i < ovf.cap) ovf.rec[i] = make_int2(pair_base + idx, __float_as_int(v * unit));
+    }
+  }
+};
+
+// Camera block of the tile's pair in LDS (wave-uniform ds_read at the point of use: 51 scalars
+// do not fit the SGPR file next to the kernel's pointers, and as VGPR residents they push the
+// two-pixel arithmetic into scratch).
+constexpr int kCamKi = 0, kCamR1 = 9, kCamR2 = 18, kCamR2T = 27, kCamK = 36, kCamT1 = 45, kCamT2 = 48, kCamFloats = 52;
+
+// Two pixels (x, x+1) of row y.  Same arithmetic as pixel<>() above, component-wise.
+// `mid()` is invoked once between the forward and the backward half: the kernel issues the
+// next pair's global loads there, when the forward-only values have died.
+template <bool GRADS, bool SHIPPED, int WW, int WH, class Mid>
+__device__ __forceinline__ void pixel2(const WarpArgs& a, const float* __restrict__ cs, const TileIO2<WW, WH>& io, float rhw,
+                                       float rhh, int y, int x, v2f d1, v2f fx, v2f fy, v2f mk, v2f s0, v2f s1,
+                                       v2f s2, float acc[4], v2f& g_d1_out, v2f g_s_out[3], Mid&& mid) {
+  const bool midas_mask = SHIPPED ? true : (a.midas_mask != 0);
+  const int disp_mode = SHIPPED ? 1 : a.disp_mode;
+  const bool loss_on_sf = SHIPPED ? false : (a.loss_on_sf != 0);
+  const v2f xf = (v2f){(float)x, (float)(x + 1)};
+  const v2f yf = vsplat((float)y);
+  // --- EXACT: ray, camera-1 point, world point
+  v2f r0, r1, r2;
+  rowvec_mat3v(xf, yf, vsplat(1.0f), cs + kCamKi, r0, r1, r2);
+  const v2f pc0 = d1 * r0, pc1 = d1 * r1, pc2 = d1 * r2;
+  v2f P0, P1, P2;
+  rowvec_mat3v(pc0, pc1, pc2, cs + kCamR1, P0, P1, P2);
+  P0 = P0 + cs[kCamT1 + 0];
+  P1 = P1 + cs[kCamT1 + 1];
+  P2 = P2 + cs[kCamT1 + 2];
+  DVD_SCHED_FENCE();
+  // --- EXACT: sampling position and bilinear weights
+  const v2f ix = sample_coord2(xf, fx, a.half_w, rhw, a.wmax);
+  const v2f iy = sample_coord2(yf, fy, a.half_h, rhh, a.hmax);
+  const v2f x0f = (v2f){floorf(ix.x), floorf(ix.y)}, y0f = (v2f){floorf(iy.x), floorf(iy.y)};
+  const v2f ww = ix - x0f, we = 1.0f - ww;
+  const v2f wn = iy - y0f, ws = 1.0f - wn;
+  const v2f w_nw = ws * we, w_ne = ws * ww, w_sw = wn * we, w_se = wn * ww;
+  // --- taps of depth_2 (LDS window; rare: global)
+  int x0[2], y0[2], cell[2];
+  bool inside[2];
+  v2f dnw, dne, dsw, dse;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    x0[k] = (int)x0f[k];
+    y0[k] = (int)y0f[k];
+    const int lx = x0[k] - io.wx0, ly = y0[k] - io.wy0;
+    inside[k] = ((unsigned)lx < (unsigned)(WW - 1)) && ((unsigned)ly < (unsigned)(WH - 1));
+    cell[k] = inside[k] ? ly * WW + lx : 0;
+    const float* p = io.win + cell[k];
+    dnw[k] = p[0];
+    dne[k] = p[1];
+    dsw[k] = p[WW];
+    dse[k] = p[WW + 1];
+    if (!inside[k]) {
+      DirectIO g{io.d2b, nullptr, io.W, 1.0f};
+      float t0, t1, t2, t3;
+      g.fetch(y0[k] * io.W + x0[k], x0[k], y0[k], (x0[k] + 1) < a.W, (y0[k] + 1) < a.H, t0, t1, t2, t3);
+      dnw[k] = t0;
+      dne[k] = t1;
+      dsw[k] = t2;
+      dse[k] = t3;
+    }
+  }
+  DVD_SCHED_FENCE();
+  // EXACT: z of the camera-2 points at the taps; W2.z
+  const v2f x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+  const v2f zn0 = (x0f * cs[kCamKi + 2] + y0f * cs[kCamKi + 5]) + cs[kCamKi + 8];
+  const v2f zn1 = (x1f * cs[kCamKi + 2] + y0f * cs[kCamKi + 5]) + cs[kCamKi + 8];
+  const v2f zs0 = (x0f * cs[kCamKi + 2] + y1f * cs[kCamKi + 5]) + cs[kCamKi + 8];
+  const v2f zs1 = (x1f * cs[kCamKi + 2] + y1f * cs[kCamKi + 5]) + cs[kCamKi + 8];
+  const v2f W2z = bilinear2(dnw * zn0, dne * zn1, dsw * zs0, dse * zs1, w_nw, w_ne, w_sw, w_se);
+  DVD_SCHED_FENCE();
+  // --- EXACT: dynamic reprojection
+  const v2f A0 = (P0 + s0) - cs[kCamT2 + 0], A1 = (P1 + s1) - cs[kCamT2 + 1], A2 = (P2 + s2) - cs[kCamT2 + 2];
+  v2f Q0, Q1, Q2, I0, I1, I2;
+  rowvec_mat3v(A0, A1, A2, cs + kCamR2T, Q0, Q1, Q2);
+  rowvec_mat3v(Q0, Q1, Q2, cs + kCamK, I0, I1, I2);
+  const v2f den = I2 + 1e-8f;
+  const bool behind[2] = {I2.x < 1e-3f, I2.y < 1e-3f};
+  const v2f yden = (v2f){rcp_refined(den.x), rcp_refined(den.y)};
+  v2f u = div_exact(I0, den, yden), v = div_exact(I1, den, yden);
+  u.x = behind[0] ? xf.x : u.x;
+  u.y = behind[1] ? xf.y : u.y;
+  v.x = behind[0] ? yf.x : v.x;
+  v.y = behind[1] ? yf.y : v.y;
+  const v2f ex = (u - xf) - fx, ey = (v - yf) - fy;
+  DVD_SCHED_FENCE();
+  // --- FAST: warped world point of frame 2
+  const v2f q0 = vfma(x0f, vsplat(cs[kCamKi + 0]), vfma(y0f, vsplat(cs[kCamKi + 3]), vsplat(cs[kCamKi + 6])));
+  const v2f q1 = vfma(x0f, vsplat(cs[kCamKi + 1]), vfma(y0f, vsplat(cs[kCamKi + 4]), vsplat(cs[kCamKi + 7])));
+  const v2f q2 = vfma(x0f, vsplat(cs[kCamKi + 2]), vfma(y0f, vsplat(cs[kCamKi + 5]), vsplat(cs[kCamKi + 8])));
+  v2f m = mk;
+  if (midas_mask) {
+    m.x = ((d1.x < 100.0f) && (W2z.x < 100.0f)) ? m.x : 0.0f;   // mask is {0,1}: 1*1*m == m
+    m.y = ((d1.y < 100.0f) && (W2z.y < 100.0f)) ? m.y : 0.0f;
+  }
+  v2f f0 = vsplat(0.f), f1 = vsplat(0.f), f2 = vsplat(0.f);
+  {
+    const v2f a_nw = w_nw * dnw, a_ne = w_ne * dne, a_sw = w_sw * dsw, a_se = w_se * dse;
+    const v2f sE = a_ne + a_se, sS = a_sw + a_se, sA = (a_nw + a_ne) + sS;
+    const v2f V0 = vfma(q0, sA, vfma(vsplat(cs[kCamKi + 0]), sE, sS * cs[kCamKi + 3]));
+    const v2f V1 = vfma(q1, sA, vfma(vsplat(cs[kCamKi + 1]), sE, sS * cs[kCamKi + 4]));
+    const v2f V2 = vfma(q2, sA, vfma(vsplat(cs[kCamKi + 2]), sE, sS * cs[kCamKi + 5]));
+    const v2f G0 = vfma(V0, vsplat(cs[kCamR2 + 0]), vfma(V1, vsplat(cs[kCamR2 + 3]), vfma(V2, vsplat(cs[kCamR2 + 6]), vsplat(cs[kCamT2 + 0]))));
+    const v2f G1 = vfma(V0, vsplat(cs[kCamR2 + 1]), vfma(V1, vsplat(cs[kCamR2 + 4]), vfma(V2, vsplat(cs[kCamR2 + 7]), vsplat(cs[kCamT2 + 1]))));
+    const v2f G2 = vfma(V0, vsplat(cs[kCamR2 + 2]), vfma(V1, vsplat(cs[kCamR2 + 5]), vfma(V2, vsplat(cs[kCamR2 + 8]), vsplat(cs[kCamT2 + 2]))));
+    f0 = (G0 - P0) - s0;
+    f1 = (G1 - P1) - s1;
+    f2 = (G2 - P2) - s2;
+  }
+  DVD_SCHED_FENCE();
+  const v2f aex = vabs(ex), aey = vabs(ey);
+  const v2f flow_err = a.crit_l2 ? (ex * ex + ey * ey) : (aex + aey);
+  v2f disp_err, rca = vsplat(0.f), rcb = vsplat(0.f), ediff = vsplat(0.f);
+  if (disp_mode == 1) {
+    rca = (v2f){__builtin_amdgcn_rcpf(fmaxf(Q2.x, 1e-3f)), __builtin_amdgcn_rcpf(fmaxf(Q2.y, 1e-3f))};
+    rcb = (v2f){__builtin_amdgcn_rcpf(fmaxf(W2z.x, 1e-3f)), __builtin_amdgcn_rcpf(fmaxf(W2z.y, 1e-3f))};
+    ediff = rca - rcb;
+    disp_err = vabs(ediff) * 100.0f;
+  } else if (disp_mode == 2) {
+    const v2f ca = (v2f){fmaxf(Q2.x, 1e-3f), fmaxf(Q2.y, 1e-3f)}, cb = (v2f){fmaxf(W2z.x, 1e-3f), fmaxf(W2z.y, 1e-3f)};
+    disp_err = (v2f){fmaxf(ca.x, cb.x) * __builtin_amdgcn_rcpf(fminf(ca.x, cb.x)) - 1.0f,
+                     fmaxf(ca.y, cb.y) * __builtin_amdgcn_rcpf(fminf(ca.y, cb.y)) - 1.0f};
+  } else {
+    disp_err = vabs(Q2 - W2z);
+  }
+  const v2f sf_err = (vabs(f0) + vabs(f1)) + vabs(f2);
+  {
+    const v2f t1v = m * flow_err, t2v = m * disp_err, t3v = m * sf_err;
+    acc[0] += m.x + m.y;
+    acc[1] += t1v.x + t1v.y;
+    acc[2] += t2v.x + t2v.y;
+    acc[3] += t3v.x + t3v.y;
+  }
+  if (!GRADS) {
+    mid();
+    return;
+  }
+  DVD_SCHED_FENCE();
+  // ------------------------------ FAST: backward (un-normalised), branch free ------------
+  // Everything that consumes forward-only values (errors, masks, reciprocals) is folded into
+  // gQ / uW2z / uG first; after `mid()` only those, the ray and the tap weights are alive.
+  v2f gQ0, gQ1, gQ2;
+  {
+    v2f fm = m * a.flow_mul;
+    fm.x = behind[0] ? 0.0f : fm.x;
+    fm.y = behind[1] ? 0.0f : fm.y;
+    v2f gu, gv;
+    if (a.crit_l2) {
+      gu = fm * 2.0f * ex;
+      gv = fm * 2.0f * ey;
+    } else {
+      gu = (v2f){signed_mag(fm.x, ex.x), signed_mag(fm.y, ex.y)};
+      gv = (v2f){signed_mag(fm.x, ey.x), signed_mag(fm.y, ey.y)};
+    }
+    // yden ~ 1/den to 1 ulp; for behind pixels it may be inf/nan but gu = gv = 0 there: select 0
+    v2f rden = yden;
+    rden.x = behind[0] ? 0.0f : rden.x;
+    rden.y = behind[1] ? 0.0f : rden.y;
+    const v2f gI0 = gu * rden, gI1 = gv * rden;
+    const v2f gI2 = -(vfma(gu, u, gv * v)) * rden;
+    gQ0 = vfma(gI0, vsplat(cs[kCamK + 0]), vfma(gI1, vsplat(cs[kCamK + 1]), gI2 * cs[kCamK + 2]));
+    gQ1 = vfma(gI0, vsplat(cs[kCamK + 3]), vfma(gI1, vsplat(cs[kCamK + 4]), gI2 * cs[kCamK + 5]));
+    gQ2 = vfma(gI0, vsplat(cs[kCamK + 6]), vfma(gI1, vsplat(cs[kCamK + 7]), gI2 * cs[kCamK + 8]));
+  }
+  v2f uW2z = vsplat(0.f), uG0 = vsplat(0.f), uG1 = vsplat(0.f), uG2 = vsplat(0.f);
+  const float dm = a.disp_mul;
+  if (!loss_on_sf) {
+    if (disp_mode == 1) {
+      const v2f m100 = m * 100.0f;
+      const v2f ue = (v2f){signed_mag(m100.x, ediff.x), signed_mag(m100.y, ediff.y)};
+      v2f ua = ue * dm;
+      ua.x = (Q2.x >= 1e-3f) ? ua.x : 0.0f;
+      ua.y = (Q2.y >= 1e-3f) ? ua.y : 0.0f;
+      gQ2 = vfma(-ua, rca * rca, gQ2);
+      uW2z = ue * (rcb * rcb);
+      uW2z.x = (W2z.x >= 1e-3f) ? uW2z.x : 0.0f;
+      uW2z.y = (W2z.y >= 1e-3f) ? uW2z.y : 0.0f;
+    }
+  } else {
+    uG0 = (v2f){signed_mag(m.x, f0.x), signed_mag(m.y, f0.y)};
+    uG1 = (v2f){signed_mag(m.x, f1.x), signed_mag(m.y, f1.y)};
+    uG2 = (v2f){signed_mag(m.x, f2.x), signed_mag(m.y, f2.y)};
+  }
+  DVD_SCHED_FENCE();
+  mid();
+  DVD_SCHED_FENCE();
+  const v2f gA0 = vfma(gQ0, vsplat(cs[kCamR2T + 0]), vfma(gQ1, vsplat(cs[kCamR2T + 1]), gQ2 * cs[kCamR2T + 2])) - uG0 * dm;
+  const v2f gA1 = vfma(gQ0, vsplat(cs[kCamR2T + 3]), vfma(gQ1, vsplat(cs[kCamR2T + 4]), gQ2 * cs[kCamR2T + 5])) - uG1 * dm;
+  const v2f gA2 = vfma(gQ0, vsplat(cs[kCamR2T + 6]), vfma(gQ1, vsplat(cs[kCamR2T + 7]), gQ2 * cs[kCamR2T + 8])) - uG2 * dm;
+  g_s_out[0] = gA0;
+  g_s_out[1] = gA1;
+  g_s_out[2] = gA2;
+  {
+    const v2f gp0 = vfma(gA0, vsplat(cs[kCamR1 + 0]), vfma(gA1, vsplat(cs[kCamR1 + 1]), gA2 * cs[kCamR1 + 2]));
+    const v2f gp1 = vfma(gA0, vsplat(cs[kCamR1 + 3]), vfma(gA1, vsplat(cs[kCamR1 + 4]), gA2 * cs[kCamR1 + 5]));
+    const v2f gp2 = vfma(gA0, vsplat(cs[kCamR1 + 6]), vfma(gA1, vsplat(cs[kCamR1 + 7]), gA2 * cs[kCamR1 + 8]));
+    g_d1_out = vfma(gp0, r0, vfma(gp1, r1, gp2 * r2));
+  }
+  DVD_SCHED_FENCE();
+  // depth_2 taps (units of disp_mul): d/d(d2_k) = w_k * (h . ray_k)
+  v2f h0 = vsplat(0.f), h1 = vsplat(0.f), h2 = uW2z;
+  if (loss_on_sf) {
+    h0 = vfma(uG0, vsplat(cs[kCamR2 + 0]), vfma(uG1, vsplat(cs[kCamR2 + 1]), uG2 * cs[kCamR2 + 2]));
+    h1 = vfma(uG0, vsplat(cs[kCamR2 + 3]), vfma(uG1, vsplat(cs[kCamR2 + 4]), uG2 * cs[kCamR2 + 5]));
+    h2 = h2 + vfma(uG0, vsplat(cs[kCamR2 + 6]), vfma(uG1, vsplat(cs[kCamR2 + 7]), uG2 * cs[kCamR2 + 8]));
+  }
+  if (a.ablate & 1) return;
+  v2f hb, hx, hy;
+  if (loss_on_sf) {
+    hb = vfma(h0, q0, vfma(h1, q1, h2 * q2));
+    hx = vfma(h0, vsplat(cs[kCamKi + 0]), vfma(h1, vsplat(cs[kCamKi + 1]), h2 * cs[kCamKi + 2]));
+    hy = vfma(h0, vsplat(cs[kCamKi + 3]), vfma(h1, vsplat(cs[kCamKi + 4]), h2 * cs[kCamKi + 5]));
+  } else {
+    hb = h2 * q2;
+    hx = h2 * cs[kCamKi + 2];
+    hy = h2 * cs[kCamKi + 5];
+  }
+  const v2f hbx = hb + hx;
+  const v2f t_nw = w_nw * hb, t_ne = w_ne * hbx, t_sw = w_sw * (hb + hy), t_se = w_se * (hbx + hy);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float tn0 = t_nw[k], tn1 = t_ne[k], ts0 = t_sw[k], ts1 = t_se[k];
+    const float big = fmaxf(fmaxf(fabsf(tn0), fabsf(tn1)), fmaxf(fabsf(ts0), fabsf(ts1)));
+    const bool fast = inside[k] && (big < kFixMax);
+    // out-of-image taps carry an exactly zero weight, and their window cells are never read back
+    unsigned long long* p = io.accw + cell[k];
+    atomicAdd(p, to_fixed(fast ? tn0 : 0.0f));
+    atomicAdd(p + 1, to_fixed(fast ? tn1 : 0.0f));
+    atomicAdd(p + WW, to_fixed(fast ? ts0 : 0.0f));
+    atomicAdd(p + WW + 1, to_fixed(fast ? ts1 : 0.0f));
+    if (!fast) {   // rare: list of (index, value) applied after the slab combine
+      const int o_n = y0[k] * io.W + x0[k];
+      const bool in_e = (x0[k] + 1) < a.W, in_s = (y0[k] + 1) < a.H;
+      io.spill(o_n, tn0);
+      if (in_e) io.spill(o_n + 1, tn1);
+      if (in_s) io.spill(o_n + io.W, ts0);
+      if (in_e && in_s) io.spill(o_n + io.W + 1, ts1);
+    }
+  }
+}
+
+template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED, bool EVEN, bool FULL>
+__global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_loss_tiled2_kernel(const WarpArgs a, const TileArgs ta) {
+  // FULL: W % TW == 0, H % TH == 0 and the tile's pixel pairs divide evenly over the threads
+  // (the shipped 384x672 with 96x32 tiles): no per-pixel bounds predicates at all.
+  constexpr int WW = TW + 2 * R + 4;
+  constexpr int WH = TH + 2 * R + 1;
+  constexpr int QW = TW / 2;                       // pixel pairs per tile row
+  constexpr int ITERS = (QW * TH + NT - 1) / NT;   // pairs per thread
+  static_assert(R % 4 == 0 && TW % 4 == 0, "tile geometry");
+  static_assert(!FULL || (QW * TH) % NT == 0, "FULL needs an even split of the tile over the threads");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ __attribute__((aligned(16))) float camS[kCamFloats];
+  unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);
+  float* win = smem + 2 * WW * WH;
+
+  const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tiles = ta.ntx * ta.nty;
+  const int b = logical / tiles;
+  const int t = logical - b * tiles;
+  const int tj = t / ta.ntx, ti = t - tj * ta.ntx;
+  const int tx0 = ti * TW, ty0 = tj * TH;
+  const int wx0 = tx0 - R, wy0 = ty0 - R;
+  if (threadIdx.x < 45) {
+    const int m = threadIdx.x / 9, e = threadIdx.x - m * 9;
+    const float* src = m == 0 ? a.Ki : (m == 1 ? a.R1 : (m == 2 ? a.R2 : (m == 3 ? a.R2T : a.K)));
+    camS[threadIdx.x] = src[b * 9 + e];
+  } else if (threadIdx.x < 51) {
+    const int e = threadIdx.x - 45;
+    camS[threadIdx.x] = e < 3 ? a.t1[b * 3 + e] : a.t2[b * 3 + e - 3];
+  }
+  const float* d2b = a.d2 + (size_t)b * a.HW;
+  constexpr bool even = EVEN;   // 8-byte vector access needs even W (rows stay 8-byte aligned)
+
+  // ---- input fetch of one pixel pair (8-byte vectors; 16 bytes of flow): uniform plane bases + one
+  //      32-bit per-lane offset
+  const float* d1b = a.d1 + (size_t)b * a.HW;
+  const float* mkb = a.mask + (size_t)b * a.HW;
+  const float* flb = a.flow + 2 * (size_t)b * a.HW;
+  const float* sf0b = a.sf + (size_t)b * 3 * a.HW;
+  const float* sf1b = sf0b + a.HW;
+  const float* sf2b = sf1b + a.HW;
+  struct In {
+    v2f d1, mk, fx, fy, s0, s1, s2;
+  };
+  auto locate = [&](int it, int& x, int& y, bool& ok0, bool& ok1) {
+    const int q = it * NT + threadIdx.x;
+    const int ly = q / QW, lx = (q - ly * QW) * 2;
+    y = ty0 + ly;
+    x = tx0 + lx;
+    ok0 = FULL || ((q < QW * TH) && (y < a.H) && (x < a.W));
+    ok1 = FULL || (ok0 && (x + 1 < a.W));
+  };
+  auto fetch = [&](int it, In& r) {
+    int x, y;
+    bool ok0, ok1;
+    locate(it, x, y, ok0, ok1);
+    const unsigned p0 = (unsigned)(y * a.W + x);
+    if (!FULL) {
+      r.d1 = vsplat(1.0f);
+      r.mk = r.fx = r.fy = r.s0 = r.s1 = r.s2 = vsplat(0.0f);
+    }
+    if (even) {
+      if (ok0) {
+        const unsigned o4 = p0 * 4u;    // < 2^31: B*H*W*3 floats were checked to fit 32-bit indexing
+        r.d1 = ld_off<v2f>(d1b, o4);
+        r.mk = ld_off<v2f>(mkb, o4);
+        const float4 f = ld_off<float4>(flb, o4 * 2u);
+        r.fx = (v2f){f.x, f.z};
+        r.fy = (v2f){f.y, f.w};
+        r.s0 = ld_off<v2f>(sf0b, o4);
+        r.s1 = ld_off<v2f>(sf1b, o4);
+        r.s2 = ld_off<v2f>(sf2b, o4);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k == 0 ? ok0 : ok1) {
+          r.d1[k] = d1b[p0 + k];
+          r.mk[k] = mkb[p0 + k];
+          r.fx[k] = flb[2 * (size_t)(p0 + k)];
+          r.fy[k] = flb[2 * (size_t)(p0 + k) + 1];
+          r.s0[k] = sf0b[p0 + k];
+          r.s1[k] = sf1b[p0 + k];
+          r.s2[k] = sf2b[p0 + k];
+        }
+      }
+    }
+  };
+  In in[ITERS];
+  fetch(0, in[0]);   // requested before the window fill, consumed after it
+
+  // ---- phase 0: fill the depth_2 window, clear the accumulator
+  const bool w4 = (a.W & 3) == 0;
+  for (int i = threadIdx.x; i < (WW / 4) * WH; i += NT) {
+    const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
+    const int iy = wy0 + wy, ixx = wx0 + wx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < a.H) {
+      if (w4) {
+        if (ixx >= 0 && ixx < a.W) v = *reinterpret_cast<const float4*>(d2b + (size_t)iy * a.W + ixx);
+      } else {
+        const float* row = d2b + (size_t)iy * a.W;
+        if (ixx >= 0 && ixx < a.W) v.x = row[ixx];
+        if (ixx + 1 >= 0 && ixx + 1 < a.W) v.y = row[ixx + 1];
+        if (ixx + 2 >= 0 && ixx + 2 < a.W) v.z = row[ixx + 2];
+        if (ixx + 3 >= 0 && ixx + 3 < a.W) v.w = row[ixx + 3];
+      }
+    }
+    *reinterpret_cast<float4*>(win + wy * WW + wx) = v;
+    if (GRADS) {
+      uint4* z = reinterpret_cast<uint4*>(accw + wy * WW + wx);
+      z[0] = make_uint4(0u, 0u, 0u, 0u);
+      z[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  __syncthreads();
+
+  const TileIO2<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, a.disp_mul, ta.ovf};
+  const float rhw = rcp_refined(a.half_w), rhh = rcp_refined(a.half_h);
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float* gd1b = a.g_d1 + (size_t)b * a.HW;
+  float* gs0b = a.g_sf + (size_t)b * 3 * a.HW;
+  float* gs1b = gs0b + a.HW;
+  float* gs2b = gs1b + a.HW;
+  // ---- phase 1 (one pair in evaluation, the next one requested half way through it)
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    int x, y;
+    bool ok0, ok1;
+    locate(it, x, y, ok0, ok1);
+    asm volatile("" ::: "memory");   // camera scalars are re-read from LDS per pair, not hoisted into 51 registers
+    auto mid = [&]() {
+      if (it + 1 < ITERS) fetch(it + 1, in[it + 1]);
+    };
+    if (!(FULL || ok0)) mid();
+    if (FULL || ok0) {
+      v2f gd1 = vsplat(0.0f), gs[3] = {vsplat(0.0f), vsplat(0.0f), vsplat(0.0f)};
+      pixel2<GRADS, SHIPPED, WW, WH>(a, camS, io, rhw, rhh, y, x, in[it].d1, in[it].fx, in[it].fy, in[it].mk,
+                                     in[it].s0, in[it].s1, in[it].s2, acc, gd1, gs, mid);
+      if (GRADS && !(a.ablate & 2)) {
+        const unsigned p0 = (unsigned)(y * a.W + x);
+        if (even) {
+          const unsigned o4 = p0 * 4u;
+          st_off<v2f>(gd1b, o4, gd1);
+          st_off<v2f>(gs0b, o4, gs[0]);
+          st_off<v2f>(gs1b, o4, gs[1]);
+          st_off<v2f>(gs2b, o4, gs[2]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k == 0 || ok1) {
+              gd1b[p0 + k] = gd1[k];
+              gs0b[p0 + k] = gs[0][k];
+              gs1b[p0 + k] = gs[1][k];
+              gs2b[p0 + k] = gs[2][k];
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
+  __syncthreads();
+  if (GRADS && !(a.ablate & 4)) {
+    float* slab = ta.slabs + (size_t)logical * (WW * WH);
+    const float back = kFixInv * a.disp_mul;
+    for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
+      const longlong2 lo = reinterpret_cast<const longlong2*>(accw)[2 * i];
+      const longlong2 hi = reinterpret_cast<const longlong2*>(accw)[2 * i + 1];
+      reinterpret_cast<float4*>(slab)[i] =
+          make_float4((float)lo.x * back, (float)lo.y * back, (float)hi.x * back, (float)hi.y * back);
+    }
+  }
+  float* red = win;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane == 0) red[wave * 4 + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.0f;
+    for (int w = 0; w < NT / 64; ++w) v += red[w * 4 + threadIdx.x];
+    a.partial[(size_t)logical * 4 + threadIdx.x] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Tiled variant, third generation: guard-banded fast arithmetic (DVD_WARP_GEN=3, the default).
+//
+// PMC on the first tiled kernel (profiles/r01_warp_loss_sq_counters.txt): 8.9e7 VALU wave
+// instructions per launch at 48x384x672 = 457 per pixel, VALU busy 63 % of the kernel time:
+// the kernel is bound by instruction issue, not by HBM.  Most of those instructions serve the
+// reference's exact rounding sequence ray -> p_cam -> P -> A -> Q -> I (five dependent 3x3
+// products, unfused), although bit-exactness is only REQUIRED where a value decides an index
+// or a mask: the tap indices, [I.z < 1e-3], [W2.z < 100], and the sign of
+// (dflow - flow) that the L1 sub-gradient takes.  So:
+//   * `warp_prepare_kernel` folds the camera block of every pair into composite matrices
+//     (computed in double): I = d1 * (c @ M3) + s @ M2 + tv, with c = (x, y, 1),
+//     M1 = K_inv R1, M2 = R2T K, M3 = M1 M2, tv = (t1 - t2) M2; p1_camera_2.z likewise from
+//     one row; the frame-2 warped point from (sum_k a_k c_k) @ (K_inv R2).  Per pixel that is
+//     ~35 FMAs instead of ~110 unfused operations, and the per-pixel live state shrinks.
+//   * every decision is taken on the fast value when it is outside a GUARD BAND around the
+//     threshold that bounds |fast - exact| from the operand magnitudes (error model in
+//     warp_prepare_kernel); inside the band (rare) the pixel re-evaluates the reference's exact
+//     sequence from the raw camera block and decides on that.  Masks, the valid-pixel count and
+//     the sub-gradient signs are therefore bit-identical to the exact kernels; everything else
+//     agrees within fp32 rounding (it was FAST arithmetic before, too).
+//   * the bilinear sampling position and weights keep the exact five-rounding sequence
+//     (tap indices), evaluated with the unscaled division of the second-generation kernel.
+
+#ifndef DVD_WARP3_SLOW
+#define DVD_WARP3_SLOW 1
+#endif
+#ifndef DVD_WARP3_PIN
+#define DVD_WARP3_PIN 0x0ull   // bit g pins floats [3g, 3g+3) of the pair record into VGPRs
+#endif
+constexpr int kPreFloats = 64;
+// layout of one pair's record (floats)
+constexpr int kpM3 = 0, kpM2 = 9, kpTV = 18, kpM4 = 21, kpR2 = 24, kpTQ = 27, kpKZ = 28, kpM1 = 31, kpT1 = 40,
+              kpM5 = 43, kpT2 = 52, kpEAxy = 55, kpEBxy = 56, kpEAz = 57, kpEBz = 58, kpTsum = 59;
+
+__global__ __launch_bounds__(64) void warp_prepare_kernel(const WarpArgs a, float* __restrict__ pre) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  double Ki[9], R1[9], R2[9], R2T[9], K[9], t1[3], t2[3];
+  for (int i = 0; i < 9; ++i) {
+    Ki[i] = a.Ki[b * 9 + i];
+    R1[i] = a.R1[b * 9 + i];
+    R2[i] = a.R2[b * 9 + i];
+    R2T[i] = a.R2T[b * 9 + i];
+    K[i] = a.K[b * 9 + i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    t1[i] = a.t1[b * 3 + i];
+    t2[i] = a.t2[b * 3 + i];
+  }
+  auto mm = [](const double* A, const double* B, double* C) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  };
+  double M1[9], M2[9], M3[9], M5[9];
+  mm(Ki, R1, M1);
+  mm(R2T, K, M2);
+  mm(M1, M2, M3);
+  mm(Ki, R2, M5);
+  float* o = pre + (size_t)b * kPreFloats;
+  for (int i = 0; i < 9; ++i) {
+    o[kpM3 + i] = (float)M3[i];
+    o[kpM2 + i] = (float)M2[i];
+    o[kpM1 + i] = (float)M1[i];
+    o[kpM5 + i] = (float)M5[i];
+  }
+  double tq = 0.0;
+  for (int j = 0; j < 3; ++j) {
+    double tv = 0.0, m4 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      tv += (t1[i] - t2[i]) * M2[i * 3 + j];
+      m4 += M1[j * 3 + i] * R2T[i * 3 + 2];
+    }
+    o[kpTV + j] = (float)tv;
+    o[kpM4 + j] = (float)m4;
+    o[kpR2 + j] = (float)R2T[j * 3 + 2];
+    o[kpKZ + j] = (float)Ki[j * 3 + 2];
+    o[kpT1 + j] = (float)t1[j];
+    o[kpT2 + j] = (float)t2[j];
+    tq += (t1[j] - t2[j]) * R2T[j * 3 + 2];
+  }
+  o[kpTQ] = (float)tq;
+  // ---- error model of the guard bands.  Row-vector products: |v @ M|_1 <= |v|_1 * n(M),
+  // n(M) = max_i sum_j |M_ij|.  For every pixel of the pair
+  //   |ray|_1 <= rb = sum_j (W |Ki_0j| + H |Ki_1j| + |Ki_2j|),
+  //   |Q|_1  <= (|d1| rb n(R1) + |t1|_1 + |t2|_1 + |s|_1) n(R2T),   |I_j| <= |Q|_1 max_i |K_ij|.
+  // Both evaluation orders (the reference's and the composite one) are sums of at most ~20
+  // products of such magnitudes, so each is within 20 * 2^-24 * bound of the real value; the band
+  // is 2^-18 * bound (> 2 * 20 * 2^-24), i.e. conservative by construction.
+  auto nrm = [](const double* M) {
+    double n = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      const double r = fabs(M[i * 3]) + fabs(M[i * 3 + 1]) + fabs(M[i * 3 + 2]);
+      n = r > n ? r : n;
+    }
+    return n;
+  };
+  double rb = 0.0;
+  for (int j = 0; j < 3; ++j) rb += a.W * fabs(Ki[j]) + a.H * fabs(Ki[3 + j]) + fabs(Ki[6 + j]);
+  auto colmax = [&](int j) {
+    const double m01 = fabs(K[j]) > fabs(K[3 + j]) ? fabs(K[j]) : fabs(K[3 + j]);
+    return m01 > fabs(K[6 + j]) ? m01 : fabs(K[6 + j]);
+  };
+  const double kxy = colmax(0) > colmax(1) ? colmax(0) : colmax(1), kz = colmax(2);
+  const double eps = 1.0 / 2097152.0;  // 2^-21
+  const double nq = nrm(R2T);
+  o[kpEAxy] = (float)(eps * kxy * nq * rb * nrm(R1));
+  o[kpEBxy] = (float)(eps * kxy * nq);
+  o[kpEAz] = (float)(eps * kz * nq * rb * nrm(R1));
+  o[kpEBz] = (float)(eps * kz * nq);
+  o[kpTsum] = (float)(fabs(t1[0]) + fabs(t1[1]) + fabs(t1[2]) + fabs(t2[0]) + fabs(t2[1]) + fabs(t2[2]));
+  for (int i = 60; i < kPreFloats; ++i) o[i] = 0.0f;
+}
+
+struct Pre {
+  float M3[9], M2[9], tv[3], m4[3], r2[3], tq, kz[3], M1[9], t1[3], M5[9], t2[3], eAxy, eBxy, eAz, eBz, tsum;
+};
+
+// The reference's exact I = (((d1 * (c @ Ki)) @ R1 + t1 + s) - t2) @ R2T @ K for one pixel, from the
+// raw camera block (only evaluated inside a guard band).
+struct CamPtrs {   // the pair's raw camera block (already offset to the pair)
+  const float *Ki, *R1, *R2T, *K, *t1, *t2;
+};
+__device__ __forceinline__ void exact_reprojection(const CamPtrs& cp, float xf, float yf, float d1, float s0, float s1,
+                                                float s2, float& I0, float& I1, float& I2) {
+  Cam c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    c.Ki[i] = cp.Ki[i];
+    c.R1[i] = cp.R1[i];
+    c.R2T[i] = cp.R2T[i];
+    c.K[i] = cp.K[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    c.t1[i] = cp.t1[i];
+    c.t2[i] = cp.t2[i];
+  }
+  float r0, r1, r2;
+  rowvec_mat3(xf, yf, 1.0f, c.Ki, r0, r1, r2);
+  const float pc0 = d1 * r0, pc1 = d1 * r1, pc2 = d1 * r2;
+  float P0, P1, P2;
+  rowvec_mat3(pc0, pc1, pc2, c.R1, P0, P1, P2);
+  P0 = P0 + c.t1[0];
+  P1 = P1 + c.t1[1];
+  P2 = P2 + c.t1[2];
+  const float A0 = (P0 + s0) - c.t2[0], A1 = (P1 + s1) - c.t2[1], A2 = (P2 + s2) - c.t2[2];
+  float Q0, Q1, Q2;
+  rowvec_mat3(A0, A1, A2, c.R2T, Q0, Q1, Q2);
+  rowvec_mat3(Q0, Q1, Q2, c.K, I0, I1, I2);
+}
+
+__device__ __forceinline__ float div_exact1(float a, float b, float y) {
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+__device__ __forceinline__ float sample_coord_x(float pix, float fl, float half, float rhalf, float maxv) {
+  float g = pix + fl;
+  g = div_exact1(g, half, rhalf);
+  g = g - 1.0f;
+  const float i = (g + 1.0f) * half;
+  return fminf(maxv, fmaxf(i, 0.0f));
+}
+
+struct RowConst {   // per image row: the y part of c @ M for the three composite matrices
+  float c3[3], c4, c1[3];
+};
+
+// One pixel, fast arithmetic + guard bands.  `k` = the pair's composite constants.
+template <bool GRADS, bool SHIPPED, int WW, int WH>
+__device__ __forceinline__ void pixel_fast(const WarpArgs& a, const Pre& k, const TileIO2<WW, WH>& io,
+                                           const CamPtrs& cp, float rhw, float rhh, const RowConst& rc, int y, int x, float d1,
+                                           float fx, float fy, float mk, float s0, float s1, float s2,
+                                           float acc[4], float& g_d1_out, float g_s_out[3]) {
+  const bool midas_mask = SHIPPED ? true : (a.midas_mask != 0);
+  const int disp_mode = SHIPPED ? 1 : a.disp_mode;
+  const bool loss_on_sf = SHIPPED ? false : (a.loss_on_sf != 0);
+  const float xf = (float)x, yf = (float)y;
+  // --- EXACT: sampling position, tap indices, bilinear weights
+  const float ix = sample_coord_x(xf, fx, a.half_w, rhw, a.wmax);
+  const float iy = sample_coord_x(yf, fy, a.half_h, rhh, a.hmax);
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const float ww = ix - x0f, we = 1.0f - ww;
+  const float wn = iy - y0f, ws = 1.0f - wn;
+  const float w_nw = ws * we, w_ne = ws * ww, w_sw = wn * we, w_se = wn * ww;
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const int lx = x0 - io.wx0, ly = y0 - io.wy0;
+  const bool inside = ((unsigned)lx < (unsigned)(WW - 1)) && ((unsigned)ly < (unsigned)(WH - 1));
+  const int cell = inside ? ly * WW + lx : 0;
+  float dnw, dne, dsw, dse;
+  {
+    const float* p = io.win + cell;
+    dnw = p[0];
+    dne = p[1];
+    dsw = p[WW];
+    dse = p[WW + 1];
+    if (!inside) {
+      DirectIO g{io.d2b, nullptr, io.W, 1.0f};
+      g.fetch(y0 * io.W + x0, x0, y0, (x0 + 1) < a.W, (y0 + 1) < a.H, dnw, dne, dsw, dse);
+    }
+  }
+  // --- frame-2 point warped to the pixel: sum_k a_k c_k with c_k = (x0+i, y0+j, 1)
+  const float a_nw = w_nw * dnw, a_ne = w_ne * dne, a_sw = w_sw * dsw, a_se = w_se * dse;
+  const float sE = a_ne + a_se, sS = a_sw + a_se, sA = (a_nw + a_ne) + sS;
+  const float vx = DVD_FMA(x0f, sA, sE), vy = DVD_FMA(y0f, sA, sS);
+  float W2z = DVD_FMA(vx, k.kz[0], DVD_FMA(vy, k.kz[1], sA * k.kz[2]));
+  bool w2_lt = W2z < 100.0f;
+  if (midas_mask && !(fabsf(W2z - 100.0f) > 1.0f)) {   // guard band (also catches NaN): the reference's sequence
+    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    const float zn0 = (x0f * k.kz[0] + y0f * k.kz[1]) + k.kz[2];
+    const float zn1 = (x1f * k.kz[0] + y0f * k.kz[1]) + k.kz[2];
+    const float zs0 = (x0f * k.kz[0] + y1f * k.kz[1]) + k.kz[2];
+    const float zs1 = (x1f * k.kz[0] + y1f * k.kz[1]) + k.kz[2];
+    const float w2e = bilinear(dnw * zn0, dne * zn1, dsw * zs0, dse * zs1, w_nw, w_ne, w_sw, w_se);
+    w2_lt = w2e < 100.0f;
+    W2z = w2e;
+  }
+  // --- reprojection of pixel 1 into image 2: I = d1 (c @ M3) + s @ M2 + tv
+  const float c30 = DVD_FMA(xf, k.M3[0], rc.c3[0]), c31 = DVD_FMA(xf, k.M3[1], rc.c3[1]),
+              c32 = DVD_FMA(xf, k.M3[2], rc.c3[2]);
+  const float c4 = DVD_FMA(xf, k.m4[0], rc.c4);
+  float I0 = DVD_FMA(d1, c30, DVD_FMA(s0, k.M2[0], DVD_FMA(s1, k.M2[3], DVD_FMA(s2, k.M2[6], k.tv[0]))));
+  float I1 = DVD_FMA(d1, c31, DVD_FMA(s0, k.M2[1], DVD_FMA(s1, k.M2[4], DVD_FMA(s2, k.M2[7], k.tv[1]))));
+  float I2 = DVD_FMA(d1, c32, DVD_FMA(s0, k.M2[2], DVD_FMA(s1, k.M2[5], DVD_FMA(s2, k.M2[8], k.tv[2]))));
+  const float Q2 = DVD_FMA(d1, c4, DVD_FMA(s0, k.r2[0], DVD_FMA(s1, k.r2[1], DVD_FMA(s2, k.r2[2], k.tq))));
+  float den = I2 + 1e-8f;
+  float rden = __builtin_amdgcn_rcpf(den);
+  bool behind = I2 < 1e-3f;
+  float u = I0 * rden, v = I1 * rden;
+  float ex = (u - xf) - fx, ey = (v - yf) - fy;
+  {
+    // guard bands: |I_fast - I_ref| <= E (see warp_prepare_kernel)
+    const float smag = (fabsf(s0) + fabsf(s1)) + (fabsf(s2) + k.tsum);
+    const float ad1 = fabsf(d1);
+    const float Exy = DVD_FMA(ad1, k.eAxy, smag * k.eBxy), Ez = DVD_FMA(ad1, k.eAz, smag * k.eBz);
+    const float gu = DVD_FMA(fmaxf(fabsf(u), fabsf(v)), Ez, Exy) * fabsf(rden) * 1.25f;
+    const bool sure_behind = I2 < 1e-3f - Ez, sure_front = I2 > 1e-3f + Ez;
+    const bool signs_ok = (fabsf(ex) > gu) && (fabsf(ey) > gu);
+    if (DVD_WARP3_SLOW && !(sure_behind || (sure_front && signs_ok))) {   // rare; NaNs land here too
+      exact_reprojection(cp, xf, yf, d1, s0, s1, s2, I0, I1, I2);
+      den = I2 + 1e-8f;
+      behind = I2 < 1e-3f;
+      const float yd = rcp_refined(den);
+      u = div_exact1(I0, den, yd);
+      v = div_exact1(I1, den, yd);
+      rden = yd;
+      ex = (u - xf) - fx;
+      ey = (v - yf) - fy;
+    }
+  }
+  if (behind) {   // the reference overwrites the projection by the pixel's own coordinates (zero gradient)
+    ex = (xf - xf) - fx;
+    ey = (yf - yf) - fy;
+    u = xf;
+    v = yf;
+  }
+  // --- sf_by_depth - sf = (sum_k a_k c_k) @ M5 + t2 - (d1 (c @ M1) + t1) - s
+  const float c10 = DVD_FMA(xf, k.M1[0], rc.c1[0]), c11 = DVD_FMA(xf, k.M1[1], rc.c1[1]),
+              c12 = DVD_FMA(xf, k.M1[2], rc.c1[2]);
+  const float f0 = DVD_FMA(vx, k.M5[0], DVD_FMA(vy, k.M5[3], DVD_FMA(sA, k.M5[6], k.t2[0]))) -
+                   (DVD_FMA(d1, c10, k.t1[0]) + s0);
+  const float f1 = DVD_FMA(vx, k.M5[1], DVD_FMA(vy, k.M5[4], DVD_FMA(sA, k.M5[7], k.t2[1]))) -
+                   (DVD_FMA(d1, c11, k.t1[1]) + s1);
+  const float f2 = DVD_FMA(vx, k.M5[2], DVD_FMA(vy, k.M5[5], DVD_FMA(sA, k.M5[8], k.t2[2]))) -
+                   (DVD_FMA(d1, c12, k.t1[2]) + s2);
+  // --- mask and per-pixel errors
+  float m = mk;
+  if (midas_mask) m = ((d1 < 100.0f) && w2_lt) ? m : 0.0f;   // mask_2 is {0,1}
+  const float flow_err = a.crit_l2 ? (ex * ex + ey * ey) : (fabsf(ex) + fabsf(ey));
+  float disp_err, rca = 0.0f, rcb = 0.0f, ediff = 0.0f;
+  if (disp_mode == 1) {
+    rca = __builtin_amdgcn_rcpf(fmaxf(Q2, 1e-3f));
+    rcb = __builtin_amdgcn_rcpf(fmaxf(W2z, 1e-3f));
+    ediff = rca - rcb;
+    disp_err = 100.0f * fabsf(ediff);
+  } else if (disp_mode == 2) {
+    const float ca = fmaxf(Q2, 1e-3f), cb = fmaxf(W2z, 1e-3f);
+    disp_err = fmaxf(ca, cb) * __builtin_amdgcn_rcpf(fminf(ca, cb)) - 1.0f;
+  } else {
+    disp_err = fabsf(Q2 - W2z);
+  }
+  const float sf_err = (fabsf(f0) + fabsf(f1)) + fabsf(f2);
+  acc[0] += m;
+  acc[1] = DVD_FMA(m, flow_err, acc[1]);
+  acc[2] = DVD_FMA(m, disp_err, acc[2]);
+  acc[3] = DVD_FMA(m, sf_err, acc[3]);
+  if (!GRADS) return;
+  // ------------------------------ backward (un-normalised), branch free ------------------
+  const float fm = behind ? 0.0f : a.flow_mul * m;
+  const float gu_ = a.crit_l2 ? fm * 2.0f * ex : signed_mag(fm, ex);
+  const float gv_ = a.crit_l2 ? fm * 2.0f * ey : signed_mag(fm, ey);
+  const float rd = behind ? 0.0f : rden;
+  const float gI0 = gu_ * rd, gI1 = gv_ * rd;
+  const float gI2 = -DVD_FMA(gu_, u, gv_ * v) * rd;
+  float gQ2 = 0.0f, uW2z = 0.0f, uG0 = 0.0f, uG1 = 0.0f, uG2 = 0.0f;
+  const float dm = a.disp_mul;
+  if (!loss_on_sf) {
+    if (disp_mode == 1) {
+      const float ue = signed_mag(m * 100.0f, ediff);
+      gQ2 = (Q2 >= 1e-3f) ? -(ue * dm) * (rca * rca) : 0.0f;
+      uW2z = (W2z >= 1e-3f) ? ue * (rcb * rcb) : 0.0f;
+    }   // !loss_on_sf implies --use_disp, i.e. disp_mode 1 (models/scene_flow_motion_field.py:310-319)
+  } else {
+    uG0 = signed_mag(m, f0);
+    uG1 = signed_mag(m, f1);
+    uG2 = signed_mag(m, f2);
+  }
+  g_s_out[0] = DVD_FMA(gI0, k.M2[0], DVD_FMA(gI1, k.M2[1], DVD_FMA(gI2, k.M2[2], DVD_FMA(gQ2, k.r2[0], -dm * uG0))));
+  g_s_out[1] = DVD_FMA(gI0, k.M2[3], DVD_FMA(gI1, k.M2[4], DVD_FMA(gI2, k.M2[5], DVD_FMA(gQ2, k.r2[1], -dm * uG1))));
+  g_s_out[2] = DVD_FMA(gI0, k.M2[6], DVD_FMA(gI1, k.M2[7], DVD_FMA(gI2, k.M2[8], DVD_FMA(gQ2, k.r2[2], -dm * uG2))));
+  float gd = DVD_FMA(gI0, c30, DVD_FMA(gI1, c31, DVD_FMA(gI2, c32, gQ2 * c4)));
+  if (loss_on_sf) gd = gd - dm * DVD_FMA(uG0, c10, DVD_FMA(uG1, c11, uG2 * c12));
+  g_d1_out = gd;
+  if (a.ablate & 1) return;
+  // depth_2 taps (units of disp_mul): d/d(a_k) = H . c_k,  H = uG @ M5^T + uW2z * kz
+  float Hx = uW2z * k.kz[0], Hy = uW2z * k.kz[1], Hz = uW2z * k.kz[2];
+  if (loss_on_sf) {
+    Hx = DVD_FMA(uG0, k.M5[0], DVD_FMA(uG1, k.M5[1], DVD_FMA(uG2, k.M5[2], Hx)));
+    Hy = DVD_FMA(uG0, k.M5[3], DVD_FMA(uG1, k.M5[4], DVD_FMA(uG2, k.M5[5], Hy)));
+    Hz = DVD_FMA(uG0, k.M5[6], DVD_FMA(uG1, k.M5[7], DVD_FMA(uG2, k.M5[8], Hz)));
+  }
+  const float hb = DVD_FMA(x0f, Hx, DVD_FMA(y0f, Hy, Hz));
+  const float hbx = hb + Hx;
+  const float tn0 = w_nw * hb, tn1 = w_ne * hbx, ts0 = w_sw * (hb + Hy), ts1 = w_se * (hbx + Hy);
+  const float big = fmaxf(fmaxf(fabsf(tn0), fabsf(tn1)), fmaxf(fabsf(ts0), fabsf(ts1)));
+  const bool fast = inside && (big < kFixMax);
+  // out-of-image taps carry an exactly zero weight, and their window cells are never read back
+  unsigned long long* p = io.accw + cell;
+  atomicAdd(p, to_fixed(fast ? tn0 : 0.0f));
+  atomicAdd(p + 1, to_fixed(fast ? tn1 : 0.0f));
+  atomicAdd(p + WW, to_fixed(fast ? ts0 : 0.0f));
+  atomicAdd(p + WW + 1, to_fixed(fast ? ts1 : 0.0f));
+  if (!fast) {   // rare: list of (index, value) applied after the slab combine
+    const int o_n = y0 * io.W + x0;
+    const bool in_e = (x0 + 1) < a.W, in_s = (y0 + 1) < a.H;
+    io.spill(o_n, tn0);
+    if (in_e) io.spill(o_n + 1, tn1);
+    if (in_s) io.spill(o_n + io.W, ts0);
+    if (in_e && in_s) io.spill(o_n + io.W + 1, ts1);
+  }
+}
+
+template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED>
+__global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_loss_tiled3_kernel(
+    const WarpArgs a, const TileArgs ta, const float* __restrict__ pre) {
+  constexpr int WW = TW + 2 * R + 4;
+  constexpr int WH = TH + 2 * R + 1;
+  constexpr int QW = TW / 4;
+  static_assert(R % 4 == 0 && TW % 4 == 0, "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);
+  float* win = smem + 2 * WW * WH;
+
+  const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int tiles = ta.ntx * ta.nty;
+  const int b = logical / tiles;
+  const int t = logical - b * tiles;
+  const int tj = t / ta.ntx, ti = t - tj * ta.ntx;
+  const int tx0 = ti * TW, ty0 = tj * TH;
+  const int wx0 = tx0 - R, wy0 = ty0 - R;
+  // composite camera constants of this pair: wave-uniform, held in VGPRs (60 scalars next to the
+  // kernel's pointers do not fit the SGPR file; as VALU operands VGPRs cost nothing extra)
+  Pre k;
+  {
+    const float* src = pre + (size_t)b * kPreFloats;
+    float t_[60];
+#pragma unroll
+    for (int i = 0; i < 60; ++i) {
+      t_[i] = src[i];
+      if ((DVD_WARP3_PIN >> (i / 3)) & 1) asm volatile("" : "+v"(t_[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      k.M3[i] = t_[kpM3 + i];
+      k.M2[i] = t_[kpM2 + i];
+      k.M1[i] = t_[kpM1 + i];
+      k.M5[i] = t_[kpM5 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      k.tv[i] = t_[kpTV + i];
+      k.m4[i] = t_[kpM4 + i];
+      k.r2[i] = t_[kpR2 + i];
+      k.kz[i] = t_[kpKZ + i];
+      k.t1[i] = t_[kpT1 + i];
+      k.t2[i] = t_[kpT2 + i];
+    }
+    k.tq = t_[kpTQ];
+    k.eAxy = t_[kpEAxy];
+    k.eBxy = t_[kpEBxy];
+    k.eAz = t_[kpEAz];
+    k.eBz = t_[kpEBz];
+    k.tsum = t_[kpTsum];
+  }
+  const CamPtrs cp{a.Ki + b * 9, a.R1 + b * 9, a.R2T + b * 9, a.K + b * 9, a.t1 + b * 3, a.t2 + b * 3};
+  const float* d2b = a.d2 + (size_t)b * a.HW;
+
+  // ---- phase 0: fill the depth_2 window, clear the accumulator
+  const bool w4 = (a.W & 3) == 0;
+  for (int i = threadIdx.x; i < (WW / 4) * WH; i += NT) {
+    const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
+    const int iy = wy0 + wy, ixx = wx0 + wx;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < a.H) {
+      if (w4) {
+        if (ixx >= 0 && ixx < a.W) v = *reinterpret_cast<const float4*>(d2b + (size_t)iy * a.W + ixx);
+      } else {
+        const float* row = d2b + (size_t)iy * a.W;
+        if (ixx >= 0 && ixx < a.W) v.x = row[ixx];
+        if (ixx + 1 >= 0 && ixx + 1 < a.W) v.y = row[ixx + 1];
+        if (ixx + 2 >= 0 && ixx + 2 < a.W) v.z = row[ixx + 2];
+        if (ixx + 3 >= 0 && ixx + 3 < a.W) v.w = row[ixx + 3];
+      }
+    }
+    *reinterpret_cast<float4*>(win + wy * WW + wx) = v;
+    if (GRADS) {
+      uint4* z = reinterpret_cast<uint4*>(accw + wy * WW + wx);
+      z[0] = make_uint4(0u, 0u, 0u, 0u);
+      z[1] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  __syncthreads();
+
+  const TileIO2<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, a.disp_mul, ta.ovf};
+  const float rhw = rcp_refined(a.half_w), rhh = rcp_refined(a.half_h);
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const float* d1b = a.d1 + (size_t)b * a.HW;
+  const float* mkb = a.mask + (size_t)b * a.HW;
+  const float* flb = a.flow + 2 * (size_t)b * a.HW;
+  const float* sf0b = a.sf + (size_t)b * 3 * a.HW;
+  const float* sf1b = sf0b + a.HW;
+  const float* sf2b = sf1b + a.HW;
+  float* gd1b = a.g_d1 + (size_t)b * a.HW;
+  float* gs0b = a.g_sf + (size_t)b * 3 * a.HW;
+  float* gs1b = gs0b + a.HW;
+  float* gs2b = gs1b + a.HW;
+  // ---- phase 1: the tile's pixels, 4 per thread per step
+  for (int q = threadIdx.x; q < QW * TH; q += NT) {
+    const int ly = q / QW, lx = (q - ly * QW) * 4;
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y >= a.H || x >= a.W) continue;
+    const unsigned p0 = (unsigned)(y * a.W + x);
+    float d1[4], mk[4], fl[8], s0[4], s1[4], s2[4];
+    const int nvalid = (a.W - x) < 4 ? (a.W - x) : 4;
+    if (w4) {
+      const unsigned o4 = p0 * 4u;
+      *reinterpret_cast<float4*>(d1) = ld_off<float4>(d1b, o4);
+      *reinterpret_cast<float4*>(mk) = ld_off<float4>(mkb, o4);
+      *reinterpret_cast<float4*>(fl) = ld_off<float4>(flb, o4 * 2u);
+      *reinterpret_cast<float4*>(fl + 4) = ld_off<float4>(flb, o4 * 2u + 16u);
+      *reinterpret_cast<float4*>(s0) = ld_off<float4>(sf0b, o4);
+      *reinterpret_cast<float4*>(s1) = ld_off<float4>(sf1b, o4);
+      *reinterpret_cast<float4*>(s2) = ld_off<float4>(sf2b, o4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = i < nvalid;
+        d1[i] = ok ? d1b[p0 + i] : 1.0f;
+        mk[i] = ok ? mkb[p0 + i] : 0.0f;
+        fl[2 * i] = ok ? flb[2 * (size_t)(p0 + i)] : 0.0f;
+        fl[2 * i + 1] = ok ? flb[2 * (size_t)(p0 + i) + 1] : 0.0f;
+        s0[i] = ok ? sf0b[p0 + i] : 0.0f;
+        s1[i] = ok ? sf1b[p0 + i] : 0.0f;
+        s2[i] = ok ? sf2b[p0 + i] : 0.0f;
+      }
+    }
+    RowConst rc;
+    {
+      const float yf = (float)y;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        rc.c3[j] = DVD_FMA(yf, k.M3[3 + j], k.M3[6 + j]);
+        rc.c1[j] = DVD_FMA(yf, k.M1[3 + j], k.M1[6 + j]);
+      }
+      rc.c4 = DVD_FMA(yf, k.m4[1], k.m4[2]);
+    }
+    float gd1[4], gs[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gd1[i] = 0.0f;
+      gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
+      if (i < nvalid)
+        pixel_fast<GRADS, SHIPPED, WW, WH>(a, k, io, cp, rhw, rhh, rc, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i],
+                                           s0[i], s1[i], s2[i], acc, gd1[i], gs[i]);
+    }
+    if (GRADS && !(a.ablate & 2)) {
+      if (w4) {
+        const unsigned o4 = p0 * 4u;
+        st_off<float4>(gd1b, o4, make_float4(gd1[0], gd1[1], gd1[2], gd1[3]));
+        st_off<float4>(gs0b, o4, make_float4(gs[0][0], gs[1][0], gs[2][0], gs[3][0]));
+        st_off<float4>(gs1b, o4, make_float4(gs[0][1], gs[1][1], gs[2][1], gs[3][1]));
+        st_off<float4>(gs2b, o4, make_float4(gs[0][2], gs[1][2], gs[2][2], gs[3][2]));
+      } else {
+        for (int i = 0; i < nvalid; ++i) {
+          gd1b[p0 + i] = gd1[i];
+          gs0b[p0 + i] = gs[i][0];
+          gs1b[p0 + i] = gs[i][1];
+          gs2b[p0 + i] = gs[i][2];
+        }
+      }
+    }
+  }
+  // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
+  __syncthreads();
+  if (GRADS && !(a.ablate & 4)) {
+    float* slab = ta.slabs + (size_t)logical * (WW * WH);
+    const float back = kFixInv * a.disp_mul;
+    for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
+      const longlong2 lo = reinterpret_cast<const longlong2*>(accw)[2 * i];
+      const longlong2 hi = reinterpret_cast<const longlong2*>(accw)[2 * i + 1];
+      reinterpret_cast<float4*>(slab)[i] =
+          make_float4((float)lo.x * back, (float)lo.y * back, (float)hi.x * back, (float)hi.y * back);
+    }
+  }
+  float* red = win;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const float v = wave_sum(acc[kk]);
+    if (lane == 0) red[wave * 4 + kk] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.0f;
+    for (int w = 0; w < NT / 64; ++w) v += red[w * 4 + threadIdx.x];
+    a.partial[(size_t)logical * 4 + threadIdx.x] = v;
+  }
+}
+
 // g_depth_2[b,y,x] = sum over the tiles whose window covers (x,y), fixed order.
 template <int TW, int TH, int R>
 __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ slabs,
@@ -734,7 +1809,7 @@ constexpr int kR = 8;  // LDS window halo: taps within |flow| <= 8 px stay on ch
 struct TileShape {
   int tw, th, nt;
 };
-static const TileShape kShapes[] = {{96, 32, 512}, {64, 48, 512}, {64, 32, 512}, {64, 32, 256}};
+static const TileShape kShapes[] = {{96, 32, 512}, {64, 48, 512}, {64, 32, 512}, {64, 32, 256}, {96, 32, 384}};
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
 static int env_int(const char* name, int dflt) {
@@ -761,7 +1836,7 @@ static int choose_shape(int H, int W) {
 
 struct Plan {
   int shape, ntx, nty, ww, wh;
-  size_t n_partials, off_count, off_slabs, off_ovf, ovf_cap, total;
+  size_t n_partials, off_count, off_pre, off_slabs, off_ovf, ovf_cap, total;
 };
 
 static Plan make_plan(int B, int H, int W) {
@@ -779,6 +1854,9 @@ static Plan make_plan(int B, int H, int W) {
   off = (off + 255) & ~(size_t)255;
   p.off_count = off;
   off += 256;
+  p.off_pre = off;
+  off += (size_t)B * kPreFloats * sizeof(float);
+  off = (off + 255) & ~(size_t)255;
   p.off_slabs = off;
   off += tiles * (size_t)p.ww * p.wh * sizeof(float);
   off = (off + 255) & ~(size_t)255;
@@ -803,9 +1881,40 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
   if (grads) DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, sizeof(unsigned), stream));
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
+  const int gen = env_int("DVD_WARP_V1", 0) ? 1 : env_int("DVD_WARP_GEN", 3);
+  const bool v1 = gen == 1;
+  if (gen == 3) {
+    float* pre = reinterpret_cast<float*>(ws + p.off_pre);
+    hipLaunchKernelGGL(warp_prepare_kernel, dim3((a.B + 63) / 64), dim3(64), 0, stream, a, pre);
+    DVD_LAUNCH_OK();
+#define DVD_TILED3_LAUNCH(G, S)                                                                           \
+  do {                                                                                                    \
+    auto k3 = warp_loss_tiled3_kernel<TW, TH, kR, NT, G, S>;                                              \
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3),                                     \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+    hipLaunchKernelGGL(k3, dim3(nblocks), dim3(NT), lds, stream, a, ta, pre);                             \
+  } while (0)
+    if (grads) {
+      if (shipped)
+        DVD_TILED3_LAUNCH(true, true);
+      else
+        DVD_TILED3_LAUNCH(true, false);
+    } else {
+      if (shipped)
+        DVD_TILED3_LAUNCH(false, true);
+      else
+        DVD_TILED3_LAUNCH(false, false);
+    }
+#undef DVD_TILED3_LAUNCH
+  } else {
+  constexpr bool kFullOk = ((TW / 2) * TH) % NT == 0;
+  const bool full = kFullOk && (a.W % TW == 0) && (a.H % TH == 0) && !env_int("DVD_WARP_NOFULL", 0);
 #define DVD_TILED_LAUNCH(G, S)                                                                            \
   do {                                                                                                    \
-    auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, G, S>;                                                \
+    auto k = v1 ? warp_loss_tiled_kernel<TW, TH, kR, NT, G, S>                                            \
+                : ((a.W & 1) ? warp_loss_tiled2_kernel<TW, TH, kR, NT, G, S, false, false>                \
+                   : (full ? warp_loss_tiled2_kernel<TW, TH, kR, NT, G, S, true, kFullOk>                  \
+                           : warp_loss_tiled2_kernel<TW, TH, kR, NT, G, S, true, false>));                \
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                      \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);                                   \
@@ -822,6 +1931,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
       DVD_TILED_LAUNCH(false, false);
   }
 #undef DVD_TILED_LAUNCH
+  }
   DVD_LAUNCH_OK();
   if (grads) {
     const int qpr = (a.W + 3) / 4;
@@ -927,6 +2037,8 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
       return launch_tiled<64, 48, 512>(a, plan, ws, grads, stream);
     case 2:
       return launch_tiled<64, 32, 512>(a, plan, ws, grads, stream);
+    case 4:
+      return launch_tiled<96, 32, 384>(a, plan, ws, grads, stream);
     default:
       return launch_tiled<64, 32, 256>(a, plan, ws, grads, stream);
   }

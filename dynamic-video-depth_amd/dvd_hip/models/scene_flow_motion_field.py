@@ -59,6 +59,9 @@ class Model(NetInterface):
         # MI355X-specific knobs (new; defaults need no tuning)
         parser.add_argument('--mlp_stash_gb', type=float, default=48.0,
                             help='HBM budget for the scene-flow MLP activation stashes; sets pairs per chunk')
+        parser.add_argument('--mlp_whole_batch_gb', type=float, default=160.0,
+                            help='HBM ceiling for keeping the forward stashes of the whole batch alive so that the '
+                                 'warp+loss kernel runs as ONE launch (falls back to one launch per chunk)')
         parser.add_argument('--depth_chunk', type=int, default=8, help='images per depth-net forward/backward chunk')
         return parser, set()
 
@@ -155,6 +158,12 @@ class Model(NetInterface):
         per_pair = self._mlp.stash_floats(HW) * 4 * max(steps, 2 if with_reg else 1) + self._mlp.gstash_floats(HW) * 4
         return int(max(1, min(B, (self.opt.mlp_stash_gb * 2 ** 30) // per_pair)))
 
+    def _whole_batch_fits(self, B, Bc, HW, steps, with_reg):
+        """Forward stashes of all B pairs + the backward / regulariser scratch of one chunk."""
+        stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
+        need = B * steps * stash + Bc * (gstash + (2 * stash if with_reg else 0))
+        return need <= float(getattr(self.opt, 'mlp_whole_batch_gb', 160.0)) * 2 ** 30
+
     # ------------------------------------------------------------------------------------
     def _train_on_batch(self, epoch, batch_ind, batch):
         opt = self.opt
@@ -204,60 +213,102 @@ class Model(NetInterface):
         use_mseg = bool(opt.use_motion_seg)
         if use_mseg:
             raise NotImplementedError('--use_motion_seg is not wired into the fused step yet')
-        for b0 in range(0, B, Bc):
-            b1 = min(B, b0 + Bc)
-            nb = b1 - b0
-            n_pix = nb * HW
-            cams = {kk: getattr(inp, kk)[b0:b1] for kk in CAM_KEYS}
-            d1c, d2c = depth_1[b0:b1], depth_2[b0:b1]
+        cfg_all = ops.warp_cfg(B, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode,
+                               loss_on_sf=not opt.use_disp, flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
+        # The MLP activation stashes bound how many pairs go through the MLP kernels at once
+        # (Bc).  If the forward stashes of the WHOLE batch fit the budget next to one chunk of
+        # backward scratch, the warp+loss kernel runs once over all pairs (one launch of
+        # B*H*W pixels fills the chip far better than B/Bc smaller ones); otherwise every
+        # chunk gets its own warp+loss launch.
+        whole = Bc < B and self._whole_batch_fits(B, Bc, HW, steps, do_reg)
+        chunks = [(b0, min(B, b0 + Bc)) for b0 in range(0, B, Bc)]
+        P1_all = ops.unproject(depth_1, inp.R_1, inp.t_1, inp.K_inv, planar=True)
+        sf_all = torch.zeros(B, 3, H, W, device=dev)
+        g_sf_all = torch.empty_like(sf_all)
+
+        def cams_of(b0, b1):
+            return {kk: getattr(inp, kk)[b0:b1] for kk in CAM_KEYS}
+
+        def mlp_forward_chunk(b0, b1):
+            """Euler integration of the scene flow over `steps` frames (:360-367)."""
             ts = inp.time_stamp_1[b0:b1] if opt.time_dependent else None
-            P1 = ops.unproject(d1c, cams['R_1'], cams['t_1'], cams['K_inv'], planar=True)
-            # Euler integration of the scene flow over `steps` frames (:360-367)
-            sf_acc = torch.zeros(nb, 3, H, W, device=dev)
-            stashes, p_cur = [], P1
+            n_pix = (b1 - b0) * HW
+            stashes, p_cur = [], P1_all[b0:b1]
             for i in range(steps):
                 st = mlp.new_stash(n_pix)
-                p_next = torch.empty_like(P1) if i + 1 < steps else None
-                mlp.forward(p_cur, ts, t_offset=i * time_step, out_scale=inv_div, p_next=p_next, acc=sf_acc, stash=st)
+                p_next = torch.empty_like(p_cur) if i + 1 < steps else None
+                mlp.forward(p_cur, ts, t_offset=i * time_step, out_scale=inv_div, p_next=p_next, acc=sf_all[b0:b1],
+                            stash=st)
                 stashes.append(st)
                 p_cur = p_next
-            cfg = ops.warp_cfg(nb, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode,
-                               loss_on_sf=not opt.use_disp, flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
+            return stashes
+
+        def warp(b0, b1):
+            cfg = cfg_all if (b0, b1) == (0, B) else ops.warp_cfg(
+                b1 - b0, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode, loss_on_sf=not opt.use_disp,
+                flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
             csum = torch.empty(4, device=dev)
-            g_sf = torch.empty_like(sf_acc)
-            ops.warp_loss_fused(cfg, d1c, d2c, inp.flow_1_2[b0:b1], mask_2[b0:b1], sf_acc, cams,
-                                out=(csum, g_d1_main[b0:b1], g_d2_main[b0:b1], g_sf))
+            ops.warp_loss_fused(cfg, depth_1[b0:b1], depth_2[b0:b1], inp.flow_1_2[b0:b1], mask_2[b0:b1],
+                                sf_all[b0:b1], cams_of(b0, b1),
+                                out=(csum, g_d1_main[b0:b1], g_d2_main[b0:b1], g_sf_all[b0:b1]))
             sums[:4] += csum
-            # backward through the Euler chain: g_p_i = g_p_{i+1} + J_i^T (g_acc + g_p_{i+1})
-            gst = mlp.new_gstash(n_pix)
+
+        def mlp_backward_chunk(b0, b1, stashes, gst):
+            """Backward through the Euler chain: g_p_i = g_p_{i+1} + J_i^T (g_acc + g_p_{i+1})."""
+            nb, n_pix = b1 - b0, (b1 - b0) * HW
+            cams = cams_of(b0, b1)
             g_p = None
             for i in reversed(range(steps)):
-                g_new = torch.empty_like(P1)
-                mlp.backward_dx(stashes[i], inv_div, g_sf, g_new, gst, gW_main[5], gb_main[5], (nb, H, W),
+                g_new = torch.empty_like(P1_all[b0:b1])
+                mlp.backward_dx(stashes[i], inv_div, g_sf_all[b0:b1], g_new, gst, gW_main[5], gb_main[5], (nb, H, W),
                                 g_out2=g_p, g_p_add=g_p)
                 mlp.backward_dw(stashes[i], gst, n_pix, gW_main[:5], gb_main[:5])
                 g_p = g_new
             ops.unproject_backward(g_p, True, cams['R_1'], cams['K_inv'], out=g_d1_main[b0:b1], accumulate=True)
-            del stashes
-            if do_reg:       # acceleration regulariser (:326-344), P1 un-detached
-                sa, sb = mlp.new_stash(n_pix), mlp.new_stash(n_pix)
-                sf0, sf1, q = torch.empty_like(P1), torch.empty_like(P1), torch.empty_like(P1)
-                mlp.forward(P1, ts, 0.0, inv_div, sf_out=sf0, p_next=q, stash=sa)
-                mlp.forward(q, ts, time_step, inv_div, sf_out=sf1, stash=sb)
-                g1 = torch.empty_like(P1)
-                ops.acc_reg(sf0, sf1, reg_coef, g1, sums[4:5], accumulate=True)
-                g_q = torch.empty_like(P1)
-                mlp.backward_dx(sb, inv_div, g1, g_q, gst, gW_reg[5], gb_reg[5], (nb, H, W))
-                mlp.backward_dw(sb, gst, n_pix, gW_reg[:5], gb_reg[:5])
-                g_P = torch.empty_like(P1)
-                mlp.backward_dx(sa, inv_div, g1, g_P, gst, gW_reg[5], gb_reg[5], (nb, H, W), gscale=-1.0, g_out2=g_q,
-                                g_p_add=g_q)
-                mlp.backward_dw(sa, gst, n_pix, gW_reg[:5], gb_reg[:5])
-                ops.unproject_backward(g_P, True, cams['R_1'], cams['K_inv'], out=g_d1_reg[b0:b1])
+
+        def reg_chunk(b0, b1, gst):
+            """Acceleration regulariser (:326-344), P1 un-detached."""
+            nb, n_pix = b1 - b0, (b1 - b0) * HW
+            cams = cams_of(b0, b1)
+            ts = inp.time_stamp_1[b0:b1] if opt.time_dependent else None
+            P1 = P1_all[b0:b1]
+            sa, sb = mlp.new_stash(n_pix), mlp.new_stash(n_pix)
+            sf0, sf1, q = torch.empty_like(P1), torch.empty_like(P1), torch.empty_like(P1)
+            mlp.forward(P1, ts, 0.0, inv_div, sf_out=sf0, p_next=q, stash=sa)
+            mlp.forward(q, ts, time_step, inv_div, sf_out=sf1, stash=sb)
+            g1 = torch.empty_like(P1)
+            ops.acc_reg(sf0, sf1, reg_coef, g1, sums[4:5], accumulate=True)
+            g_q = torch.empty_like(P1)
+            mlp.backward_dx(sb, inv_div, g1, g_q, gst, gW_reg[5], gb_reg[5], (nb, H, W))
+            mlp.backward_dw(sb, gst, n_pix, gW_reg[:5], gb_reg[:5])
+            g_P = torch.empty_like(P1)
+            mlp.backward_dx(sa, inv_div, g1, g_P, gst, gW_reg[5], gb_reg[5], (nb, H, W), gscale=-1.0, g_out2=g_q,
+                            g_p_add=g_q)
+            mlp.backward_dw(sa, gst, n_pix, gW_reg[:5], gb_reg[:5])
+            ops.unproject_backward(g_P, True, cams['R_1'], cams['K_inv'], out=g_d1_reg[b0:b1])
+
+        gst = mlp.new_gstash(min(Bc, B) * HW)
+        if whole or Bc >= B:
+            kept = [mlp_forward_chunk(b0, b1) for b0, b1 in chunks]
+            warp(0, B)
+            for (b0, b1), st in zip(chunks, kept):
+                mlp_backward_chunk(b0, b1, st, gst)
+                del st[:]
+            del kept
+            if do_reg:
+                for b0, b1 in chunks:
+                    reg_chunk(b0, b1, gst)
+        else:
+            for b0, b1 in chunks:
+                st = mlp_forward_chunk(b0, b1)
+                warp(b0, b1)
+                mlp_backward_chunk(b0, b1, st, gst)
+                del st
+                if do_reg:
+                    reg_chunk(b0, b1, gst)
+        del gst
         # the batch-global normaliser: all-reduce the loss sums first (SURVEY.md section 8e)
         parallel.all_reduce_sum_(sums)
-        cfg_all = ops.warp_cfg(B, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode,
-                               loss_on_sf=not opt.use_disp, flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
         scalars = ops.loss_finalize(cfg_all, sums)
         inv = scalars[0:1]
         # scene-flow MLP gradient = inv * main + reg   (flat buffers; one all-reduce)

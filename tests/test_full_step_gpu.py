@@ -97,11 +97,14 @@ def test_two_steps_run_and_change_the_loss():
     assert model._flat_sf.step_count == 2 and model._flat_depth.step_count == 2
 
 
-def test_pair_chunking_is_invisible():
-    """A stash budget that forces one pair per chunk gives the same step."""
+@pytest.mark.parametrize('whole_gb', [160.0, 0.0])
+def test_pair_chunking_is_invisible(whole_gb):
+    """A stash budget that forces one pair per MLP chunk gives the same step, both when the
+    warp+loss kernel still runs once over the whole batch (forward stashes of all chunks kept
+    alive) and when it runs once per chunk."""
     gd = helpers.load_golden('fullstep_hourglass_b2_32x48_train')
     m1, _, batch = _build(gd)
-    m2, _, _ = _build(gd, mlp_stash_gb=1e-6, depth_chunk=1)
+    m2, _, _ = _build(gd, mlp_stash_gb=1e-6, depth_chunk=1, mlp_whole_batch_gb=whole_gb)
     a = m1._train_on_batch(6, 0, helpers.loader_batch(batch))
     b = m2._train_on_batch(6, 0, helpers.loader_batch({k: v.clone() if torch.is_tensor(v) else v for k, v in batch.items()}))
     for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):

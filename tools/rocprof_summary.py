@@ -29,6 +29,6 @@ def summarise(db):
 
 if __name__ == '__main__':
     for pat in sys.argv[1:]:
-        for db in sorted(glob.glob(pat)):
+        for db in sorted(set(glob.glob(pat, recursive=True))):
             print('# ' + db)
             print(summarise(db))
