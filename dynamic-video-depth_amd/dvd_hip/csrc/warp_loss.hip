@@ -631,45 +631,12 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
 }
 
 // ---------------------------------------------------------------------------
-// Tiled variant, second generation (the production path; DVD_WARP_V1=1 selects the kernel above).
-//
-// The first tiled kernel issues ~375 VALU + ~250 SALU instructions per pixel and runs VALU-
-// and latency-bound (233 us at 48x384x672, ~3.2 TB/s of real traffic).  This one keeps the
-// same data flow (LDS depth_2 window + Q31.32 LDS accumulator window + slab combine) and
-// the same rounding sequence, but
-//   * a thread works on TWO horizontally adjacent pixels held in float2 vectors, so the
-//     multiply/add/fma bulk becomes v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (two pixels
-//     per instruction, IEEE rounding per component, so EXACT results are unchanged);
-//   * IEEE divisions are evaluated with the unscaled form of the hardware division
-//     sequence (rcp, one Newton step on the reciprocal, two fma corrections of the
-//     quotient: exactly what the compiler emits between v_div_scale and v_div_fixup, whose
-//     scaling is the identity for the operand ranges here); the reciprocal of the constant
-//     (W-1)/2, (H-1)/2 is hoisted and the one of I.z is shared between u and v;
-//   * every data-dependent branch of the per-pixel code is a select; the only divergent
-//     paths left are the two rare ones (tap outside the LDS window, fixed-point overflow);
-//   * the tile's inputs for ALL of a thread's pixels are requested before the first pixel
-//     is evaluated (the loop is fully unrolled; 14 VGPRs per pixel pair in flight).
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef DVD_WARP_PREFETCH
-#define DVD_WARP_PREFETCH 2
-#endif
-// Scheduling fence between the sections of pixel2(): without it the scheduler interleaves
-// the sections for ILP and the live set of the two-pixel arithmetic overflows 128 VGPRs.
-#ifndef DVD_WARP_FENCE
-#define DVD_WARP_FENCE 1
-#endif
-#if DVD_WARP_FENCE
-#define DVD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define DVD_SCHED_FENCE() ((void)0)
-#endif
-#ifndef DVD_WARP_PIN
-#define DVD_WARP_PIN 15
-#endif
-
-__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f vsplat(float s) { return (v2f){s, s}; }
+// Helpers shared by the tiled kernels: unscaled exact division, fixed-point conversion,
+// branch-free sign, uniform-base addressing.
+// IEEE division is evaluated with the unscaled form of the hardware division sequence (rcp, one
+// Newton step on the reciprocal, two fma corrections of the quotient: exactly what the compiler
+// emits between v_div_scale and v_div_fixup, whose scaling is the identity for the operand
+// ranges here), so the reciprocal of a loop-invariant divisor is computed once.
 
 // reciprocal refined as in the f32 division expansion: y1 = y0 + y0*(1 - b*y0)
 __device__ __forceinline__ float rcp_refined(float b) {
@@ -677,39 +644,10 @@ __device__ __forceinline__ float rcp_refined(float b) {
   const float e = __builtin_fmaf(-b, y0, 1.0f);
   return __builtin_fmaf(e, y0, y0);
 }
-// a / b given y = rcp_refined(b): q0 = a*y, two residual corrections (correctly rounded
-// whenever the IEEE sequence needs no operand scaling, i.e. for normal-range b and a/b).
-__device__ __forceinline__ v2f div_exact(v2f a, v2f b, v2f y) {
-  v2f q = a * y;
-  v2f r = vfma(-b, q, a);
-  q = vfma(r, y, q);
-  r = vfma(-b, q, a);
-  return vfma(r, y, q);
-}
-__device__ __forceinline__ v2f sample_coord2(v2f pix, v2f fl, float half, float rhalf, float maxv) {
-  v2f g = pix + fl;
-  g = div_exact(g, vsplat(half), vsplat(rhalf));
-  g = g - 1.0f;
-  const v2f i = (g + 1.0f) * half;
-  return (v2f){fminf(maxv, fmaxf(i.x, 0.0f)), fminf(maxv, fmaxf(i.y, 0.0f))};
-}
-__device__ __forceinline__ void rowvec_mat3v(v2f v0, v2f v1, v2f v2, const float* __restrict__ M, v2f& o0,
-                                             v2f& o1, v2f& o2) {
-  o0 = (v0 * M[0] + v1 * M[3]) + v2 * M[6];
-  o1 = (v0 * M[1] + v1 * M[4]) + v2 * M[7];
-  o2 = (v0 * M[2] + v1 * M[5]) + v2 * M[8];
-}
-__device__ __forceinline__ v2f bilinear2(v2f vnw, v2f vne, v2f vsw, v2f vse, v2f wnw, v2f wne, v2f wsw, v2f wse) {
-  v2f r = vnw * wnw;
-  r = vfma(vne, wne, r);
-  r = vfma(vsw, wsw, r);
-  return vfma(vse, wse, r);
-}
 // mag * sign(x), 0 when x == 0 (v_bfi + select)
 __device__ __forceinline__ float signed_mag(float mag, float x) {
   return (x == 0.0f) ? 0.0f : __builtin_copysignf(mag, x);
 }
-__device__ __forceinline__ v2f vabs(v2f a) { return (v2f){fabsf(a.x), fabsf(a.y)}; }
 
 // uniform base + 32-bit per-lane BYTE offset: lets the backend use the saddr+voffset addressing
 // form (no 64-bit VALU address arithmetic, one VGPR of address per lane)
@@ -745,433 +683,6 @@ struct TileIO2 {
     }
   }
 };
-
-// Camera block of the tile's pair in LDS (wave-uniform ds_read at the point of use: 51 scalars
-// do not fit the SGPR file next to the kernel's pointers, and as VGPR residents they push the
-// two-pixel arithmetic into scratch).
-constexpr int kCamKi = 0, kCamR1 = 9, kCamR2 = 18, kCamR2T = 27, kCamK = 36, kCamT1 = 45, kCamT2 = 48, kCamFloats = 52;
-
-// Two pixels (x, x+1) of row y.  Same arithmetic as pixel<>() above, component-wise.
-// `mid()` is invoked once between the forward and the backward half: the kernel issues the
-// next pair's global loads there, when the forward-only values have died.
-template <bool GRADS, bool SHIPPED, int WW, int WH, class Mid>
-__device__ __forceinline__ void pixel2(const WarpArgs& a, const float* __restrict__ cs, const TileIO2<WW, WH>& io, float rhw,
-                                       float rhh, int y, int x, v2f d1, v2f fx, v2f fy, v2f mk, v2f s0, v2f s1,
-                                       v2f s2, float acc[4], v2f& g_d1_out, v2f g_s_out[3], Mid&& mid) {
-  const bool midas_mask = SHIPPED ? true : (a.midas_mask != 0);
-  const int disp_mode = SHIPPED ? 1 : a.disp_mode;
-  const bool loss_on_sf = SHIPPED ? false : (a.loss_on_sf != 0);
-  const v2f xf = (v2f){(float)x, (float)(x + 1)};
-  const v2f yf = vsplat((float)y);
-  // --- EXACT: ray, camera-1 point, world point
-  v2f r0, r1, r2;
-  rowvec_mat3v(xf, yf, vsplat(1.0f), cs + kCamKi, r0, r1, r2);
-  const v2f pc0 = d1 * r0, pc1 = d1 * r1, pc2 = d1 * r2;
-  v2f P0, P1, P2;
-  rowvec_mat3v(pc0, pc1, pc2, cs + kCamR1, P0, P1, P2);
-  P0 = P0 + cs[kCamT1 + 0];
-  P1 = P1 + cs[kCamT1 + 1];
-  P2 = P2 + cs[kCamT1 + 2];
-  DVD_SCHED_FENCE();
-  // --- EXACT: sampling position and bilinear weights
-  const v2f ix = sample_coord2(xf, fx, a.half_w, rhw, a.wmax);
-  const v2f iy = sample_coord2(yf, fy, a.half_h, rhh, a.hmax);
-  const v2f x0f = (v2f){floorf(ix.x), floorf(ix.y)}, y0f = (v2f){floorf(iy.x), floorf(iy.y)};
-  const v2f ww = ix - x0f, we = 1.0f - ww;
-  const v2f wn = iy - y0f, ws = 1.0f - wn;
-  const v2f w_nw = ws * we, w_ne = ws * ww, w_sw = wn * we, w_se = wn * ww;
-  // --- taps of depth_2 (LDS window; rare: global)
-  int x0[2], y0[2], cell[2];
-  bool inside[2];
-  v2f dnw, dne, dsw, dse;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    x0[k] = (int)x0f[k];
-    y0[k] = (int)y0f[k];
-    const int lx = x0[k] - io.wx0, ly = y0[k] - io.wy0;
-    inside[k] = ((unsigned)lx < (unsigned)(WW - 1)) && ((unsigned)ly < (unsigned)(WH - 1));
-    cell[k] = inside[k] ? ly * WW + lx : 0;
-    const float* p = io.win + cell[k];
-    dnw[k] = p[0];
-    dne[k] = p[1];
-    dsw[k] = p[WW];
-    dse[k] = p[WW + 1];
-    if (!inside[k]) {
-      DirectIO g{io.d2b, nullptr, io.W, 1.0f};
-      float t0, t1, t2, t3;
-      g.fetch(y0[k] * io.W + x0[k], x0[k], y0[k], (x0[k] + 1) < a.W, (y0[k] + 1) < a.H, t0, t1, t2, t3);
-      dnw[k] = t0;
-      dne[k] = t1;
-      dsw[k] = t2;
-      dse[k] = t3;
-    }
-  }
-  DVD_SCHED_FENCE();
-  // EXACT: z of the camera-2 points at the taps; W2.z
-  const v2f x1f = x0f + 1.0f, y1f = y0f + 1.0f;
-  const v2f zn0 = (x0f * cs[kCamKi + 2] + y0f * cs[kCamKi + 5]) + cs[kCamKi + 8];
-  const v2f zn1 = (x1f * cs[kCamKi + 2] + y0f * cs[kCamKi + 5]) + cs[kCamKi + 8];
-  const v2f zs0 = (x0f * cs[kCamKi + 2] + y1f * cs[kCamKi + 5]) + cs[kCamKi + 8];
-  const v2f zs1 = (x1f * cs[kCamKi + 2] + y1f * cs[kCamKi + 5]) + cs[kCamKi + 8];
-  const v2f W2z = bilinear2(dnw * zn0, dne * zn1, dsw * zs0, dse * zs1, w_nw, w_ne, w_sw, w_se);
-  DVD_SCHED_FENCE();
-  // --- EXACT: dynamic reprojection
-  const v2f A0 = (P0 + s0) - cs[kCamT2 + 0], A1 = (P1 + s1) - cs[kCamT2 + 1], A2 = (P2 + s2) - cs[kCamT2 + 2];
-  v2f Q0, Q1, Q2, I0, I1, I2;
-  rowvec_mat3v(A0, A1, A2, cs + kCamR2T, Q0, Q1, Q2);
-  rowvec_mat3v(Q0, Q1, Q2, cs + kCamK, I0, I1, I2);
-  const v2f den = I2 + 1e-8f;
-  const bool behind[2] = {I2.x < 1e-3f, I2.y < 1e-3f};
-  const v2f yden = (v2f){rcp_refined(den.x), rcp_refined(den.y)};
-  v2f u = div_exact(I0, den, yden), v = div_exact(I1, den, yden);
-  u.x = behind[0] ? xf.x : u.x;
-  u.y = behind[1] ? xf.y : u.y;
-  v.x = behind[0] ? yf.x : v.x;
-  v.y = behind[1] ? yf.y : v.y;
-  const v2f ex = (u - xf) - fx, ey = (v - yf) - fy;
-  DVD_SCHED_FENCE();
-  // --- FAST: warped world point of frame 2
-  const v2f q0 = vfma(x0f, vsplat(cs[kCamKi + 0]), vfma(y0f, vsplat(cs[kCamKi + 3]), vsplat(cs[kCamKi + 6])));
-  const v2f q1 = vfma(x0f, vsplat(cs[kCamKi + 1]), vfma(y0f, vsplat(cs[kCamKi + 4]), vsplat(cs[kCamKi + 7])));
-  const v2f q2 = vfma(x0f, vsplat(cs[kCamKi + 2]), vfma(y0f, vsplat(cs[kCamKi + 5]), vsplat(cs[kCamKi + 8])));
-  v2f m = mk;
-  if (midas_mask) {
-    m.x = ((d1.x < 100.0f) && (W2z.x < 100.0f)) ? m.x : 0.0f;   // mask is {0,1}: 1*1*m == m
-    m.y = ((d1.y < 100.0f) && (W2z.y < 100.0f)) ? m.y : 0.0f;
-  }
-  v2f f0 = vsplat(0.f), f1 = vsplat(0.f), f2 = vsplat(0.f);
-  {
-    const v2f a_nw = w_nw * dnw, a_ne = w_ne * dne, a_sw = w_sw * dsw, a_se = w_se * dse;
-    const v2f sE = a_ne + a_se, sS = a_sw + a_se, sA = (a_nw + a_ne) + sS;
-    const v2f V0 = vfma(q0, sA, vfma(vsplat(cs[kCamKi + 0]), sE, sS * cs[kCamKi + 3]));
-    const v2f V1 = vfma(q1, sA, vfma(vsplat(cs[kCamKi + 1]), sE, sS * cs[kCamKi + 4]));
-    const v2f V2 = vfma(q2, sA, vfma(vsplat(cs[kCamKi + 2]), sE, sS * cs[kCamKi + 5]));
-    const v2f G0 = vfma(V0, vsplat(cs[kCamR2 + 0]), vfma(V1, vsplat(cs[kCamR2 + 3]), vfma(V2, vsplat(cs[kCamR2 + 6]), vsplat(cs[kCamT2 + 0]))));
-    const v2f G1 = vfma(V0, vsplat(cs[kCamR2 + 1]), vfma(V1, vsplat(cs[kCamR2 + 4]), vfma(V2, vsplat(cs[kCamR2 + 7]), vsplat(cs[kCamT2 + 1]))));
-    const v2f G2 = vfma(V0, vsplat(cs[kCamR2 + 2]), vfma(V1, vsplat(cs[kCamR2 + 5]), vfma(V2, vsplat(cs[kCamR2 + 8]), vsplat(cs[kCamT2 + 2]))));
-    f0 = (G0 - P0) - s0;
-    f1 = (G1 - P1) - s1;
-    f2 = (G2 - P2) - s2;
-  }
-  DVD_SCHED_FENCE();
-  const v2f aex = vabs(ex), aey = vabs(ey);
-  const v2f flow_err = a.crit_l2 ? (ex * ex + ey * ey) : (aex + aey);
-  v2f disp_err, rca = vsplat(0.f), rcb = vsplat(0.f), ediff = vsplat(0.f);
-  if (disp_mode == 1) {
-    rca = (v2f){__builtin_amdgcn_rcpf(fmaxf(Q2.x, 1e-3f)), __builtin_amdgcn_rcpf(fmaxf(Q2.y, 1e-3f))};
-    rcb = (v2f){__builtin_amdgcn_rcpf(fmaxf(W2z.x, 1e-3f)), __builtin_amdgcn_rcpf(fmaxf(W2z.y, 1e-3f))};
-    ediff = rca - rcb;
-    disp_err = vabs(ediff) * 100.0f;
-  } else if (disp_mode == 2) {
-    const v2f ca = (v2f){fmaxf(Q2.x, 1e-3f), fmaxf(Q2.y, 1e-3f)}, cb = (v2f){fmaxf(W2z.x, 1e-3f), fmaxf(W2z.y, 1e-3f)};
-    disp_err = (v2f){fmaxf(ca.x, cb.x) * __builtin_amdgcn_rcpf(fminf(ca.x, cb.x)) - 1.0f,
-                     fmaxf(ca.y, cb.y) * __builtin_amdgcn_rcpf(fminf(ca.y, cb.y)) - 1.0f};
-  } else {
-    disp_err = vabs(Q2 - W2z);
-  }
-  const v2f sf_err = (vabs(f0) + vabs(f1)) + vabs(f2);
-  {
-    const v2f t1v = m * flow_err, t2v = m * disp_err, t3v = m * sf_err;
-    acc[0] += m.x + m.y;
-    acc[1] += t1v.x + t1v.y;
-    acc[2] += t2v.x + t2v.y;
-    acc[3] += t3v.x + t3v.y;
-  }
-  if (!GRADS) {
-    mid();
-    return;
-  }
-  DVD_SCHED_FENCE();
-  // ------------------------------ FAST: backward (un-normalised), branch free ------------
-  // Everything that consumes forward-only values (errors, masks, reciprocals) is folded into
-  // gQ / uW2z / uG first; after `mid()` only those, the ray and the tap weights are alive.
-  v2f gQ0, gQ1, gQ2;
-  {
-    v2f fm = m * a.flow_mul;
-    fm.x = behind[0] ? 0.0f : fm.x;
-    fm.y = behind[1] ? 0.0f : fm.y;
-    v2f gu, gv;
-    if (a.crit_l2) {
-      gu = fm * 2.0f * ex;
-      gv = fm * 2.0f * ey;
-    } else {
-      gu = (v2f){signed_mag(fm.x, ex.x), signed_mag(fm.y, ex.y)};
-      gv = (v2f){signed_mag(fm.x, ey.x), signed_mag(fm.y, ey.y)};
-    }
-    // yden ~ 1/den to 1 ulp; for behind pixels it may be inf/nan but gu = gv = 0 there: select 0
-    v2f rden = yden;
-    rden.x = behind[0] ? 0.0f : rden.x;
-    rden.y = behind[1] ? 0.0f : rden.y;
-    const v2f gI0 = gu * rden, gI1 = gv * rden;
-    const v2f gI2 = -(vfma(gu, u, gv * v)) * rden;
-    gQ0 = vfma(gI0, vsplat(cs[kCamK + 0]), vfma(gI1, vsplat(cs[kCamK + 1]), gI2 * cs[kCamK + 2]));
-    gQ1 = vfma(gI0, vsplat(cs[kCamK + 3]), vfma(gI1, vsplat(cs[kCamK + 4]), gI2 * cs[kCamK + 5]));
-    gQ2 = vfma(gI0, vsplat(cs[kCamK + 6]), vfma(gI1, vsplat(cs[kCamK + 7]), gI2 * cs[kCamK + 8]));
-  }
-  v2f uW2z = vsplat(0.f), uG0 = vsplat(0.f), uG1 = vsplat(0.f), uG2 = vsplat(0.f);
-  const float dm = a.disp_mul;
-  if (!loss_on_sf) {
-    if (disp_mode == 1) {
-      const v2f m100 = m * 100.0f;
-      const v2f ue = (v2f){signed_mag(m100.x, ediff.x), signed_mag(m100.y, ediff.y)};
-      v2f ua = ue * dm;
-      ua.x = (Q2.x >= 1e-3f) ? ua.x : 0.0f;
-      ua.y = (Q2.y >= 1e-3f) ? ua.y : 0.0f;
-      gQ2 = vfma(-ua, rca * rca, gQ2);
-      uW2z = ue * (rcb * rcb);
-      uW2z.x = (W2z.x >= 1e-3f) ? uW2z.x : 0.0f;
-      uW2z.y = (W2z.y >= 1e-3f) ? uW2z.y : 0.0f;
-    }
-  } else {
-    uG0 = (v2f){signed_mag(m.x, f0.x), signed_mag(m.y, f0.y)};
-    uG1 = (v2f){signed_mag(m.x, f1.x), signed_mag(m.y, f1.y)};
-    uG2 = (v2f){signed_mag(m.x, f2.x), signed_mag(m.y, f2.y)};
-  }
-  DVD_SCHED_FENCE();
-  mid();
-  DVD_SCHED_FENCE();
-  const v2f gA0 = vfma(gQ0, vsplat(cs[kCamR2T + 0]), vfma(gQ1, vsplat(cs[kCamR2T + 1]), gQ2 * cs[kCamR2T + 2])) - uG0 * dm;
-  const v2f gA1 = vfma(gQ0, vsplat(cs[kCamR2T + 3]), vfma(gQ1, vsplat(cs[kCamR2T + 4]), gQ2 * cs[kCamR2T + 5])) - uG1 * dm;
-  const v2f gA2 = vfma(gQ0, vsplat(cs[kCamR2T + 6]), vfma(gQ1, vsplat(cs[kCamR2T + 7]), gQ2 * cs[kCamR2T + 8])) - uG2 * dm;
-  g_s_out[0] = gA0;
-  g_s_out[1] = gA1;
-  g_s_out[2] = gA2;
-  {
-    const v2f gp0 = vfma(gA0, vsplat(cs[kCamR1 + 0]), vfma(gA1, vsplat(cs[kCamR1 + 1]), gA2 * cs[kCamR1 + 2]));
-    const v2f gp1 = vfma(gA0, vsplat(cs[kCamR1 + 3]), vfma(gA1, vsplat(cs[kCamR1 + 4]), gA2 * cs[kCamR1 + 5]));
-    const v2f gp2 = vfma(gA0, vsplat(cs[kCamR1 + 6]), vfma(gA1, vsplat(cs[kCamR1 + 7]), gA2 * cs[kCamR1 + 8]));
-    g_d1_out = vfma(gp0, r0, vfma(gp1, r1, gp2 * r2));
-  }
-  DVD_SCHED_FENCE();
-  // depth_2 taps (units of disp_mul): d/d(d2_k) = w_k * (h . ray_k)
-  v2f h0 = vsplat(0.f), h1 = vsplat(0.f), h2 = uW2z;
-  if (loss_on_sf) {
-    h0 = vfma(uG0, vsplat(cs[kCamR2 + 0]), vfma(uG1, vsplat(cs[kCamR2 + 1]), uG2 * cs[kCamR2 + 2]));
-    h1 = vfma(uG0, vsplat(cs[kCamR2 + 3]), vfma(uG1, vsplat(cs[kCamR2 + 4]), uG2 * cs[kCamR2 + 5]));
-    h2 = h2 + vfma(uG0, vsplat(cs[kCamR2 + 6]), vfma(uG1, vsplat(cs[kCamR2 + 7]), uG2 * cs[kCamR2 + 8]));
-  }
-  if (a.ablate & 1) return;
-  v2f hb, hx, hy;
-  if (loss_on_sf) {
-    hb = vfma(h0, q0, vfma(h1, q1, h2 * q2));
-    hx = vfma(h0, vsplat(cs[kCamKi + 0]), vfma(h1, vsplat(cs[kCamKi + 1]), h2 * cs[kCamKi + 2]));
-    hy = vfma(h0, vsplat(cs[kCamKi + 3]), vfma(h1, vsplat(cs[kCamKi + 4]), h2 * cs[kCamKi + 5]));
-  } else {
-    hb = h2 * q2;
-    hx = h2 * cs[kCamKi + 2];
-    hy = h2 * cs[kCamKi + 5];
-  }
-  const v2f hbx = hb + hx;
-  const v2f t_nw = w_nw * hb, t_ne = w_ne * hbx, t_sw = w_sw * (hb + hy), t_se = w_se * (hbx + hy);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    float tn0 = t_nw[k], tn1 = t_ne[k], ts0 = t_sw[k], ts1 = t_se[k];
-    const float big = fmaxf(fmaxf(fabsf(tn0), fabsf(tn1)), fmaxf(fabsf(ts0), fabsf(ts1)));
-    const bool fast = inside[k] && (big < kFixMax);
-    // out-of-image taps carry an exactly zero weight, and their window cells are never read back
-    unsigned long long* p = io.accw + cell[k];
-    atomicAdd(p, to_fixed(fast ? tn0 : 0.0f));
-    atomicAdd(p + 1, to_fixed(fast ? tn1 : 0.0f));
-    atomicAdd(p + WW, to_fixed(fast ? ts0 : 0.0f));
-    atomicAdd(p + WW + 1, to_fixed(fast ? ts1 : 0.0f));
-    if (!fast) {   // rare: list of (index, value) applied after the slab combine
-      const int o_n = y0[k] * io.W + x0[k];
-      const bool in_e = (x0[k] + 1) < a.W, in_s = (y0[k] + 1) < a.H;
-      io.spill(o_n, tn0);
-      if (in_e) io.spill(o_n + 1, tn1);
-      if (in_s) io.spill(o_n + io.W, ts0);
-      if (in_e && in_s) io.spill(o_n + io.W + 1, ts1);
-    }
-  }
-}
-
-template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED, bool EVEN, bool FULL>
-__global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_loss_tiled2_kernel(const WarpArgs a, const TileArgs ta) {
-  // FULL: W % TW == 0, H % TH == 0 and the tile's pixel pairs divide evenly over the threads
-  // (the shipped 384x672 with 96x32 tiles): no per-pixel bounds predicates at all.
-  constexpr int WW = TW + 2 * R + 4;
-  constexpr int WH = TH + 2 * R + 1;
-  constexpr int QW = TW / 2;                       // pixel pairs per tile row
-  constexpr int ITERS = (QW * TH + NT - 1) / NT;   // pairs per thread
-  static_assert(R % 4 == 0 && TW % 4 == 0, "tile geometry");
-  static_assert(!FULL || (QW * TH) % NT == 0, "FULL needs an even split of the tile over the threads");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ __attribute__((aligned(16))) float camS[kCamFloats];
-  unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);
-  float* win = smem + 2 * WW * WH;
-
-  const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const int tiles = ta.ntx * ta.nty;
-  const int b = logical / tiles;
-  const int t = logical - b * tiles;
-  const int tj = t / ta.ntx, ti = t - tj * ta.ntx;
-  const int tx0 = ti * TW, ty0 = tj * TH;
-  const int wx0 = tx0 - R, wy0 = ty0 - R;
-  if (threadIdx.x < 45) {
-    const int m = threadIdx.x / 9, e = threadIdx.x - m * 9;
-    const float* src = m == 0 ? a.Ki : (m == 1 ? a.R1 : (m == 2 ? a.R2 : (m == 3 ? a.R2T : a.K)));
-    camS[threadIdx.x] = src[b * 9 + e];
-  } else if (threadIdx.x < 51) {
-    const int e = threadIdx.x - 45;
-    camS[threadIdx.x] = e < 3 ? a.t1[b * 3 + e] : a.t2[b * 3 + e - 3];
-  }
-  const float* d2b = a.d2 + (size_t)b * a.HW;
-  constexpr bool even = EVEN;   // 8-byte vector access needs even W (rows stay 8-byte aligned)
-
-  // ---- input fetch of one pixel pair (8-byte vectors; 16 bytes of flow): uniform plane bases + one
-  //      32-bit per-lane offset
-  const float* d1b = a.d1 + (size_t)b * a.HW;
-  const float* mkb = a.mask + (size_t)b * a.HW;
-  const float* flb = a.flow + 2 * (size_t)b * a.HW;
-  const float* sf0b = a.sf + (size_t)b * 3 * a.HW;
-  const float* sf1b = sf0b + a.HW;
-  const float* sf2b = sf1b + a.HW;
-  struct In {
-    v2f d1, mk, fx, fy, s0, s1, s2;
-  };
-  auto locate = [&](int it, int& x, int& y, bool& ok0, bool& ok1) {
-    const int q = it * NT + threadIdx.x;
-    const int ly = q / QW, lx = (q - ly * QW) * 2;
-    y = ty0 + ly;
-    x = tx0 + lx;
-    ok0 = FULL || ((q < QW * TH) && (y < a.H) && (x < a.W));
-    ok1 = FULL || (ok0 && (x + 1 < a.W));
-  };
-  auto fetch = [&](int it, In& r) {
-    int x, y;
-    bool ok0, ok1;
-    locate(it, x, y, ok0, ok1);
-    const unsigned p0 = (unsigned)(y * a.W + x);
-    if (!FULL) {
-      r.d1 = vsplat(1.0f);
-      r.mk = r.fx = r.fy = r.s0 = r.s1 = r.s2 = vsplat(0.0f);
-    }
-    if (even) {
-      if (ok0) {
-        const unsigned o4 = p0 * 4u;    // < 2^31: B*H*W*3 floats were checked to fit 32-bit indexing
-        r.d1 = ld_off<v2f>(d1b, o4);
-        r.mk = ld_off<v2f>(mkb, o4);
-        const float4 f = ld_off<float4>(flb, o4 * 2u);
-        r.fx = (v2f){f.x, f.z};
-        r.fy = (v2f){f.y, f.w};
-        r.s0 = ld_off<v2f>(sf0b, o4);
-        r.s1 = ld_off<v2f>(sf1b, o4);
-        r.s2 = ld_off<v2f>(sf2b, o4);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (k == 0 ? ok0 : ok1) {
-          r.d1[k] = d1b[p0 + k];
-          r.mk[k] = mkb[p0 + k];
-          r.fx[k] = flb[2 * (size_t)(p0 + k)];
-          r.fy[k] = flb[2 * (size_t)(p0 + k) + 1];
-          r.s0[k] = sf0b[p0 + k];
-          r.s1[k] = sf1b[p0 + k];
-          r.s2[k] = sf2b[p0 + k];
-        }
-      }
-    }
-  };
-  In in[ITERS];
-  fetch(0, in[0]);   // requested before the window fill, consumed after it
-
-  // ---- phase 0: fill the depth_2 window, clear the accumulator
-  const bool w4 = (a.W & 3) == 0;
-  for (int i = threadIdx.x; i < (WW / 4) * WH; i += NT) {
-    const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
-    const int iy = wy0 + wy, ixx = wx0 + wx;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iy >= 0 && iy < a.H) {
-      if (w4) {
-        if (ixx >= 0 && ixx < a.W) v = *reinterpret_cast<const float4*>(d2b + (size_t)iy * a.W + ixx);
-      } else {
-        const float* row = d2b + (size_t)iy * a.W;
-        if (ixx >= 0 && ixx < a.W) v.x = row[ixx];
-        if (ixx + 1 >= 0 && ixx + 1 < a.W) v.y = row[ixx + 1];
-        if (ixx + 2 >= 0 && ixx + 2 < a.W) v.z = row[ixx + 2];
-        if (ixx + 3 >= 0 && ixx + 3 < a.W) v.w = row[ixx + 3];
-      }
-    }
-    *reinterpret_cast<float4*>(win + wy * WW + wx) = v;
-    if (GRADS) {
-      uint4* z = reinterpret_cast<uint4*>(accw + wy * WW + wx);
-      z[0] = make_uint4(0u, 0u, 0u, 0u);
-      z[1] = make_uint4(0u, 0u, 0u, 0u);
-    }
-  }
-  __syncthreads();
-
-  const TileIO2<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, a.disp_mul, ta.ovf};
-  const float rhw = rcp_refined(a.half_w), rhh = rcp_refined(a.half_h);
-  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  float* gd1b = a.g_d1 + (size_t)b * a.HW;
-  float* gs0b = a.g_sf + (size_t)b * 3 * a.HW;
-  float* gs1b = gs0b + a.HW;
-  float* gs2b = gs1b + a.HW;
-  // ---- phase 1 (one pair in evaluation, the next one requested half way through it)
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    int x, y;
-    bool ok0, ok1;
-    locate(it, x, y, ok0, ok1);
-    asm volatile("" ::: "memory");   // camera scalars are re-read from LDS per pair, not hoisted into 51 registers
-    auto mid = [&]() {
-      if (it + 1 < ITERS) fetch(it + 1, in[it + 1]);
-    };
-    if (!(FULL || ok0)) mid();
-    if (FULL || ok0) {
-      v2f gd1 = vsplat(0.0f), gs[3] = {vsplat(0.0f), vsplat(0.0f), vsplat(0.0f)};
-      pixel2<GRADS, SHIPPED, WW, WH>(a, camS, io, rhw, rhh, y, x, in[it].d1, in[it].fx, in[it].fy, in[it].mk,
-                                     in[it].s0, in[it].s1, in[it].s2, acc, gd1, gs, mid);
-      if (GRADS && !(a.ablate & 2)) {
-        const unsigned p0 = (unsigned)(y * a.W + x);
-        if (even) {
-          const unsigned o4 = p0 * 4u;
-          st_off<v2f>(gd1b, o4, gd1);
-          st_off<v2f>(gs0b, o4, gs[0]);
-          st_off<v2f>(gs1b, o4, gs[1]);
-          st_off<v2f>(gs2b, o4, gs[2]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            if (k == 0 || ok1) {
-              gd1b[p0 + k] = gd1[k];
-              gs0b[p0 + k] = gs[0][k];
-              gs1b[p0 + k] = gs[1][k];
-              gs2b[p0 + k] = gs[2][k];
-            }
-          }
-        }
-      }
-    }
-  }
-  // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
-  __syncthreads();
-  if (GRADS && !(a.ablate & 4)) {
-    float* slab = ta.slabs + (size_t)logical * (WW * WH);
-    const float back = kFixInv * a.disp_mul;
-    for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
-      const longlong2 lo = reinterpret_cast<const longlong2*>(accw)[2 * i];
-      const longlong2 hi = reinterpret_cast<const longlong2*>(accw)[2 * i + 1];
-      reinterpret_cast<float4*>(slab)[i] =
-          make_float4((float)lo.x * back, (float)lo.y * back, (float)hi.x * back, (float)hi.y * back);
-    }
-  }
-  float* red = win;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float v = wave_sum(acc[k]);
-    if (lane == 0) red[wave * 4 + k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    float v = 0.0f;
-    for (int w = 0; w < NT / 64; ++w) v += red[w * 4 + threadIdx.x];
-    a.partial[(size_t)logical * 4 + threadIdx.x] = v;
-  }
-}
 
 // ---------------------------------------------------------------------------
 // Tiled variant, third generation: guard-banded fast arithmetic (DVD_WARP_GEN=3, the default).
@@ -1881,8 +1392,9 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
   if (grads) DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, sizeof(unsigned), stream));
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
-  const int gen = env_int("DVD_WARP_V1", 0) ? 1 : env_int("DVD_WARP_GEN", 3);
-  const bool v1 = gen == 1;
+  // generation 1 = exact arithmetic everywhere (default: the fastest kernel that is exact today);
+  // generation 3 = guard-banded fast arithmetic (DVD_WARP_GEN=3; see its header for where it stands)
+  const int gen = env_int("DVD_WARP_GEN", 1);
   if (gen == 3) {
     float* pre = reinterpret_cast<float*>(ws + p.off_pre);
     hipLaunchKernelGGL(warp_prepare_kernel, dim3((a.B + 63) / 64), dim3(64), 0, stream, a, pre);
@@ -1907,29 +1419,24 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
     }
 #undef DVD_TILED3_LAUNCH
   } else {
-  constexpr bool kFullOk = ((TW / 2) * TH) % NT == 0;
-  const bool full = kFullOk && (a.W % TW == 0) && (a.H % TH == 0) && !env_int("DVD_WARP_NOFULL", 0);
 #define DVD_TILED_LAUNCH(G, S)                                                                            \
   do {                                                                                                    \
-    auto k = v1 ? warp_loss_tiled_kernel<TW, TH, kR, NT, G, S>                                            \
-                : ((a.W & 1) ? warp_loss_tiled2_kernel<TW, TH, kR, NT, G, S, false, false>                \
-                   : (full ? warp_loss_tiled2_kernel<TW, TH, kR, NT, G, S, true, kFullOk>                  \
-                           : warp_loss_tiled2_kernel<TW, TH, kR, NT, G, S, true, false>));                \
+    auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, G, S>;                                                \
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                      \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);                                   \
   } while (0)
-  if (grads) {
-    if (shipped)
-      DVD_TILED_LAUNCH(true, true);
-    else
-      DVD_TILED_LAUNCH(true, false);
-  } else {
-    if (shipped)
-      DVD_TILED_LAUNCH(false, true);
-    else
-      DVD_TILED_LAUNCH(false, false);
-  }
+    if (grads) {
+      if (shipped)
+        DVD_TILED_LAUNCH(true, true);
+      else
+        DVD_TILED_LAUNCH(true, false);
+    } else {
+      if (shipped)
+        DVD_TILED_LAUNCH(false, true);
+      else
+        DVD_TILED_LAUNCH(false, false);
+    }
 #undef DVD_TILED_LAUNCH
   }
   DVD_LAUNCH_OK();

@@ -14,17 +14,21 @@ from oracle import losses as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['tiled', 'tile64x32', 'direct'], autouse=True)
+@pytest.fixture(params=['tiled', 'tile64x32', 'direct', 'gen3', 'gen3_tile64x32'], autouse=True)
 def warp_variant(request, monkeypatch):
     """Every case runs on the production tiled kernel (auto tile shape), on the
-    smallest tile shape (more tile seams / halo traffic) and on the
-    global-atomics reference variant."""
-    monkeypatch.delenv('DVD_WARP_DIRECT', raising=False)
-    monkeypatch.delenv('DVD_WARP_TILE', raising=False)
+    smallest tile shape (more tile seams / halo traffic), on the global-atomics
+    reference variant, and on the guard-banded fast-arithmetic generation of the
+    tiled kernel (DVD_WARP_GEN=3), which must reproduce the same masks, counts and
+    sub-gradient signs."""
+    for k in ('DVD_WARP_DIRECT', 'DVD_WARP_TILE', 'DVD_WARP_GEN'):
+        monkeypatch.delenv(k, raising=False)
     if request.param == 'direct':
         monkeypatch.setenv('DVD_WARP_DIRECT', '1')
-    elif request.param == 'tile64x32':
+    if request.param.endswith('tile64x32'):
         monkeypatch.setenv('DVD_WARP_TILE', '3')
+    if request.param.startswith('gen3'):
+        monkeypatch.setenv('DVD_WARP_GEN', '3')
     return request.param
 
 CAM_KEYS = ('R_1', 'R_2', 'R_1_T', 'R_2_T', 't_1', 't_2', 'K', 'K_inv')
@@ -198,3 +202,30 @@ def test_full_size_properties():
     s_i, *_ = ops.warp_loss_fused(cfg, d1, d1, z(batch['flow_1_2']), batch['mask_2'], z(sf), ident)
     s_i = s_i.cpu().numpy()
     assert s_i[0] > 0 and abs(s_i[1]) <= 2e-3 * s_i[0] and s_i[2] <= 1e-3 * s_i[0] and s_i[3] <= 1e-4 * s_i[0]
+
+
+def test_guard_banded_generation_matches_exact_generation_at_full_size(monkeypatch):
+    """DVD_WARP_GEN=3 (fast composite-matrix arithmetic, exact re-evaluation only inside the
+    guard bands) against generation 1 (the reference's rounding sequence everywhere) on
+    16 x 384 x 672 pixels: identical valid-pixel count, and no pixel whose gradient differs by
+    more than fp32 noise -- i.e. no mask bit and no L1 sub-gradient sign was decided differently."""
+    from dvd_hip import ops, synthetic
+    B, H, W = 16, 384, 672
+    batch = synthetic.make_batch(B, H, W, device='cuda', with_images=False, behind_camera_pairs=1)
+    d1, d2 = synthetic.make_depths(B, H, W, device='cuda', far_depth_frac=0.01)
+    sf = synthetic.make_scene_flow(B, H, W, device='cuda')
+    cams = {k: batch[k] for k in CAM_KEYS}
+    cfg = ops.warp_cfg(B, H, W, flow_mul=1.0, disp_mul=1.0)
+    out = {}
+    for gen in ('1', '3'):
+        monkeypatch.delenv('DVD_WARP_DIRECT', raising=False)
+        monkeypatch.delenv('DVD_WARP_TILE', raising=False)
+        monkeypatch.setenv('DVD_WARP_GEN', gen)
+        out[gen] = [t.clone() for t in ops.warp_loss_fused(cfg, d1, d2, batch['flow_1_2'], batch['mask_2'], sf, cams)]
+    s1, s3 = out['1'][0].cpu().numpy(), out['3'][0].cpu().numpy()
+    assert s1[0] == s3[0]
+    np.testing.assert_allclose(s3, s1, rtol=1e-5)
+    for name, a, b in zip(('g_depth_1', 'g_depth_2', 'g_sf'), out['1'][1:], out['3'][1:]):
+        scale = float(a.abs().max())
+        bad = ((a - b).abs() > 1e-4 * a.abs() + 1e-5 * scale).sum().item()
+        assert bad == 0, '%s: %d elements differ between generations' % (name, bad)
