@@ -76,11 +76,30 @@ __device__ __forceinline__ void load_cam(const WarpArgs& a, int b, Cam& c) {
   }
 }
 
+// IEEE division evaluated with the unscaled form of the hardware division sequence (rcp, one
+// Newton step on the reciprocal, two fma corrections of the quotient: exactly what the compiler
+// emits between v_div_scale and v_div_fixup, whose scaling is the identity for the operand
+// ranges here: divisors (W-1)/2, (H-1)/2 and I.z + 1e-8 >= 1e-3, quotients far from the
+// denormal range).  The reciprocal of a loop-invariant divisor is then computed once, and the
+// two divisions by I.z share theirs.
+__device__ __forceinline__ float rcp_refined(float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, y0, 1.0f);
+  return __builtin_fmaf(e, y0, y0);
+}
+__device__ __forceinline__ float div_exact1(float a, float b, float y) {
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+
 // (x + flow) -> normalised -> un-normalised -> border clamp: the five fp32
 // roundings of backward_warp + torch's grid_sample (align_corners=True).
 __device__ __forceinline__ float sample_coord(float pix, float fl, float half, float maxv) {
   float g = pix + fl;
-  g = g / half;
+  g = div_exact1(g, half, rcp_refined(half));   // == g / half (IEEE); the reciprocal is loop invariant
   g = g - 1.0f;
   float i = (g + 1.0f) * half;
   return fminf(maxv, fmaxf(i, 0.0f));
@@ -166,8 +185,9 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
   rowvec_mat3(Q0, Q1, Q2, c.K, I0, I1, I2);
   const float den = I2 + 1e-8f;
   const bool behind = I2 < 1e-3f;
-  const float u = behind ? xf : I0 / den;  // IEEE divides: sign(dflow - flow) must match the reference
-  const float v = behind ? yf : I1 / den;
+  const float yden = rcp_refined(den);     // IEEE-exact quotients: sign(dflow - flow) must match the reference
+  const float u = behind ? xf : div_exact1(I0, den, yden);
+  const float v = behind ? yf : div_exact1(I1, den, yden);
   const float ex = (u - xf) - fx, ey = (v - yf) - fy;  // dflow - flow
 
   // --- FAST: warped world point of frame 2, G = sum_k w_k (d2_k ray_k @ R2 + t2), via
@@ -487,11 +507,14 @@ constexpr int tile_waves_per_simd(int tw, int th, int r, int nt) {
   return (tile_blocks_per_cu(tw, th, r) * nt + 255) / 256 > 4 ? 4 : (tile_blocks_per_cu(tw, th, r) * nt + 255) / 256;
 }
 
-template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED>
+// PX = pixels per thread-step (4: 16-byte vectors; 2: 8-byte vectors, which splits a 96x32 tile evenly
+// over 512 threads -- 3 steps each instead of 1 or 2).
+template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED, int PX>
 __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_loss_tiled_kernel(const WarpArgs a, const TileArgs ta) {
   constexpr int WW = TW + 2 * R + 4;  // multiple of 4: window rows are float4-aligned
   constexpr int WH = TH + 2 * R + 1;
-  constexpr int QW = TW / 4;
+  constexpr int QW = TW / PX;
+  typedef float vecf __attribute__((ext_vector_type(PX)));
   static_assert(R % 4 == 0 && TW % 4 == 0, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);  // [WH][WW] u64 first (8-byte aligned)
@@ -546,27 +569,28 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
 
   TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, a.disp_mul, ta.ovf};
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  // ---- phase 1: the tile's pixels, 4 per thread per step
+  // ---- phase 1: the tile's pixels, PX per thread per step
+  const bool wv = (a.W % PX) == 0;   // rows stay vector aligned
   for (int q = threadIdx.x; q < QW * TH; q += NT) {
-    const int ly = q / QW, lx = (q - ly * QW) * 4;
+    const int ly = q / QW, lx = (q - ly * QW) * PX;
     const int y = ty0 + ly, x = tx0 + lx;
     if (y >= a.H || x >= a.W) continue;
     const int p0 = y * a.W + x;
     const size_t base = (size_t)b * a.HW + p0;
     const float* sfb = a.sf + (size_t)b * 3 * a.HW + p0;
-    float d1[4], mk[4], fl[8], s0[4], s1[4], s2[4];
-    const int nvalid = (a.W - x) < 4 ? (a.W - x) : 4;
-    if (w4) {
-      *reinterpret_cast<float4*>(d1) = *reinterpret_cast<const float4*>(a.d1 + base);
-      *reinterpret_cast<float4*>(mk) = *reinterpret_cast<const float4*>(a.mask + base);
-      *reinterpret_cast<float4*>(fl) = *reinterpret_cast<const float4*>(a.flow + 2 * base);
-      *reinterpret_cast<float4*>(fl + 4) = *reinterpret_cast<const float4*>(a.flow + 2 * base + 4);
-      *reinterpret_cast<float4*>(s0) = *reinterpret_cast<const float4*>(sfb);
-      *reinterpret_cast<float4*>(s1) = *reinterpret_cast<const float4*>(sfb + a.HW);
-      *reinterpret_cast<float4*>(s2) = *reinterpret_cast<const float4*>(sfb + 2 * a.HW);
+    float d1[PX], mk[PX], fl[2 * PX], s0[PX], s1[PX], s2[PX];
+    const int nvalid = (a.W - x) < PX ? (a.W - x) : PX;
+    if (wv) {
+      *reinterpret_cast<vecf*>(d1) = *reinterpret_cast<const vecf*>(a.d1 + base);
+      *reinterpret_cast<vecf*>(mk) = *reinterpret_cast<const vecf*>(a.mask + base);
+      *reinterpret_cast<vecf*>(fl) = *reinterpret_cast<const vecf*>(a.flow + 2 * base);
+      *reinterpret_cast<vecf*>(fl + PX) = *reinterpret_cast<const vecf*>(a.flow + 2 * base + PX);
+      *reinterpret_cast<vecf*>(s0) = *reinterpret_cast<const vecf*>(sfb);
+      *reinterpret_cast<vecf*>(s1) = *reinterpret_cast<const vecf*>(sfb + a.HW);
+      *reinterpret_cast<vecf*>(s2) = *reinterpret_cast<const vecf*>(sfb + 2 * a.HW);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < PX; ++i) {
         const bool ok = i < nvalid;
         d1[i] = ok ? a.d1[base + i] : 1.0f;
         mk[i] = ok ? a.mask[base + i] : 0.0f;
@@ -577,28 +601,31 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
         s2[i] = ok ? sfb[2 * a.HW + i] : 0.0f;
       }
     }
-    float gd1[4], gs[4][3];
+    float gd1[PX], g0[PX], g1[PX], g2[PX];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PX; ++i) {
+      float gs[3] = {0.0f, 0.0f, 0.0f};
       gd1[i] = 0.0f;
-      gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
       if (i < nvalid)
         pixel<GRADS, SHIPPED>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
-                              gd1[i], gs[i]);
+                              gd1[i], gs);
+      g0[i] = gs[0];
+      g1[i] = gs[1];
+      g2[i] = gs[2];
     }
     if (GRADS && !(a.ablate & 2)) {
       float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
-      if (w4) {
-        *reinterpret_cast<float4*>(a.g_d1 + base) = make_float4(gd1[0], gd1[1], gd1[2], gd1[3]);
-        *reinterpret_cast<float4*>(gsb) = make_float4(gs[0][0], gs[1][0], gs[2][0], gs[3][0]);
-        *reinterpret_cast<float4*>(gsb + a.HW) = make_float4(gs[0][1], gs[1][1], gs[2][1], gs[3][1]);
-        *reinterpret_cast<float4*>(gsb + 2 * a.HW) = make_float4(gs[0][2], gs[1][2], gs[2][2], gs[3][2]);
+      if (wv) {
+        *reinterpret_cast<vecf*>(a.g_d1 + base) = *reinterpret_cast<const vecf*>(gd1);
+        *reinterpret_cast<vecf*>(gsb) = *reinterpret_cast<const vecf*>(g0);
+        *reinterpret_cast<vecf*>(gsb + a.HW) = *reinterpret_cast<const vecf*>(g1);
+        *reinterpret_cast<vecf*>(gsb + 2 * a.HW) = *reinterpret_cast<const vecf*>(g2);
       } else {
         for (int i = 0; i < nvalid; ++i) {
           a.g_d1[base + i] = gd1[i];
-          gsb[i] = gs[i][0];
-          gsb[a.HW + i] = gs[i][1];
-          gsb[2 * a.HW + i] = gs[i][2];
+          gsb[i] = g0[i];
+          gsb[a.HW + i] = g1[i];
+          gsb[2 * a.HW + i] = g2[i];
         }
       }
     }
@@ -633,17 +660,6 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
 // ---------------------------------------------------------------------------
 // Helpers shared by the tiled kernels: unscaled exact division, fixed-point conversion,
 // branch-free sign, uniform-base addressing.
-// IEEE division is evaluated with the unscaled form of the hardware division sequence (rcp, one
-// Newton step on the reciprocal, two fma corrections of the quotient: exactly what the compiler
-// emits between v_div_scale and v_div_fixup, whose scaling is the identity for the operand
-// ranges here), so the reciprocal of a loop-invariant divisor is computed once.
-
-// reciprocal refined as in the f32 division expansion: y1 = y0 + y0*(1 - b*y0)
-__device__ __forceinline__ float rcp_refined(float b) {
-  const float y0 = __builtin_amdgcn_rcpf(b);
-  const float e = __builtin_fmaf(-b, y0, 1.0f);
-  return __builtin_fmaf(e, y0, y0);
-}
 // mag * sign(x), 0 when x == 0 (v_bfi + select)
 __device__ __forceinline__ float signed_mag(float mag, float x) {
   return (x == 0.0f) ? 0.0f : __builtin_copysignf(mag, x);
@@ -836,13 +852,6 @@ __device__ __forceinline__ void exact_reprojection(const CamPtrs& cp, float xf, 
   rowvec_mat3(Q0, Q1, Q2, c.K, I0, I1, I2);
 }
 
-__device__ __forceinline__ float div_exact1(float a, float b, float y) {
-  float q = a * y;
-  float r = __builtin_fmaf(-b, q, a);
-  q = __builtin_fmaf(r, y, q);
-  r = __builtin_fmaf(-b, q, a);
-  return __builtin_fmaf(r, y, q);
-}
 __device__ __forceinline__ float sample_coord_x(float pix, float fl, float half, float rhalf, float maxv) {
   float g = pix + fl;
   g = div_exact1(g, half, rhalf);
@@ -1419,9 +1428,12 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
     }
 #undef DVD_TILED3_LAUNCH
   } else {
+    // 2 pixels per thread-step when that splits the tile evenly over the block and 4 does not
+    constexpr bool kEven4 = ((TW / 4) * TH) % NT == 0, kEven2 = ((TW / 2) * TH) % NT == 0;
+    const bool px2 = env_int("DVD_WARP_PX", (kEven2 && !kEven4) ? 2 : 4) == 2;
 #define DVD_TILED_LAUNCH(G, S)                                                                            \
   do {                                                                                                    \
-    auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, G, S>;                                                \
+    auto k = px2 ? warp_loss_tiled_kernel<TW, TH, kR, NT, G, S, 2> : warp_loss_tiled_kernel<TW, TH, kR, NT, G, S, 4>; \
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                      \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);                                   \
