@@ -69,6 +69,11 @@ SIGNATURES = {
     'dvd_acc_reg': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     'dvd_adam_step': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,
                               c_float, c_float, c_float, c_int, c_void_p]),
+    'dvd_gconv3x3_c8_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_gconv3x3_c8_bwd_data': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_gconv3x3_c8_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'dvd_gconv3x3_c8_bwd_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int,
+                                           c_int, c_void_p]),
     'dvd_sf_mlp_bwd_dw': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_longlong, ctypes.POINTER(PtrArr5),
                                   ctypes.POINTER(PtrArr5), c_void_p]),
 }

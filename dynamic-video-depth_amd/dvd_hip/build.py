@@ -26,6 +26,7 @@ SOURCES = [
     ('warp_loss.hip', ['-ffp-contract=off']),
     ('sf_mlp.hip', []),
     ('elementwise.hip', ['-ffp-contract=off']),
+    ('gconv.hip', []),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

@@ -1,0 +1,73 @@
+"""Convolutions of the depth networks that run on hand-written HIP kernels.
+
+`GroupedConv3x3C8` is `nn.Conv2d(C, C, 3, padding=1, groups=C // 8, bias=False)` -- the
+`conv2` of the ResNeXt-101 32x8d stage-1 bottlenecks inside the MiDaS encoder (reference:
+third_party/midas_blocks.py:35-50; torchvision resnet.py Bottleneck with groups=32,
+width_per_group=8).  Same parameter name and shape (`weight [C, 8, 3, 3]`), so
+state_dicts interchange.  Forward, backward-data and backward-weight go through
+`dvd_gconv3x3_c8_*` (csrc/gconv.hip); MIOpen's immediate mode serves the backward of this
+shape at 0.3 TFLOP/s (profiles/r01_depthnet_profile.txt), which made three small
+convolutions 38 % of the depth net's time.
+
+Tensors that the kernels do not cover (CPU tensors of the oracle/tests, other dtypes)
+take `F.conv2d`; on a GPU in fp32 the HIP path is the one that runs.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib
+from .ops import _p, _stream, _workspace
+
+
+class _GConv3x3C8(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x = x.contiguous()
+        w = w.contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        lib = _lib.load()
+        _lib.check(lib.dvd_gconv3x3_c8_fwd(_p(x), _p(w), _p(y), N, C, H, W, _stream()), 'dvd_gconv3x3_c8_fwd')
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C, H, W = x.shape
+        lib = _lib.load()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(lib.dvd_gconv3x3_c8_bwd_data(_p(gy), _p(w), _p(gx), N, C, H, W, _stream()),
+                       'dvd_gconv3x3_c8_bwd_data')
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            nws = lib.dvd_gconv3x3_c8_wgrad_workspace_bytes(N, C, H, W)
+            ws = _workspace(nws, x.device)
+            _lib.check(lib.dvd_gconv3x3_c8_bwd_weight(_p(x), _p(gy), _p(gw), 0, _p(ws), ctypes.c_size_t(ws.numel()),
+                                                      N, C, H, W, _stream()), 'dvd_gconv3x3_c8_bwd_weight')
+        return gx, gw
+
+
+def gconv3x3_c8(x, weight):
+    """y = conv2d(x, weight, padding=1, groups=C // 8) for weight [C, 8, 3, 3]."""
+    if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
+        return _GConv3x3C8.apply(x, weight)
+    return F.conv2d(x, weight, None, 1, 1, 1, x.shape[1] // 8)
+
+
+class GroupedConv3x3C8(nn.Conv2d):
+    """Drop-in for nn.Conv2d(C, C, 3, stride=1, padding=1, groups=C // 8, bias=False)."""
+
+    def __init__(self, channels):
+        if channels % 8:
+            raise ValueError('GroupedConv3x3C8 needs a multiple of 8 channels')
+        super().__init__(channels, channels, 3, stride=1, padding=1, groups=channels // 8, bias=False)
+
+    def forward(self, x):
+        return gconv3x3_c8(x, self.weight)

@@ -187,6 +187,22 @@ int dvd_adam_step(float* param, const float* grad1, float scale, const float* sc
                   const float* grad2, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                   float beta1, float beta2, float eps, int step, dvd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Grouped 3x3 convolution, 8 channels per group, stride 1, pad 1, NCHW fp32.
+ * Replaces the `conv2` of the ResNeXt-101 32x8d stage-1 bottlenecks inside the MiDaS encoder
+ * (third_party/midas_blocks.py:35-50 -> torchvision ResNet(Bottleneck, groups=32,
+ * width_per_group=8): stage 1 is 256 channels = 32 groups x 8) -- forward, backward-data and
+ * backward-weight of nn.Conv2d(C, C, 3, padding=1, groups=C/8, bias=False).
+ * x, y, gy, gx: [N,C,H,W]; w, gw: [C,8,3,3].  bwd_weight needs a workspace
+ * (per-tile partial sums, reduced in a fixed order: deterministic); accumulate != 0 adds into gw. */
+int dvd_gconv3x3_c8_fwd(const float* x, const float* w, float* y, int N, int C, int H, int W,
+                        dvd_stream_t stream);
+int dvd_gconv3x3_c8_bwd_data(const float* gy, const float* w, float* gx, int N, int C, int H, int W,
+                             dvd_stream_t stream);
+size_t dvd_gconv3x3_c8_wgrad_workspace_bytes(int N, int C, int H, int W);
+int dvd_gconv3x3_c8_bwd_weight(const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                               size_t workspace_bytes, int N, int C, int H, int W, dvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

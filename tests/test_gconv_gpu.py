@@ -1,0 +1,60 @@
+"""Grouped 3x3 convolution kernels (8 channels per group) against torch's fp32 CPU
+convolution: forward, backward-data, backward-weight.  Tolerance: rtol 1e-5 of max|.|
+forward / backward-data (72-term fp32 dot products in a different order), 2e-5 for the weight
+gradient (sums over N*H*W pixels)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, gy):
+    x = x.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1, 1, x.shape[1] // 8)
+    y.backward(gy)
+    return y.detach(), x.grad, w.grad
+
+
+@pytest.mark.parametrize('N,C,H,W', [(2, 16, 20, 36), (1, 256, 48, 84), (3, 8, 17, 67), (2, 32, 16, 64),
+                                     (1, 24, 5, 3), (2, 256, 96, 168)])
+def test_matches_torch_cpu(N, C, H, W):
+    from dvd_hip.conv import GroupedConv3x3C8, gconv3x3_c8
+    g = torch.Generator().manual_seed(N * 1000 + C + H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 8, 3, 3, generator=g) / 8.0
+    gy = torch.randn(N, C, H, W, generator=g)
+    y_ref, gx_ref, gw_ref = _ref(x, w, gy)
+    xg = x.cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    y = gconv3x3_c8(xg, wg)
+    y.backward(gy.cuda())
+    torch.cuda.synchronize()
+    for name, got, want, tol in (('y', y, y_ref, 1e-5), ('gx', xg.grad, gx_ref, 1e-5), ('gw', wg.grad, gw_ref, 2e-5)):
+        got = got.detach().cpu().numpy()
+        want = want.numpy()
+        assert np.abs(got - want).max() <= tol * np.abs(want).max() + 1e-6, name
+    # module form: same parameter name/shape as the nn.Conv2d it replaces, deterministic weight gradient
+    m = GroupedConv3x3C8(C).cuda()
+    assert tuple(m.weight.shape) == (C, 8, 3, 3) and list(m.state_dict()) == ['weight']
+    with torch.no_grad():
+        m.weight.copy_(w)
+    a = m(x.cuda())
+    a.backward(gy.cuda())
+    g1 = m.weight.grad.clone()
+    m.weight.grad = None
+    m(x.cuda()).backward(gy.cuda())
+    assert torch.equal(g1, m.weight.grad)
+    assert torch.equal(a, y.detach())
+
+
+def test_midas_stage1_uses_the_hip_kernels():
+    from dvd_hip.conv import GroupedConv3x3C8
+    from dvd_hip.third_party.MiDaS import MidasNet
+    net = MidasNet()
+    blocks = list(net.pretrained.layer1[4])
+    assert len(blocks) == 3 and all(isinstance(b.conv2, GroupedConv3x3C8) for b in blocks)
+    assert not isinstance(net.pretrained.layer2[0].conv2, GroupedConv3x3C8)     # stride 2: MIOpen
+    assert 'pretrained.layer1.4.0.conv2.weight' in net.state_dict()
