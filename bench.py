@@ -126,7 +126,10 @@ def main():
     a = ap.parse_args()
 
     from dvd_hip import parallel, synthetic
-    local = parallel.init_from_env()
+    # DVD_DIST_BACKEND=gloo lets two ranks share one GPU (smoke test of the N>1 path on a 1-GPU box);
+    # the driver's multi-GPU runs use the default, nccl = RCCL over xGMI, one rank per GPU
+    local = parallel.init_from_env(backend=os.environ.get('DVD_DIST_BACKEND'))
+    local = local % max(torch.cuda.device_count(), 1)
     world, rank = parallel.world_size(), parallel.rank()
     if a.gpus != world:
         if world == 1 and a.gpus > 1:
@@ -164,6 +167,9 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
     ms_per_step = dt / a.steps * 1e3
+    if parallel.is_distributed():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
     out = {

@@ -41,7 +41,7 @@ def init_from_env(backend=None):
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # 'nccl' is RCCL on ROCm
     if backend == 'nccl':
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group(backend=backend)
     return local

@@ -111,3 +111,74 @@ def test_pair_chunking_is_invisible(whole_gb):
         np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-9, err_msg=k)
     ga, gb = m1._flat_sf.grad, m2._flat_sf.grad
     assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
+
+
+def _dp_worker(rank, world, port, name, q):
+    """One rank of a 2-process data-parallel step.  gpurun boxes have ONE GPU, so both ranks
+    share cuda:0 and talk over gloo (RCCL refuses two ranks on one device); the code path above
+    the backend (shard -> step -> all-reduce of the loss sums and of the flat gradient buffers
+    -> Adam) is the one bench.py runs with nccl on 8 GPUs."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.join(os.path.dirname(here), 'dynamic-video-depth_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0')
+    import warnings
+    import torch.distributed as dist
+    from dvd_hip import parallel
+    import helpers as H
+    parallel.init_from_env(backend='gloo')
+    try:
+        gd = H.load_golden(name)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model, opt, batch = _build(gd, global_rank=rank)
+        B = int(gd['B'])
+        lo, hi = parallel.shard_range(B)
+        shard = {k: (v[lo:hi].contiguous() if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B) else v)
+                 for k, v in batch.items()}
+        log = model._train_on_batch(int(gd['epoch']), 0, H.loader_batch(shard))
+        torch.cuda.synchronize()
+        q.put((rank, log, model._flat_sf.flat.cpu().numpy(), model._flat_depth.flat.cpu().numpy(),
+               model._flat_sf.grad.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_data_parallel_step_equals_single_process():
+    """Pairs sharded over 2 ranks reproduce the 1-process step on the whole batch: same batch_log
+    (batch-global normaliser), same summed gradients, same parameters after Adam on both ranks."""
+    import socket
+    import torch.multiprocessing as mp
+    name = 'fullstep_hourglass_b2_32x48_train'
+    gd = helpers.load_golden(name)
+    model, opt, batch = _build(gd)
+    ref = model._train_on_batch(int(gd['epoch']), 0, helpers.loader_batch(batch))
+    torch.cuda.synchronize()
+    ref_sf, ref_depth, ref_g = (model._flat_sf.flat.cpu().numpy(), model._flat_depth.flat.cpu().numpy(),
+                                model._flat_sf.grad.cpu().numpy())
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, log, sf, depth, g in res:
+        for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
+            np.testing.assert_allclose(log[k], ref[k], rtol=1e-5, atol=1e-9, err_msg='rank %d %s' % (rank, k))
+        assert np.abs(g - ref_g).max() <= 2e-4 * np.abs(ref_g).max()
+        lr_sf, lr_d = opt.lr * opt.scene_lr_mul, opt.lr
+        assert np.abs(sf - ref_sf).max() <= 2.5 * lr_sf          # Adam's first step is ~lr*sign(g)
+        assert np.abs(depth - ref_depth).max() <= 2.5 * lr_d
+    np.testing.assert_array_equal(res[0][2], res[1][2])            # ranks stay in lock step
+    np.testing.assert_array_equal(res[0][3], res[1][3])
