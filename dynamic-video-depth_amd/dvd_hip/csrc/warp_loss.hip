@@ -701,7 +701,7 @@ struct TileIO2 {
 };
 
 // ---------------------------------------------------------------------------
-// Tiled variant, third generation: guard-banded fast arithmetic (DVD_WARP_GEN=3, the default).
+// Tiled variant, third generation: guard-banded fast arithmetic (DVD_WARP_GEN=3; experimental, see launch_tiled).
 //
 // PMC on the first tiled kernel (profiles/r01_warp_loss_sq_counters.txt): 8.9e7 VALU wave
 // instructions per launch at 48x384x672 = 457 per pixel, VALU busy 63 % of the kernel time:
@@ -716,19 +716,20 @@ struct TileIO2 {
 //     one row; the frame-2 warped point from (sum_k a_k c_k) @ (K_inv R2).  Per pixel that is
 //     ~35 FMAs instead of ~110 unfused operations, and the per-pixel live state shrinks.
 //   * every decision is taken on the fast value when it is outside a GUARD BAND around the
-//     threshold that bounds |fast - exact| from the operand magnitudes (error model in
-//     warp_prepare_kernel); inside the band (rare) the pixel re-evaluates the reference's exact
-//     sequence from the raw camera block and decides on that.  Masks, the valid-pixel count and
-//     the sub-gradient signs are therefore bit-identical to the exact kernels; everything else
-//     agrees within fp32 rounding (it was FAST arithmetic before, too).
+//     threshold, sized from the operand magnitudes (error model in warp_prepare_kernel).  A
+//     pixel inside a band (about 1 in 1000) is NOT evaluated by the tile kernel at all: it
+//     contributes nothing there and its index goes to a fix-up list; `warp_post_kernel`
+//     (which also applies the window-overflow list) then evaluates exactly those pixels with the
+//     reference's exact sequence (the pixel<>() of the first generation) and adds their sums and
+//     gradients.  Masks, the valid-pixel count and the sub-gradient signs are therefore those of
+//     the exact kernels; everything else agrees within fp32 rounding (it was FAST arithmetic
+//     before, too).  Keeping the exact sequence out of the tile kernel is what makes it lean:
+//     inlined as a rare branch it cost 75 us of spills and divergence at 48x384x672.
 //   * the bilinear sampling position and weights keep the exact five-rounding sequence
 //     (tap indices), evaluated with the unscaled division of the second-generation kernel.
 
-#ifndef DVD_WARP3_SLOW
-#define DVD_WARP3_SLOW 1
-#endif
 #ifndef DVD_WARP3_PIN
-#define DVD_WARP3_PIN 0x0ull   // bit g pins floats [3g, 3g+3) of the pair record into VGPRs
+#define DVD_WARP3_PIN 0x3ffull   // bit g pins floats [3g, 3g+3) of the pair record into VGPRs
 #endif
 constexpr int kPreFloats = 64;
 // layout of one pair's record (floats)
@@ -820,38 +821,7 @@ struct Pre {
 
 // The reference's exact I = (((d1 * (c @ Ki)) @ R1 + t1 + s) - t2) @ R2T @ K for one pixel, from the
 // raw camera block (only evaluated inside a guard band).
-struct CamPtrs {   // the pair's raw camera block (already offset to the pair)
-  const float *Ki, *R1, *R2T, *K, *t1, *t2;
-};
-__device__ __forceinline__ void exact_reprojection(const CamPtrs& cp, float xf, float yf, float d1, float s0, float s1,
-                                                float s2, float& I0, float& I1, float& I2) {
-  Cam c;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    c.Ki[i] = cp.Ki[i];
-    c.R1[i] = cp.R1[i];
-    c.R2T[i] = cp.R2T[i];
-    c.K[i] = cp.K[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    c.t1[i] = cp.t1[i];
-    c.t2[i] = cp.t2[i];
-  }
-  float r0, r1, r2;
-  rowvec_mat3(xf, yf, 1.0f, c.Ki, r0, r1, r2);
-  const float pc0 = d1 * r0, pc1 = d1 * r1, pc2 = d1 * r2;
-  float P0, P1, P2;
-  rowvec_mat3(pc0, pc1, pc2, c.R1, P0, P1, P2);
-  P0 = P0 + c.t1[0];
-  P1 = P1 + c.t1[1];
-  P2 = P2 + c.t1[2];
-  const float A0 = (P0 + s0) - c.t2[0], A1 = (P1 + s1) - c.t2[1], A2 = (P2 + s2) - c.t2[2];
-  float Q0, Q1, Q2;
-  rowvec_mat3(A0, A1, A2, c.R2T, Q0, Q1, Q2);
-  rowvec_mat3(Q0, Q1, Q2, c.K, I0, I1, I2);
-}
-
+// The reference's exact sequence for guard-band pixels lives in warp_post_kernel (below).
 __device__ __forceinline__ float sample_coord_x(float pix, float fl, float half, float rhalf, float maxv) {
   float g = pix + fl;
   g = div_exact1(g, half, rhalf);
@@ -866,8 +836,8 @@ struct RowConst {   // per image row: the y part of c @ M for the three composit
 
 // One pixel, fast arithmetic + guard bands.  `k` = the pair's composite constants.
 template <bool GRADS, bool SHIPPED, int WW, int WH>
-__device__ __forceinline__ void pixel_fast(const WarpArgs& a, const Pre& k, const TileIO2<WW, WH>& io,
-                                           const CamPtrs& cp, float rhw, float rhh, const RowConst& rc, int y, int x, float d1,
+__device__ __forceinline__ bool pixel_fast(const WarpArgs& a, const Pre& k, const TileIO2<WW, WH>& io,
+                                           float rhw, float rhh, const RowConst& rc, int y, int x, float d1,
                                            float fx, float fy, float mk, float s0, float s1, float s2,
                                            float acc[4], float& g_d1_out, float g_s_out[3]) {
   const bool midas_mask = SHIPPED ? true : (a.midas_mask != 0);
@@ -902,30 +872,23 @@ __device__ __forceinline__ void pixel_fast(const WarpArgs& a, const Pre& k, cons
   const float sE = a_ne + a_se, sS = a_sw + a_se, sA = (a_nw + a_ne) + sS;
   const float vx = DVD_FMA(x0f, sA, sE), vy = DVD_FMA(y0f, sA, sS);
   float W2z = DVD_FMA(vx, k.kz[0], DVD_FMA(vy, k.kz[1], sA * k.kz[2]));
-  bool w2_lt = W2z < 100.0f;
-  if (midas_mask && !(fabsf(W2z - 100.0f) > 1.0f)) {   // guard band (also catches NaN): the reference's sequence
-    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
-    const float zn0 = (x0f * k.kz[0] + y0f * k.kz[1]) + k.kz[2];
-    const float zn1 = (x1f * k.kz[0] + y0f * k.kz[1]) + k.kz[2];
-    const float zs0 = (x0f * k.kz[0] + y1f * k.kz[1]) + k.kz[2];
-    const float zs1 = (x1f * k.kz[0] + y1f * k.kz[1]) + k.kz[2];
-    const float w2e = bilinear(dnw * zn0, dne * zn1, dsw * zs0, dse * zs1, w_nw, w_ne, w_sw, w_se);
-    w2_lt = w2e < 100.0f;
-    W2z = w2e;
-  }
+  const bool w2_lt = W2z < 100.0f;
+  // guard band of [W2.z < 100] (also catches NaN); the composite value is within 1e-3 of the reference's
+  bool unsure = midas_mask && !(fabsf(W2z - 100.0f) > 1.0f);
   // --- reprojection of pixel 1 into image 2: I = d1 (c @ M3) + s @ M2 + tv
   const float c30 = DVD_FMA(xf, k.M3[0], rc.c3[0]), c31 = DVD_FMA(xf, k.M3[1], rc.c3[1]),
               c32 = DVD_FMA(xf, k.M3[2], rc.c3[2]);
   const float c4 = DVD_FMA(xf, k.m4[0], rc.c4);
-  float I0 = DVD_FMA(d1, c30, DVD_FMA(s0, k.M2[0], DVD_FMA(s1, k.M2[3], DVD_FMA(s2, k.M2[6], k.tv[0]))));
-  float I1 = DVD_FMA(d1, c31, DVD_FMA(s0, k.M2[1], DVD_FMA(s1, k.M2[4], DVD_FMA(s2, k.M2[7], k.tv[1]))));
-  float I2 = DVD_FMA(d1, c32, DVD_FMA(s0, k.M2[2], DVD_FMA(s1, k.M2[5], DVD_FMA(s2, k.M2[8], k.tv[2]))));
+  const float I0 = DVD_FMA(d1, c30, DVD_FMA(s0, k.M2[0], DVD_FMA(s1, k.M2[3], DVD_FMA(s2, k.M2[6], k.tv[0]))));
+  const float I1 = DVD_FMA(d1, c31, DVD_FMA(s0, k.M2[1], DVD_FMA(s1, k.M2[4], DVD_FMA(s2, k.M2[7], k.tv[1]))));
+  const float I2 = DVD_FMA(d1, c32, DVD_FMA(s0, k.M2[2], DVD_FMA(s1, k.M2[5], DVD_FMA(s2, k.M2[8], k.tv[2]))));
   const float Q2 = DVD_FMA(d1, c4, DVD_FMA(s0, k.r2[0], DVD_FMA(s1, k.r2[1], DVD_FMA(s2, k.r2[2], k.tq))));
-  float den = I2 + 1e-8f;
-  float rden = __builtin_amdgcn_rcpf(den);
-  bool behind = I2 < 1e-3f;
-  float u = I0 * rden, v = I1 * rden;
-  float ex = (u - xf) - fx, ey = (v - yf) - fy;
+  const float den = I2 + 1e-8f;
+  const float rden = __builtin_amdgcn_rcpf(den);
+  const bool behind = I2 < 1e-3f;
+  // the reference overwrites the projection of a behind-camera point by the pixel's own coordinates
+  const float u = behind ? xf : I0 * rden, v = behind ? yf : I1 * rden;
+  const float ex = (u - xf) - fx, ey = (v - yf) - fy;
   {
     // guard bands: |I_fast - I_ref| <= E (see warp_prepare_kernel)
     const float smag = (fabsf(s0) + fabsf(s1)) + (fabsf(s2) + k.tsum);
@@ -933,25 +896,11 @@ __device__ __forceinline__ void pixel_fast(const WarpArgs& a, const Pre& k, cons
     const float Exy = DVD_FMA(ad1, k.eAxy, smag * k.eBxy), Ez = DVD_FMA(ad1, k.eAz, smag * k.eBz);
     const float gu = DVD_FMA(fmaxf(fabsf(u), fabsf(v)), Ez, Exy) * fabsf(rden) * 1.25f;
     const bool sure_behind = I2 < 1e-3f - Ez, sure_front = I2 > 1e-3f + Ez;
-    const bool signs_ok = (fabsf(ex) > gu) && (fabsf(ey) > gu);
-    if (DVD_WARP3_SLOW && !(sure_behind || (sure_front && signs_ok))) {   // rare; NaNs land here too
-      exact_reprojection(cp, xf, yf, d1, s0, s1, s2, I0, I1, I2);
-      den = I2 + 1e-8f;
-      behind = I2 < 1e-3f;
-      const float yd = rcp_refined(den);
-      u = div_exact1(I0, den, yd);
-      v = div_exact1(I1, den, yd);
-      rden = yd;
-      ex = (u - xf) - fx;
-      ey = (v - yf) - fy;
-    }
+    // the L1 sub-gradient takes sign(dflow - flow); the squared criterion of the warm phase does not
+    const bool signs_ok = a.crit_l2 || ((fabsf(ex) > gu) && (fabsf(ey) > gu));
+    unsure = unsure || !(sure_behind || (sure_front && signs_ok));   // NaNs land here too
   }
-  if (behind) {   // the reference overwrites the projection by the pixel's own coordinates (zero gradient)
-    ex = (xf - xf) - fx;
-    ey = (yf - yf) - fy;
-    u = xf;
-    v = yf;
-  }
+  if (unsure) mk = 0.0f;   // evaluated by warp_post_kernel instead: contributes nothing here
   // --- sf_by_depth - sf = (sum_k a_k c_k) @ M5 + t2 - (d1 (c @ M1) + t1) - s
   const float c10 = DVD_FMA(xf, k.M1[0], rc.c1[0]), c11 = DVD_FMA(xf, k.M1[1], rc.c1[1]),
               c12 = DVD_FMA(xf, k.M1[2], rc.c1[2]);
@@ -979,10 +928,10 @@ __device__ __forceinline__ void pixel_fast(const WarpArgs& a, const Pre& k, cons
   }
   const float sf_err = (fabsf(f0) + fabsf(f1)) + fabsf(f2);
   acc[0] += m;
-  acc[1] = DVD_FMA(m, flow_err, acc[1]);
-  acc[2] = DVD_FMA(m, disp_err, acc[2]);
-  acc[3] = DVD_FMA(m, sf_err, acc[3]);
-  if (!GRADS) return;
+  acc[1] = DVD_FMA(m, unsure ? 0.0f : flow_err, acc[1]);   // exactly nothing from a pixel left to the fix-up pass
+  acc[2] = DVD_FMA(m, unsure ? 0.0f : disp_err, acc[2]);
+  acc[3] = DVD_FMA(m, unsure ? 0.0f : sf_err, acc[3]);
+  if (!GRADS) return unsure;
   // ------------------------------ backward (un-normalised), branch free ------------------
   const float fm = behind ? 0.0f : a.flow_mul * m;
   const float gu_ = a.crit_l2 ? fm * 2.0f * ex : signed_mag(fm, ex);
@@ -1009,7 +958,7 @@ __device__ __forceinline__ void pixel_fast(const WarpArgs& a, const Pre& k, cons
   float gd = DVD_FMA(gI0, c30, DVD_FMA(gI1, c31, DVD_FMA(gI2, c32, gQ2 * c4)));
   if (loss_on_sf) gd = gd - dm * DVD_FMA(uG0, c10, DVD_FMA(uG1, c11, uG2 * c12));
   g_d1_out = gd;
-  if (a.ablate & 1) return;
+  if (a.ablate & 1) return unsure;
   // depth_2 taps (units of disp_mul): d/d(a_k) = H . c_k,  H = uG @ M5^T + uW2z * kz
   float Hx = uW2z * k.kz[0], Hy = uW2z * k.kz[1], Hz = uW2z * k.kz[2];
   if (loss_on_sf) {
@@ -1021,14 +970,14 @@ __device__ __forceinline__ void pixel_fast(const WarpArgs& a, const Pre& k, cons
   const float hbx = hb + Hx;
   const float tn0 = w_nw * hb, tn1 = w_ne * hbx, ts0 = w_sw * (hb + Hy), ts1 = w_se * (hbx + Hy);
   const float big = fmaxf(fmaxf(fabsf(tn0), fabsf(tn1)), fmaxf(fabsf(ts0), fabsf(ts1)));
-  const bool fast = inside && (big < kFixMax);
+  const bool fast = inside && (big < kFixMax) && !unsure;
   // out-of-image taps carry an exactly zero weight, and their window cells are never read back
   unsigned long long* p = io.accw + cell;
   atomicAdd(p, to_fixed(fast ? tn0 : 0.0f));
   atomicAdd(p + 1, to_fixed(fast ? tn1 : 0.0f));
   atomicAdd(p + WW, to_fixed(fast ? ts0 : 0.0f));
   atomicAdd(p + WW + 1, to_fixed(fast ? ts1 : 0.0f));
-  if (!fast) {   // rare: list of (index, value) applied after the slab combine
+  if (!fast && !unsure) {   // rare: list of (index, value) applied after the slab combine
     const int o_n = y0 * io.W + x0;
     const bool in_e = (x0 + 1) < a.W, in_s = (y0 + 1) < a.H;
     io.spill(o_n, tn0);
@@ -1036,14 +985,16 @@ __device__ __forceinline__ void pixel_fast(const WarpArgs& a, const Pre& k, cons
     if (in_s) io.spill(o_n + io.W, ts0);
     if (in_e && in_s) io.spill(o_n + io.W + 1, ts1);
   }
+  return unsure;
 }
 
-template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED>
+template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED, int PX>
 __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_loss_tiled3_kernel(
-    const WarpArgs a, const TileArgs ta, const float* __restrict__ pre) {
+    const WarpArgs a, const TileArgs ta, const float* __restrict__ pre, const Overflow fix) {
   constexpr int WW = TW + 2 * R + 4;
   constexpr int WH = TH + 2 * R + 1;
-  constexpr int QW = TW / 4;
+  constexpr int QW = TW / PX;
+  typedef float vecf __attribute__((ext_vector_type(PX)));
   static_assert(R % 4 == 0 && TW % 4 == 0, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);
@@ -1090,7 +1041,6 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
     k.eBz = t_[kpEBz];
     k.tsum = t_[kpTsum];
   }
-  const CamPtrs cp{a.Ki + b * 9, a.R1 + b * 9, a.R2T + b * 9, a.K + b * 9, a.t1 + b * 3, a.t2 + b * 3};
   const float* d2b = a.d2 + (size_t)b * a.HW;
 
   // ---- phase 0: fill the depth_2 window, clear the accumulator
@@ -1132,71 +1082,108 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   float* gs0b = a.g_sf + (size_t)b * 3 * a.HW;
   float* gs1b = gs0b + a.HW;
   float* gs2b = gs1b + a.HW;
-  // ---- phase 1: the tile's pixels, 4 per thread per step
-  for (int q = threadIdx.x; q < QW * TH; q += NT) {
-    const int ly = q / QW, lx = (q - ly * QW) * 4;
-    const int y = ty0 + ly, x = tx0 + lx;
-    if (y >= a.H || x >= a.W) continue;
+  // ---- phase 1: the tile's pixels, PX per thread per step; the inputs of step i+1 are requested
+  //      before step i is evaluated (all waves of a block leave the barrier together, so without
+  //      this every load latency of the block is exposed at the same time)
+  const bool wv = (a.W % PX) == 0;
+  struct In {
+    float d1[PX], mk[PX], fl[2 * PX], s0[PX], s1[PX], s2[PX];
+  };
+  auto locate = [&](int q, int& x, int& y) {
+    const int ly = q / QW, lx = (q - ly * QW) * PX;
+    y = ty0 + ly;
+    x = tx0 + lx;
+    return (q < QW * TH) && (y < a.H) && (x < a.W);
+  };
+  auto fetch = [&](int q, In& r) {
+    int x, y;
+    if (!locate(q, x, y)) return;
     const unsigned p0 = (unsigned)(y * a.W + x);
-    float d1[4], mk[4], fl[8], s0[4], s1[4], s2[4];
-    const int nvalid = (a.W - x) < 4 ? (a.W - x) : 4;
-    if (w4) {
+    const int nvalid = (a.W - x) < PX ? (a.W - x) : PX;
+    if (wv) {
       const unsigned o4 = p0 * 4u;
-      *reinterpret_cast<float4*>(d1) = ld_off<float4>(d1b, o4);
-      *reinterpret_cast<float4*>(mk) = ld_off<float4>(mkb, o4);
-      *reinterpret_cast<float4*>(fl) = ld_off<float4>(flb, o4 * 2u);
-      *reinterpret_cast<float4*>(fl + 4) = ld_off<float4>(flb, o4 * 2u + 16u);
-      *reinterpret_cast<float4*>(s0) = ld_off<float4>(sf0b, o4);
-      *reinterpret_cast<float4*>(s1) = ld_off<float4>(sf1b, o4);
-      *reinterpret_cast<float4*>(s2) = ld_off<float4>(sf2b, o4);
+      *reinterpret_cast<vecf*>(r.d1) = ld_off<vecf>(d1b, o4);
+      *reinterpret_cast<vecf*>(r.mk) = ld_off<vecf>(mkb, o4);
+      *reinterpret_cast<vecf*>(r.fl) = ld_off<vecf>(flb, o4 * 2u);
+      *reinterpret_cast<vecf*>(r.fl + PX) = ld_off<vecf>(flb, o4 * 2u + 4u * PX);
+      *reinterpret_cast<vecf*>(r.s0) = ld_off<vecf>(sf0b, o4);
+      *reinterpret_cast<vecf*>(r.s1) = ld_off<vecf>(sf1b, o4);
+      *reinterpret_cast<vecf*>(r.s2) = ld_off<vecf>(sf2b, o4);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < PX; ++i) {
         const bool ok = i < nvalid;
-        d1[i] = ok ? d1b[p0 + i] : 1.0f;
-        mk[i] = ok ? mkb[p0 + i] : 0.0f;
-        fl[2 * i] = ok ? flb[2 * (size_t)(p0 + i)] : 0.0f;
-        fl[2 * i + 1] = ok ? flb[2 * (size_t)(p0 + i) + 1] : 0.0f;
-        s0[i] = ok ? sf0b[p0 + i] : 0.0f;
-        s1[i] = ok ? sf1b[p0 + i] : 0.0f;
-        s2[i] = ok ? sf2b[p0 + i] : 0.0f;
+        r.d1[i] = ok ? d1b[p0 + i] : 1.0f;
+        r.mk[i] = ok ? mkb[p0 + i] : 0.0f;
+        r.fl[2 * i] = ok ? flb[2 * (size_t)(p0 + i)] : 0.0f;
+        r.fl[2 * i + 1] = ok ? flb[2 * (size_t)(p0 + i) + 1] : 0.0f;
+        r.s0[i] = ok ? sf0b[p0 + i] : 0.0f;
+        r.s1[i] = ok ? sf1b[p0 + i] : 0.0f;
+        r.s2[i] = ok ? sf2b[p0 + i] : 0.0f;
       }
     }
-    RowConst rc;
-    {
-      const float yf = (float)y;
+  };
+  In cur, nxt;
+  fetch(threadIdx.x, cur);
+  for (int q = threadIdx.x; q < QW * TH; q += NT) {
+    fetch(q + NT, nxt);
+    int x, y;
+    if (locate(q, x, y)) {
+      const unsigned p0 = (unsigned)(y * a.W + x);
+      const int nvalid = (a.W - x) < PX ? (a.W - x) : PX;
+      RowConst rc;
+      {
+        const float yf = (float)y;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        rc.c3[j] = DVD_FMA(yf, k.M3[3 + j], k.M3[6 + j]);
-        rc.c1[j] = DVD_FMA(yf, k.M1[3 + j], k.M1[6 + j]);
+        for (int j = 0; j < 3; ++j) {
+          rc.c3[j] = DVD_FMA(yf, k.M3[3 + j], k.M3[6 + j]);
+          rc.c1[j] = DVD_FMA(yf, k.M1[3 + j], k.M1[6 + j]);
+        }
+        rc.c4 = DVD_FMA(yf, k.m4[1], k.m4[2]);
       }
-      rc.c4 = DVD_FMA(yf, k.m4[1], k.m4[2]);
-    }
-    float gd1[4], gs[4][3];
+      float gd1[PX], g0[PX], g1[PX], g2[PX];
+      unsigned unsure_bits = 0u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      gd1[i] = 0.0f;
-      gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
-      if (i < nvalid)
-        pixel_fast<GRADS, SHIPPED, WW, WH>(a, k, io, cp, rhw, rhh, rc, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i],
-                                           s0[i], s1[i], s2[i], acc, gd1[i], gs[i]);
-    }
-    if (GRADS && !(a.ablate & 2)) {
-      if (w4) {
-        const unsigned o4 = p0 * 4u;
-        st_off<float4>(gd1b, o4, make_float4(gd1[0], gd1[1], gd1[2], gd1[3]));
-        st_off<float4>(gs0b, o4, make_float4(gs[0][0], gs[1][0], gs[2][0], gs[3][0]));
-        st_off<float4>(gs1b, o4, make_float4(gs[0][1], gs[1][1], gs[2][1], gs[3][1]));
-        st_off<float4>(gs2b, o4, make_float4(gs[0][2], gs[1][2], gs[2][2], gs[3][2]));
-      } else {
-        for (int i = 0; i < nvalid; ++i) {
-          gd1b[p0 + i] = gd1[i];
-          gs0b[p0 + i] = gs[i][0];
-          gs1b[p0 + i] = gs[i][1];
-          gs2b[p0 + i] = gs[i][2];
+      for (int i = 0; i < PX; ++i) {
+        float gs[3] = {0.0f, 0.0f, 0.0f};
+        gd1[i] = 0.0f;
+        if (i < nvalid) {
+          const bool un = pixel_fast<GRADS, SHIPPED, WW, WH>(a, k, io, rhw, rhh, rc, y, x + i, cur.d1[i], cur.fl[2 * i],
+                                                             cur.fl[2 * i + 1], cur.mk[i], cur.s0[i], cur.s1[i],
+                                                             cur.s2[i], acc, gd1[i], gs);
+          unsure_bits |= un ? (1u << i) : 0u;
+        }
+        g0[i] = gs[0];
+        g1[i] = gs[1];
+        g2[i] = gs[2];
+      }
+      if (unsure_bits) {   // about 1 pixel in 1000: left to warp_post_kernel
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+          if (unsure_bits & (1u << i)) {
+            const unsigned slot = atomicAdd(fix.count, 1u);
+            if (slot < fix.cap) reinterpret_cast<int*>(fix.rec)[slot] = (int)(b * a.HW + p0 + i);
+          }
+        }
+      }
+      if (GRADS && !(a.ablate & 2)) {
+        if (wv) {
+          const unsigned o4 = p0 * 4u;
+          st_off<vecf>(gd1b, o4, *reinterpret_cast<const vecf*>(gd1));
+          st_off<vecf>(gs0b, o4, *reinterpret_cast<const vecf*>(g0));
+          st_off<vecf>(gs1b, o4, *reinterpret_cast<const vecf*>(g1));
+          st_off<vecf>(gs2b, o4, *reinterpret_cast<const vecf*>(g2));
+        } else {
+          for (int i = 0; i < nvalid; ++i) {
+            gd1b[p0 + i] = gd1[i];
+            gs0b[p0 + i] = g0[i];
+            gs1b[p0 + i] = g1[i];
+            gs2b[p0 + i] = g2[i];
+          }
         }
       }
     }
+    cur = nxt;
   }
   // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
   __syncthreads();
@@ -1222,6 +1209,74 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
     float v = 0.0f;
     for (int w = 0; w < NT / 64; ++w) v += red[w * 4 + threadIdx.x];
     a.partial[(size_t)logical * 4 + threadIdx.x] = v;
+  }
+}
+
+// After the slab combine: (1) the window-overflow records, (2) the guard-band pixels of the
+// third-generation tile kernel, evaluated with the reference's exact sequence (pixel<>() of the
+// first generation on global memory); their four loss terms are accumulated in Q31.32 integers
+// (order independent) that reduce_partials_kernel adds to the block partials.
+struct FixIO {
+  const float* d2b;
+  float* gb;
+  int W;
+  float unit;
+  __device__ __forceinline__ void fetch(int o_n, int x0, int y0, bool in_e, bool in_s, float& dnw, float& dne,
+                                        float& dsw, float& dse) const {
+    DirectIO g{d2b, nullptr, W, 1.0f};
+    g.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
+  }
+  __device__ __forceinline__ void scatter(int o_n, int, int, bool in_e, bool in_s, float tnw, float tne, float tsw,
+                                          float tse) const {
+    unsafeAtomicAdd(gb + o_n, tnw * unit);
+    if (in_e) unsafeAtomicAdd(gb + o_n + 1, tne * unit);
+    if (in_s) unsafeAtomicAdd(gb + o_n + W, tsw * unit);
+    if (in_e && in_s) unsafeAtomicAdd(gb + o_n + W + 1, tse * unit);
+  }
+};
+
+template <bool GRADS>
+__global__ __launch_bounds__(256) void warp_post_kernel(const WarpArgs a, const Overflow ovf, const Overflow fix,
+                                                        unsigned long long* __restrict__ fix_sums) {
+  if (GRADS) {
+    unsigned n = *ovf.count;
+    if (n > ovf.cap) n = ovf.cap;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+      const int2 r = ovf.rec[i];
+      unsafeAtomicAdd(a.g_d2 + r.x, __int_as_float(r.y));
+    }
+  }
+  unsigned nf = *fix.count;
+  if (nf > fix.cap) nf = fix.cap;
+  unsigned long long tot[4] = {0ull, 0ull, 0ull, 0ull};
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nf; i += gridDim.x * 256) {
+    const int lin = reinterpret_cast<const int*>(fix.rec)[i];
+    const int b = lin / a.HW, p0 = lin - b * a.HW;
+    const int y = p0 / a.W, x = p0 - y * a.W;
+    Cam c;
+    load_cam(a, b, c);
+    FixIO io{a.d2 + (size_t)b * a.HW, GRADS ? a.g_d2 + (size_t)b * a.HW : nullptr, a.W, a.disp_mul};
+    const float* sfb = a.sf + (size_t)b * 3 * a.HW + p0;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gd1 = 0.0f, gs[3] = {0.0f, 0.0f, 0.0f};
+    pixel<GRADS, false>(a, c, io, y, x, a.d1[lin], a.flow[2 * (size_t)lin], a.flow[2 * (size_t)lin + 1], a.mask[lin],
+                        sfb[0], sfb[a.HW], sfb[2 * a.HW], acc, gd1, gs);
+    if (GRADS) {
+      float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
+      a.g_d1[lin] = gd1;
+      gsb[0] = gs[0];
+      gsb[a.HW] = gs[1];
+      gsb[2 * a.HW] = gs[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tot[j] += to_fixed(fminf(acc[j], kFixMax));
+  }
+  // integer sums: exact and order independent; one atomic per wave and term
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned long long v = tot[j];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0ull) atomicAdd(fix_sums + j, v);
   }
 }
 
@@ -1283,7 +1338,8 @@ __global__ __launch_bounds__(256) void apply_overflow_kernel(const unsigned* __r
 
 // Second stage: fixed-order sum of the per-block partials (deterministic).
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int n,
-                                                               float* __restrict__ sums) {
+                                                               float* __restrict__ sums,
+                                                               const unsigned long long* __restrict__ fix_sums) {
   __shared__ double sh[1024][4];
   double acc[4] = {0, 0, 0, 0};
   for (int i = threadIdx.x; i < n; i += 1024) {
@@ -1303,7 +1359,11 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     }
     __syncthreads();
   }
-  if (threadIdx.x < 4) sums[threadIdx.x] = (float)sh[0][threadIdx.x];
+  if (threadIdx.x < 4) {
+    double v = sh[0][threadIdx.x];
+    if (fix_sums) v += (double)(long long)fix_sums[threadIdx.x] * (1.0 / 4294967296.0);   // guard-band pixels (generation 3)
+    sums[threadIdx.x] = (float)v;
+  }
 }
 
 __global__ void loss_finalize_kernel(const float* __restrict__ sums, float flow_mul, float disp_mul,
@@ -1356,7 +1416,7 @@ static int choose_shape(int H, int W) {
 
 struct Plan {
   int shape, ntx, nty, ww, wh;
-  size_t n_partials, off_count, off_pre, off_slabs, off_ovf, ovf_cap, total;
+  size_t n_partials, off_count, off_pre, off_slabs, off_ovf, ovf_cap, off_fix, fix_cap, total;
 };
 
 static Plan make_plan(int B, int H, int W) {
@@ -1383,6 +1443,9 @@ static Plan make_plan(int B, int H, int W) {
   p.off_ovf = off;
   p.ovf_cap = (size_t)4 * B * H * W;  // every tap of every pixel: the list can never overflow
   off += p.ovf_cap * sizeof(int2);
+  p.off_fix = off;
+  p.fix_cap = (size_t)B * H * W;       // guard-band pixel list of generation 3: one slot per pixel, cannot overflow
+  off += p.fix_cap * sizeof(int);
   p.total = off;
   return p;
 }
@@ -1399,21 +1462,34 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.nty = p.nty;
   const int nblocks = p.ntx * p.nty * a.B;
   const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
-  if (grads) DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, sizeof(unsigned), stream));
+  // counter block (256 B): [0] overflow count, [16] fix-up count, [32..63] four Q31.32 fix-up sums
+  DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, 64, stream));
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
-  // generation 1 = exact arithmetic everywhere (default: the fastest kernel that is exact today);
-  // generation 3 = guard-banded fast arithmetic (DVD_WARP_GEN=3; see its header for where it stands)
+  // generation 1 (default) = the reference's rounding sequence for every pixel; generation 3
+  // (DVD_WARP_GEN=3) = guard-banded fast arithmetic + exact fix-up pass.  Measured at 48x384x672
+  // (profiles/r01_warp_loss_microbench.jsonl): generation 3 needs 121 us for loads + arithmetic
+  // against 147 us, but its extra prepare / fix-up launches and a slower scatter phase leave the
+  // whole launch at 299 us against 260 us, so generation 1 stays the production kernel until the
+  // slab round trip (the common 65 us + 33 us of both) is gone.
   const int gen = env_int("DVD_WARP_GEN", 1);
+  // 2 pixels per thread-step when that splits the tile evenly over the block and 4 does not
+  constexpr bool kEven4 = ((TW / 4) * TH) % NT == 0, kEven2 = ((TW / 2) * TH) % NT == 0;
+  const bool px2 = env_int("DVD_WARP_PX", (kEven2 && !kEven4) ? 2 : 4) == 2;
+  Overflow fix;
+  fix.count = ta.ovf.count + 4;
+  fix.rec = reinterpret_cast<int2*>(ws + p.off_fix);
+  fix.cap = (unsigned)(p.fix_cap > 0xffffffffULL ? 0xffffffffULL : p.fix_cap);
+  unsigned long long* fix_sums = reinterpret_cast<unsigned long long*>(ta.ovf.count + 8);
   if (gen == 3) {
     float* pre = reinterpret_cast<float*>(ws + p.off_pre);
     hipLaunchKernelGGL(warp_prepare_kernel, dim3((a.B + 63) / 64), dim3(64), 0, stream, a, pre);
     DVD_LAUNCH_OK();
 #define DVD_TILED3_LAUNCH(G, S)                                                                           \
   do {                                                                                                    \
-    auto k3 = warp_loss_tiled3_kernel<TW, TH, kR, NT, G, S>;                                              \
+    auto k3 = px2 ? warp_loss_tiled3_kernel<TW, TH, kR, NT, G, S, 2> : warp_loss_tiled3_kernel<TW, TH, kR, NT, G, S, 4>; \
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3),                                     \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-    hipLaunchKernelGGL(k3, dim3(nblocks), dim3(NT), lds, stream, a, ta, pre);                             \
+    hipLaunchKernelGGL(k3, dim3(nblocks), dim3(NT), lds, stream, a, ta, pre, fix);                        \
   } while (0)
     if (grads) {
       if (shipped)
@@ -1428,9 +1504,6 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
     }
 #undef DVD_TILED3_LAUNCH
   } else {
-    // 2 pixels per thread-step when that splits the tile evenly over the block and 4 does not
-    constexpr bool kEven4 = ((TW / 4) * TH) % NT == 0, kEven2 = ((TW / 2) * TH) % NT == 0;
-    const bool px2 = env_int("DVD_WARP_PX", (kEven2 && !kEven4) ? 2 : 4) == 2;
 #define DVD_TILED_LAUNCH(G, S)                                                                            \
   do {                                                                                                    \
     auto k = px2 ? warp_loss_tiled_kernel<TW, TH, kR, NT, G, S, 2> : warp_loss_tiled_kernel<TW, TH, kR, NT, G, S, 4>; \
@@ -1458,11 +1531,21 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
     hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, stream,
                        ta.slabs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads);
     DVD_LAUNCH_OK();
-    hipLaunchKernelGGL(apply_overflow_kernel, dim3(64), dim3(256), 0, stream, ta.ovf.count, ta.ovf.rec, ta.ovf.cap,
-                       a.g_d2);
+    if (gen != 3) {
+      hipLaunchKernelGGL(apply_overflow_kernel, dim3(64), dim3(256), 0, stream, ta.ovf.count, ta.ovf.rec,
+                         ta.ovf.cap, a.g_d2);
+      DVD_LAUNCH_OK();
+    }
+  }
+  if (gen == 3) {
+    if (grads)
+      hipLaunchKernelGGL(warp_post_kernel<true>, dim3(128), dim3(256), 0, stream, a, ta.ovf, fix, fix_sums);
+    else
+      hipLaunchKernelGGL(warp_post_kernel<false>, dim3(128), dim3(256), 0, stream, a, ta.ovf, fix, fix_sums);
     DVD_LAUNCH_OK();
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nblocks, a.sums);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nblocks, a.sums,
+                     gen == 3 ? (const unsigned long long*)fix_sums : (const unsigned long long*)nullptr);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -1544,7 +1627,8 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
         hipLaunchKernelGGL((warp_loss_kernel<1, false>), grid, block, 0, stream, a);
     }
     DVD_LAUNCH_OK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nbx * cfg->B, sums);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nbx * cfg->B, sums,
+                       (const unsigned long long*)nullptr);
     DVD_LAUNCH_OK();
     return DVD_OK;
   }

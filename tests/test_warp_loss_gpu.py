@@ -14,19 +14,21 @@ from oracle import losses as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['tiled', 'tile64x32', 'direct', 'gen3', 'gen3_tile64x32'], autouse=True)
+@pytest.fixture(params=['tiled', 'tile64x32', 'px4', 'direct', 'gen3', 'gen3_tile64x32'], autouse=True)
 def warp_variant(request, monkeypatch):
-    """Every case runs on the production tiled kernel (auto tile shape), on the
-    smallest tile shape (more tile seams / halo traffic), on the global-atomics
-    reference variant, and on the guard-banded fast-arithmetic generation of the
-    tiled kernel (DVD_WARP_GEN=3), which must reproduce the same masks, counts and
-    sub-gradient signs."""
-    for k in ('DVD_WARP_DIRECT', 'DVD_WARP_TILE', 'DVD_WARP_GEN'):
+    """Every case runs on the production tiled kernel (generation 1: the reference's rounding
+    sequence for every pixel; auto tile shape), on the smallest tile shape (more tile seams /
+    halo traffic), with 4 pixels per thread-step, on the global-atomics reference variant, and
+    on generation 3 of the tiled kernel (guard-banded fast arithmetic + exact fix-up pass).  All
+    of them must reproduce the oracle's masks, counts and sub-gradient signs."""
+    for k in ('DVD_WARP_DIRECT', 'DVD_WARP_TILE', 'DVD_WARP_GEN', 'DVD_WARP_PX'):
         monkeypatch.delenv(k, raising=False)
     if request.param == 'direct':
         monkeypatch.setenv('DVD_WARP_DIRECT', '1')
     if request.param.endswith('tile64x32'):
         monkeypatch.setenv('DVD_WARP_TILE', '3')
+    if request.param == 'px4':
+        monkeypatch.setenv('DVD_WARP_PX', '4')
     if request.param.startswith('gen3'):
         monkeypatch.setenv('DVD_WARP_GEN', '3')
     return request.param
@@ -218,8 +220,8 @@ def test_guard_banded_generation_matches_exact_generation_at_full_size(monkeypat
     cfg = ops.warp_cfg(B, H, W, flow_mul=1.0, disp_mul=1.0)
     out = {}
     for gen in ('1', '3'):
-        monkeypatch.delenv('DVD_WARP_DIRECT', raising=False)
-        monkeypatch.delenv('DVD_WARP_TILE', raising=False)
+        for k in ('DVD_WARP_DIRECT', 'DVD_WARP_TILE', 'DVD_WARP_PX'):
+            monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv('DVD_WARP_GEN', gen)
         out[gen] = [t.clone() for t in ops.warp_loss_fused(cfg, d1, d2, batch['flow_1_2'], batch['mask_2'], sf, cams)]
     s1, s3 = out['1'][0].cpu().numpy(), out['3'][0].cpu().numpy()
