@@ -29,6 +29,14 @@ class WarpCfg(ctypes.Structure):
                 ('disp_mode', c_int), ('loss_on_sf', c_int), ('flow_mul', c_float), ('disp_mul', c_float)]
 
 
+SURFACE_KEYS = ('global_p1', 'warped_global_p2', 'sf_by_depth', 'staticflow_1_2', 'dflow_1_2', 'depth_image_1_2',
+                'depth_warp_1_2', 'p1_camera_2', 'warped_p2_camera_2')
+
+
+class Surfaces(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in SURFACE_KEYS]
+
+
 class MlpDesc(ctypes.Structure):
     _fields_ = [('n_freq_xyz', c_int), ('n_freq_t', c_int), ('time_dependent', c_int), ('freqs_xyz', c_void_p),
                 ('freqs_t', c_void_p)]
@@ -69,6 +77,10 @@ SIGNATURES = {
     'dvd_acc_reg': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     'dvd_adam_step': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,
                               c_float, c_float, c_float, c_int, c_void_p]),
+    'dvd_warp_surfaces': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Cameras),
+                                  ctypes.POINTER(Surfaces), c_int, c_int, c_int, c_void_p]),
+    'dvd_flow_warp_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_flow_warp_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_bwd_data': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -27,6 +27,7 @@ SOURCES = [
     ('sf_mlp.hip', []),
     ('elementwise.hip', ['-ffp-contract=off']),
     ('gconv.hip', []),
+    ('surfaces.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

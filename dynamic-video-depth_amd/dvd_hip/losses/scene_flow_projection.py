@@ -10,7 +10,9 @@ The training step does not go through these modules: Model._train_on_batch calls
 fused kernel (dvd_warp_loss_fused), which never materialises the ten per-pixel
 surfaces.  The module forms exist for the drop-in surface (the reference Model
 discovers their argument names with inspect, scene_flow_motion_field.py:128-138) and
-for visualisation / inference code that wants the surfaces.
+for visualisation / export / inference code that wants the surfaces: they return the
+reference's dict keys, shapes and values (dvd_warp_surfaces, same fp32 operation order),
+forward only.  BackwardWarp is differentiable w.r.t. its buffer like the reference's.
 """
 import torch
 from torch import nn
@@ -38,28 +40,31 @@ class unproject_ptcld(nn.Module):
         return _Unproject.apply(depth_1, R_1, t_1, K_inv)
 
 
-class _SurfaceModule(nn.Module):
-    what = ''
-
-    def _unavailable(self):
-        raise NotImplementedError(
-            '%s: the per-pixel surface form is not built yet (round 1 ships the fused training kernel '
-            'dvd_warp_loss_fused and unproject); see DESIGN.md "next"' % self.what)
+def _no_autograd(name, *tensors):
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+        raise RuntimeError('%s: the module form produces forward values only (visualisation / export / inference); '
+                           'the differentiable training path is Model._train_on_batch -> dvd_warp_loss_fused. '
+                           'Call it under torch.no_grad() or on detached tensors.' % name)
 
 
-class flow_by_depth(_SurfaceModule):
-    what = 'flow_by_depth'
+class flow_by_depth(nn.Module):
+    """losses/scene_flow_projection.py:95-153: rigid-scene flow and the scene flow implied by the two depth maps."""
 
     def __init__(self, is_one_way=True):
         super().__init__()
         self.one_way = is_one_way
 
     def forward(self, depth_1, depth_2, flow_1_2, R_1, R_2, R_1_T, R_2_T, t_1, t_2, K, K_inv):
-        self._unavailable()
+        _no_autograd('flow_by_depth', depth_1, depth_2)
+        cams = dict(R_1=R_1, R_2=R_2, R_1_T=R_1_T, R_2_T=R_2_T, t_1=t_1, t_2=t_2, K=K, K_inv=K_inv)
+        s = ops.warp_surfaces(depth_1.detach(), depth_2.detach(), flow_1_2, cams,
+                              want=('staticflow_1_2', 'sf_by_depth', 'warped_global_p2', 'global_p1'))
+        return {'dflow_1_2': s['staticflow_1_2'], 'sf_by_depth': s['sf_by_depth'],
+                'warped_global_p2': s['warped_global_p2'], 'global_p1': s['global_p1']}
 
 
-class scene_flow_projection_slack(_SurfaceModule):
-    what = 'scene_flow_projection_slack'
+class scene_flow_projection_slack(nn.Module):
+    """losses/scene_flow_projection.py:204-278: reprojection of the scene-flow-advected points (ten surfaces)."""
 
     def __init__(self, is_one_way=False):
         super().__init__()
@@ -67,15 +72,35 @@ class scene_flow_projection_slack(_SurfaceModule):
 
     def forward(self, depth_1, depth_2, flow_1_2, flow_2_1, R_1, R_2, R_1_T, R_2_T, t_1, t_2, K, K_inv, sflow_1_2,
                 sflow_2_1):
-        self._unavailable()
+        _no_autograd('scene_flow_projection_slack', depth_1, depth_2, sflow_1_2)
+        cams = dict(R_1=R_1, R_2=R_2, R_1_T=R_1_T, R_2_T=R_2_T, t_1=t_1, t_2=t_2, K=K, K_inv=K_inv)
+        B, _, H, W = depth_1.shape
+        s = ops.warp_surfaces(depth_1.detach(), depth_2.detach(), flow_1_2, cams, sflow_1_2=sflow_1_2.detach(),
+                              want=('dflow_1_2', 'depth_image_1_2', 'depth_warp_1_2', 'global_p1', 'staticflow_1_2',
+                                    'p1_camera_2', 'warped_p2_camera_2'))
+        s.update(depth_1=depth_1.view(B, 1, H, W), depth_2=depth_2.view(B, 1, H, W), scenef_1_2=sflow_1_2)
+        return s
 
 
-class BackwardWarp(_SurfaceModule):
-    what = 'BackwardWarp'
+class _FlowWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, buffer, flow_1_2):
+        ctx.save_for_backward(flow_1_2)
+        return ops.flow_warp(buffer, flow_1_2)
+
+    @staticmethod
+    def backward(ctx, g):
+        (flow_1_2,) = ctx.saved_tensors
+        return ops.flow_warp_backward(g.contiguous(), flow_1_2), None
+
+
+class BackwardWarp(nn.Module):
+    """losses/scene_flow_projection.py:281-307: bilinear sample of `buffer` [B,C,H,W] at (x,y)+flow,
+    border clamp, align_corners=True; differentiable w.r.t. the buffer (flow is data)."""
 
     def __init__(self, is_one_way=False):
         super().__init__()
         self.is_one_way = is_one_way
 
     def forward(self, buffer, flow_1_2):
-        self._unavailable()
+        return _FlowWarp.apply(buffer, flow_1_2)

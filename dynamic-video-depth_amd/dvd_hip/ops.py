@@ -139,6 +139,51 @@ def loss_finalize(cfg, sums, out=None):
     return out
 
 
+_SURFACE_SHAPES = {'global_p1': 3, 'warped_global_p2': 3, 'sf_by_depth': 3, 'p1_camera_2': 3, 'warped_p2_camera_2': 3,
+                   'staticflow_1_2': 2, 'dflow_1_2': 2, 'depth_image_1_2': 1, 'depth_warp_1_2': 1}
+
+
+def warp_surfaces(depth_1, depth_2, flow_1_2, cams, sflow_1_2=None, want=_lib.SURFACE_KEYS):
+    """The per-pixel surfaces of flow_by_depth / scene_flow_projection_slack (forward values).
+    Returns a dict name -> tensor: 3-vectors [B,H,W,1,3], flows [B,H,W,2], depths [B,1,H,W]."""
+    depth_1, depth_2, flow_1_2 = _dev32(depth_1, 'depth_1'), _dev32(depth_2, 'depth_2'), _dev32(flow_1_2, 'flow_1_2')
+    B, _, H, W = depth_1.shape
+    if sflow_1_2 is not None:
+        sflow_1_2 = _dev32(sflow_1_2, 'sflow_1_2')
+        if sflow_1_2.numel() != 3 * B * H * W:
+            raise RuntimeError('sflow_1_2 must be [B,H,W,1,3]')
+    cst, keep = pack_cameras(cams)
+    out, st = {}, _lib.Surfaces()
+    for k in want:
+        c = _SURFACE_SHAPES[k]
+        shape = (B, H, W, 1, 3) if c == 3 else ((B, H, W, 2) if c == 2 else (B, 1, H, W))
+        out[k] = torch.empty(shape, device=depth_1.device, dtype=torch.float32)
+        setattr(st, k, out[k].data_ptr())
+    lib = _lib.load()
+    _lib.check(lib.dvd_warp_surfaces(_p(depth_1), _p(depth_2), _p(flow_1_2), _p(sflow_1_2), ctypes.byref(cst),
+                                     ctypes.byref(st), B, H, W, _stream()), 'dvd_warp_surfaces')
+    del keep
+    return out
+
+
+def flow_warp(buffer, flow_1_2):
+    buffer, flow_1_2 = _dev32(buffer, 'buffer'), _dev32(flow_1_2, 'flow_1_2')
+    B, C, H, W = buffer.shape
+    out = torch.empty_like(buffer)
+    lib = _lib.load()
+    _lib.check(lib.dvd_flow_warp_fwd(_p(buffer), _p(flow_1_2), _p(out), B, C, H, W, _stream()), 'dvd_flow_warp_fwd')
+    return out
+
+
+def flow_warp_backward(g_out, flow_1_2):
+    g_out, flow_1_2 = _dev32(g_out, 'g_out'), _dev32(flow_1_2, 'flow_1_2')
+    B, C, H, W = g_out.shape
+    g = torch.empty_like(g_out)
+    lib = _lib.load()
+    _lib.check(lib.dvd_flow_warp_bwd(_p(g_out), _p(flow_1_2), _p(g), B, C, H, W, _stream()), 'dvd_flow_warp_bwd')
+    return g
+
+
 # ---------------------------------------------------------------------------------------
 # scene-flow field MLP
 

@@ -188,6 +188,39 @@ int dvd_adam_step(float* param, const float* grad1, float scale, const float* sc
                   float beta1, float beta2, float eps, int step, dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Per-pixel surfaces of the warp modules (forward values; the training gradient path is
+ * dvd_warp_loss_fused, which never materialises them).  Replaces, for visualisation / export /
+ * inference callers (models/scene_flow_motion_field.py:215-225, models/video_base.py:105-126),
+ *   flow_by_depth.forward                losses/scene_flow_projection.py:114-153
+ *   scene_flow_projection_slack.forward  losses/scene_flow_projection.py:222-278
+ * Every output is optional (NULL = not wanted).  3-vectors are interleaved [B,H,W,3] (the
+ * reference's [B,H,W,1,3]), flows [B,H,W,2], depths [B,1,H,W].  sflow_1_2 is the reference's
+ * interleaved scene flow [B,H,W,(1,)3] or NULL for zero.  Same fp32 operation order as the
+ * reference, so index masks and tap indices are bit-identical to its CPU path. */
+typedef struct dvd_surfaces {
+  float* global_p1;          /* P1 = (d1 (x,y,1) K_inv) R_1 + t_1                      (:127-131,235-237) */
+  float* warped_global_p2;   /* bilinear sample of frame 2's world points at the flow target (:133-135) */
+  float* sf_by_depth;        /* warped_global_p2 - global_p1                              (:136)         */
+  float* staticflow_1_2;     /* rigid-scene flow (= flow_by_depth's dflow_1_2)           (:138-149,267) */
+  float* dflow_1_2;          /* flow of the scene-flow-advected point                     (:244-265)     */
+  float* depth_image_1_2;    /* z of the advected point in image 2                        (:268)         */
+  float* depth_warp_1_2;     /* bilinear sample of depth_2                                (:274-276)     */
+  float* p1_camera_2;        /* (P1 + sflow - t_2) R_2_T                                  (:244)         */
+  float* warped_p2_camera_2; /* bilinear sample of frame 2's camera-space points          (:240-242)     */
+} dvd_surfaces;
+int dvd_warp_surfaces(const float* depth_1, const float* depth_2, const float* flow_1_2, const float* sflow_1_2,
+                      const dvd_cameras* cams, const dvd_surfaces* out, int B, int H, int W, dvd_stream_t stream);
+
+/* Stand-alone flow warp: BackwardWarp.forward (losses/scene_flow_projection.py:281-307) =
+ * F.grid_sample(buffer, (x,y)+flow, bilinear, padding_mode='border', align_corners=True) on
+ * buffer [B,C,H,W]; bwd = its gradient w.r.t. the buffer (bilinear scatter-add; g_buffer is
+ * zeroed inside the call). */
+int dvd_flow_warp_fwd(const float* buffer, const float* flow_1_2, float* out, int B, int C, int H, int W,
+                      dvd_stream_t stream);
+int dvd_flow_warp_bwd(const float* g_out, const float* flow_1_2, float* g_buffer, int B, int C, int H, int W,
+                      dvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Grouped 3x3 convolution, 8 channels per group, stride 1, pad 1, NCHW fp32.
  * Replaces the `conv2` of the ResNeXt-101 32x8d stage-1 bottlenecks inside the MiDaS encoder
  * (third_party/midas_blocks.py:35-50 -> torchvision ResNet(Bottleneck, groups=32,
