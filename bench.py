@@ -42,7 +42,7 @@ def make_opt(**over):
              batch_size=1, global_rank=0, use_cnn=False, use_embedding=False, midas=True, use_disp=True,
              use_disp_ratio=False, time_dependent=True, flow_mul=1.0, disp_mul=1.0, acc_mul=1.0, sf_mag_div=100.0,
              interp_steps=5, warm_reg=False, weight_steps=False, use_motion_seg=False, n_freq_xyz=16, n_freq_t=16,
-             warm_sf=5, mlp_stash_gb=64.0, depth_chunk=8, full_logdir='/tmp')
+             warm_sf=5, mlp_stash_gb=64.0, depth_chunk=16, full_logdir='/tmp')
     o.update(over)
     return SimpleNamespace(**o)
 
@@ -123,6 +123,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (48 = the BASELINE configuration)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
     a = ap.parse_args()
 
     from dvd_hip import parallel, synthetic
@@ -139,7 +140,7 @@ def main():
 
     if os.environ.get('DVD_CUDNN_BENCHMARK'):
         torch.backends.cudnn.benchmark = True     # MIOpen find mode (experiments; the default run uses FAST immediate mode)
-    opt = make_opt(global_rank=rank)
+    opt = make_opt(global_rank=rank, depth_chunk=a.depth_chunk)
     model = build_model(opt, device, seed=0)
     batch = synthetic.make_batch(a.pairs, H, W, gap=GAP, seed=1234, rank=rank, device=device)
     epoch = opt.warm_sf + 1            # non-warm phase
@@ -188,8 +189,8 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'warp_loss_pmc.json')
         if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            try:   # PMC passes of the same launch at 48 x 384 x 672 (tools/gpu_round.sh pmc, tools/pmc_to_json.py)
+                traffic = json.load(open(pmc)).get('hbm_bytes_per_launch') * warp['pixels_per_launch'] / (48.0 * H * W)
             except Exception:
                 traffic = None
         out['roofline'] = {'bound': 'hbm', 'kernel': 'dvd_warp_loss_fused (tiled warp/loss kernel + slab combine + reductions)',

@@ -62,7 +62,7 @@ class Model(NetInterface):
         parser.add_argument('--mlp_whole_batch_gb', type=float, default=160.0,
                             help='HBM ceiling for keeping the forward stashes of the whole batch alive so that the '
                                  'warp+loss kernel runs as ONE launch (falls back to one launch per chunk)')
-        parser.add_argument('--depth_chunk', type=int, default=8, help='images per depth-net forward/backward chunk')
+        parser.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
         return parser, set()
 
     # ------------------------------------------------------------------------------------
@@ -200,7 +200,7 @@ class Model(NetInterface):
         sums = torch.zeros(8, device=dev)            # [S0..S3, sum|sf1-sf0|, 0, 0, 0]
         g_d1_main = torch.empty_like(depth_1)
         g_d2_main = torch.empty_like(depth_2)
-        g_d1_reg = torch.zeros_like(depth_1) if do_reg else None
+        g_d1_reg = None                              # allocated only by the per-chunk fallback path
         mlp, k = self._mlp, self._flat_sf
         mlp.pack([p for p in self.net_sceneflow.parameter_list()[0::2]], self.net_sceneflow.parameter_list()[1::2])
         gW_main = [k.view(self._sf_grad_main, 2 * i) for i in range(6)]
@@ -229,19 +229,24 @@ class Model(NetInterface):
         def cams_of(b0, b1):
             return {kk: getattr(inp, kk)[b0:b1] for kk in CAM_KEYS}
 
-        def mlp_forward_chunk(b0, b1):
-            """Euler integration of the scene flow over `steps` frames (:360-367)."""
+        def mlp_forward_chunk(b0, b1, keep_first=None):
+            """Euler integration of the scene flow over `steps` frames (:360-367).  keep_first: also
+            return sf_0 and q = P1 + sf_0 of the first evaluation (the regulariser's sf_0, see below)."""
             ts = inp.time_stamp_1[b0:b1] if opt.time_dependent else None
             n_pix = (b1 - b0) * HW
-            stashes, p_cur = [], P1_all[b0:b1]
+            stashes, p_cur, first = [], P1_all[b0:b1], None
             for i in range(steps):
                 st = mlp.new_stash(n_pix)
-                p_next = torch.empty_like(p_cur) if i + 1 < steps else None
-                mlp.forward(p_cur, ts, t_offset=i * time_step, out_scale=inv_div, p_next=p_next, acc=sf_all[b0:b1],
-                            stash=st)
+                want_next = i + 1 < steps or (keep_first and i == 0)
+                p_next = torch.empty_like(p_cur) if want_next else None
+                sf_i = torch.empty_like(p_cur) if (keep_first and i == 0 and steps > 1) else None
+                mlp.forward(p_cur, ts, t_offset=i * time_step, out_scale=inv_div, sf_out=sf_i, p_next=p_next,
+                            acc=sf_all[b0:b1], stash=st)
+                if keep_first and i == 0:
+                    first = (sf_i, p_next)          # sf_i is None when steps == 1: sf_0 is the accumulated flow itself
                 stashes.append(st)
                 p_cur = p_next
-            return stashes
+            return (stashes, first) if keep_first is not None else stashes
 
         def warp(b0, b1):
             cfg = cfg_all if (b0, b1) == (0, B) else ops.warp_cfg(
@@ -287,18 +292,67 @@ class Model(NetInterface):
             mlp.backward_dw(sa, gst, n_pix, gW_reg[:5], gb_reg[:5])
             ops.unproject_backward(g_P, True, cams['R_1'], cams['K_inv'], out=g_d1_reg[b0:b1])
 
+        def merged_backward_chunk(b0, b1, stashes, first, gst, inv):
+            """Main loss and acceleration regulariser through ONE backward of the first evaluation.
+
+            The regulariser's sf_0 = MLP(P1, t_1) (:329-333) is the first Euler evaluation of the main
+            path (:360-367: same points, same time, same weights), so its forward, stash, dX and dW
+            passes are shared: with G = inv * g_sf (main, late normaliser already known) the first
+            evaluation receives  G + g_p1 - g1 + g_q  where g1 = dR/dsf_1, g_q = J_b^T g1, and
+            g_P1 = g_p1 + g_q + J_0^T(...).  One MLP evaluation per step less than the reference."""
+            nb, n_pix = b1 - b0, (b1 - b0) * HW
+            cams = cams_of(b0, b1)
+            ts = inp.time_stamp_1[b0:b1] if opt.time_dependent else None
+            P1, g_sf = P1_all[b0:b1], g_sf_all[b0:b1]
+            g_q = g1 = None
+            if do_reg:
+                sf0 = first[0] if first[0] is not None else sf_all[b0:b1]
+                sb, sf1 = mlp.new_stash(n_pix), torch.empty_like(P1)
+                mlp.forward(first[1], ts, time_step, inv_div, sf_out=sf1, stash=sb)
+                g1 = torch.empty_like(P1)
+                ops.acc_reg(sf0, sf1, reg_coef, g1, sums[4:5], accumulate=True)
+                g_q = torch.empty_like(P1)
+                mlp.backward_dx(sb, inv_div, g1, g_q, gst, gW_reg[5], gb_reg[5], (nb, H, W))
+                mlp.backward_dw(sb, gst, n_pix, gW_reg[:5], gb_reg[:5])
+                del sb, sf1
+            g_p = None
+            for i in reversed(range(1, steps)):
+                g_new = torch.empty_like(P1)
+                mlp.backward_dx(stashes[i], inv_div, g_sf, g_new, gst, gW_reg[5], gb_reg[5], (nb, H, W), scale_ptr=inv,
+                                g_out2=g_p, g_p_add=g_p)
+                mlp.backward_dw(stashes[i], gst, n_pix, gW_reg[:5], gb_reg[:5])
+                g_p = g_new
+            extra, add = g_p, g_p                    # gradient reaching sf_0 besides G, and reaching P1 directly
+            if do_reg:
+                extra = ops.scale_add(torch.empty_like(P1), g1, scale=-1.0, b=g_q)          # -g1 + g_q
+                add = g_q
+                if g_p is not None:
+                    extra = ops.scale_add(extra, g_p, b=extra)
+                    add = ops.scale_add(torch.empty_like(P1), g_p, b=g_q)
+            g_P = torch.empty_like(P1)
+            mlp.backward_dx(stashes[0], inv_div, g_sf, g_P, gst, gW_reg[5], gb_reg[5], (nb, H, W), scale_ptr=inv,
+                            g_out2=extra, g_p_add=add)
+            mlp.backward_dw(stashes[0], gst, n_pix, gW_reg[:5], gb_reg[:5])
+            ops.unproject_backward(g_P, True, cams['R_1'], cams['K_inv'], out=g_d1_main[b0:b1], accumulate=True)
+
         gst = mlp.new_gstash(min(Bc, B) * HW)
-        if whole or Bc >= B:
-            kept = [mlp_forward_chunk(b0, b1) for b0, b1 in chunks]
+        early_norm = whole or Bc >= B
+        if early_norm:
+            kept = [mlp_forward_chunk(b0, b1, keep_first=bool(do_reg)) for b0, b1 in chunks]
             warp(0, B)
-            for (b0, b1), st in zip(chunks, kept):
-                mlp_backward_chunk(b0, b1, st, gst)
+            # the batch-global normaliser is known before the MLP backward: all-reduce the four loss sums
+            # now (SURVEY.md section 8e) and hand 1/(S0+1e-8) to the backward kernels as a device scalar
+            parallel.all_reduce_sum_(sums[:4])
+            scalars = ops.loss_finalize(cfg_all, sums)
+            inv = scalars[0:1]
+            ops.scale_add(g_d1_main, g_d1_main, scale_ptr=inv)
+            for (b0, b1), (st, first) in zip(chunks, kept):
+                merged_backward_chunk(b0, b1, st, first, gst, inv)
                 del st[:]
             del kept
-            if do_reg:
-                for b0, b1 in chunks:
-                    reg_chunk(b0, b1, gst)
+            parallel.all_reduce_sum_(sums[4:])
         else:
+            g_d1_reg = torch.zeros_like(depth_1) if do_reg else None
             for b0, b1 in chunks:
                 st = mlp_forward_chunk(b0, b1)
                 warp(b0, b1)
@@ -307,17 +361,21 @@ class Model(NetInterface):
                 if do_reg:
                     reg_chunk(b0, b1, gst)
         del gst
-        # the batch-global normaliser: all-reduce the loss sums first
-        parallel.all_reduce_sum_(sums)
-        scalars = ops.loss_finalize(cfg_all, sums)
-        inv = scalars[0:1]
-        # scene-flow MLP gradient = inv * main + reg   (flat buffers; one all-reduce)
-        ops.scale_add(k.grad, self._sf_grad_main, scale_ptr=inv, b=k.grad)
+        if not early_norm:
+            # per-chunk launches: the batch-global normaliser only exists now.  All-reduce the loss sums
+            # (SURVEY.md section 8e), then scene-flow MLP gradient = inv * main + reg
+            parallel.all_reduce_sum_(sums)
+            scalars = ops.loss_finalize(cfg_all, sums)
+            inv = scalars[0:1]
+            ops.scale_add(k.grad, self._sf_grad_main, scale_ptr=inv, b=k.grad)
         h_sf = k.all_reduce_grads(async_op=True)
 
         # ---- phase 3: depth-net backward from the depth gradients
         if not warm:
-            g_d1 = ops.scale_add(g_d1_main, g_d1_main, scale_ptr=inv, b=g_d1_reg)
+            if early_norm:
+                g_d1 = g_d1_main                      # already normalised, regulariser included
+            else:
+                g_d1 = ops.scale_add(g_d1_main, g_d1_main, scale_ptr=inv, b=g_d1_reg)
             g_d2 = ops.scale_add(g_d2_main, g_d2_main, scale_ptr=inv)
             self._depth_backward(inp.img_1, fid1, g_d1)
             self._depth_backward(inp.img_2, fid2, g_d2)
