@@ -81,11 +81,20 @@ SIGNATURES = {
                                   ctypes.POINTER(Surfaces), c_int, c_int, c_int, c_void_p]),
     'dvd_flow_warp_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_flow_warp_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_upsample_bilinear_fwd': (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_upsample_bilinear_bwd': (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_bwd_data': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'dvd_gconv3x3_c8_bwd_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int,
                                            c_int, c_void_p]),
+    'dvd_gconv3x3_c32_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'dvd_gconv3x3_c32_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
+                                     c_void_p]),
+    'dvd_gconv3x3_c32_bwd_data': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
+                                          c_void_p]),
+    'dvd_gconv3x3_c32_bwd_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int,
+                                            c_int, c_int, c_void_p]),
     'dvd_sf_mlp_bwd_dw': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_longlong, ctypes.POINTER(PtrArr5),
                                   ctypes.POINTER(PtrArr5), c_void_p]),
 }

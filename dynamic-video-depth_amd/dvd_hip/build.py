@@ -27,7 +27,9 @@ SOURCES = [
     ('sf_mlp.hip', []),
     ('elementwise.hip', ['-ffp-contract=off']),
     ('gconv.hip', []),
+    ('gconv32.hip', []),
     ('surfaces.hip', ['-ffp-contract=off']),
+    ('upsample.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

@@ -22,6 +22,37 @@ from . import _lib
 from .ops import _p, _stream, _workspace
 
 
+class _UpsampleBilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_hw, align_corners):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        Ho, Wo = out_hw
+        y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=x.dtype)
+        lib = _lib.load()
+        _lib.check(lib.dvd_upsample_bilinear_fwd(_p(x), _p(y), N * C, H, W, Ho, Wo, int(align_corners), _stream()),
+                   'dvd_upsample_bilinear_fwd')
+        ctx.shape, ctx.align = (N, C, H, W, Ho, Wo), int(align_corners)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W, Ho, Wo = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty(N, C, H, W, device=gy.device, dtype=gy.dtype)
+        lib = _lib.load()
+        _lib.check(lib.dvd_upsample_bilinear_bwd(_p(gy), _p(gx), N * C, H, W, Ho, Wo, ctx.align, _stream()),
+                   'dvd_upsample_bilinear_bwd')
+        return gx, None, None
+
+
+def upsample_bilinear2x(x, align_corners):
+    """F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=...) of the MiDaS decoder."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return _UpsampleBilinear.apply(x, (2 * x.shape[2], 2 * x.shape[3]), bool(align_corners))
+    return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=align_corners)
+
+
 class _GConv3x3C8(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
@@ -52,6 +83,58 @@ class _GConv3x3C8(torch.autograd.Function):
             _lib.check(lib.dvd_gconv3x3_c8_bwd_weight(_p(x), _p(gy), _p(gw), 0, _p(ws), ctypes.c_size_t(ws.numel()),
                                                       N, C, H, W, _stream()), 'dvd_gconv3x3_c8_bwd_weight')
         return gx, gw
+
+
+class _GConv3x3C32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x = x.contiguous()
+        w = w.contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        lib = _lib.load()
+        ws = _workspace(lib.dvd_gconv3x3_c32_workspace_bytes(N, C, H, W), x.device)
+        _lib.check(lib.dvd_gconv3x3_c32_fwd(_p(x), _p(w), _p(y), _p(ws), ctypes.c_size_t(ws.numel()), N, C, H, W,
+                                            _stream()), 'dvd_gconv3x3_c32_fwd')
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C, H, W = x.shape
+        lib = _lib.load()
+        ws = _workspace(lib.dvd_gconv3x3_c32_workspace_bytes(N, C, H, W), x.device)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(lib.dvd_gconv3x3_c32_bwd_data(_p(gy), _p(w), _p(gx), _p(ws), ctypes.c_size_t(ws.numel()), N, C, H,
+                                                     W, _stream()), 'dvd_gconv3x3_c32_bwd_data')
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            _lib.check(lib.dvd_gconv3x3_c32_bwd_weight(_p(x), _p(gy), _p(gw), 0, _p(ws), ctypes.c_size_t(ws.numel()),
+                                                       N, C, H, W, _stream()), 'dvd_gconv3x3_c32_bwd_weight')
+        return gx, gw
+
+
+def gconv3x3_c32(x, weight):
+    """y = conv2d(x, weight, padding=1, groups=C // 32) for weight [C, 32, 3, 3]."""
+    if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
+        return _GConv3x3C32.apply(x, weight)
+    return F.conv2d(x, weight, None, 1, 1, 1, x.shape[1] // 32)
+
+
+class GroupedConv3x3C32(nn.Conv2d):
+    """Drop-in for nn.Conv2d(C, C, 3, stride=1, padding=1, groups=C // 32, bias=False) (fp32 MFMA kernels)."""
+
+    def __init__(self, channels):
+        if channels % 32:
+            raise ValueError('GroupedConv3x3C32 needs a multiple of 32 channels')
+        super().__init__(channels, channels, 3, stride=1, padding=1, groups=channels // 32, bias=False)
+
+    def forward(self, x):
+        return gconv3x3_c32(x, self.weight)
 
 
 def gconv3x3_c8(x, weight):

@@ -236,6 +236,28 @@ size_t dvd_gconv3x3_c8_wgrad_workspace_bytes(int N, int C, int H, int W);
 int dvd_gconv3x3_c8_bwd_weight(const float* x, const float* gy, float* gw, int accumulate, void* workspace,
                                size_t workspace_bytes, int N, int C, int H, int W, dvd_stream_t stream);
 
+/* Same convolution with 32 channels per group (fp32 MFMA): the stride-1 bottlenecks of ResNeXt
+ * stage 3 (width 1024 = 32 groups x 32).  w, gw: [C,32,3,3].  All three entry points take a workspace
+ * of dvd_gconv3x3_c32_workspace_bytes (fragment-ordered weights for fwd / bwd_data, per-block
+ * partial sums for bwd_weight). */
+size_t dvd_gconv3x3_c32_workspace_bytes(int N, int C, int H, int W);
+int dvd_gconv3x3_c32_fwd(const float* x, const float* w, float* y, void* workspace, size_t workspace_bytes, int N,
+                         int C, int H, int W, dvd_stream_t stream);
+int dvd_gconv3x3_c32_bwd_data(const float* gy, const float* w, float* gx, void* workspace, size_t workspace_bytes,
+                              int N, int C, int H, int W, dvd_stream_t stream);
+int dvd_gconv3x3_c32_bwd_weight(const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                                size_t workspace_bytes, int N, int C, int H, int W, dvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Bilinear up-sampling of [planes, H_in, W_in] -> [planes, H_out, W_out] (planes = N*C) and its backward.
+ * Replaces F.interpolate(mode='bilinear') of the MiDaS decoder: align_corners=True at the end of every
+ * FeatureFusionBlock (third_party/midas_blocks.py:164-166), align_corners=False in the output head
+ * (midas_blocks.py:71-99, MiDaS.py:190).  Same source-index / weight formulas as ATen. */
+int dvd_upsample_bilinear_fwd(const float* x, float* y, long long planes, int H_in, int W_in, int H_out, int W_out,
+                              int align_corners, dvd_stream_t stream);
+int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int H_in, int W_in, int H_out,
+                              int W_out, int align_corners, dvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,3 +58,48 @@ def test_midas_stage1_uses_the_hip_kernels():
     assert len(blocks) == 3 and all(isinstance(b.conv2, GroupedConv3x3C8) for b in blocks)
     assert not isinstance(net.pretrained.layer2[0].conv2, GroupedConv3x3C8)     # stride 2: MIOpen
     assert 'pretrained.layer1.4.0.conv2.weight' in net.state_dict()
+
+
+@pytest.mark.parametrize('N,C,H,W', [(2, 32, 9, 13), (1, 64, 24, 42), (3, 32, 5, 3), (2, 1024, 24, 42), (1, 32, 33, 40),
+                                     (1, 32, 20, 84)])
+def test_c32_matches_torch_cpu(N, C, H, W):
+    """32 channels per group (fp32 MFMA kernels): forward, backward-data, backward-weight against
+    torch's fp32 CPU convolution.  288-term dot products per output (fp32, different summation
+    order): 2e-5 of max|.|; the weight gradient sums N*H*W products: 5e-5."""
+    from dvd_hip.conv import GroupedConv3x3C32, gconv3x3_c32
+    g = torch.Generator().manual_seed(N * 1000 + C + H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(C, 32, 3, 3, generator=g) / 17.0
+    gy = torch.randn(N, C, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1, 1, C // 32)
+    yr.backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    y = gconv3x3_c32(xg, wg)
+    y.backward(gy.cuda())
+    torch.cuda.synchronize()
+    for name, got, want, tol in (('y', y, yr, 2e-5), ('gx', xg.grad, xr.grad, 2e-5), ('gw', wg.grad, wr.grad, 5e-5)):
+        got = got.detach().cpu().numpy()
+        want = want.detach().numpy()
+        assert np.abs(got - want).max() <= tol * np.abs(want).max() + 1e-6, name
+    m = GroupedConv3x3C32(C).cuda()
+    assert tuple(m.weight.shape) == (C, 32, 3, 3) and list(m.state_dict()) == ['weight']
+    with torch.no_grad():
+        m.weight.copy_(w)
+    m(x.cuda()).backward(gy.cuda())
+    g1 = m.weight.grad.clone()
+    m.weight.grad = None
+    m(x.cuda()).backward(gy.cuda())
+    assert torch.equal(g1, m.weight.grad)                      # deterministic weight gradient
+
+
+def test_midas_stage3_uses_the_mfma_kernels():
+    from dvd_hip.conv import GroupedConv3x3C32
+    from dvd_hip.third_party.MiDaS import MidasNet
+    net = MidasNet()
+    blocks = list(net.pretrained.layer3)
+    assert len(blocks) == 23 and not isinstance(blocks[0].conv2, GroupedConv3x3C32)     # stride 2: MIOpen
+    assert all(isinstance(b.conv2, GroupedConv3x3C32) for b in blocks[1:])
+    assert 'pretrained.layer3.5.conv2.weight' in net.state_dict()
