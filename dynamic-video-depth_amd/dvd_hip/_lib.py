@@ -72,6 +72,7 @@ SIGNATURES = {
     'dvd_sf_mlp_bwd_dx': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p,
                                   c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p]),
+    'dvd_mul_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p]),
     'dvd_scale_add': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_longlong, c_void_p]),
     'dvd_acc_reg_workspace_bytes': (c_size_t, []),
     'dvd_acc_reg': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),

@@ -44,6 +44,15 @@ __global__ __launch_bounds__(256) void scale_add_kernel(float* __restrict__ out,
   }
 }
 
+// out[b, c, p] = a[b, c, p] * m[b, p]   (planar [B,C,HW] times a per-pixel mask [B,HW]; out may alias a)
+__global__ __launch_bounds__(256) void mul_mask_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                       const float* __restrict__ m, int C, long long HW, long long n) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long plane = i / HW, p = i - plane * HW;
+    out[i] = a[i] * m[(plane / C) * HW + p];
+  }
+}
+
 // g1 = coef * sign(sf1 - sf0);  partial[block] = sum |sf1 - sf0|
 __global__ __launch_bounds__(256) void acc_reg_kernel(const float* __restrict__ sf0, const float* __restrict__ sf1,
                                                       float coef, float* __restrict__ g1, float* __restrict__ partial,
@@ -139,6 +148,15 @@ static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace dvd
 
 extern "C" {
+
+int dvd_mul_mask(float* out, const float* a, const float* mask, int B, int C, long long HW, dvd_stream_t stream) {
+  DVD_REQUIRE(out && a && mask && B > 0 && C > 0 && HW > 0, "mul_mask: bad arguments");
+  const long long n = (long long)B * C * HW;
+  hipLaunchKernelGGL(dvd::mul_mask_kernel, dim3(dvd::grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), out,
+                     a, mask, C, HW, n);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
 
 int dvd_scale_add(float* out, const float* a, float scale, const float* scale_ptr, const float* b, long long n,
                   dvd_stream_t stream) {

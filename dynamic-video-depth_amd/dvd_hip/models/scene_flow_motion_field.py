@@ -210,9 +210,9 @@ class Model(NetInterface):
         inv_div = 1.0 / opt.sf_mag_div
         Bc = self._pairs_per_chunk(B, HW, steps, do_reg)
         mask_2 = inp.mask_2.reshape(B, H, W)
-        use_mseg = bool(opt.use_motion_seg)
-        if use_mseg:
-            raise NotImplementedError('--use_motion_seg is not wired into the fused step yet')
+        # --use_motion_seg (:253-254): the integrated scene flow is multiplied by motion_seg_1 before the
+        # warp; the un-masked field still drives the Euler chain and the regulariser
+        mseg = inp.motion_seg_1.reshape(B, H, W) if opt.use_motion_seg else None
         cfg_all = ops.warp_cfg(B, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode,
                                loss_on_sf=not opt.use_disp, flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
         # The MLP activation stashes bound how many pairs go through the MLP kernels at once
@@ -249,13 +249,18 @@ class Model(NetInterface):
             return (stashes, first) if keep_first is not None else stashes
 
         def warp(b0, b1):
+            sf_used = sf_all[b0:b1]
+            if mseg is not None:
+                sf_used = ops.mul_mask(torch.empty_like(sf_used), sf_used, mseg[b0:b1])
             cfg = cfg_all if (b0, b1) == (0, B) else ops.warp_cfg(
                 b1 - b0, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode, loss_on_sf=not opt.use_disp,
                 flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
             csum = torch.empty(4, device=dev)
             ops.warp_loss_fused(cfg, depth_1[b0:b1], depth_2[b0:b1], inp.flow_1_2[b0:b1], mask_2[b0:b1],
-                                sf_all[b0:b1], cams_of(b0, b1),
+                                sf_used, cams_of(b0, b1),
                                 out=(csum, g_d1_main[b0:b1], g_d2_main[b0:b1], g_sf_all[b0:b1]))
+            if mseg is not None:
+                ops.mul_mask(g_sf_all[b0:b1], g_sf_all[b0:b1], mseg[b0:b1])
             sums[:4] += csum
 
         def mlp_backward_chunk(b0, b1, stashes, gst):

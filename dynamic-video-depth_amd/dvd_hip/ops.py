@@ -295,6 +295,17 @@ def scale_add(out, a, scale=1.0, scale_ptr=None, b=None):
     return out
 
 
+def mul_mask(out, a, mask):
+    """out[b,c,h,w] = a[b,c,h,w] * mask[b,h,w]  (planar a, per-pixel mask; out may alias a)."""
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // (B * C)
+    if mask.numel() != B * HW:
+        raise RuntimeError('mul_mask: mask must have one value per pixel')
+    lib = _lib.load()
+    _lib.check(lib.dvd_mul_mask(_p(out), _p(_dev32(a, 'a')), _p(_dev32(mask, 'mask')), B, C, HW, _stream()), 'dvd_mul_mask')
+    return out
+
+
 def acc_reg(sf0, sf1, coef, g_sf1, abs_sum, accumulate=True):
     lib = _lib.load()
     ws = _workspace(lib.dvd_acc_reg_workspace_bytes(), sf0.device)

@@ -180,6 +180,9 @@ int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, const void* gsta
  *   options/options_train.py:84-87) on a flat buffer with grad = s*grad1 + grad2. */
 int dvd_scale_add(float* out, const float* a, float scale, const float* scale_ptr, const float* b,
                   long long n, dvd_stream_t stream);
+/* out[b,c,p] = a[b,c,p] * mask[b,p]: `sf_1_2 *= motion_seg_1` of --use_motion_seg
+ * (models/scene_flow_motion_field.py:253-254) and the matching gradient mask; out may alias a. */
+int dvd_mul_mask(float* out, const float* a, const float* mask, int B, int C, long long HW, dvd_stream_t stream);
 size_t dvd_acc_reg_workspace_bytes(void);
 int dvd_acc_reg(const float* sf0, const float* sf1, float coef, float* g_sf1, void* workspace,
                 float* abs_sum, int accumulate, long long n, dvd_stream_t stream);

@@ -194,7 +194,7 @@ def case_step(name, B, H, W, gap, behind, seed, warm, **opt_over):
     print('wrote', name, {k: float(out['loss_' + k]) for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg')})
 
 
-def case_full_step(name, midas, B, H, W, gap, epoch, seed):
+def case_full_step(name, midas, B, H, W, gap, epoch, seed, over=None):
     """The REAL reference Model._train_on_batch (models/scene_flow_motion_field.py:152-227)
     on CPU: depth net (hourglass, or MiDaS with the locally defined ResNeXt encoder since
     torch.hub is unreachable) + scene-flow MLP + warp + losses + both backward passes + Adam."""
@@ -210,6 +210,7 @@ def case_full_step(name, midas, B, H, W, gap, epoch, seed):
     from dvd_hip.third_party.MiDaS import make_resnext101_32x8d_backbone
     o = dict(helpers.FULL_STEP_OPT)
     o.update(midas=midas, full_logdir=tempfile.mkdtemp())
+    o.update(over or {})
     opt = SimpleNamespace(**o)
 
     class _Loggers(object):
@@ -235,7 +236,8 @@ def case_full_step(name, midas, B, H, W, gap, epoch, seed):
     batch = synthetic.make_batch(B, H, W, gap=gap, seed=seed + 2)
     log = model._train_on_batch(epoch, 0, helpers.loader_batch(batch))
     out = {'B': np.array(B), 'H': np.array(H), 'W': np.array(W), 'gap': np.array(gap), 'epoch': np.array(epoch),
-           'seed': np.array(seed), 'midas': np.array(int(midas))}
+           'seed': np.array(seed), 'midas': np.array(int(midas)),
+           'over_keys': np.array(sorted(over or {})), 'over_vals': np.array([float((over or {})[k]) for k in sorted(over or {})])}
     for k, v in log.items():
         out['log_' + k] = np.array(float(v), dtype=np.float64)
     names, gnorm, pnorm = [], [], []
@@ -277,6 +279,8 @@ def main():
     case_full_step('fullstep_hourglass_b2_32x48_train', midas=False, B=2, H=32, W=48, gap=1, epoch=6, seed=101)
     case_full_step('fullstep_hourglass_b2_32x48_warm', midas=False, B=2, H=32, W=48, gap=2, epoch=1, seed=103)
     case_full_step('fullstep_midas_b1_64x96_train', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=107)
+    case_full_step('fullstep_hourglass_b2_32x48_mseg_gap2', midas=False, B=2, H=32, W=48, gap=2, epoch=6, seed=109,
+                   over=dict(use_motion_seg=True))
 
 
 if __name__ == '__main__':

@@ -24,6 +24,9 @@ def _build(gd, **over):
     from dvd_hip.models.scene_flow_motion_field import Model
     o = dict(helpers.FULL_STEP_OPT)
     o.update(midas=bool(gd['midas']), full_logdir='/tmp')
+    if 'over_keys' in gd:                     # option overrides the fixture was generated with
+        o.update({str(k): (bool(v) if isinstance(o.get(str(k)), bool) else float(v))
+                  for k, v in zip(gd['over_keys'], gd['over_vals'])})
     o.update(over)
     opt = SimpleNamespace(**o)
     with pytest.warns(UserWarning):          # checkpoints are absent: random weights announced
@@ -41,7 +44,7 @@ def _build(gd, **over):
 
 
 @pytest.mark.parametrize('name', ['fullstep_hourglass_b2_32x48_train', 'fullstep_hourglass_b2_32x48_warm',
-                                  'fullstep_midas_b1_64x96_train'])
+                                  'fullstep_midas_b1_64x96_train', 'fullstep_hourglass_b2_32x48_mseg_gap2'])
 def test_train_on_batch_matches_reference(name):
     gd = helpers.load_golden(name)
     model, opt, batch = _build(gd)
