@@ -82,6 +82,10 @@ SIGNATURES = {
                                   ctypes.POINTER(Surfaces), c_int, c_int, c_int, c_void_p]),
     'dvd_flow_warp_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_flow_warp_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_bnrelu_fwd': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_bnrelu_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'dvd_bnrelu_bwd': (c_int, [c_void_p] * 6 + [c_float] + [c_void_p] * 5 + [c_size_t, c_int, c_int, c_int, c_int,
+                                                                           c_void_p]),
     'dvd_upsample_bilinear_fwd': (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_upsample_bilinear_bwd': (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

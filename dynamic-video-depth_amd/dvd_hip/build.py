@@ -30,6 +30,7 @@ SOURCES = [
     ('gconv32.hip', []),
     ('surfaces.hip', ['-ffp-contract=off']),
     ('upsample.hip', ['-ffp-contract=off']),
+    ('bnrelu.hip', []),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

@@ -22,6 +22,54 @@ from . import _lib
 from .ops import _p, _stream, _workspace
 
 
+class _BnRelu(torch.autograd.Function):
+    """y = relu(bn_eval(x) (+ residual)); see csrc/bnrelu.hip."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, mean, var, eps, relu):
+        x = x.contiguous()
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        if residual is not None:
+            residual = residual.contiguous()
+        y = torch.empty_like(x)
+        lib = _lib.load()
+        _lib.check(lib.dvd_bnrelu_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(y), N, C,
+                                      HW, int(relu), _stream()), 'dvd_bnrelu_fwd')
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, var)
+        ctx.cfg = (N, C, HW, float(eps), int(relu), residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, mean, var = ctx.saved_tensors
+        N, C, HW, eps, relu, has_res = ctx.cfg
+        gy = gy.contiguous()
+        need = ctx.needs_input_grad
+        gx = torch.empty_like(x) if need[0] else None
+        gr = torch.empty_like(x) if (has_res and need[1]) else None
+        gg = torch.empty_like(gamma) if need[2] else None
+        gb = torch.empty_like(gamma) if need[3] else None
+        lib = _lib.load()
+        ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, C, HW), x.device)
+        _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(mean), _p(var), eps, _p(gx), _p(gr), _p(gg),
+                                      _p(gb), _p(ws), ctypes.c_size_t(ws.numel()), N, C, HW, relu, _stream()),
+                   'dvd_bnrelu_bwd')
+        return gx, gr, gg, gb, None, None, None, None
+
+
+def bn_eval_relu(bn, x, residual=None, relu=True):
+    """relu(bn(x) (+ residual)) for an nn.BatchNorm2d in eval mode (running statistics; gamma / beta keep
+    their gradients) on the fused HIP kernel; anything else (training-mode BN, CPU, other dtypes) takes the
+    ATen ops the reference uses."""
+    if (not bn.training and bn.affine and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32):
+        return _BnRelu.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, out_hw, align_corners):

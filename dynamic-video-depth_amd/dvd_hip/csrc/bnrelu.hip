@@ -1,0 +1,189 @@
+// Fused eval-mode BatchNorm + (residual add) + ReLU for NCHW fp32, forward and backward (gfx950).
+//
+// What it replaces: `relu(bn(conv(x)))` and `relu(bn3(conv3(.)) + skip)` of the ResNeXt bottlenecks
+// inside the MiDaS encoder (torchvision resnet.py Bottleneck, reached through
+// third_party/midas_blocks.py:35-50).  The depth nets are ALWAYS in eval mode while training
+// (models/scene_flow_motion_field.py:157,168): BatchNorm uses its running statistics but gamma and
+// beta still receive gradients.  ATen runs this as 3-4 kernels per site and direction
+// (batch_norm, add_, clamp_min_ / threshold_backward, batch_norm_backward): ~250 ms of a
+// 2.2 s step (profiles/r01_bench_kernel_trace_summary.txt).
+//
+//   forward :  y = max(0, x * s[c] + b[c] (+ r)),  s = gamma / sqrt(var + eps),  b = beta - mean * s
+//   backward:  g = gy * [y > 0];  gx = g * s[c];  gr = g;
+//              gbeta[c] = sum g;   ggamma[c] = sum g * (x - mean[c]) / sqrt(var[c] + eps)
+// Roofline: HBM -- forward 8 B (+4 with a residual) per element, backward 12 B read + 4 (+4)
+// written.  One block = one (image, channel) plane segment, 16-byte accesses; the two channel
+// sums of the backward are reduced per block, written as partials and summed in a fixed order by
+// a second kernel (deterministic).
+
+#include "dvd_common.h"
+
+namespace dvd {
+
+constexpr int kBnChunk = 4096;   // elements of one plane handled by a block (1024 float4)
+
+__global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         float eps, float* __restrict__ y, int C, int HW, int chunks,
+                                                         int relu) {
+  const int chunk = blockIdx.x % chunks;
+  const long long pl = blockIdx.x / chunks;   // n * C + c
+  const int c = (int)(pl % C);
+  const float s = gamma[c] / sqrtf(var[c] + eps);
+  const float b = beta[c] - mean[c] * s;
+  const long long base = pl * HW;
+  const int lo = chunk * kBnChunk, hi = min(HW, lo + kBnChunk);
+  if ((HW & 3) == 0) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      float4 v = *reinterpret_cast<const float4*>(x + base + i);
+      v.x = __builtin_fmaf(v.x, s, b);
+      v.y = __builtin_fmaf(v.y, s, b);
+      v.z = __builtin_fmaf(v.z, s, b);
+      v.w = __builtin_fmaf(v.w, s, b);
+      if (res) {
+        const float4 r = *reinterpret_cast<const float4*>(res + base + i);
+        v.x += r.x;
+        v.y += r.y;
+        v.z += r.z;
+        v.w += r.w;
+      }
+      if (relu) {
+        v.x = fmaxf(v.x, 0.0f);
+        v.y = fmaxf(v.y, 0.0f);
+        v.z = fmaxf(v.z, 0.0f);
+        v.w = fmaxf(v.w, 0.0f);
+      }
+      *reinterpret_cast<float4*>(y + base + i) = v;
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      float v = __builtin_fmaf(x[base + i], s, b);
+      if (res) v += res[base + i];
+      y[base + i] = relu ? fmaxf(v, 0.0f) : v;
+    }
+  }
+}
+
+// partial[(c * N + n) * chunks + chunk] = (sum g, sum g * (x - mean[c])) of the block
+__global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                         const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         float eps, float* __restrict__ gx, float* __restrict__ gres,
+                                                         float2* __restrict__ partial, int N, int C, int HW,
+                                                         int chunks, int relu) {
+  const int chunk = blockIdx.x % chunks;
+  const long long pl = blockIdx.x / chunks;
+  const int c = (int)(pl % C), n = (int)(pl / C);
+  const float s = gamma[c] / sqrtf(var[c] + eps);
+  const float mu = mean[c];
+  const long long base = pl * HW;
+  const int lo = chunk * kBnChunk, hi = min(HW, lo + kBnChunk);
+  float sg = 0.0f, sgx = 0.0f;
+  if ((HW & 3) == 0) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+      float4 g = *reinterpret_cast<const float4*>(gy + base + i);
+      if (relu) {
+        const float4 o = *reinterpret_cast<const float4*>(y + base + i);
+        g.x = o.x > 0.0f ? g.x : 0.0f;
+        g.y = o.y > 0.0f ? g.y : 0.0f;
+        g.z = o.z > 0.0f ? g.z : 0.0f;
+        g.w = o.w > 0.0f ? g.w : 0.0f;
+      }
+      const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+      sg += (g.x + g.y) + (g.z + g.w);
+      sgx = __builtin_fmaf(g.x, v.x - mu,
+                           __builtin_fmaf(g.y, v.y - mu, __builtin_fmaf(g.z, v.z - mu, __builtin_fmaf(g.w, v.w - mu, sgx))));
+      if (gres) *reinterpret_cast<float4*>(gres + base + i) = g;
+      if (gx) *reinterpret_cast<float4*>(gx + base + i) = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      float g = gy[base + i];
+      if (relu) g = y[base + i] > 0.0f ? g : 0.0f;
+      sg += g;
+      sgx = __builtin_fmaf(g, x[base + i] - mu, sgx);
+      if (gres) gres[base + i] = g;
+      if (gx) gx[base + i] = g * s;
+    }
+  }
+  __shared__ float red[2][4];
+  sg = wave_sum(sg);
+  sgx = wave_sum(sgx);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = sg;
+    red[1][wave] = sgx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partial[((size_t)c * N + n) * chunks + chunk] =
+        make_float2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+}
+
+// ggamma[c] = sum g (x - mean) / sqrt(var + eps), gbeta[c] = sum g   (fixed order over the records)
+__global__ __launch_bounds__(64) void bnrelu_param_grad_kernel(const float2* __restrict__ partial,
+                                                               const float* __restrict__ var, float eps,
+                                                               float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                               int C, int records) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int r = 0; r < records; ++r) {
+    const float2 v = partial[(size_t)c * records + r];
+    sg += v.x;
+    sgx += v.y;
+  }
+  if (gbeta) gbeta[c] = (float)sg;
+  if (ggamma) ggamma[c] = (float)(sgx / sqrt((double)var[c] + (double)eps));
+}
+
+}  // namespace dvd
+
+extern "C" {
+
+int dvd_bnrelu_fwd(const float* x, const float* residual, const float* gamma, const float* beta, const float* mean,
+                   const float* var, float eps, float* y, int N, int C, int HW, int relu, dvd_stream_t stream) {
+  DVD_REQUIRE(x && gamma && beta && mean && var && y, "bnrelu fwd: null pointer");
+  DVD_REQUIRE(N > 0 && C > 0 && HW > 0, "bnrelu fwd: bad shape");
+  const int chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
+  const long long blocks = (long long)N * C * chunks;
+  DVD_REQUIRE(blocks < (1LL << 31), "bnrelu fwd: grid too large");
+  hipLaunchKernelGGL(dvd::bnrelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     residual, gamma, beta, mean, var, eps, y, C, HW, chunks, relu);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+size_t dvd_bnrelu_bwd_workspace_bytes(int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  const size_t chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
+  return (size_t)N * C * chunks * sizeof(float2);
+}
+
+int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* mean,
+                   const float* var, float eps, float* gx, float* g_residual, float* g_gamma, float* g_beta,
+                   void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu, dvd_stream_t stream) {
+  DVD_REQUIRE(gy && x && gamma && mean && var && workspace, "bnrelu bwd: null pointer");
+  DVD_REQUIRE(!relu || y, "bnrelu bwd: the ReLU mask needs the forward output");
+  DVD_REQUIRE(N > 0 && C > 0 && HW > 0, "bnrelu bwd: bad shape");
+  if (workspace_bytes < dvd_bnrelu_bwd_workspace_bytes(N, C, HW)) {
+    dvd::set_error("bnrelu bwd: workspace too small");
+    return DVD_ENOSPC;
+  }
+  const int chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
+  const long long blocks = (long long)N * C * chunks;
+  DVD_REQUIRE(blocks < (1LL << 31), "bnrelu bwd: grid too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dvd::bnrelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, y, x, gamma, mean, var, eps, gx,
+                     g_residual, static_cast<float2*>(workspace), N, C, HW, chunks, relu);
+  DVD_LAUNCH_OK();
+  if (g_gamma || g_beta) {
+    hipLaunchKernelGGL(dvd::bnrelu_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, s,
+                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, N * chunks);
+    DVD_LAUNCH_OK();
+  }
+  return DVD_OK;
+}
+
+}  // extern "C"

@@ -252,6 +252,21 @@ int dvd_gconv3x3_c32_bwd_weight(const float* x, const float* gy, float* gw, int 
                                 size_t workspace_bytes, int N, int C, int H, int W, dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Fused eval-mode BatchNorm (+ residual add) (+ ReLU), NCHW fp32.  Replaces
+ * relu(bn(x)) / relu(bn3(x) + skip) of the ResNeXt bottlenecks of the MiDaS encoder (torchvision
+ * resnet.py Bottleneck via third_party/midas_blocks.py:35-50); the depth nets are in eval mode while
+ * training (models/scene_flow_motion_field.py:157,168), so running statistics are used and gamma/beta
+ * still get gradients.  y = max(0, x*s[c] + b[c] (+ residual)), s = gamma/sqrt(var+eps), b = beta - mean*s.
+ * bwd: gx = g*s, g_residual = g, g_beta = sum g, g_gamma = sum g*(x-mean)/sqrt(var+eps), g = gy*[y>0];
+ * any of gx, g_residual, g_gamma, g_beta may be NULL; channel sums are deterministic (two stages). */
+int dvd_bnrelu_fwd(const float* x, const float* residual, const float* gamma, const float* beta, const float* mean,
+                   const float* var, float eps, float* y, int N, int C, int HW, int relu, dvd_stream_t stream);
+size_t dvd_bnrelu_bwd_workspace_bytes(int N, int C, int HW);
+int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* mean,
+                   const float* var, float eps, float* gx, float* g_residual, float* g_gamma, float* g_beta,
+                   void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu, dvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Bilinear up-sampling of [planes, H_in, W_in] -> [planes, H_out, W_out] (planes = N*C) and its backward.
  * Replaces F.interpolate(mode='bilinear') of the MiDaS decoder: align_corners=True at the end of every
  * FeatureFusionBlock (third_party/midas_blocks.py:164-166), align_corners=False in the output head
