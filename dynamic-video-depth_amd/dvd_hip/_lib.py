@@ -118,10 +118,19 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libdvd_hip.so must bind to the HIP runtime torch has loaded (the one that owns the
+    # tensors and streams handed to it), not pull a second libamdhip64 of its own into the process
+    import torch  # noqa: F401
     with _lock:
         if _lib is not None:
             return _lib
         path = library_path()
+        if not os.path.exists(path) and 'DVD_HIP_LIB' not in os.environ:
+            try:                                  # fresh checkout: compile in-tree (hipcc cross-compiles gfx950)
+                _build.build_library()
+            except Exception as e:                # noqa: BLE001 -- reported below as the missing-library error
+                raise RuntimeError('libdvd_hip.so not found at %s and building it failed (%s); '
+                                   'dvd_hip has no CPU fallback' % (path, e))
         if not os.path.exists(path):
             raise RuntimeError('libdvd_hip.so not found at %s -- run `python -m dvd_hip.build`; '
                                'dvd_hip has no CPU fallback' % path)

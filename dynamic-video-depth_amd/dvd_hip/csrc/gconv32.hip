@@ -79,12 +79,17 @@ __global__ __launch_bounds__(256, 2) void gconv32_mfma_kernel(const float* __res
     }
   }
   // input band with halo, zero outside the image
-  for (int i = threadIdx.x; i < kG32 * PS; i += 256) {
-    const int c = i / PS, r = i - c * PS, yy = r / WS, xx = r - yy * WS;
-    const int gy = y0 + yy - 1, gx = xx - 1;
-    float v = 0.0f;
-    if (yy < rows + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W) v = inb[(size_t)c * plane + (size_t)gy * W + gx];
-    s_x[i] = v;
+  // one wave per (channel, row) of the haloed band, lanes along x: coalesced row reads, no per-element divisions
+  for (int rho = wave; rho < kG32 * (TH + 2); rho += 4) {
+    const int c = rho / (TH + 2), yy = rho - c * (TH + 2);
+    const int gy = y0 + yy - 1;
+    const bool row_ok = yy < rows + 2 && gy >= 0 && gy < H;
+    const float* src = inb + (size_t)c * plane + (size_t)(row_ok ? gy : 0) * W;
+    float* dstrow = s_x + c * PS + yy * WS;
+    for (int xx = lane; xx < WS; xx += 64) {
+      const int gx = xx - 1;
+      dstrow[xx] = (row_ok && gx >= 0 && gx < W) ? src[gx] : 0.0f;
+    }
   }
   __syncthreads();
 
@@ -135,18 +140,23 @@ __global__ __launch_bounds__(192, 2) void gconv32_wgrad_kernel(const float* __re
   const float* xb = x + ((size_t)n * C + (size_t)g * kG32) * plane;
   const float* gb = gy + ((size_t)n * C + (size_t)g * kG32) * plane;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int xin = (TH + 2) * WS;
-  for (int i = threadIdx.x; i < kG32 * xin; i += 192) {
-    const int c = i / xin, r = i - c * xin, yy = r / WS, xx = r - yy * WS;
-    const int py = y0 + yy - 1, px = xx - 1;
-    float v = 0.0f;
-    if (yy < rows + 2 && py >= 0 && py < H && px >= 0 && px < W) v = xb[(size_t)c * plane + (size_t)py * W + px];
-    s_x[c * PSX + r] = v;
+  // one wave per (channel, row): coalesced row reads, no per-element divisions
+  for (int rho = wave; rho < kG32 * (TH + 2); rho += 3) {
+    const int c = rho / (TH + 2), yy = rho - c * (TH + 2);
+    const int py = y0 + yy - 1;
+    const bool row_ok = yy < rows + 2 && py >= 0 && py < H;
+    const float* src = xb + (size_t)c * plane + (size_t)(row_ok ? py : 0) * W;
+    float* dstrow = s_x + c * PSX + yy * WS;
+    for (int xx = lane; xx < WS; xx += 64) {
+      const int px = xx - 1;
+      dstrow[xx] = (row_ok && px >= 0 && px < W) ? src[px] : 0.0f;
+    }
   }
   const int npix = rows * W;
-  for (int i = threadIdx.x; i < kG32 * TH * W; i += 192) {
-    const int c = i / (TH * W), r = i - c * (TH * W);
-    s_g[c * PSG + r] = r < npix ? gb[(size_t)c * plane + (size_t)y0 * W + r] : 0.0f;
+  for (int c = wave; c < kG32; c += 3) {     // the band's rows of one channel are contiguous in memory
+    const float* src = gb + (size_t)c * plane + (size_t)y0 * W;
+    float* dstp = s_g + c * PSG;
+    for (int r = lane; r < TH * W; r += 64) dstp[r] = r < npix ? src[r] : 0.0f;
   }
   __syncthreads();
 
