@@ -49,6 +49,38 @@ __global__ __launch_bounds__(256) void gconv32_pack_kernel(const float* __restri
   packed[i] = w[((size_t)(g * kG32 + co) * kG32 + ci) * 9 + tap];
 }
 
+constexpr int kFillU = 8;
+
+// s_x[c][yy][xx] (plane stride PS, row stride WS) <- rows y0-1 .. y0+rows of the 32 planes at `src`, with a
+// 1-pixel zero halo; NW waves, wave w takes row ids w*kFillU .. +kFillU-1, then strides by NW*kFillU
+template <int NW>
+__device__ __forceinline__ void fill_band(float* s_x, int PS, int WS, const float* __restrict__ src, size_t plane,
+                                          int H, int W, int TH, int rows, int y0, int wave, int lane) {
+  const int nrow = kG32 * (TH + 2);
+  for (int rho0 = wave * kFillU; rho0 < nrow; rho0 += NW * kFillU) {
+    for (int xx = lane; xx < WS; xx += 64) {
+      const int gx = xx - 1;
+      float v[kFillU];
+#pragma unroll
+      for (int u = 0; u < kFillU; ++u) {
+        const int rho = rho0 + u;
+        const int c = rho / (TH + 2), yy = rho - c * (TH + 2);
+        const int gy = y0 + yy - 1;
+        const bool ok = rho < nrow && yy < rows + 2 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        v[u] = ok ? src[(size_t)c * plane + (size_t)gy * W + gx] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kFillU; ++u) {
+        const int rho = rho0 + u;
+        if (rho < nrow) {
+          const int c = rho / (TH + 2), yy = rho - c * (TH + 2);
+          s_x[c * PS + yy * WS + xx] = v[u];
+        }
+      }
+    }
+  }
+}
+
 // out[n, g*32 + m, p] = sum_{t, k} A_t[m][k] * in[n, g*32 + k, p + tap_t]
 __global__ __launch_bounds__(256, 2) void gconv32_mfma_kernel(const float* __restrict__ in,
                                                               const float* __restrict__ packed,
@@ -79,18 +111,9 @@ __global__ __launch_bounds__(256, 2) void gconv32_mfma_kernel(const float* __res
     }
   }
   // input band with halo, zero outside the image
-  // one wave per (channel, row) of the haloed band, lanes along x: coalesced row reads, no per-element divisions
-  for (int rho = wave; rho < kG32 * (TH + 2); rho += 4) {
-    const int c = rho / (TH + 2), yy = rho - c * (TH + 2);
-    const int gy = y0 + yy - 1;
-    const bool row_ok = yy < rows + 2 && gy >= 0 && gy < H;
-    const float* src = inb + (size_t)c * plane + (size_t)(row_ok ? gy : 0) * W;
-    float* dstrow = s_x + c * PS + yy * WS;
-    for (int xx = lane; xx < WS; xx += 64) {
-      const int gx = xx - 1;
-      dstrow[xx] = (row_ok && gx >= 0 && gx < W) ? src[gx] : 0.0f;
-    }
-  }
+  // LDS fill: one wave per (channel, row) of the haloed band, lanes along x.  kFillU rows are requested
+  // before the first one is stored, so a wave has kFillU loads in flight instead of one.
+  fill_band<4>(s_x, PS, WS, inb, plane, H, W, TH, rows, y0, wave, lane);
   __syncthreads();
 
   const int npix = rows * W;
@@ -140,23 +163,20 @@ __global__ __launch_bounds__(192, 2) void gconv32_wgrad_kernel(const float* __re
   const float* xb = x + ((size_t)n * C + (size_t)g * kG32) * plane;
   const float* gb = gy + ((size_t)n * C + (size_t)g * kG32) * plane;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // one wave per (channel, row): coalesced row reads, no per-element divisions
-  for (int rho = wave; rho < kG32 * (TH + 2); rho += 3) {
-    const int c = rho / (TH + 2), yy = rho - c * (TH + 2);
-    const int py = y0 + yy - 1;
-    const bool row_ok = yy < rows + 2 && py >= 0 && py < H;
-    const float* src = xb + (size_t)c * plane + (size_t)(row_ok ? py : 0) * W;
-    float* dstrow = s_x + c * PSX + yy * WS;
-    for (int xx = lane; xx < WS; xx += 64) {
-      const int px = xx - 1;
-      dstrow[xx] = (row_ok && px >= 0 && px < W) ? src[px] : 0.0f;
-    }
-  }
+  fill_band<3>(s_x, PSX, WS, xb, plane, H, W, TH, rows, y0, wave, lane);
   const int npix = rows * W;
-  for (int c = wave; c < kG32; c += 3) {     // the band's rows of one channel are contiguous in memory
-    const float* src = gb + (size_t)c * plane + (size_t)y0 * W;
-    float* dstp = s_g + c * PSG;
-    for (int r = lane; r < TH * W; r += 64) dstp[r] = r < npix ? src[r] : 0.0f;
+  for (int c0 = wave * kFillU; c0 < kG32; c0 += 3 * kFillU) {   // the band's rows of a channel are contiguous in memory
+    for (int r = lane; r < TH * W; r += 64) {
+      float v[kFillU];
+#pragma unroll
+      for (int u = 0; u < kFillU; ++u) {
+        const int c = c0 + u;
+        v[u] = (c < kG32 && r < npix) ? gb[(size_t)c * plane + (size_t)y0 * W + r] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kFillU; ++u)
+        if (c0 + u < kG32) s_g[(c0 + u) * PSG + r] = v[u];
+    }
   }
   __syncthreads();
 
