@@ -56,12 +56,27 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_kernel(const float* __restric
       s_w[co][2 - ky][2 - kx][ci] = v;      // src = co, dst = ci, taps flipped
   }
   // input tile with halo (zero outside the image)
-  for (int i = threadIdx.x; i < kCPG * IH * (kFT_W + 2); i += 256) {
-    const int c = i / (IH * (kFT_W + 2)), r = i - c * (IH * (kFT_W + 2)), yy = r / (kFT_W + 2), xx = r - yy * (kFT_W + 2);
-    const int gy = y0 + yy - 1, gx = x0 + xx - 1;
-    float v = 0.0f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = inb[(size_t)c * plane + (size_t)gy * W + gx];
-    s_in[c][yy][xx] = v;
+  // kU loads are requested before the first one is stored (a thread has kU loads in flight, not one)
+  {
+    constexpr int kU = 8, kRow = kFT_W + 2, kTot = kCPG * IH * kRow;
+    for (int i0 = threadIdx.x; i0 < kTot; i0 += 256 * kU) {
+      float v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int i = i0 + u * 256;
+        const int c = i / (IH * kRow), r = i - c * (IH * kRow), yy = r / kRow, xx = r - yy * kRow;
+        const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+        v[u] = (i < kTot && gy >= 0 && gy < H && gx >= 0 && gx < W) ? inb[(size_t)c * plane + (size_t)gy * W + gx] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int i = i0 + u * 256;
+        if (i < kTot) {
+          const int c = i / (IH * kRow), r = i - c * (IH * kRow), yy = r / kRow, xx = r - yy * kRow;
+          s_in[c][yy][xx] = v[u];
+        }
+      }
+    }
   }
   __syncthreads();
   const int sx = threadIdx.x & 15, sy = threadIdx.x >> 4;   // strip of 4 pixels, row
@@ -127,19 +142,43 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_wgrad_kernel(const float* __r
   const size_t plane = (size_t)H * W;
   const float* xb = x + ((size_t)n * C + (size_t)g * kCPG) * plane;
   const float* gb = gy + ((size_t)n * C + (size_t)g * kCPG) * plane;
-  for (int i = threadIdx.x; i < kCPG * IH * (kWT_W + 2); i += 256) {
-    const int c = i / (IH * (kWT_W + 2)), r = i - c * (IH * (kWT_W + 2)), yy = r / (kWT_W + 2), xx = r - yy * (kWT_W + 2);
-    const int py = y0 + yy - 1, px = x0 + xx - 1;
-    float v = 0.0f;
-    if (py >= 0 && py < H && px >= 0 && px < W) v = xb[(size_t)c * plane + (size_t)py * W + px];
-    s_x[c * XP + yy * IW + xx] = v;
-  }
-  for (int i = threadIdx.x; i < kCPG * kWT_H * kWT_W; i += 256) {
-    const int c = i / (kWT_H * kWT_W), r = i - c * (kWT_H * kWT_W), yy = r / kWT_W, xx = r - yy * kWT_W;
-    const int py = y0 + yy, px = x0 + xx;
-    float v = 0.0f;
-    if (py < H && px < W) v = gb[(size_t)c * plane + (size_t)py * W + px];
-    s_g[c * GP + yy * GW + xx] = v;
+  {
+    constexpr int kU = 8, kRow = kWT_W + 2, kTot = kCPG * IH * kRow;
+    for (int i0 = threadIdx.x; i0 < kTot; i0 += 256 * kU) {
+      float v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int i = i0 + u * 256;
+        const int c = i / (IH * kRow), r = i - c * (IH * kRow), yy = r / kRow, xx = r - yy * kRow;
+        const int py = y0 + yy - 1, px = x0 + xx - 1;
+        v[u] = (i < kTot && py >= 0 && py < H && px >= 0 && px < W) ? xb[(size_t)c * plane + (size_t)py * W + px] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int i = i0 + u * 256;
+        if (i < kTot) {
+          const int c = i / (IH * kRow), r = i - c * (IH * kRow), yy = r / kRow, xx = r - yy * kRow;
+          s_x[c * XP + yy * IW + xx] = v[u];
+        }
+      }
+    }
+    constexpr int kTotG = kCPG * kWT_H * kWT_W;   // 4096: a multiple of 256 * kU
+    for (int i0 = threadIdx.x; i0 < kTotG; i0 += 256 * kU) {
+      float v[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int i = i0 + u * 256;
+        const int c = i / (kWT_H * kWT_W), r = i - c * (kWT_H * kWT_W), yy = r / kWT_W, xx = r - yy * kWT_W;
+        const int py = y0 + yy, px = x0 + xx;
+        v[u] = (py < H && px < W) ? gb[(size_t)c * plane + (size_t)py * W + px] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int i = i0 + u * 256;
+        const int c = i / (kWT_H * kWT_W), r = i - c * (kWT_H * kWT_W), yy = r / kWT_W, xx = r - yy * kWT_W;
+        s_g[c * GP + yy * GW + xx] = v[u];
+      }
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
