@@ -29,6 +29,10 @@
 
 #include "dvd_common.h"
 
+#ifndef DVD_WARP_PREFETCH
+#define DVD_WARP_PREFETCH 0
+#endif
+
 namespace dvd {
 
 struct WarpArgs {
@@ -541,94 +545,134 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   }
   const float* d2b = a.d2 + (size_t)b * a.HW;
 
-  // ---- phase 0: fill the depth_2 window, clear the accumulator
+  // ---- phase 0: fill the depth_2 window, clear the accumulator.  All of a thread's window loads are
+  //      requested before the first one is consumed (the trip count is a compile-time constant).
   const bool w4 = (a.W & 3) == 0;
-  for (int i = threadIdx.x; i < (WW / 4) * WH; i += NT) {
-    const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
-    const int iy = wy0 + wy, ixx = wx0 + wx;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iy >= 0 && iy < a.H) {
-      if (w4) {
-        if (ixx >= 0 && ixx < a.W) v = *reinterpret_cast<const float4*>(d2b + (size_t)iy * a.W + ixx);
-      } else {
-        const float* row = d2b + (size_t)iy * a.W;
-        if (ixx >= 0 && ixx < a.W) v.x = row[ixx];
-        if (ixx + 1 >= 0 && ixx + 1 < a.W) v.y = row[ixx + 1];
-        if (ixx + 2 >= 0 && ixx + 2 < a.W) v.z = row[ixx + 2];
-        if (ixx + 3 >= 0 && ixx + 3 < a.W) v.w = row[ixx + 3];
+  {
+    constexpr int kCells = (WW / 4) * WH;
+    constexpr int kIt = (kCells + NT - 1) / NT;
+    float4 v[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int i = it * NT + threadIdx.x;
+      const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
+      const int iy = wy0 + wy, ixx = wx0 + wx;
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < kCells && iy >= 0 && iy < a.H) {
+        if (w4) {
+          if (ixx >= 0 && ixx < a.W) v[it] = *reinterpret_cast<const float4*>(d2b + (size_t)iy * a.W + ixx);
+        } else {
+          const float* row = d2b + (size_t)iy * a.W;
+          if (ixx >= 0 && ixx < a.W) v[it].x = row[ixx];
+          if (ixx + 1 >= 0 && ixx + 1 < a.W) v[it].y = row[ixx + 1];
+          if (ixx + 2 >= 0 && ixx + 2 < a.W) v[it].z = row[ixx + 2];
+          if (ixx + 3 >= 0 && ixx + 3 < a.W) v[it].w = row[ixx + 3];
+        }
       }
     }
-    *reinterpret_cast<float4*>(win + wy * WW + wx) = v;
-    if (GRADS) {
-      uint4* z = reinterpret_cast<uint4*>(accw + wy * WW + wx);
-      z[0] = make_uint4(0u, 0u, 0u, 0u);
-      z[1] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int i = it * NT + threadIdx.x;
+      if (i < kCells) {
+        const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
+        *reinterpret_cast<float4*>(win + wy * WW + wx) = v[it];
+        if (GRADS) {
+          uint4* z = reinterpret_cast<uint4*>(accw + wy * WW + wx);
+          z[0] = make_uint4(0u, 0u, 0u, 0u);
+          z[1] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
     }
   }
   __syncthreads();
 
   TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, a.disp_mul, ta.ovf};
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  // ---- phase 1: the tile's pixels, PX per thread per step
+  // ---- phase 1: the tile's pixels, PX per thread per step.  The inputs of step i+1 are requested before
+  //      step i is evaluated: all waves of a block leave the barrier together, so without this every
+  //      load latency of the block is exposed at the same time.  Build-time switch DVD_WARP_PREFETCH, off by
+  //      default: measured 297 us with it (the 14 extra live registers spill) against 259 us without
   const bool wv = (a.W % PX) == 0;   // rows stay vector aligned
-  for (int q = threadIdx.x; q < QW * TH; q += NT) {
+  struct In {
+    float d1[PX], mk[PX], fl[2 * PX], s0[PX], s1[PX], s2[PX];
+  };
+  auto locate = [&](int q, int& x, int& y) {
     const int ly = q / QW, lx = (q - ly * QW) * PX;
-    const int y = ty0 + ly, x = tx0 + lx;
-    if (y >= a.H || x >= a.W) continue;
+    y = ty0 + ly;
+    x = tx0 + lx;
+    return (q < QW * TH) && (y < a.H) && (x < a.W);
+  };
+  auto fetch = [&](int q, In& r) {
+    int x, y;
+    if (!locate(q, x, y)) return;
     const int p0 = y * a.W + x;
     const size_t base = (size_t)b * a.HW + p0;
     const float* sfb = a.sf + (size_t)b * 3 * a.HW + p0;
-    float d1[PX], mk[PX], fl[2 * PX], s0[PX], s1[PX], s2[PX];
     const int nvalid = (a.W - x) < PX ? (a.W - x) : PX;
     if (wv) {
-      *reinterpret_cast<vecf*>(d1) = *reinterpret_cast<const vecf*>(a.d1 + base);
-      *reinterpret_cast<vecf*>(mk) = *reinterpret_cast<const vecf*>(a.mask + base);
-      *reinterpret_cast<vecf*>(fl) = *reinterpret_cast<const vecf*>(a.flow + 2 * base);
-      *reinterpret_cast<vecf*>(fl + PX) = *reinterpret_cast<const vecf*>(a.flow + 2 * base + PX);
-      *reinterpret_cast<vecf*>(s0) = *reinterpret_cast<const vecf*>(sfb);
-      *reinterpret_cast<vecf*>(s1) = *reinterpret_cast<const vecf*>(sfb + a.HW);
-      *reinterpret_cast<vecf*>(s2) = *reinterpret_cast<const vecf*>(sfb + 2 * a.HW);
+      *reinterpret_cast<vecf*>(r.d1) = *reinterpret_cast<const vecf*>(a.d1 + base);
+      *reinterpret_cast<vecf*>(r.mk) = *reinterpret_cast<const vecf*>(a.mask + base);
+      *reinterpret_cast<vecf*>(r.fl) = *reinterpret_cast<const vecf*>(a.flow + 2 * base);
+      *reinterpret_cast<vecf*>(r.fl + PX) = *reinterpret_cast<const vecf*>(a.flow + 2 * base + PX);
+      *reinterpret_cast<vecf*>(r.s0) = *reinterpret_cast<const vecf*>(sfb);
+      *reinterpret_cast<vecf*>(r.s1) = *reinterpret_cast<const vecf*>(sfb + a.HW);
+      *reinterpret_cast<vecf*>(r.s2) = *reinterpret_cast<const vecf*>(sfb + 2 * a.HW);
     } else {
 #pragma unroll
       for (int i = 0; i < PX; ++i) {
         const bool ok = i < nvalid;
-        d1[i] = ok ? a.d1[base + i] : 1.0f;
-        mk[i] = ok ? a.mask[base + i] : 0.0f;
-        fl[2 * i] = ok ? a.flow[2 * (base + i)] : 0.0f;
-        fl[2 * i + 1] = ok ? a.flow[2 * (base + i) + 1] : 0.0f;
-        s0[i] = ok ? sfb[i] : 0.0f;
-        s1[i] = ok ? sfb[a.HW + i] : 0.0f;
-        s2[i] = ok ? sfb[2 * a.HW + i] : 0.0f;
+        r.d1[i] = ok ? a.d1[base + i] : 1.0f;
+        r.mk[i] = ok ? a.mask[base + i] : 0.0f;
+        r.fl[2 * i] = ok ? a.flow[2 * (base + i)] : 0.0f;
+        r.fl[2 * i + 1] = ok ? a.flow[2 * (base + i) + 1] : 0.0f;
+        r.s0[i] = ok ? sfb[i] : 0.0f;
+        r.s1[i] = ok ? sfb[a.HW + i] : 0.0f;
+        r.s2[i] = ok ? sfb[2 * a.HW + i] : 0.0f;
       }
     }
-    float gd1[PX], g0[PX], g1[PX], g2[PX];
+  };
+  In cur, nxt;
+  fetch(threadIdx.x, cur);
+  for (int q = threadIdx.x; q < QW * TH; q += NT) {
+    if (DVD_WARP_PREFETCH) fetch(q + NT, nxt);
+    int x, y;
+    if (locate(q, x, y)) {
+      const int p0 = y * a.W + x;
+      const size_t base = (size_t)b * a.HW + p0;
+      const int nvalid = (a.W - x) < PX ? (a.W - x) : PX;
+      float gd1[PX], g0[PX], g1[PX], g2[PX];
 #pragma unroll
-    for (int i = 0; i < PX; ++i) {
-      float gs[3] = {0.0f, 0.0f, 0.0f};
-      gd1[i] = 0.0f;
-      if (i < nvalid)
-        pixel<GRADS, SHIPPED>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
-                              gd1[i], gs);
-      g0[i] = gs[0];
-      g1[i] = gs[1];
-      g2[i] = gs[2];
-    }
-    if (GRADS && !(a.ablate & 2)) {
-      float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
-      if (wv) {
-        *reinterpret_cast<vecf*>(a.g_d1 + base) = *reinterpret_cast<const vecf*>(gd1);
-        *reinterpret_cast<vecf*>(gsb) = *reinterpret_cast<const vecf*>(g0);
-        *reinterpret_cast<vecf*>(gsb + a.HW) = *reinterpret_cast<const vecf*>(g1);
-        *reinterpret_cast<vecf*>(gsb + 2 * a.HW) = *reinterpret_cast<const vecf*>(g2);
-      } else {
-        for (int i = 0; i < nvalid; ++i) {
-          a.g_d1[base + i] = gd1[i];
-          gsb[i] = g0[i];
-          gsb[a.HW + i] = g1[i];
-          gsb[2 * a.HW + i] = g2[i];
+      for (int i = 0; i < PX; ++i) {
+        float gs[3] = {0.0f, 0.0f, 0.0f};
+        gd1[i] = 0.0f;
+        if (i < nvalid)
+          pixel<GRADS, SHIPPED>(a, c, io, y, x + i, cur.d1[i], cur.fl[2 * i], cur.fl[2 * i + 1], cur.mk[i], cur.s0[i],
+                                cur.s1[i], cur.s2[i], acc, gd1[i], gs);
+        g0[i] = gs[0];
+        g1[i] = gs[1];
+        g2[i] = gs[2];
+      }
+      if (GRADS && !(a.ablate & 2)) {
+        float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
+        if (wv) {
+          *reinterpret_cast<vecf*>(a.g_d1 + base) = *reinterpret_cast<const vecf*>(gd1);
+          *reinterpret_cast<vecf*>(gsb) = *reinterpret_cast<const vecf*>(g0);
+          *reinterpret_cast<vecf*>(gsb + a.HW) = *reinterpret_cast<const vecf*>(g1);
+          *reinterpret_cast<vecf*>(gsb + 2 * a.HW) = *reinterpret_cast<const vecf*>(g2);
+        } else {
+          for (int i = 0; i < nvalid; ++i) {
+            a.g_d1[base + i] = gd1[i];
+            gsb[i] = g0[i];
+            gsb[a.HW + i] = g1[i];
+            gsb[2 * a.HW + i] = g2[i];
+          }
         }
       }
     }
+    if (DVD_WARP_PREFETCH)
+      cur = nxt;
+    else
+      fetch(q + NT, cur);
   }
   // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
   __syncthreads();
