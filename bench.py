@@ -123,6 +123,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (48 = the BASELINE configuration)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '0')),
+                    help='1: replay the depth net from HIP graphs')
     ap.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
     a = ap.parse_args()
 
@@ -140,7 +142,7 @@ def main():
 
     if os.environ.get('DVD_CUDNN_BENCHMARK'):
         torch.backends.cudnn.benchmark = True     # MIOpen find mode (experiments; the default run uses FAST immediate mode)
-    opt = make_opt(global_rank=rank, depth_chunk=a.depth_chunk)
+    opt = make_opt(global_rank=rank, depth_chunk=a.depth_chunk, depth_graphs=bool(a.depth_graphs))
     model = build_model(opt, device, seed=0)
     batch = synthetic.make_batch(a.pairs, H, W, gap=GAP, seed=1234, rank=rank, device=device)
     epoch = opt.warm_sf + 1            # non-warm phase

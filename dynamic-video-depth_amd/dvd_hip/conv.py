@@ -13,6 +13,7 @@ Tensors that the kernels do not cover (CPU tensors of the oracle/tests, other dt
 take `F.conv2d`; on a GPU in fp32 the HIP path is the one that runs.
 """
 import ctypes
+import os as _os
 
 import torch
 import torch.nn.functional as F
@@ -183,6 +184,33 @@ class GroupedConv3x3C32(nn.Conv2d):
 
     def forward(self, x):
         return gconv3x3_c32(x, self.weight)
+
+
+def _pair_groups_of_16(weight):
+    """[C,16,3,3] (16 channels per group) -> the equivalent [C,32,3,3] with groups paired into blocks of 32
+    channels and zeros off the 16x16 diagonal blocks (exact: the extra products are with 0.0)."""
+    C = weight.shape[0]
+    w = weight.view(C // 32, 2, 16, 16, 3, 3)
+    w32 = weight.new_zeros(C // 32, 2, 16, 2, 16, 3, 3)
+    w32[:, 0, :, 0] = w[:, 0]
+    w32[:, 1, :, 1] = w[:, 1]
+    return w32.view(C, 32, 3, 3)
+
+
+class GroupedConv3x3C16(nn.Conv2d):
+    """nn.Conv2d(C, C, 3, stride=1, padding=1, groups=C // 16, bias=False) (ResNeXt stage 2, stride-1 blocks)
+    on the 32-channel MFMA kernels: two groups share one 32x32 tile with a block-diagonal weight.  MIOpen's
+    immediate mode runs this shape per image as im2col + small GEMMs (~80 launches per call)."""
+
+    def __init__(self, channels):
+        if channels % 32:
+            raise ValueError('GroupedConv3x3C16 needs a multiple of 32 channels')
+        super().__init__(channels, channels, 3, stride=1, padding=1, groups=channels // 16, bias=False)
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and not _os.environ.get('DVD_NO_C16'):
+            return gconv3x3_c32(x, _pair_groups_of_16(self.weight))
+        return F.conv2d(x, self.weight, None, 1, 1, 1, self.groups)
 
 
 def gconv3x3_c8(x, weight):

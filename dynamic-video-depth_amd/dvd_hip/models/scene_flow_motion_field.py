@@ -63,6 +63,9 @@ class Model(NetInterface):
                             help='HBM ceiling for keeping the forward stashes of the whole batch alive so that the '
                                  'warp+loss kernel runs as ONE launch (falls back to one launch per chunk)')
         parser.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
+        parser.add_argument('--depth_graphs', action='store_true',
+                            help='capture the depth net per chunk shape in HIP graphs (forward, forward+backward) '
+                                 'and replay them: removes ~17 000 host-side launches per step')
         return parser, set()
 
     # ------------------------------------------------------------------------------------
@@ -103,6 +106,7 @@ class Model(NetInterface):
         self._flat_depth = self._flat_sf = None     # created by .to(device)
         self._optimizers = []
         self._steps_cache = {}
+        self._depth_graphs = {}
         self.warm = False
 
     # flat parameter buffers + fused Adam replace the two torch.optim.Adam objects (:113-115)
@@ -127,21 +131,88 @@ class Model(NetInterface):
             return self.net_depth(img)
         return self.net_depth(img, frame_ids.long() if frame_ids is not None else None)
 
+    # -- HIP graphs for the depth net -------------------------------------------------------
+    # A MiDaS forward+backward of one chunk is ~1 500 kernel launches; 12 chunk passes per step make the
+    # step launch-bound on the host (rocprofv3: 2.14 s of kernels in a 2.7 s step).  With --depth_graphs
+    # each chunk shape is captured once (forward-only graph for phase 1, forward+backward graph for
+    # phase 3, static input / output / output-gradient buffers; parameter gradients accumulate in place
+    # into the flat gradient buffer) and replayed; anything that cannot be captured falls back to eager.
+    def _graph_key(self, kind, img):
+        return (kind, tuple(img.shape), bool(self.opt.midas))
+
+    def _capture_depth_graph(self, kind, img, fid):
+        """Returns (graph, static_in, static_out, static_gout) or None if capture is not possible."""
+        key = self._graph_key(kind, img)
+        if key in self._depth_graphs:
+            return self._depth_graphs[key]
+        entry = None
+        try:
+            static_in = img.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            grad_backup = self._flat_depth.grad.clone() if kind == 'fb' else None
+            with torch.cuda.stream(side):                  # warm-up outside the capture (allocator, MIOpen handles)
+                for _ in range(2):
+                    if kind == 'f':
+                        with torch.no_grad():
+                            self._depth_forward(static_in, fid)
+                    else:
+                        with torch.enable_grad():
+                            d = self._depth_forward(static_in, fid)
+                        d.backward(torch.zeros_like(d))
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            if kind == 'f':
+                with torch.no_grad(), torch.cuda.graph(graph):
+                    static_out = self._depth_forward(static_in, fid)
+                entry = (graph, static_in, static_out, None)
+            else:
+                static_g = torch.zeros(img.shape[0], 1, img.shape[2], img.shape[3], device=img.device)
+                with torch.cuda.graph(graph):
+                    with torch.enable_grad():
+                        static_out = self._depth_forward(static_in, fid)
+                    static_out.backward(static_g)
+                entry = (graph, static_in, static_out, static_g)
+                self._flat_depth.grad.copy_(grad_backup)   # warm-up / capture passes used zero output gradients
+        except Exception as e:                             # noqa: BLE001 -- capture is an optimisation only
+            warnings.warn('depth-net HIP graph capture failed (%s); running eagerly' % (str(e).splitlines()[0],))
+            torch.cuda.synchronize()
+            entry = None
+        self._depth_graphs[key] = entry
+        return entry
+
+    def _use_graphs(self, img, frame_ids):
+        return bool(getattr(self.opt, 'depth_graphs', False)) and (frame_ids is None or not self.opt.use_embedding)
+
     def _depths_nograd(self, img, frame_ids):
         out = []
         c = max(1, int(self.opt.depth_chunk))
         with torch.no_grad():
             for b0 in range(0, img.shape[0], c):
                 fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
-                out.append(self._depth_forward(img[b0:b0 + c], fid))
+                chunk = img[b0:b0 + c]
+                g = self._capture_depth_graph('f', chunk, fid) if self._use_graphs(chunk, fid) else None
+                if g is not None:
+                    g[1].copy_(chunk)
+                    g[0].replay()
+                    out.append(g[2].clone())
+                else:
+                    out.append(self._depth_forward(chunk, fid))
         return torch.cat(out, 0).contiguous()
 
     def _depth_backward(self, img, frame_ids, g_depth):
         c = max(1, int(self.opt.depth_chunk))
         for b0 in range(0, img.shape[0], c):
             fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
+            chunk = img[b0:b0 + c]
+            g = self._capture_depth_graph('fb', chunk, fid) if self._use_graphs(chunk, fid) else None
+            if g is not None:
+                g[1].copy_(chunk)
+                g[3].copy_(g_depth[b0:b0 + c])
+                g[0].replay()
+                continue
             with torch.enable_grad():
-                d = self._depth_forward(img[b0:b0 + c], fid)
+                d = self._depth_forward(chunk, fid)
             d.backward(g_depth[b0:b0 + c])
 
     def _integer_steps(self, batch_or_input):

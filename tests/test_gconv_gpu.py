@@ -103,3 +103,27 @@ def test_midas_stage3_uses_the_mfma_kernels():
     assert len(blocks) == 23 and not isinstance(blocks[0].conv2, GroupedConv3x3C32)     # stride 2: MIOpen
     assert all(isinstance(b.conv2, GroupedConv3x3C32) for b in blocks[1:])
     assert 'pretrained.layer3.5.conv2.weight' in net.state_dict()
+
+
+def test_c16_pairs_groups_on_the_mfma_kernels():
+    """16 channels per group (ResNeXt stage 2) run as block-diagonal 32-channel groups: same values and
+    gradients as torch's grouped convolution, same parameter shape."""
+    from dvd_hip.conv import GroupedConv3x3C16
+    N, C, H, W = 2, 64, 12, 21
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, C, H, W, generator=g)
+    gy = torch.randn(N, C, H, W, generator=g)
+    m = GroupedConv3x3C16(C)
+    assert tuple(m.weight.shape) == (C, 16, 3, 3)
+    xr = x.clone().requires_grad_(True)
+    yr = m(xr)                                    # CPU: F.conv2d with groups = C // 16
+    yr.backward(gy)
+    want_gw = m.weight.grad.clone()
+    m.weight.grad = None
+    mg = m.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = mg(xg)
+    y.backward(gy.cuda())
+    for name, got, want, tol in (('y', y, yr, 2e-5), ('gx', xg.grad, xr.grad, 2e-5), ('gw', mg.weight.grad, want_gw, 5e-5)):
+        a, b = got.detach().cpu().numpy(), want.detach().numpy()
+        assert np.abs(a - b).max() <= tol * np.abs(b).max() + 1e-6, name
