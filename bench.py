@@ -124,7 +124,7 @@ def main():
     ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (48 = the BASELINE configuration)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '0')),
-                    help='1: replay the depth net from HIP graphs')
+                    help='1: replay the depth net from HIP graphs (experimental); 0 (default): eager launches')
     ap.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
     a = ap.parse_args()
 

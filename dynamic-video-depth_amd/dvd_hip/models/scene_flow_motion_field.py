@@ -63,9 +63,11 @@ class Model(NetInterface):
                             help='HBM ceiling for keeping the forward stashes of the whole batch alive so that the '
                                  'warp+loss kernel runs as ONE launch (falls back to one launch per chunk)')
         parser.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
-        parser.add_argument('--depth_graphs', action='store_true',
-                            help='capture the depth net per chunk shape in HIP graphs (forward, forward+backward) '
-                                 'and replay them: removes ~17 000 host-side launches per step')
+        parser.add_argument('--depth_graphs', type=int, default=0,
+                            help='1: capture the depth net per chunk shape in HIP graphs (forward, forward+backward) and '
+                                 'replay them (removes ~17 000 host-side launches per step; falls back to eager '
+                                 'execution if a capture fails); 0 (default): eager.  Experimental: measured 2.23 s vs '
+                                 '2.9 s per step on a host-bound box but 3.7 s vs 2.08 s on a GPU-bound one')
         return parser, set()
 
     # ------------------------------------------------------------------------------------
@@ -133,7 +135,9 @@ class Model(NetInterface):
 
     # -- HIP graphs for the depth net -------------------------------------------------------
     # A MiDaS forward+backward of one chunk is ~1 500 kernel launches; 12 chunk passes per step make the
-    # step launch-bound on the host (rocprofv3: 2.14 s of kernels in a 2.7 s step).  With --depth_graphs
+    # step launch-bound on hosts with slower cores (rocprofv3: 2.14 s of kernels in a 2.7 s step on one
+    # box, 2.08 s wall on another).  EXPERIMENTAL, off by default (replay time varied between boxes, see
+    # --depth_graphs).  With --depth_graphs 1
     # each chunk shape is captured once (forward-only graph for phase 1, forward+backward graph for
     # phase 3, static input / output / output-gradient buffers; parameter gradients accumulate in place
     # into the flat gradient buffer) and replayed; anything that cannot be captured falls back to eager.
@@ -162,13 +166,16 @@ class Model(NetInterface):
                         d.backward(torch.zeros_like(d))
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
+            # thread_local: calls made by other threads (the RCCL watchdog polling its events) do not invalidate
+            # the capture; the step also keeps collectives out of flight while a graph is being captured
+            mode = dict(capture_error_mode='thread_local')
             if kind == 'f':
-                with torch.no_grad(), torch.cuda.graph(graph):
+                with torch.no_grad(), torch.cuda.graph(graph, **mode):
                     static_out = self._depth_forward(static_in, fid)
                 entry = (graph, static_in, static_out, None)
             else:
                 static_g = torch.zeros(img.shape[0], 1, img.shape[2], img.shape[3], device=img.device)
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, **mode):
                     with torch.enable_grad():
                         static_out = self._depth_forward(static_in, fid)
                     static_out.backward(static_g)
@@ -444,7 +451,11 @@ class Model(NetInterface):
             scalars = ops.loss_finalize(cfg_all, sums)
             inv = scalars[0:1]
             ops.scale_add(k.grad, self._sf_grad_main, scale_ptr=inv, b=k.grad)
-        h_sf = k.all_reduce_grads(async_op=True)
+        # the MLP gradient all-reduce overlaps the depth-net backward, except in a step that still has to
+        # capture the depth net's forward+backward graph (no collective in flight during a capture)
+        capturing = (not warm and getattr(opt, 'depth_graphs', False)
+                     and self._graph_key('fb', inp.img_1[:max(1, int(opt.depth_chunk))]) not in self._depth_graphs)
+        h_sf = None if capturing else k.all_reduce_grads(async_op=True)
 
         # ---- phase 3: depth-net backward from the depth gradients
         if not warm:
@@ -457,6 +468,8 @@ class Model(NetInterface):
             self._depth_backward(inp.img_2, fid2, g_d2)
             self._flat_depth.all_reduce_grads()
             self._flat_depth.adam_step()
+        if capturing:
+            k.all_reduce_grads()
         if h_sf is not None:
             h_sf.wait()
         k.adam_step()

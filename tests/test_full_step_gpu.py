@@ -137,7 +137,7 @@ def _dp_worker(rank, world, port, name, q):
         gd = H.load_golden(name)
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            model, opt, batch = _build(gd, global_rank=rank)
+            model, opt, batch = _build(gd, global_rank=rank, depth_graphs=True)
         B = int(gd['B'])
         lo, hi = parallel.shard_range(B)
         shard = {k: (v[lo:hi].contiguous() if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B) else v)
@@ -185,3 +185,35 @@ def test_two_rank_data_parallel_step_equals_single_process():
         assert np.abs(depth - ref_depth).max() <= 2.5 * lr_d
     np.testing.assert_array_equal(res[0][2], res[1][2])            # ranks stay in lock step
     np.testing.assert_array_equal(res[0][3], res[1][3])
+
+
+def test_depth_net_hip_graphs_equal_eager_execution():
+    """--depth_graphs replays the depth net (forward, forward+backward per chunk) from captured HIP graphs:
+    a step must give the logs and depth-net gradients of eager execution.  MIOpen's weight-gradient kernels
+    accumulate with atomics, so two EAGER runs already differ at rounding level; the graph run must be within
+    a few times that noise (a capture bug -- a missing or doubled chunk -- would be O(1))."""
+    gd = helpers.load_golden('fullstep_midas_b1_64x96_train')
+    outs = []
+    for graphs in (False, False, True):
+        model, opt, batch = _build(gd, depth_graphs=graphs, depth_chunk=1)
+        log = model._train_on_batch(6, 0, helpers.loader_batch(dict(batch)))
+        torch.cuda.synchronize()
+        if graphs:
+            assert sum(v is not None for v in model._depth_graphs.values()) == 2, 'forward and forward+backward graphs'
+            log2 = model._train_on_batch(6, 1, helpers.loader_batch(dict(batch)))      # replays only
+            assert np.isfinite(log2['loss'])
+        outs.append((log, model._flat_depth.grad.clone() if not graphs else None, model))
+    (la, ga, _), (lb, gb, _), (lc, _, mc) = outs
+    for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
+        np.testing.assert_allclose(lc[k], la[k], rtol=1e-5, atol=1e-9, err_msg=k)
+    # gradients of the FIRST step of a fresh graph model (same weights as the eager models)
+    mg, _, batch = _build(gd, depth_graphs=True, depth_chunk=1)
+    mg.opt.lr = 0.0
+    mg._flat_depth.lr = 0.0
+    mg._train_on_batch(6, 0, helpers.loader_batch(dict(batch)))
+    gc = mg._flat_depth.grad
+    scale = float(ga.abs().max())
+    noise = float((ga - gb).abs().max()) / scale
+    rel = float((ga - gc).abs().max()) / scale
+    print('eager-vs-eager %.3e, graph-vs-eager %.3e of max|g|' % (noise, rel))
+    assert rel <= max(2e-3, 5 * noise), 'depth-net gradients: graph %.3e vs eager noise %.3e of max|g|' % (rel, noise)
