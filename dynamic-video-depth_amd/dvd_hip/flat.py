@@ -45,6 +45,26 @@ class FlatNet(object):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
 
+    # -- gradient accumulation over several backward passes (depth-net chunks) ----------------
+    # With `.grad` pre-attached autograd adds every parameter's gradient with its own tiny kernel
+    # (~620 launches per MiDaS backward).  Instead: detach the views, let the engine hand over the
+    # fresh gradient tensors, and add them all into the flat buffer with one multi-tensor call.
+    def detach_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def absorb_grads(self):
+        views, fresh = [], []
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            v = self.grad[o:o + p.numel()].view_as(p)
+            if g is not None:
+                views.append(v)
+                fresh.append(g if g.is_contiguous() else g.contiguous())
+            p.grad = v
+        if views:
+            torch._foreach_add_(views, fresh)
+
     def all_reduce_grads(self, async_op=False):
         if async_op:
             return parallel.all_reduce_sum_async_(self.grad)
