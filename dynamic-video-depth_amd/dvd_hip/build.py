@@ -62,7 +62,8 @@ def build_library(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')]
     headers.append(os.path.join(INCLUDE, 'dvd_hip.h'))
-    objs, relink = [], force or not os.path.exists(lib_path())
+    objs, jobs = [], []
+    relink = force or not os.path.exists(lib_path())
     for src, extra in SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
@@ -70,16 +71,24 @@ def build_library(force=False, verbose=False):
         dig = _digest([sp] + headers, COMMON + extra)
         fresh = os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig
         if force or not fresh:
-            cmd = [_hipcc()] + COMMON + extra + ['-c', sp, '-o', obj]
-            if verbose:
-                print(' '.join(cmd))
-            r = subprocess.run(cmd, capture_output=True, text=True)
-            if r.returncode != 0:
-                raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
-            with open(stamp, 'w') as f:
-                f.write(dig)
-            relink = True
+            jobs.append((src, [_hipcc()] + COMMON + extra + ['-c', sp, '-o', obj], stamp, dig))
         objs.append(obj)
+
+    def compile_one(job):
+        src, cmd, stamp, dig = job
+        if verbose:
+            print(' '.join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+        with open(stamp, 'w') as f:
+            f.write(dig)
+
+    if jobs:                                    # translation units are independent: compile them concurrently
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(compile_one, jobs))
+        relink = True
     if relink:
         cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', lib_path()]
         r = subprocess.run(cmd, capture_output=True, text=True)
