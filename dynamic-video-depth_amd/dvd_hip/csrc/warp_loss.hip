@@ -1369,17 +1369,6 @@ __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void apply_overflow_kernel(const unsigned* __restrict__ count,
-                                                             const int2* __restrict__ rec, unsigned cap,
-                                                             float* g_d2) {
-  unsigned n = *count;
-  if (n > cap) n = cap;
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int2 r = rec[i];
-    unsafeAtomicAdd(g_d2 + r.x, __int_as_float(r.y));
-  }
-}
-
 // Second stage: fixed-order sum of the per-block partials (deterministic).
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int n,
                                                                float* __restrict__ sums,
@@ -1407,6 +1396,45 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     double v = sh[0][threadIdx.x];
     if (fix_sums) v += (double)(long long)fix_sums[threadIdx.x] * (1.0 / 4294967296.0);   // guard-band pixels (generation 3)
     sums[threadIdx.x] = (float)v;
+  }
+}
+
+// Last launch of the generation-1 sequence: block 0 sums the per-tile partials (as reduce_partials_kernel),
+// the other blocks apply the window-overflow records with hardware fp32 atomics -- the two are independent,
+// so they share a launch.
+__global__ __launch_bounds__(1024) void warp_finish_kernel(const float* __restrict__ partial, int n,
+                                                           float* __restrict__ sums,
+                                                           const unsigned* __restrict__ count,
+                                                           const int2* __restrict__ rec, unsigned cap, float* g_d2) {
+  if (blockIdx.x == 0) {
+    __shared__ double sh[1024][4];
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)i * 4);
+      acc[0] += v.x;
+      acc[1] += v.y;
+      acc[2] += v.z;
+      acc[3] += v.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + s][k];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < 4) sums[threadIdx.x] = (float)sh[0][threadIdx.x];
+    return;
+  }
+  if (g_d2 == nullptr) return;
+  unsigned m = *count;
+  if (m > cap) m = cap;
+  for (unsigned i = (blockIdx.x - 1) * 1024 + threadIdx.x; i < m; i += (gridDim.x - 1) * 1024) {
+    const int2 r = rec[i];
+    unsafeAtomicAdd(g_d2 + r.x, __int_as_float(r.y));
   }
 }
 
@@ -1575,11 +1603,6 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
     hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, stream,
                        ta.slabs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads);
     DVD_LAUNCH_OK();
-    if (gen != 3) {
-      hipLaunchKernelGGL(apply_overflow_kernel, dim3(64), dim3(256), 0, stream, ta.ovf.count, ta.ovf.rec,
-                         ta.ovf.cap, a.g_d2);
-      DVD_LAUNCH_OK();
-    }
   }
   if (gen == 3) {
     if (grads)
@@ -1587,9 +1610,13 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
     else
       hipLaunchKernelGGL(warp_post_kernel<false>, dim3(128), dim3(256), 0, stream, a, ta.ovf, fix, fix_sums);
     DVD_LAUNCH_OK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nblocks, a.sums,
+                       (const unsigned long long*)fix_sums);
+  } else {
+    // partial-sum reduction and overflow records in one launch
+    hipLaunchKernelGGL(warp_finish_kernel, dim3(grads ? 17 : 1), dim3(1024), 0, stream, a.partial, nblocks, a.sums,
+                       ta.ovf.count, ta.ovf.rec, ta.ovf.cap, grads ? a.g_d2 : (float*)nullptr);
   }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nblocks, a.sums,
-                     gen == 3 ? (const unsigned long long*)fix_sums : (const unsigned long long*)nullptr);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
