@@ -5,8 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): synthetic 384x672 video, 48 frame pairs per GPU,
-MiDaS depth net (ResNeXt-101 32x8d, random init + calibrated head) + scene-flow MLP,
-non-warm phase (L1 + acceleration regulariser), gap 1, fp32.  A "step" is one
+MiDaS depth net (ResNeXt-101 32x8d, random init + calibrated head; dense convolutions on
+MIOpen, grouped convolutions / BatchNorm+ReLU / up-sampling on the HIP kernels of
+dvd_hip/csrc) + scene-flow MLP, non-warm phase (L1 + acceleration regulariser), gap 1, fp32.  A "step" is one
 `Model._train_on_batch`: depth nets forward, geometry + MLP + fused warp/loss forward and
 backward, depth-net backward, gradient all-reduce (N>1) and both Adam updates.  Inputs are
 resident in HBM before the timed region.
