@@ -1,0 +1,71 @@
+"""Drop-in surface of `Model` that can be checked without a GPU: the flag set of
+`add_arguments` (names, types, defaults) and the attribute contract after construction, compared with the
+reference's own class when the reference checkout is present (build container), and against the recorded
+expectations otherwise."""
+import argparse
+import os
+import sys
+import unittest.mock as mock
+from types import SimpleNamespace
+
+import pytest
+
+import helpers
+
+REF = '/root/reference'
+EXPECTED_FLAGS = {
+    'l1_mul', 'disp_mul', 'loss_type', 'scene_lr_mul', 'n_down', 'sf_min_mul', 'sf_quantile', 'static_mul', 'flow_mul',
+    'acc_mul', 'si_mul', 'cos_mul', 'warm_mul', 'interp_steps', 'warm_sf', 'n_freq_xyz', 'n_freq_t', 'sf_mag_div',
+    'one_way', 'weight_steps', 'static', 'motion_seg_hard', 'warm_static', 'use_disp', 'use_disp_ratio',
+    'time_dependent', 'use_cnn', 'use_embedding', 'use_motion_seg', 'warm_reg', 'midas'}
+OWN_FLAGS = {'mlp_stash_gb', 'mlp_whole_batch_gb', 'depth_chunk', 'depth_graphs'}
+
+
+def _flags(model_cls):
+    parser = argparse.ArgumentParser()
+    parser, unique = model_cls.add_arguments(parser)
+    assert unique == set()
+    return {a.dest: (a.type, a.default, type(a).__name__) for a in parser._actions if a.dest != 'help'}
+
+
+def test_flag_set():
+    from dvd_hip.models.scene_flow_motion_field import Model
+    ours = _flags(Model)
+    assert set(ours) == EXPECTED_FLAGS | OWN_FLAGS
+    if not os.path.isdir(REF):
+        return
+    sys.path.insert(0, REF)
+    try:
+        import visualize.html_visualizer as HV
+        with mock.patch.object(HV, 'Pool', lambda n: None):
+            from models.scene_flow_motion_field import Model as RefModel
+        ref = _flags(RefModel)
+    finally:
+        sys.path.remove(REF)
+        for m in [m for m in list(sys.modules) if getattr(sys.modules[m], '__file__', None) and REF in sys.modules[m].__file__]:
+            del sys.modules[m]
+    assert set(ref) == EXPECTED_FLAGS                      # the recorded expectation is the reference's flag set
+    for k, v in ref.items():                                  # same type, default and action kind for every shared flag
+        assert ours[k] == v, (k, ours[k], v)
+
+
+def test_attribute_contract_after_construction():
+    from dvd_hip.models.scene_flow_motion_field import Model
+    from dvd_hip.networks.sceneflow_field import SceneFlowFieldNet
+    from dvd_hip.third_party.hourglass import HourglassModel_Embed
+    o = dict(helpers.FULL_STEP_OPT)
+    o.update(full_logdir='/tmp')
+    with pytest.warns(UserWarning):                           # checkpoint absent: random weights announced
+        m = Model(SimpleNamespace(**o), None)
+    assert [type(n) for n in m._nets] == [HourglassModel_Embed, SceneFlowFieldNet]
+    assert m._metrics == ['flow_loss_1_2', 'loss', 'disp_loss_1_2', 'data_time', 'acc_reg', 'sf_loss']
+    for name in ('img_1', 'img_2', 'flow_1_2', 'mask_2', 'R_1', 'R_2', 'R_1_T', 'R_2_T', 't_1', 't_2', 'K', 'K_inv',
+                 'time_stamp_1', 'time_stamp_2', 'time_step', 'motion_seg_1', 'frame_id_1', 'frame_id_2'):
+        assert name in m.input_names and name in m.requires and hasattr(m._input, name)
+    assert m.num_parameters() == 5357730 + 297987              # hourglass + scene-flow MLP
+    # the model is a GPU implementation: moving it to the CPU is an explicit error, not a silent fallback
+    import torch
+    with pytest.raises(RuntimeError, match='GPU only'):
+        m.to(torch.device('cpu'))
+    with pytest.raises(NotImplementedError):
+        Model(SimpleNamespace(**dict(o, use_cnn=True)), None)
