@@ -44,7 +44,7 @@ def train_step(opt, depth_net, sd_mlp, batch, warm, lr_depth, lr_mlp, betas=(0.5
         loss.backward(retain_graph=True)
         reg = L.acceleration_reg(opt, leaves, batch, pred['global_p1'])
         reg.backward()
-        acc = float(reg)
+        acc = float(reg.detach())
     else:
         loss.backward()
         acc = 0.0

@@ -92,3 +92,34 @@ def test_step_losses_and_grads(name):
     m_gold = (gd['in_mask_2'][..., 0, 0] * (gd['in_depth_1'][:, 0] < 100) *
               (gd['pred_warped_p2_camera_2'][..., 0, 2] < 100)).astype(np.float32)
     assert np.array_equal(out['occ'][..., 0].numpy(), m_gold)
+
+
+@pytest.mark.parametrize('name', ['fullstep_hourglass_b2_32x48_train', 'fullstep_hourglass_b2_32x48_warm',
+                                  'fullstep_hourglass_b2_32x48_mseg_gap2'])
+def test_full_step_oracle_reproduces_the_reference_logs(name):
+    """oracle.train_step (what bench.py times as cpu_baseline) against the batch_log the REAL reference
+    Model._train_on_batch produced for the same seeded weights and batch (tests/golden/make_golden.py)."""
+    import helpers
+    from dvd_hip import synthetic
+    from dvd_hip.networks.sceneflow_field import SceneFlowFieldNet
+    from dvd_hip.third_party.hourglass import HourglassModel_Embed
+    from oracle import train_step as T
+    gd = load_golden(name)
+    o = dict(helpers.FULL_STEP_OPT)
+    if 'over_keys' in gd:
+        o.update({str(k): (bool(v) if isinstance(o.get(str(k)), bool) else float(v))
+                  for k, v in zip(gd['over_keys'], gd['over_vals'])})
+    opt = L.default_opt(**{k: o[k] for k in ('midas', 'use_disp', 'use_disp_ratio', 'time_dependent', 'flow_mul', 'disp_mul',
+                                             'acc_mul', 'sf_mag_div', 'interp_steps', 'warm_reg', 'weight_steps',
+                                             'use_motion_seg', 'n_freq_xyz', 'n_freq_t')})
+    seed = int(gd['seed'])
+    depth = helpers.seeded_fill_(HourglassModel_Embed(noexp=False, use_embedding=False), seed)
+    mlp = helpers.seeded_fill_(SceneFlowFieldNet(net_width=256, n_layers=4, time_dependent=True, N_freq_xyz=16,
+                                                 N_freq_t=16), seed + 1)
+    sd = T.mlp_state_from_module(mlp)
+    batch = synthetic.make_batch(int(gd['B']), int(gd['H']), int(gd['W']), gap=int(gd['gap']), seed=seed + 2)
+    warm = int(gd['epoch']) <= o['warm_sf']
+    log, _ = T.train_step(opt, depth, sd, batch, warm, lr_depth=o['lr'], lr_mlp=o['lr'] * o['scene_lr_mul'])
+    for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss'):
+        np.testing.assert_allclose(log[k], float(gd['log_' + k]), rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(log['acc_reg'], float(gd['log_acc_reg']), rtol=1e-4, atol=1e-10)
