@@ -63,6 +63,7 @@ def train_step(opt, depth_net, sd_mlp, batch, warm, lr_depth, lr_mlp, betas=(0.5
         state[name].step()
     for k in sd_mlp:
         sd_mlp[k] = leaves[k].detach()
-    log = {'loss': float(loss), 'flow_loss_1_2': float(parts['flow_loss_1_2']),
-           'disp_loss_1_2': float(parts['disp_loss_1_2']), 'sf_loss': float(parts['sf_loss']), 'acc_reg': acc}
+    log = {'loss': float(loss.detach()), 'flow_loss_1_2': float(parts['flow_loss_1_2'].detach()),
+           'disp_loss_1_2': float(parts['disp_loss_1_2'].detach()), 'sf_loss': float(parts['sf_loss'].detach()),
+           'acc_reg': acc}
     return log, {'total_s': time.time() - t0, 'fwd_bwd_s': t_grad - t0}
