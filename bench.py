@@ -94,10 +94,22 @@ class WarpTimer(object):
                 'GBps': px * WARP_BYTES_PER_PIXEL / ms / 1e6}
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The oracle step on the host cores, on ONE pair of the same workload (the full 48-pair
-    step needs >400 GB of autograd state on the CPU path)."""
-    import copy
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(timed_steps=3, budget_s=240.0):
+    """The oracle step (a port of the reference's `_train_on_batch`, pinned to the real reference's logs by
+    tests/golden/fullstep_*.npz) on the host cores: ONE frame pair of the same workload at 384x672 -- the
+    48-pair step needs >400 GB of autograd state on the CPU path -- 1 warm-up step +
+    `timed_steps` timed steps, median; value = pairs/s / 48.  Stops timing early
+    once `budget_s` of CPU time is spent (at least one timed step)."""
     from dvd_hip import synthetic
     from dvd_hip.third_party.MiDaS import MidasNet, calibrate_head_for_random_init
     from oracle import sceneflow_mlp as M
@@ -109,12 +121,25 @@ def cpu_baseline(seconds_budget=30.0):
     opt = default_opt()
     batch = synthetic.make_batch(1, H, W, gap=GAP, seed=1234)
     threads = torch.get_num_threads()
-    t0 = time.time()
-    log, tim = T.train_step(opt, net, sd, batch, warm=False, lr_depth=1e-6, lr_mlp=1e-3)
-    dt = time.time() - t0
-    return {'value': (1.0 / dt) / PAIRS, 'unit': 'iters/s (48-pair steps)', 'cores': threads, 'kind': 'port',
-            'sample': '1 frame pair at %dx%d (one oracle step, %.1f s); value = pairs/s / 48' % (H, W, dt),
-            'pairs_per_s': 1.0 / dt, 'loss': log['loss']}
+    state, times, log = {}, [], None
+    t_all = time.time()
+    for i in range(1 + timed_steps):
+        t0 = time.time()
+        log, _ = T.train_step(opt, net, sd, batch, warm=False, lr_depth=1e-6, lr_mlp=1e-3, adam_state=state)
+        dt = time.time() - t0
+        if i > 0:
+            times.append(dt)
+        if i > 0 and time.time() - t_all > budget_s:
+            break
+        warm_s = dt if i == 0 else warm_s
+    times.sort()
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    return {'value': (1.0 / med) / PAIRS, 'unit': 'iters/s (48-pair steps)', 'cores': threads, 'kind': 'port',
+            'sample': '1 frame pair at %dx%d, gap %d: 1 warm-up step (%.1f s) + %d timed oracle steps, median %.1f s '
+                      '(all: %s); value = pairs/s / 48' % (H, W, GAP, warm_s, len(times), med,
+                                                           ', '.join('%.1f' % t for t in times)),
+            'pairs_per_s': 1.0 / med, 'loss': log['loss'], 'cpu_model': _cpu_model(), 'os_cpu_count': os.cpu_count(),
+            'torch_threads': threads}
 
 
 def main():
@@ -124,6 +149,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (48 = the BASELINE configuration)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--cpu_steps', type=int, default=3, help='timed oracle steps of the cpu_baseline leg (after 1 warm-up)')
     ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '0')),
                     help='1: replay the depth net from HIP graphs (experimental); 0 (default): eager launches')
     ap.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
@@ -202,7 +228,7 @@ def main():
                            'algorithmic_bytes_per_launch': warp['pixels_per_launch'] * WARP_BYTES_PER_PIXEL,
                            'avg_launch_ms': warp['avg_ms'], 'launches_timed': warp['launches']}
     if world == 1 and not a.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline()
+        out['cpu_baseline'] = cpu_baseline(timed_steps=max(1, a.cpu_steps))
     print(json.dumps(out))
 
 

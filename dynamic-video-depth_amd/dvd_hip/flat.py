@@ -77,12 +77,52 @@ class FlatNet(object):
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
                       self.betas[1], self.eps, scale=scale, scale_ptr=scale_ptr, grad2=extra_grad)
 
-    # torch.optim-compatible state for checkpoints (netinterface.py:528-536 stores optimizer.state_dict())
+    # Checkpoints carry `optimizer.state_dict()` of a torch.optim.Adam (netinterface.py:528-536, written by
+    # ModelSaveLogger with save_optimizer=True); emit and accept exactly that layout -- per-parameter
+    # `step` / `exp_avg` / `exp_avg_sq` keyed by the parameter's index in `module.parameters()` order, one
+    # param group -- so checkpoints written by either implementation resume in the other.
     def state_dict(self):
-        return {'step': self.step_count, 'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(),
-                'lr': self.lr, 'betas': self.betas, 'eps': self.eps}
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                n = p.numel()
+                state[i] = {'step': torch.tensor(float(self.step_count)),
+                            'exp_avg': self.exp_avg[o:o + n].view_as(p).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[o:o + n].view_as(p).clone()}
+        group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'decoupled_weight_decay': False, 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd['step'])
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        """Accepts a torch.optim.Adam state_dict (any torch version: `step` int or tensor) and keeps this
+        run's lr / betas / eps (optimizer_load_state_dict(keep_training_params=True), netinterface.py:565-574).
+        Parameters without state (never stepped) keep zero moments."""
+        if 'state' not in sd:                      # round-1 flat layout
+            self.step_count = int(sd['step'])
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            return
+        groups = sd['param_groups']
+        order = [i for g in groups for i in g['params']]
+        if len(order) != len(self.params):
+            raise ValueError('optimizer state has %d parameters, the network %d' % (len(order), len(self.params)))
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for slot, key in enumerate(order):
+            st = sd['state'].get(key)
+            if not st:
+                continue
+            p, o = self.params[slot], self.offsets[slot]
+            n = p.numel()
+            if st['exp_avg'].numel() != n:
+                raise ValueError('optimizer state of parameter %d has %d elements, expected %d'
+                                 % (slot, st['exp_avg'].numel(), n))
+            self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('per-parameter Adam step counts differ (%s): the fused optimiser keeps one count per '
+                             'network' % sorted(steps))
+        self.step_count = steps.pop() if steps else 0

@@ -103,6 +103,7 @@ class NetInterface(object):
         self.input_names, self.gt_names, self.aux_names = [], [], []
         self._input, self._gt, self._aux = SimpleNamespace(), SimpleNamespace(), SimpleNamespace()
         self.device = torch.device('cpu')
+        self._pending_optimizer_state = None
 
     def init_vars(self, add_path=True):
         for name in self.input_names:
@@ -180,10 +181,18 @@ class NetInterface(object):
         for net, s in zip(self._nets, sd['nets']):
             net.load_state_dict(s)
         if load_optimizer:
-            assert len(self._optimizers) == len(sd['optimizers'])
-            for o, s in zip(self._optimizers, sd['optimizers']):
-                o.load_state_dict(s)
+            if not self._optimizers:
+                # train.py:256 restores the checkpoint BEFORE model.to(device) (:279); the flat Adam buffers
+                # only exist on the device, so the state is held here and applied by to()
+                self._pending_optimizer_state = list(sd['optimizers'])
+            else:
+                self._apply_optimizer_state(sd['optimizers'])
         return {k: v for k, v in sd.items() if k not in ('nets', 'optimizers')}
+
+    def _apply_optimizer_state(self, states):
+        assert len(self._optimizers) == len(states)
+        for o, s in zip(self._optimizers, states):
+            o.load_state_dict(s)       # keeps this run's lr / betas / eps (netinterface.py:565-574)
 
     # -- loop ----------------------------------------------------------------------------
     def _train_on_batch(self, epoch, batch_ind, batch):
@@ -195,12 +204,56 @@ class NetInterface(object):
     def test_on_batch(self, batch_ind, batch):
         raise NotImplementedError
 
+    def _register_tensorboard(self, tblogger):
+        self.tensorboard_logger = tblogger
+
     def train_epoch(self, dataloader, *, dataloader_vali=None, max_batches_per_train=None, max_batches_per_vali=None,
-                    epochs=1, initial_epoch=1, verbose=1, reset_dataset=None, vali_at_start=False):
+                    epochs=1, initial_epoch=1, verbose=1, reset_dataset=None, vali_at_start=False, global_rank=0,
+                    train_epoch_callback=None):
+        """Signature and callback order of netinterface.py:193-360: per epoch `reset_dataset.reset()`,
+        `on_epoch_begin`, per batch `on_batch_begin` / `_train_on_batch` / `on_batch_end`, `on_epoch_end` with the
+        (rank-averaged) epoch means, then `train_epoch_callback(epoch)` (train.py passes
+        `DistributedSampler.set_epoch`, :308-310,339-348), then validation."""
         logger = self._logger
-        steps = len(dataloader) if hasattr(dataloader, '__len__') else None
-        if max_batches_per_train is not None:
-            steps = max_batches_per_train if steps is None else min(steps, max_batches_per_train)
+
+        def n_samples(loader):
+            bs = getattr(loader, 'batch_sampler', None)
+            try:
+                return len(bs.sampler) if bs is not None else len(loader)
+            except TypeError:
+                return None
+
+        def limits():
+            st = len(dataloader) if hasattr(dataloader, '__len__') else None
+            sa = n_samples(dataloader) if st is not None else None
+            if max_batches_per_train is not None:
+                st = max_batches_per_train if st is None else min(st, max_batches_per_train)
+            sv = 0
+            if dataloader_vali is not None:
+                sv = len(dataloader_vali)
+                if max_batches_per_vali is not None:
+                    sv = min(sv, max_batches_per_vali)
+            return st, sa, sv
+
+        def announce():
+            st, sa, sv = limits()
+            logger.set_params({'epochs': epochs + initial_epoch - 1, 'steps': st, 'steps_eval': sv, 'samples': sa,
+                               'samples_eval': sv, 'verbose': verbose, 'metrics': self._metrics})
+            return st, sv
+
+        steps, steps_eval = announce()
+        logger.set_model(self)
+        logger.on_train_begin()
+        dataset_size = [0]
+
+        def epoch_log():
+            elog = self._internal_logger.get_epoch_log()
+            if parallel.is_distributed():
+                for k in sorted(elog):
+                    v = torch.tensor(elog[k], device=self.device, dtype=torch.float64)
+                    parallel.all_reduce_sum_(v)
+                    elog[k] = float(v) / parallel.world_size()
+            return elog
 
         def run(epoch, loader, on_batch, limit, is_train):
             (self.train if is_train else self.eval)()
@@ -211,37 +264,37 @@ class NetInterface(object):
             for i, data in enumerate(loader):
                 if limit is not None and i >= limit:
                     break
-                data_time = time.time() - t0
+                start = time.time()
+                data_time = start - t0
                 logger.on_batch_begin(i)
                 log = on_batch(epoch, i, data)
                 if log is None:
-                    t0 = time.time()
-                    continue
-                log.update(batch=i, epoch=epoch, data_time=data_time, batch_time=time.time() - t0)
+                    raise ValueError('Batch log is not returned by _train_on_batch method. Aborting.')
+                log.update(batch=i, epoch=epoch, data_time=data_time, batch_time=time.time() - start)
                 self._internal_logger.add(log)
                 logger.on_batch_end(i, log)
                 t0 = time.time()
-            elog = self._internal_logger.get_epoch_log()
-            if parallel.is_distributed():
-                for k in sorted(elog):
-                    v = torch.tensor(elog[k], device=self.device, dtype=torch.float64)
-                    parallel.all_reduce_sum_(v)
-                    elog[k] = float(v) / parallel.world_size()
+            elog = epoch_log()
             logger.on_epoch_end(epoch, elog)
             return elog
 
-        logger.set_params({'epochs': epochs + initial_epoch - 1, 'steps': steps, 'verbose': verbose})
-        logger.on_train_begin()
         last = None
-        if vali_at_start and dataloader_vali is not None:
+        if vali_at_start:
+            if dataloader_vali is None:
+                raise ValueError('eval_at_beginning is set to True but no eval data is given.')
             with torch.no_grad():
-                run(initial_epoch - 1, dataloader_vali, self._vali_on_batch, max_batches_per_vali, False)
+                run(initial_epoch - 1, dataloader_vali, self._vali_on_batch, steps_eval, False)
         for epoch in range(initial_epoch, initial_epoch + epochs):
             if reset_dataset is not None:
-                reset_dataset()
+                (reset_dataset.reset if hasattr(reset_dataset, 'reset') else reset_dataset)()
+                if hasattr(reset_dataset, '__len__') and dataset_size[0] != len(reset_dataset):
+                    steps, steps_eval = announce()
+                    dataset_size[0] = len(reset_dataset)
             last = run(epoch, dataloader, self._train_on_batch, steps, True)
+            if train_epoch_callback is not None:
+                train_epoch_callback(epoch)
             if dataloader_vali is not None:
                 with torch.no_grad():
-                    run(epoch, dataloader_vali, self._vali_on_batch, max_batches_per_vali, False)
+                    run(epoch, dataloader_vali, self._vali_on_batch, steps_eval, False)
         logger.on_train_end()
         return last

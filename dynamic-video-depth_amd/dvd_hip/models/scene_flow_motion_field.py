@@ -107,7 +107,6 @@ class Model(NetInterface):
         self.visualizer = None
         self._flat_depth = self._flat_sf = None     # created by .to(device)
         self._optimizers = []
-        self._steps_cache = {}
         self._depth_graphs = {}
         self.warm = False
 
@@ -123,6 +122,9 @@ class Model(NetInterface):
         self._optimizers = [self._flat_depth, self._flat_sf]
         self._sf_grad_main = torch.zeros_like(self._flat_sf.grad)
         self._mlp = self.net_sceneflow.kernels(self.device)
+        if self._pending_optimizer_state is not None:      # checkpoint restored before .to() (train.py:256,279)
+            self._apply_optimizer_state(self._pending_optimizer_state)
+            self._pending_optimizer_state = None
         if parallel.is_distributed():      # every rank starts from rank 0's weights (train.py:290-292)
             parallel.broadcast_(self._flat_depth.flat)
             parallel.broadcast_(self._flat_sf.flat)
@@ -228,14 +230,14 @@ class Model(NetInterface):
                 self._flat_depth.absorb_grads()
 
     def _integer_steps(self, batch_or_input):
+        """Euler steps of this batch = round(mean(ts2 - ts1) / time_step) (:248-250), recomputed every step:
+        consecutive batches mix frame gaps and allocators reuse addresses, so nothing about the tensors'
+        identity says the gap is unchanged (one tiny reduction + read-back per 2 s step)."""
         ts1, ts2 = batch_or_input['time_stamp_1'], batch_or_input['time_stamp_2']
         step = batch_or_input['time_step']
-        key = (ts1.data_ptr(), ts2.data_ptr(), tuple(ts1.shape))
-        if key not in self._steps_cache:
-            time_step = float(step.squeeze().item()) if torch.is_tensor(step) else float(step)
-            gap = torch.mean(ts2.float() - ts1.float())
-            self._steps_cache = {key: (int((gap / time_step).round().long().item()), time_step)}
-        return self._steps_cache[key]
+        time_step = float(step.squeeze().item()) if torch.is_tensor(step) else float(step)
+        gap = torch.mean(ts2.float() - ts1.float())
+        return int((gap / time_step).round().long().item()), time_step
 
     def _pairs_per_chunk(self, B, HW, steps, with_reg):
         per_pair = self._mlp.stash_floats(HW) * 4 * max(steps, 2 if with_reg else 1) + self._mlp.gstash_floats(HW) * 4
@@ -278,8 +280,6 @@ class Model(NetInterface):
         do_reg = opt.interp_steps > 0 and (not warm or opt.warm_reg) and opt.acc_mul > 0
         mul = steps if opt.weight_steps else 1
         disp_mode = 1 if opt.use_disp else (2 if opt.use_disp_ratio else 0)
-        n_global = B * parallel.world_size()         # pairs in the whole (sharded) batch
-        reg_coef = opt.acc_mul / (3.0 * n_global * HW + 1e-6)
         sums = torch.zeros(8, device=dev)            # [S0..S3, sum|sf1-sf0|, 0, 0, 0]
         g_d1_main = torch.empty_like(depth_1)
         g_d2_main = torch.empty_like(depth_2)
@@ -304,6 +304,11 @@ class Model(NetInterface):
         # B*H*W pixels fills the chip far better than B/Bc smaller ones); otherwise every
         # chunk gets its own warp+loss launch.
         whole = Bc < B and self._whole_batch_fits(B, Bc, HW, steps, do_reg)
+        # ranks may hold different batch sizes / frame gaps: agree on the schedule (early or late normaliser)
+        # and on the size of the global batch before the first data-dependent collective
+        late, n_global = parallel.agree_on_step_plan(dev, not (whole or Bc >= B), B)
+        early_norm = not late
+        reg_coef = opt.acc_mul / (3.0 * n_global * HW + 1e-6)
         chunks = [(b0, min(B, b0 + Bc)) for b0 in range(0, B, Bc)]
         P1_all = ops.unproject(depth_1, inp.R_1, inp.t_1, inp.K_inv, planar=True)
         sf_all = torch.zeros(B, 3, H, W, device=dev)
@@ -424,7 +429,6 @@ class Model(NetInterface):
             ops.unproject_backward(g_P, True, cams['R_1'], cams['K_inv'], out=g_d1_main[b0:b1], accumulate=True)
 
         gst = mlp.new_gstash(min(Bc, B) * HW)
-        early_norm = whole or Bc >= B
         if early_norm:
             kept = [mlp_forward_chunk(b0, b1, keep_first=bool(do_reg)) for b0, b1 in chunks]
             warp(0, B)
@@ -481,7 +485,9 @@ class Model(NetInterface):
 
         host = torch.cat([scalars, sums[4:5]]).tolist()          # the only host synchronisation of the step
         acc_reg = opt.acc_mul * host[8] / (3.0 * n_global * HW + 1e-6) if do_reg else 0
-        batch_log = {'size': opt.batch_size, 'loss': host[1], 'total_loss': host[1], 'flow_loss_1_2': host[2],
+        # --weight_steps scales the gradient only: the logged loss is the unweighted one (`**loss_data`
+        # overwrites 'loss' at :226)
+        batch_log = {'size': opt.batch_size, 'loss': host[1] / mul, 'total_loss': host[1] / mul, 'flow_loss_1_2': host[2],
                      'disp_loss_1_2': host[3], 'sf_loss': host[4], 'acc_reg': acc_reg}
         self._last = {'depth_1': depth_1, 'depth_2': depth_2, 'mask_sum': host[5]}
         return batch_log

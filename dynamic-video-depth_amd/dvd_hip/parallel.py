@@ -60,6 +60,21 @@ def all_reduce_sum_async_(t):
     return None
 
 
+def agree_on_step_plan(device, needs_late_normaliser, n_pairs):
+    """Makes the collective schedule of a step independent of rank-local data.
+
+    Whether a rank can keep the whole batch's MLP stashes alive (and so all-reduces the loss sums
+    BEFORE its MLP backward) depends on its own batch size and frame gap; ranks that decided
+    differently would issue mismatched collectives.  One 2-element sum all-reduce at the start of the
+    step settles it: returns (any rank needs the late normaliser, pairs in the global batch)."""
+    if not is_distributed():
+        return bool(needs_late_normaliser), int(n_pairs)
+    v = torch.tensor([1.0 if needs_late_normaliser else 0.0, float(n_pairs)], device=device, dtype=torch.float64)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    late, total = v.tolist()
+    return late > 0.5, int(round(total))
+
+
 def broadcast_(t, src=0):
     if is_distributed():
         dist.broadcast(t, src)

@@ -37,6 +37,7 @@ def train_step(opt, depth_net, sd_mlp, batch, warm, lr_depth, lr_mlp, betas=(0.5
         d2 = depth_net(batch['img_2'])
     pred = L.predict_train(opt, leaves, batch, d1, d2)
     loss, parts, _ = L.train_losses(opt, warm, batch, pred)
+    logged_loss = float(loss.detach())        # `**loss_data` overwrites 'loss' with the unweighted value (:226)
     if opt.weight_steps:
         loss = loss * pred['_steps']
     do_reg = opt.interp_steps > 0 and (not warm or opt.warm_reg) and opt.acc_mul > 0
@@ -63,7 +64,7 @@ def train_step(opt, depth_net, sd_mlp, batch, warm, lr_depth, lr_mlp, betas=(0.5
         state[name].step()
     for k in sd_mlp:
         sd_mlp[k] = leaves[k].detach()
-    log = {'loss': float(loss.detach()), 'flow_loss_1_2': float(parts['flow_loss_1_2'].detach()),
+    log = {'loss': logged_loss, 'flow_loss_1_2': float(parts['flow_loss_1_2'].detach()),
            'disp_loss_1_2': float(parts['disp_loss_1_2'].detach()), 'sf_loss': float(parts['sf_loss'].detach()),
            'acc_reg': acc}
     return log, {'total_s': time.time() - t0, 'fwd_bwd_s': t_grad - t0}

@@ -267,6 +267,9 @@ def case_full_step(name, midas, B, H, W, gap, epoch, seed, over=None):
 
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'midas_192x384':       # only the configs[0]-shape fixture (round 2)
+        case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
+        return
     case_geometry('geom_b2_24x32', B=2, H=24, W=32, gap=1, behind=0, seed=11)
     case_geometry('geom_b3_16x40_behind', B=3, H=16, W=40, gap=2, behind=1, seed=23)
     case_mlp('mlp_b2_8x16', B=2, H=8, W=16, seed=5)
@@ -281,6 +284,8 @@ def main():
     case_full_step('fullstep_midas_b1_64x96_train', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=107)
     case_full_step('fullstep_hourglass_b2_32x48_mseg_gap2', midas=False, B=2, H=32, W=48, gap=2, epoch=6, seed=109,
                    over=dict(use_motion_seg=True))
+    # BASELINE configs[0] shape (192x384, the reference's training resolution of record), MiDaS, 2 pairs
+    case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
 
 
 if __name__ == '__main__':

@@ -206,6 +206,39 @@ def test_full_size_properties():
     assert s_i[0] > 0 and abs(s_i[1]) <= 2e-3 * s_i[0] and s_i[2] <= 1e-3 * s_i[0] and s_i[3] <= 1e-4 * s_i[0]
 
 
+def test_oracle_parity_at_the_baseline_image_size():
+    """The CPU oracle at BASELINE's image size (2 pairs x 384 x 672 -- what fits the oracle in seconds) on the
+    production tile shape: 7 x 12 tiles of 96 x 32 per pair with their halo seams, flows up to tens of pixels
+    (window overflow path), far depths, one behind-camera pair.  Valid-pixel count exact, per-pixel support of
+    the gradients identical to the oracle's (no mask bit decided differently anywhere), sums rtol 1e-5,
+    gradients rtol 1e-4."""
+    from dvd_hip import ops, synthetic
+    B, H, W = 2, 384, 672
+    opt = L.default_opt()
+    batch = synthetic.make_batch(B, H, W, gap=1, seed=2024, behind_camera_pairs=1, with_images=False)
+    g = torch.Generator().manual_seed(7)
+    big = (torch.rand(B, H, W, 1, generator=g) < 0.02).float()          # 2 % of the pixels: |flow| ~ 10-40 px
+    batch['flow_1_2'] = batch['flow_1_2'] * (1.0 + 9.0 * big)
+    batch['flow_1_2'][0, 100:140, 200:300] += torch.tensor([35.0, -22.0])   # a coherent fast-moving region
+    batch['flow_2_1'] = -batch['flow_1_2']
+    d1, d2 = synthetic.make_depths(B, H, W, seed=77, far_depth_frac=0.01)
+    sf = synthetic.make_scene_flow(B, H, W, seed=9)
+    ref = L.warp_loss_leaf_sf(opt, False, batch, d1, d2, sf)
+    bg = {k: (v.cuda() if k != 'time_step' else v) for k, v in batch.items()}
+    cfg = _cfg_from_opt(ops, opt, False, B, H, W)
+    sums, sc, g1, g2, gs = _run_hip(ops, cfg, bg, d1.cuda(), d2.cuda(), sf.cuda())
+    _compare(ref, sums, sc, g1, g2, gs)
+    assert bool(ref['behind'].any()) and float(ref['occ'].sum()) == sums[0]
+    # per-pixel: a pixel carries gradient iff the oracle's pixel does (valid-pixel mask, [d1<100], [W2.z<100])
+    occ = ref['occ'].reshape(B, H, W).numpy() > 0
+    for name, got in (('g_depth_1', g1), ('g_sf', gs)):
+        want = ref[name].numpy()
+        sup_got = np.abs(got.reshape(B, -1, H, W)).sum(1) > 0
+        sup_want = np.abs(want.reshape(B, -1, H, W)).sum(1) > 0
+        assert (sup_got != sup_want).sum() == 0, '%s: support differs at %d pixels' % (name, (sup_got != sup_want).sum())
+        assert not (sup_got & ~occ).any(), name + ': gradient on a masked pixel'
+
+
 def test_guard_banded_generation_matches_exact_generation_at_full_size(monkeypatch):
     """DVD_WARP_GEN=3 (fast composite-matrix arithmetic, exact re-evaluation only inside the
     guard bands) against generation 1 (the reference's rounding sequence everywhere) on

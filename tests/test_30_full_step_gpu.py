@@ -44,7 +44,8 @@ def _build(gd, **over):
 
 
 @pytest.mark.parametrize('name', ['fullstep_hourglass_b2_32x48_train', 'fullstep_hourglass_b2_32x48_warm',
-                                  'fullstep_midas_b1_64x96_train', 'fullstep_hourglass_b2_32x48_mseg_gap2'])
+                                  'fullstep_midas_b1_64x96_train', 'fullstep_hourglass_b2_32x48_mseg_gap2',
+                                  'fullstep_midas_b2_192x384_train'])      # BASELINE configs[0] shape, 2 pairs
 def test_train_on_batch_matches_reference(name):
     gd = helpers.load_golden(name)
     model, opt, batch = _build(gd)
@@ -116,11 +117,15 @@ def test_pair_chunking_is_invisible(whole_gb):
     assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
 
 
-def _dp_worker(rank, world, port, name, q):
+def _dp_worker(rank, world, port, name, q, mode='fixture'):
     """One rank of a 2-process data-parallel step.  gpurun boxes have ONE GPU, so both ranks
     share cuda:0 and talk over gloo (RCCL refuses two ranks on one device); the code path above
     the backend (shard -> step -> all-reduce of the loss sums and of the flat gradient buffers
-    -> Adam) is the one bench.py runs with nccl on 8 GPUs."""
+    -> Adam) is the one bench.py runs with nccl on 8 GPUs.
+
+    mode 'fixture': the golden batch split in two.  'mixed_plan': a 4-pair batch where rank 0's memory
+    budget forces one MLP chunk per pair and per-chunk warp+loss launches (late normaliser) while rank 1
+    could keep the whole batch (early normaliser).  'mixed_gap': the ranks hold different frame gaps."""
     import os
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
@@ -130,18 +135,27 @@ def _dp_worker(rank, world, port, name, q):
                       LOCAL_RANK='0')
     import warnings
     import torch.distributed as dist
-    from dvd_hip import parallel
+    from dvd_hip import parallel, synthetic
     import helpers as H
     parallel.init_from_env(backend='gloo')
     try:
         gd = H.load_golden(name)
+        over = dict(global_rank=rank)
+        if mode != 'fixture' and rank == 0:
+            over.update(mlp_stash_gb=1e-6, depth_chunk=1, mlp_whole_batch_gb=0.0)
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            model, opt, batch = _build(gd, global_rank=rank, depth_graphs=True)
+            model, opt, batch = _build(gd, **over)
         B = int(gd['B'])
-        lo, hi = parallel.shard_range(B)
-        shard = {k: (v[lo:hi].contiguous() if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B) else v)
-                 for k, v in batch.items()}
+        if mode == 'mixed_plan':
+            B = 4
+            batch = synthetic.make_batch(B, int(gd['H']), int(gd['W']), gap=1, seed=4242)
+        if mode == 'mixed_gap':
+            shard = synthetic.make_batch(2, int(gd['H']), int(gd['W']), gap=1 + rank, seed=99 + rank)
+        else:
+            lo, hi = parallel.shard_range(B)
+            shard = {k: (v[lo:hi].contiguous() if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B) else v)
+                     for k, v in batch.items()}
         log = model._train_on_batch(int(gd['epoch']), 0, H.loader_batch(shard))
         torch.cuda.synchronize()
         q.put((rank, log, model._flat_sf.flat.cpu().numpy(), model._flat_depth.flat.cpu().numpy(),
@@ -150,12 +164,62 @@ def _dp_worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
+def _run_two_ranks(name, mode):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, name, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(600)
+def test_ranks_with_different_local_plans_issue_the_same_collectives():
+    """Rank 0 can only afford per-chunk warp+loss launches (late normaliser), rank 1 could run the early
+    schedule: they agree on the late one (parallel.agree_on_step_plan) instead of hanging in mismatched
+    all-reduces, and the step still equals the single-process step on the 4-pair batch."""
+    from dvd_hip import synthetic
+    name = 'fullstep_hourglass_b2_32x48_train'
+    gd = helpers.load_golden(name)
+    model, opt, _ = _build(gd)
+    batch = synthetic.make_batch(4, int(gd['H']), int(gd['W']), gap=1, seed=4242)
+    ref = model._train_on_batch(int(gd['epoch']), 0, helpers.loader_batch(batch))
+    torch.cuda.synchronize()
+    ref_g = model._flat_sf.grad.cpu().numpy()
+    res = _run_two_ranks(name, 'mixed_plan')
+    for rank, log, sf, depth, g in res:
+        for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
+            np.testing.assert_allclose(log[k], ref[k], rtol=1e-5, atol=1e-9, err_msg='rank %d %s' % (rank, k))
+        assert np.abs(g - ref_g).max() <= 2e-4 * np.abs(ref_g).max()
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.timeout(600)
+def test_ranks_with_different_frame_gaps_complete_a_step_in_lock_step():
+    """The dataset mixes frame gaps 1-4, so ranks draw different Euler step counts; the step's collectives do
+    not depend on them: both ranks finish, log the same global losses and hold identical weights."""
+    res = _run_two_ranks('fullstep_hourglass_b2_32x48_train', 'mixed_gap')
+    for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
+        assert np.isfinite(res[0][1][k]) and res[0][1][k] == res[1][1][k], k
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+
+
 @pytest.mark.timeout(600)
 def test_two_rank_data_parallel_step_equals_single_process():
     """Pairs sharded over 2 ranks reproduce the 1-process step on the whole batch: same batch_log
     (batch-global normaliser), same summed gradients, same parameters after Adam on both ranks."""
-    import socket
-    import torch.multiprocessing as mp
     name = 'fullstep_hourglass_b2_32x48_train'
     gd = helpers.load_golden(name)
     model, opt, batch = _build(gd)
@@ -163,19 +227,7 @@ def test_two_rank_data_parallel_step_equals_single_process():
     torch.cuda.synchronize()
     ref_sf, ref_depth, ref_g = (model._flat_sf.flat.cpu().numpy(), model._flat_depth.flat.cpu().numpy(),
                                 model._flat_sf.grad.cpu().numpy())
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, name, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda r: r[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = _run_two_ranks(name, 'fixture')
     for rank, log, sf, depth, g in res:
         for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
             np.testing.assert_allclose(log[k], ref[k], rtol=1e-5, atol=1e-9, err_msg='rank %d %s' % (rank, k))
@@ -187,6 +239,9 @@ def test_two_rank_data_parallel_step_equals_single_process():
     np.testing.assert_array_equal(res[0][3], res[1][3])
 
 
+@pytest.mark.skipif(not __import__('os').environ.get('DVD_TEST_DEPTH_GRAPHS'),
+                    reason='--depth_graphs is experimental and off by default (replay timing and MIOpen solver choice '
+                           'under capture vary between boxes, DESIGN.md section 7.1); opt in with DVD_TEST_DEPTH_GRAPHS=1')
 def test_depth_net_hip_graphs_equal_eager_execution():
     """--depth_graphs replays the depth net (forward, forward+backward per chunk) from captured HIP graphs:
     a step must give the logs and depth-net gradients of eager execution.  MIOpen's weight-gradient kernels

@@ -54,4 +54,7 @@ def test_state_dict_round_trip():
     a.exp_avg_sq.uniform_()
     a.step_count = 7
     b.load_state_dict(a.state_dict())
-    assert b.step_count == 7 and torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+    assert b.step_count == 7
+    for i in range(len(a.params)):               # (the alignment padding between segments carries no state)
+        assert torch.equal(a.view(a.exp_avg, i), b.view(b.exp_avg, i))
+        assert torch.equal(a.view(a.exp_avg_sq, i), b.view(b.exp_avg_sq, i))

@@ -4,7 +4,7 @@ OUT=gpurun_out/${1:-ab}; mkdir -p $OUT
 ROOT=$(pwd)
 V=$ROOT/dynamic-video-depth_amd/dvd_hip/lib/variants
 run() { echo "== $*" >> $OUT/ab.log; env "$@" timeout 120 python tools/microbench_warp.py --iters 30 2>&1 | grep kernel >> $OUT/ab.log; }
-timeout 900 python -m pytest tests/test_warp_loss_gpu.py -x -q > $OUT/pytest_warp.log 2>&1; tail -3 $OUT/pytest_warp.log
+timeout 900 python -m pytest tests/test_00_warp_loss_gpu.py -x -q > $OUT/pytest_warp.log 2>&1; tail -3 $OUT/pytest_warp.log
 run DVD_X=default
 for f in $V/libdvd_hip_*.so; do [ -f $f ] && run DVD_HIP_LIB=$f; done
 run DVD_WARP_PX=4
