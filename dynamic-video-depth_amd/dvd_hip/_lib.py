@@ -100,6 +100,11 @@ SIGNATURES = {
                                           c_void_p]),
     'dvd_gconv3x3_c32_bwd_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int,
                                             c_int, c_int, c_void_p]),
+    'dvd_xconv_packed_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'dvd_xconv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_xconv_fwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    'dvd_xwgrad_workspace_bytes': (c_size_t, [c_int] * 6),
+    'dvd_xwgrad': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     'dvd_sf_mlp_bwd_dw': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_longlong, ctypes.POINTER(PtrArr5),
                                   ctypes.POINTER(PtrArr5), c_void_p]),
 }

@@ -31,6 +31,8 @@ SOURCES = [
     ('surfaces.hip', ['-ffp-contract=off']),
     ('upsample.hip', ['-ffp-contract=off']),
     ('bnrelu.hip', []),
+    ('xconv.hip', []),
+    ('xwgrad.hip', []),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

@@ -63,8 +63,12 @@ def bn_eval_relu(bn, x, residual=None, relu=True):
     """relu(bn(x) (+ residual)) for an nn.BatchNorm2d in eval mode (running statistics; gamma / beta keep
     their gradients) on the fused HIP kernel; anything else (training-mode BN, CPU, other dtypes) takes the
     ATen ops the reference uses."""
-    if (not bn.training and bn.affine and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32):
-        return _BnRelu.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, relu)
+    if (not bn.training and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32):
+        if bn.affine:
+            gamma, beta = bn.weight, bn.bias
+        else:                                   # hourglass inception blocks: BatchNorm2d(affine=False)
+            gamma, beta = torch.ones_like(bn.running_mean), torch.zeros_like(bn.running_mean)
+        return _BnRelu.apply(x, residual, gamma, beta, bn.running_mean, bn.running_var, bn.eps, relu)
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -230,3 +234,141 @@ class GroupedConv3x3C8(nn.Conv2d):
 
     def forward(self, x):
         return gconv3x3_c8(x, self.weight)
+
+
+# ---------------------------------------------------------------------------------------
+# Dense stride-1 convolutions on the split-bf16 MFMA kernels (csrc/xconv.hip)
+
+def xconv_packed(weight, transposed):
+    """Fragment-ordered, pre-split copy of a conv weight [Cout,Cin,k,k].  The copy hangs on the weight
+    tensor OBJECT (not on its address: allocators reuse addresses) and is rebuilt when the weight changed:
+    new storage, autograd version counter, or an optimiser step of the fused Adam (ops.WEIGHT_EPOCH)."""
+    from . import ops
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    Cout, Cin, KS, _ = w.shape
+    key = (w.data_ptr(), weight._version, ops.WEIGHT_EPOCH[0], tuple(w.shape))
+    cache = getattr(weight, '_dvd_xpack', None)
+    if cache is None:
+        cache = {}
+        weight._dvd_xpack = cache
+    hit = cache.get(bool(transposed))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    lib = _lib.load()
+    nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, int(transposed))
+    if nbytes == 0:
+        raise RuntimeError('xconv: unsupported weight shape %s' % (tuple(w.shape),))
+    packed = hit[1] if (hit is not None and hit[1].numel() == nbytes) else torch.empty(nbytes, device=w.device,
+                                                                                       dtype=torch.uint8)
+    _lib.check(lib.dvd_xconv_pack(_p(w), _p(packed), Cout, Cin, KS, int(transposed), _stream()), 'dvd_xconv_pack')
+    cache[bool(transposed)] = (key, packed)
+    return packed
+
+
+def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, relu_in=False, relu_out=False,
+               res_relu=False):
+    N, Cin, H, W = x.shape
+    y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
+    flags = int(bool(relu_in)) | (int(bool(relu_out)) << 1) | (int(bool(res_relu)) << 2)
+    lib = _lib.load()
+    _lib.check(lib.dvd_xconv_fwd(_p(x), _p(packed), _p(bias), _p(residual), _p(mask_src), _p(y), N, Cin, Cout, H, W, KS,
+                                 flags, _stream()), 'dvd_xconv_fwd')
+    return y
+
+
+class _XConv(torch.autograd.Function):
+    """y = conv2d(act(x), w, stride 1, padding k//2) + bias + res'   with act = ReLU or identity and
+    res' = residual or relu(residual).  Forward and backward-data on csrc/xconv.hip; backward-weight on
+    csrc/xwgrad.hip (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, relu_in, res_relu):
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        Cout, _, KS, _ = weight.shape
+        y = _xconv_run(x, xconv_packed(weight, False), Cout, KS, bias=bias, residual=residual, relu_in=relu_in,
+                       res_relu=res_relu)
+        ctx.save_for_backward(x, residual if res_relu else None)
+        ctx.wparam = weight          # the tensor object that carries the packed copies
+        ctx.cfg = (bool(relu_in), bool(res_relu), bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, residual = ctx.saved_tensors
+        weight = ctx.wparam
+        relu_in, res_relu, has_bias, has_res = ctx.cfg
+        gy = gy.contiguous()
+        Cout, Cin, KS, _ = weight.shape
+        need = ctx.needs_input_grad
+        gx = gw = gb = gr = None
+        if need[0]:
+            gx = _xconv_run(gy, xconv_packed(weight, True), Cin, KS, mask_src=x if relu_in else None)
+        if need[1]:
+            gw = xconv_wgrad(x, gy, weight.shape, relu_in)
+        if has_bias and need[2]:
+            gb = gy.sum((0, 2, 3))
+        if has_res and need[3]:
+            gr = gy * (residual > 0).to(gy.dtype) if res_relu else gy
+        return gx, gw, gb, gr, None, None
+
+
+def xconv_wgrad(x, gy, wshape, relu_in):
+    """dW[co][ci][tap] = sum_{n,p} gy[n][co][p] * act(x)[n][ci][p + tap]."""
+    lib = _lib.load()
+    if wshape[2] in (1, 3) and not _os.environ.get('DVD_NO_XWGRAD'):
+        N, Cin, H, W = x.shape
+        Cout, _, KS, _ = wshape
+        gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+        nws = lib.dvd_xwgrad_workspace_bytes(N, Cin, Cout, H, W, KS)
+        ws = _workspace(nws, x.device)
+        _lib.check(lib.dvd_xwgrad(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W, KS,
+                                  int(bool(relu_in)), _stream()), 'dvd_xwgrad')
+        return gw
+    # larger kernels (hourglass inception branches): MIOpen's weight-gradient kernels
+    xin = torch.relu(x) if relu_in else x
+    KS = wshape[2]
+    return torch.ops.aten.convolution_backward(gy, xin, torch.empty(wshape, device=x.device), None, [1, 1],
+                                               [KS // 2, KS // 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+
+
+def xconv_supported(conv, x):
+    k = conv.kernel_size
+    return (x.is_cuda and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and conv.groups == 1 and
+            k[0] == k[1] and k[0] % 2 == 1 and k[0] <= 11 and tuple(conv.stride) == (1, 1) and
+            tuple(conv.dilation) == (1, 1) and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and
+            conv.padding_mode == 'zeros' and not _os.environ.get('DVD_NO_XCONV'))
+
+
+def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False):
+    """`conv(relu(x) if relu_in else x) + (relu(residual) if res_relu else residual)` for an nn.Conv2d `conv`.
+    GPU fp32 tensors of a dense stride-1 'same' convolution run on the HIP kernels; CPU tensors (the oracle /
+    golden-fixture generator instantiates these modules on the CPU) take the ATen ops the reference uses."""
+    if xconv_supported(conv, x):
+        return _XConv.apply(x, conv.weight, conv.bias, residual, relu_in, res_relu)
+    if x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and tuple(conv.stride) == (1, 1) and \
+            not _os.environ.get('DVD_NO_XCONV'):
+        raise RuntimeError('xconv2d: convolution %r is not covered by the HIP kernels' % (conv,))
+    y = conv(F.relu(x) if relu_in else x)
+    if residual is not None:
+        y = y + (F.relu(residual) if res_relu else residual)
+    return y
+
+
+class XConv2d(nn.Conv2d):
+    """Drop-in nn.Conv2d (same parameters / state_dict keys) whose dense stride-1 'same' case runs on the HIP
+    kernels; a strided 1x1 convolution without padding (the ResNeXt down-sampling shortcut) is the 1x1 kernel on
+    the sub-sampled input.  Anything else, and CPU tensors, take ATen."""
+
+    def forward(self, x):
+        if xconv_supported(self, x):
+            return _XConv.apply(x, self.weight, self.bias, None, False, False)
+        if (x.is_cuda and x.dtype == torch.float32 and self.kernel_size == (1, 1) and self.groups == 1 and
+                tuple(self.padding) == (0, 0) and self.stride[0] == self.stride[1] and self.stride[0] > 1 and
+                not _os.environ.get('DVD_NO_XCONV')):
+            st = self.stride[0]
+            return _XConv.apply(x[:, :, ::st, ::st].contiguous(), self.weight, self.bias, None, False, False)
+        return super().forward(x)

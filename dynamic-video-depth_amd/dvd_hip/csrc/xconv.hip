@@ -1,0 +1,545 @@
+// Dense stride-1 "same" convolution (1x1, 3x3, ... odd k x k), NCHW fp32 in / fp32 out, as an
+// implicit GEMM on the bf16 matrix cores of gfx950 with fp32-class accuracy: forward and
+// backward-data (the same kernel with the weights packed transposed and the taps flipped).
+//
+// What it replaces (reference, /root/reference): every dense nn.Conv2d of the depth networks --
+//   third_party/midas_blocks.py:102-168   ResidualConvUnit / FeatureFusionBlock 3x3, 256 -> 256
+//   third_party/MiDaS.py:186-195          scratch.layerK_rn (3x3, {256..2048} -> 256), output_conv
+//   third_party/midas_blocks.py:35-50     the 1x1 convolutions of the ResNeXt-101 32x8d bottlenecks
+//   third_party/hourglass.py:21-57        the 1x1 and k x k branches of the inception blocks
+// and their autograd backward w.r.t. the input (MIOpen: fp32 Winograd / Tensile GEMMs + layout
+// transposes in profiles/r01_bench_kernel_trace_summary.txt).
+//
+// Arithmetic.  gfx950 has no TF32-like fast path for fp32 operands: v_mfma_f32_32x32x2_f32 runs at the
+// fp32 VECTOR rate (157 TF), 1/16 of the bf16 matrix rate.  So every fp32 operand is split exactly into
+// three bf16 terms  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); 24 significant
+// bits, the residuals are exact in fp32) and a product  x*w  is evaluated as the six largest of the
+// nine partial products  hh' + hm' + mh' + mm' + hl' + lh',  each on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation.  The dropped terms (ml', lm', ll') are below 2^-23 |x w|: the result carries about
+// one more ulp of error per product than an fp32 FMA chain (far below the difference between two fp32
+// summation orders over K = 2304 terms) at 16/6 = 2.7x the fp32 MFMA rate.
+//
+// Mapping.  GEMM M = output channel, N = pixel, K = input channel (x taps).  D tile 32x32
+// (row = channel, column = pixel; accumulator layout of the 32x32 MFMAs: row = (r&3) + 8 (r>>2) + 4 (lane>>5),
+// column = lane & 31).  One K step = 16 input channels: lane l holds A[m = l&31][k = 8 (l>>5) .. +7] and
+// B[k = 8 (l>>5) .. +7][n = l&31] as eight bf16 (16 bytes) per split term.
+//   * weights: packed once per weight update (dvd_xconv_pack) into fragment order, already split; per K step
+//     (16 channels x one tap) the block copies its A fragments L2 -> registers -> LDS two steps ahead of use
+//     (first version: every wave streamed its own fragments from L2 -- 15 GB of L1 traffic per decoder
+//     convolution, the kernel ran at the L1 rate, not the MFMA rate).
+//   * activations: a block owns a TR x TC tile of one image and all input channels in chunks of 16.  The
+//     chunk's haloed tile is read from HBM as fp32 (coalesced along x), split, and written to LDS as
+//     [term][channel group of 8][position][8 bf16]; positions are linear in the PADDED tile,
+//     q = r * (TC + 2 pad) + c, so the B fragment of tap (ky, kx) is the fragment of the centre tap at a
+//     constant LDS offset ky * P + kx -- 32 consecutive 16-byte cells, conflict free -- and an N tile of 32
+//     consecutive q may straddle rows (the 2 pad columns per row are computed and dropped).  The raw fp32
+//     values of the next chunk are requested before the MFMAs of the current one.
+//   * epilogue: + bias[co], + residual (optionally relu'd), * [mask_src > 0], ReLU; coalesced stores.
+#include "dvd_common.h"
+
+namespace dvd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of it stay in registers
+
+// (a, b) -> three dwords of two bf16 each: a in the low half, b in the high half
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  const f32x2 v = {a, b};
+  const bf16x2 hb = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
+  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
+  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+
+__device__ __forceinline__ void split8(const float v[8], uint4& h, uint4& m, uint4& l) {
+  split_pair(v[0], v[1], h.x, m.x, l.x);
+  split_pair(v[2], v[3], h.y, m.y, l.y);
+  split_pair(v[4], v[5], h.z, m.z, l.z);
+  split_pair(v[6], v[7], h.w, m.w, l.w);
+}
+
+// packed[(((mt * nkc + kc) * T + tap) * 3 + term) * 64 + lane] : 8 bf16
+//   forward:    A[m][k] = w[co = m][ci = k][tap]
+//   transposed: A[m][k] = w[co = k][ci = m][T - 1 - tap]      (backward-data: roles swapped, taps flipped)
+// rows m >= M and columns k >= K are zero (M, K are padded to the block / K-step granularity).
+__global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
+                                                         int Cin, int T, int transposed, int mtiles, int nkc) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)mtiles * nkc * T * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const long long f = idx >> 6;
+  const int tap = (int)(f % T);
+  const int kc = (int)((f / T) % nkc);
+  const int mt = (int)(f / T / nkc);
+  const int m = mt * 32 + (lane & 31);
+  const int k0 = kc * 16 + 8 * (lane >> 5);
+  const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    float val = 0.0f;
+    if (m < M && k < K) {
+      const int co = transposed ? k : m, ci = transposed ? m : k, tp = transposed ? T - 1 - tap : tap;
+      val = w[((size_t)co * Cin + ci) * T + tp];
+    }
+    v[e] = val;
+  }
+  uint4 h, mm, l;
+  split8(v, h, mm, l);
+  packed[(f * 3 + 0) * 64 + lane] = h;
+  packed[(f * 3 + 1) * 64 + lane] = mm;
+  packed[(f * 3 + 2) * 64 + lane] = l;
+}
+
+struct XArgs {
+  const float* __restrict__ x;
+  const uint4* __restrict__ wp;
+  const float* __restrict__ bias;
+  const float* __restrict__ res;
+  const float* __restrict__ mask_src;
+  float* __restrict__ y;
+  int N, Cin, Cout, H, W;   // Cin = real K, Cout = real M of this launch
+  int KS, pad, T;
+  int TR, TC, P, ntr, ntc, NV;
+  int nkc, npos, nfi;     // nfi: B staging items per thread (FI == 0 kernels loop over them at run time)
+  int relu_in, relu_out, res_relu;
+};
+
+// One block = WM x WN waves, each wave TM x TN tiles of 32 x 32; A and B double buffered in LDS, one barrier per
+// K step (16 channels x one tap); two blocks share a CU, so one block's staging / barrier / epilogue overlaps
+// the other's MFMAs.
+template <int TM, int TN, int WM, int WN, int FIT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr bool kDirect = FIT == 0;             // big halos (k >= 5): stage without the register prefetch
+  constexpr int FI = kDirect ? 1 : FIT;
+  constexpr int MT = WM * TM;                    // 32-channel tiles per block
+  constexpr int AU = MT * 3 * 64;                // uint4 per A stage (all tiles, three terms)
+  constexpr int AI = (AU + NT - 1) / NT;         // staging loads per thread
+  constexpr int AS = AI * NT;                    // LDS cells per A stage (>= AU)
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  u32x4* sA = smem;                              // [2][AS] : [MT][3][64] + padding
+  u32x4* sB = smem + 2 * AS;                     // [2][term 3][channel group 2][npos]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int tr = blockIdx.x / a.ntc, tc = blockIdx.x - tr * a.ntc;
+  const int r0 = tr * a.TR, c0 = tc * a.TC;
+  const int mt0 = blockIdx.y * MT;
+  const int n = blockIdx.z;
+  const size_t plane = (size_t)a.H * a.W;
+  const float* xn = a.x + (size_t)n * a.Cin * plane;
+  const int npos = a.npos, P = a.P, T = a.T, KS = a.KS;
+  const int nkt = a.nkc * T;
+
+  // ---- B staging bookkeeping: item = channel group * NV + position of the haloed tile.  Every thread runs
+  //      every staging step unconditionally (no divergent branches around loads: hipcc would serialise them
+  //      with vmcnt(0) waits and park the staging registers in scratch): items beyond the tile load a valid
+  //      dummy address and store to the spare cell npos - 1 of the first plane.
+  int goff[FI], lidx[FI], cig8[FI];
+  bool gok[FI];
+#pragma unroll
+  for (int it = 0; it < FI; ++it) {
+    const int item = it * NT + tid;
+    const int cig = item >= a.NV ? 1 : 0;
+    const int p = item - cig * a.NV;
+    const int rr = p / P, cc = p - rr * P;
+    const int row = r0 - a.pad + rr, col = c0 - a.pad + cc;
+    const bool live = item < 2 * a.NV;
+    gok[it] = live && row >= 0 && row < a.H && col >= 0 && col < a.W;
+    goff[it] = gok[it] ? (row * a.W + col) : 0;
+    lidx[it] = live ? (cig * npos + p) : (npos - 1);
+    cig8[it] = live ? cig * 8 : 0;
+  }
+  float raw[FI][8];
+  auto load_raw = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < FI; ++it) {
+      const int ch0 = kc * 16 + cig8[it];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = (ch0 + e) < a.Cin ? (ch0 + e) : (a.Cin - 1);
+        raw[it][e] = xn[(size_t)ch * plane + goff[it]];
+      }
+    }
+  };
+  auto split_write = [&](int buf, int kc) {
+    u32x4* dst = sB + buf * 6 * npos;
+#pragma unroll
+    for (int it = 0; it < FI; ++it) {
+      const int ch0 = kc * 16 + cig8[it];
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (gok[it] && (ch0 + e) < a.Cin) ? raw[it][e] : 0.0f;
+        v[e] = a.relu_in ? fmaxf(t, 0.0f) : t;
+      }
+      uint4 h, m, l;
+      split8(v, h, m, l);
+      dst[lidx[it]] = (u32x4){h.x, h.y, h.z, h.w};
+      dst[2 * npos + lidx[it]] = (u32x4){m.x, m.y, m.z, m.w};
+      dst[4 * npos + lidx[it]] = (u32x4){l.x, l.y, l.z, l.w};
+    }
+  };
+
+  // direct staging (kDirect): load, split and store item by item, nothing kept in registers across the MFMAs
+  auto stage_direct = [&](int buf, int kc) {
+    u32x4* dst = sB + buf * 6 * npos;
+    for (int it = 0; it < a.nfi; ++it) {
+      const int item = it * NT + tid;
+      const int cig = item >= a.NV ? 1 : 0;
+      const int p = item - cig * a.NV;
+      const int rr = p / P, cc = p - rr * P;
+      const int row = r0 - a.pad + rr, col = c0 - a.pad + cc;
+      const bool live = item < 2 * a.NV;
+      const bool ok = live && row >= 0 && row < a.H && col >= 0 && col < a.W;
+      const int go = ok ? (row * a.W + col) : 0;
+      const int ch0 = kc * 16 + (live ? cig * 8 : 0);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = (ch0 + e) < a.Cin ? (ch0 + e) : (a.Cin - 1);
+        v[e] = xn[(size_t)ch * plane + go];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = (ok && (ch0 + e) < a.Cin) ? v[e] : 0.0f;
+        v[e] = a.relu_in ? fmaxf(t, 0.0f) : t;
+      }
+      uint4 h, m, l;
+      split8(v, h, m, l);
+      const int li = live ? (cig * npos + p) : (npos - 1);
+      dst[li] = (u32x4){h.x, h.y, h.z, h.w};
+      dst[2 * npos + li] = (u32x4){m.x, m.y, m.z, m.w};
+      dst[4 * npos + li] = (u32x4){l.x, l.y, l.z, l.w};
+    }
+  };
+
+  // ---- A staging: the block's AU uint4 of K step kt are MT pieces of 192 uint4 in the packed buffer; the
+  //      LDS stage is padded to AI * NT cells so that every thread loads and stores unconditionally
+  const u32x4* asrc[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int j = i * NT + tid;
+    const int jj = j < AU ? j : 0;
+    const int mtl = jj / 192, rem = jj - mtl * 192;
+    asrc[i] = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(mt0 + mtl) * nkt) * 192 + rem;
+  }
+  struct ARegs {
+    u32x4 v[AI];
+  };
+  auto load_a = [&](ARegs& r, int kt) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) r.v[i] = asrc[i][(size_t)kt * 192];
+  };
+  auto write_a = [&](const ARegs& r, int buf) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) sA[buf * AS + i * NT + tid] = r.v[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  int qb[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) qb[tn] = (wn * TN + tn) * 32 + (lane & 31);
+  const int bl = (lane >> 5) * npos;
+  const int al = (wm * TM) * 192 + lane;
+
+  // Order inside a K step: barrier | fragments of step kt from LDS | 6 * TM * TN MFMAs | stage A(kt + 1)
+  // (requested two steps ago) into the other A buffer, request A(kt + 3) | on the last tap of a chunk: split
+  // the raw values of the next chunk into the other B buffer, request the chunk after it.  The waits for
+  // global data sit BEHIND the wave's own MFMAs, so the matrix pipe works while they resolve (first version:
+  // staging at the top of the step -- every step waited an L2 round trip before its first MFMA, pipe 60 % busy).
+  struct Frag {
+    bf16x8 a[TM][3], b[TN][3];
+  };
+  auto read_frags = [&](Frag& f, int abuf, int kc, int off) {
+    const u32x4* Ac = sA + abuf * AS + al;
+    const u32x4* Bc = sB + (kc & 1) * 6 * npos + bl + off;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) f.a[tm][s] = __builtin_bit_cast(bf16x8, Ac[(tm * 3 + s) * 64]);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) f.b[tn][s] = __builtin_bit_cast(bf16x8, Bc[s * 2 * npos + qb[tn]]);
+  };
+  auto mfmas = [&](const Frag& f) {
+    // six partial products, small terms first; the TM * TN accumulators are interleaved so that consecutive
+    // MFMAs are independent
+#define DVD_XTERM(SA, SB)                                                                             \
+  _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) \
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[tm][SA], f.b[tn][SB], acc[tm][tn], 0, 0, 0);
+    DVD_XTERM(2, 0)
+    DVD_XTERM(0, 2)
+    DVD_XTERM(1, 1)
+    DVD_XTERM(1, 0)
+    DVD_XTERM(0, 1)
+    DVD_XTERM(0, 0)
+#undef DVD_XTERM
+  };
+
+  // ---- prologue: A(0), B(0) staged; A(1), A(2) and raw(1) in flight
+  ARegs ra, rb;
+  load_a(ra, 0);
+  if (!kDirect) load_raw(0);
+  write_a(ra, 0);
+  load_a(rb, nkt > 1 ? 1 : 0);                     // set of odd steps
+  load_a(ra, nkt > 2 ? 2 : 0);                     // set of even steps
+  if (kDirect) {
+    stage_direct(0, 0);
+  } else {
+    split_write(0, 0);
+    load_raw(a.nkc > 1 ? 1 : 0);
+  }
+
+  int kc = 0, ky = 0, kx = 0;
+  auto step = [&](int kt, ARegs& rn) {             // rn holds A(kt + 1)
+    __syncthreads();
+    Frag f;
+    read_frags(f, kt & 1, kc, ky * P + kx);
+    mfmas(f);
+    write_a(rn, (kt + 1) & 1);                      // (a spare write after the last step is harmless)
+    load_a(rn, kt + 3 < nkt ? kt + 3 : kt);
+    if (++kx == KS) {
+      kx = 0;
+      if (++ky == KS) {                             // last tap of the chunk (block-uniform)
+        ky = 0;
+        if (kDirect) {
+          if (kc + 1 < a.nkc) stage_direct((kc + 1) & 1, kc + 1);
+        } else {
+          split_write((kc + 1) & 1, kc + 1);
+          load_raw(kc + 2 < a.nkc ? kc + 2 : kc);
+        }
+        ++kc;
+      }
+    }
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(kt, rb);
+    if (kt + 1 < nkt) step(kt + 1, ra);
+  }
+
+  // ---- epilogue (uniform branches only; the optional operands are loaded in batches of 16; 32-bit offsets
+  //      from the image's base: the host checks Cout * H * W < 2^31)
+  const int TRv = (a.H - r0) < a.TR ? (a.H - r0) : a.TR;
+  const int TCv = (a.W - c0) < a.TC ? (a.W - c0) : a.TC;
+  const size_t ibase = (size_t)n * a.Cout * plane;
+  float* __restrict__ yb = a.y + ibase;
+  const int iplane = (int)plane;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int q = qb[tn];
+    const int rr = q / P, cc = q - rr * P;
+    const bool pok = rr < TRv && cc < TCv;
+    const int pix = pok ? (r0 + rr) * a.W + (c0 + cc) : 0;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int cob = (mt0 + wm * TM + tm) * 32 + 4 * (lane >> 5);
+      const int o0 = cob * iplane + pix;            // offset of accumulator register 0; register r adds
+                                                    // ((r & 3) + 8 (r >> 2)) planes
+      const bool full = cob + 28 <= a.Cout - 4;     // all 16 channels of this lane exist (block-uniform in practice)
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r];
+      if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cob + (r & 3) + 8 * (r >> 2);
+          v[r] += a.bias[co < a.Cout ? co : a.Cout - 1];
+        }
+      }
+      if (a.res) {
+        const float* __restrict__ rb = a.res + ibase;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cob + (r & 3) + 8 * (r >> 2);
+          rv[r] = rb[(full || co < a.Cout) ? o0 + ((r & 3) + 8 * (r >> 2)) * iplane : pix];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += a.res_relu ? fmaxf(rv[r], 0.0f) : rv[r];
+      }
+      if (a.mask_src) {
+        const float* __restrict__ mb = a.mask_src + ibase;
+        float mv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cob + (r & 3) + 8 * (r >> 2);
+          mv[r] = mb[(full || co < a.Cout) ? o0 + ((r & 3) + 8 * (r >> 2)) * iplane : pix];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = mv[r] > 0.0f ? v[r] : 0.0f;
+      }
+      if (a.relu_out) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cob + (r & 3) + 8 * (r >> 2);
+        if (pok && (full || co < a.Cout)) yb[o0 + ((r & 3) + 8 * (r >> 2)) * iplane] = v[r];
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+struct XCfg {
+  int TM, TN, WM, WN;
+  int blockM() const { return TM * WM * 32; }
+  int NQ() const { return TN * WN * 32; }
+  int NT() const { return 64 * WM * WN; }
+};
+static XCfg pick_cfg(int M) {
+  if (M <= 32) return {1, 2, 1, 4};     // 32 channels x 256 positions
+  if (M <= 64) return {2, 2, 1, 4};     // 64 x 256
+  return {2, 2, 2, 2};                  // 128 x 128
+}
+constexpr int kXLdsBudget = 78 * 1024;    // two blocks per CU
+constexpr int kXMaxFI = 3;       // register-prefetched staging; larger halos use the direct-staging kernels
+constexpr int kXMaxFIDirect = 16;
+
+struct XTile {
+  int TR, TC, P, ntr, ntc, NV, npos, FI;
+  size_t lds;
+};
+static size_t xconv_lds(const XCfg& c, int npos) {
+  const int AU = c.WM * c.TM * 192, NT = c.NT();
+  const int AS = (AU + NT - 1) / NT * NT;
+  return ((size_t)2 * AS + (size_t)12 * npos) * sizeof(uint4);
+}
+// Tile of the image per block: TR x TC outputs, TR * (TC + 2 pad) <= NQ positions; choose the split of the
+// width that wastes the fewest positions, subject to the LDS budget and the staging-iteration bound.
+static bool pick_tile_budget(int H, int W, int KS, const XCfg& c, XTile& best, int budget) {
+  const int pad = KS / 2, NQ = c.NQ(), NT = c.NT();
+  double best_eff = -1.0;
+  for (int nct = 1; nct <= W; ++nct) {
+    const int TC = (W + nct - 1) / nct;
+    const int P = TC + 2 * pad;
+    if (P > NQ) continue;
+    const int ntc = (W + TC - 1) / TC;
+    const int npos = NQ + (KS - 1) * (P + 1) + 1;        // + the spare cell of the staging code
+    if (xconv_lds(c, npos) > (size_t)budget) continue;
+    int trmax = NQ / P;
+    if (trmax > H) trmax = H;
+    for (int tr0 = trmax; tr0 >= 1; --tr0) {
+      const int ntr = (H + tr0 - 1) / tr0;
+      const int TR = (H + ntr - 1) / ntr;               // even out the rows
+      const int NV = (TR + 2 * pad) * P;
+      const int FI = (2 * NV + NT - 1) / NT;
+      if (FI > kXMaxFIDirect) continue;
+      // useful positions per computed position, minus what the halo costs in staging work
+      const double eff = (double)H * W / ((double)ntr * ntc * NQ) - 0.02 * (double)NV / (TR * TC) - 1e-6 * nct;
+      if (eff > best_eff) {
+        best_eff = eff;
+        best = {TR, TC, P, ntr, ntc, NV, npos, FI, xconv_lds(c, npos)};
+      }
+      break;                                             // smaller TR only lowers the efficiency
+    }
+    if (TC <= 8) break;
+  }
+  return best_eff > -1.0;
+}
+
+static bool pick_tile(int H, int W, int KS, const XCfg& c, XTile& best) {
+  // two blocks per CU where the haloed tile allows it, one block (big kernels: k >= 7) otherwise
+  return pick_tile_budget(H, W, KS, c, best, kXLdsBudget) || pick_tile_budget(H, W, KS, c, best, 156 * 1024);
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t s) {
+  auto go = [&](auto kern) -> int {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
+    DVD_LAUNCH_OK();
+    return DVD_OK;
+  };
+  switch (FI) {
+    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1>);
+    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2>);
+    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3>);
+    default: return go(xconv_kernel<TM, TN, WM, WN, 0>);
+  }
+}
+
+static int xconv_mtiles(int M) {
+  const XCfg c = pick_cfg(M);
+  return (M + c.blockM() - 1) / c.blockM() * (c.blockM() / 32);
+}
+
+}  // namespace dvd
+
+extern "C" {
+
+size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int transposed) {
+  if (Cout <= 0 || Cin <= 0 || KS <= 0 || !(KS & 1)) return 0;
+  const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
+  return (size_t)dvd::xconv_mtiles(M) * ((K + 15) / 16) * KS * KS * 3 * 64 * sizeof(uint4);
+}
+
+int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int transposed, dvd_stream_t stream) {
+  DVD_REQUIRE(w && packed, "xconv_pack: null pointer");
+  DVD_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && (KS & 1) && KS <= 11, "xconv_pack: bad shape Cout=%d Cin=%d KS=%d", Cout, Cin, KS);
+  const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
+  const int mtiles = dvd::xconv_mtiles(M), nkc = (K + 15) / 16, T = KS * KS;
+  const long long total = (long long)mtiles * nkc * T * 64;
+  hipLaunchKernelGGL(dvd::xconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), w, static_cast<uint4*>(packed), Cout, Cin, T, transposed ? 1 : 0,
+                     mtiles, nkc);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
+                  float* y, int N, int Cin, int Cout, int H, int W, int KS, int flags, dvd_stream_t stream) {
+  DVD_REQUIRE(x && packed && y, "xconv: null pointer");
+  DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xconv: bad shape N=%d Cin=%d Cout=%d H=%d W=%d", N, Cin,
+              Cout, H, W);
+  DVD_REQUIRE(KS > 0 && (KS & 1) && KS <= 11, "xconv: kernel size %d (odd sizes up to 11)", KS);
+  DVD_REQUIRE(N <= 65535, "xconv: too many images for the grid");
+  DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xconv: image too large for 32-bit offsets");
+  const dvd::XCfg c = dvd::pick_cfg(Cout);
+  int Hh = H, Ww = W;
+  if (KS == 1) {           // no spatial structure: one row of H * W positions
+    Hh = 1;
+    Ww = H * W;
+  }
+  dvd::XTile t;
+  DVD_REQUIRE(dvd::pick_tile(Hh, Ww, KS, c, t), "xconv: no tile of a %dx%d image with a %dx%d kernel fits the LDS", H, W, KS, KS);
+  dvd::XArgs a;
+  a.x = x;
+  a.wp = static_cast<const uint4*>(packed);
+  a.bias = bias;
+  a.res = residual;
+  a.mask_src = mask_src;
+  a.y = y;
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = Hh; a.W = Ww;
+  a.KS = KS; a.pad = KS / 2; a.T = KS * KS;
+  a.TR = t.TR; a.TC = t.TC; a.P = t.P; a.ntr = t.ntr; a.ntc = t.ntc; a.NV = t.NV;
+  a.nkc = (Cin + 15) / 16; a.npos = t.npos; a.nfi = t.FI;
+  a.relu_in = flags & 1; a.relu_out = (flags >> 1) & 1; a.res_relu = (flags >> 2) & 1;
+  const int mblocks = (Cout + c.blockM() - 1) / c.blockM();
+  DVD_REQUIRE(mblocks <= 65535, "xconv: too many channel blocks");
+  const dim3 grid(t.ntr * t.ntc, mblocks, N);
+  const size_t lds = t.lds;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2>(a, t.FI, grid, lds, s);
+  if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4>(a, t.FI, grid, lds, s);
+  return dvd::launch_fi<1, 2, 1, 4>(a, t.FI, grid, lds, s);
+}
+
+}  // extern "C"

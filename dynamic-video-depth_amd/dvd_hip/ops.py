@@ -313,8 +313,14 @@ def acc_reg(sf0, sf1, coef, g_sf1, abs_sum, accumulate=True):
                                sf0.numel(), _stream()), 'dvd_acc_reg')
 
 
+# Bumped by every optimiser step: the fused Adam kernel rewrites parameters behind autograd's back
+# (no `_version` change), and per-weight derived buffers (fragment-ordered conv weights) key on it.
+WEIGHT_EPOCH = [0]
+
+
 def adam_step(param, grad1, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps=1e-8, scale=1.0, scale_ptr=None,
               grad2=None):
+    WEIGHT_EPOCH[0] += 1
     lib = _lib.load()
     _lib.check(lib.dvd_adam_step(_p(param), _p(grad1), float(scale), _p(scale_ptr), _p(grad2), _p(exp_avg),
                                  _p(exp_avg_sq), param.numel(), float(lr), float(beta1), float(beta2), float(eps),

@@ -276,6 +276,34 @@ int dvd_upsample_bilinear_fwd(const float* x, float* y, long long planes, int H_
 int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int H_in, int W_in, int H_out,
                               int W_out, int align_corners, dvd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Dense stride-1 "same" convolution (odd k x k up to 11, any channel counts), NCHW fp32, on the bf16
+ * matrix cores with every fp32 operand split into three bf16 terms (six partial products, fp32
+ * accumulation: fp32-class accuracy at 2.7x the fp32 MFMA rate; csrc/xconv.hip).  Replaces the dense
+ * nn.Conv2d forward and backward-data of the depth networks:
+ *   third_party/midas_blocks.py:102-168 (ResidualConvUnit / FeatureFusionBlock 3x3),
+ *   third_party/MiDaS.py:186-195 (scratch.layerK_rn, output_conv),
+ *   third_party/midas_blocks.py:35-50 (1x1 convolutions of the ResNeXt-101 32x8d bottlenecks),
+ *   third_party/hourglass.py:21-57 (1x1 / k x k inception branches).
+ * dvd_xconv_pack re-orders w [Cout,Cin,k,k] into MFMA fragment order, already split (once per weight
+ * update); transposed != 0 packs the backward-data operator (channel roles swapped, taps flipped), which
+ * is then run by the same dvd_xconv_fwd with Cin/Cout exchanged.
+ * dvd_xconv_fwd: y = act_out( conv(act_in(x)) + bias + res' ) * [mask_src > 0]
+ *   flags bit0: act_in = ReLU on the input as it is staged (conv(relu(x)) of ResidualConvUnit),
+ *         bit1: act_out = ReLU, bit2: res' = relu(residual) instead of residual;
+ *   bias [Cout], residual / mask_src [N,Cout,H,W] may be NULL.  mask_src is the ReLU mask of the
+ *   backward-data pass (gx = dgrad(gy) * [x > 0]). */
+size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int transposed);
+int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int transposed, dvd_stream_t stream);
+int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
+                  float* y, int N, int Cin, int Cout, int H, int W, int KS, int flags, dvd_stream_t stream);
+/* Backward-weight of the same convolutions (k = 1 and 3), exact fp32 MFMA, deterministic two-stage sum
+ * (csrc/xwgrad.hip): gw[Cout,Cin,k,k] = sum_{n,p} gy[n,co,p] * act(x)[n,ci,p + tap], act = ReLU if relu_in.
+ * Replaces the autograd weight gradient of the nn.Conv2d named above (MIOpen accumulates it with atomics). */
+size_t dvd_xwgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int KS);
+int dvd_xwgrad(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
+               int Cout, int H, int W, int KS, int relu_in, dvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,168 @@
+"""Dense convolutions on the split-bf16 MFMA kernels (csrc/xconv.hip, csrc/xwgrad.hip) against F.conv2d on the
+CPU in float64 (the reference's nn.Conv2d arithmetic, third_party/midas_blocks.py:102-168, MiDaS.py:186-195,
+hourglass.py:21-57).
+
+Tolerance: fp32 class.  Every product is evaluated from three bf16 terms per operand (six partial products,
+fp32 accumulation), so the error against the float64 result must be of the size of an fp32 convolution's own
+rounding error: max |err| <= 4e-6 * max |y| (an fp32 CPU convolution of the same data measures 1-2e-6 on these
+shapes; a plain bf16 product would be 4e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 4e-6
+
+
+def _ref(x, w, b, relu_in=False, res=None, res_relu=False):
+    xd = x.double()
+    if relu_in:
+        xd = xd.relu()
+    y = F.conv2d(xd, w.double(), None if b is None else b.double(), padding=w.shape[-1] // 2)
+    if res is not None:
+        y = y + (res.double().relu() if res_relu else res.double())
+    return y
+
+
+def _err(got, want):
+    return float((got.double().cpu() - want).abs().max() / want.abs().max())
+
+
+def _where(got, want, names):
+    d = (got.double().cpu() - want).abs()
+    i = np.unravel_index(int(d.argmax()), d.shape)
+    bad = (d > TOL * float(want.abs().max())).sum().item()
+    return 'worst at %s=%s, %d of %d elements off' % (names, tuple(int(v) for v in i), bad, d.numel())
+
+
+def test_identity_weights_copy_the_input():
+    """W = centre-tap identity: the output IS the input -- isolates the staging layout and the output mapping."""
+    from dvd_hip import conv as C
+    torch.manual_seed(0)
+    for KS in (1, 3):
+        for (N, Cc, H, W) in ((1, 32, 7, 40), (2, 160, 13, 21)):
+            x = torch.randn(N, Cc, H, W)
+            conv = torch.nn.Conv2d(Cc, Cc, KS, padding=KS // 2, bias=False)
+            with torch.no_grad():
+                conv.weight.zero_()
+                conv.weight[torch.arange(Cc), torch.arange(Cc), KS // 2, KS // 2] = 1.0
+            conv = conv.cuda()
+            y = C.xconv2d(conv, x.cuda())
+            assert _err(y, x.double()) < 1e-7, 'KS=%d %s: %s' % (KS, (N, Cc, H, W), _where(y, x.double(), 'n,c,y,x'))
+
+
+@pytest.mark.parametrize('tap', [0, 2, 4, 6, 8])
+def test_single_tap_shifts_the_input(tap):
+    """Only one tap non-zero: the output is the input shifted by that tap (zero padded) -- isolates the tap offsets."""
+    from dvd_hip import conv as C
+    torch.manual_seed(1)
+    N, Cc, H, W = 1, 32, 9, 37
+    x = torch.randn(N, Cc, H, W)
+    conv = torch.nn.Conv2d(Cc, Cc, 3, padding=1, bias=False)
+    with torch.no_grad():
+        conv.weight.zero_()
+        conv.weight[torch.arange(Cc), torch.arange(Cc), tap // 3, tap % 3] = 1.0
+    want = _ref(x, conv.weight.detach(), None)
+    y = C.xconv2d(conv.cuda(), x.cuda())
+    assert _err(y, want) < 1e-7, _where(y, want, 'n,c,y,x')
+
+
+CASES = [
+    # N, Cin, Cout, H, W, KS
+    (2, 256, 256, 24, 42, 3),        # the MiDaS decoder convolution (refinenet3 level)
+    (1, 256, 256, 48, 84, 3),
+    (2, 64, 256, 24, 42, 1),         # ResNeXt bottleneck 1x1
+    (1, 1024, 256, 12, 21, 3),       # scratch.layer3_rn
+    (1, 256, 128, 20, 36, 3),        # output_conv[0]
+    (1, 128, 32, 30, 70, 3),         # output_conv[2]: 32 output channels
+    (1, 32, 1, 17, 29, 1),           # output_conv[4]: one output channel
+    (2, 20, 40, 11, 19, 3),          # channel counts that are multiples of nothing
+    (1, 48, 64, 19, 23, 5),          # hourglass inception branches
+    (1, 32, 32, 21, 33, 7),
+    (1, 32, 32, 24, 40, 11),
+    (1, 3, 64, 16, 24, 7),           # 3 input channels
+]
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W,KS', CASES)
+def test_forward_and_input_gradient(N, Cin, Cout, H, W, KS):
+    from dvd_hip import conv as C
+    torch.manual_seed(Cin + Cout + KS)
+    x = torch.randn(N, Cin, H, W)
+    conv = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2, bias=True)
+    want = _ref(x, conv.weight.detach(), conv.bias.detach())
+    xg = x.cuda().requires_grad_(True)
+    cg = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2, bias=True).cuda()
+    cg.load_state_dict(conv.state_dict())
+    y = C.xconv2d(cg, xg)
+    e = _err(y.detach(), want)
+    e32 = _err(conv(x).detach(), want)
+    print('fwd err %.2e of max|y| (fp32 CPU conv: %.2e)' % (e, e32))
+    assert e < TOL, _where(y.detach(), want, 'n,co,y,x')
+    # backward: input gradient, weight gradient, bias gradient against float64 autograd
+    gy = torch.randn(N, Cout, H, W)
+    xd = x.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True)
+    F.conv2d(xd, wd, bd, padding=KS // 2).backward(gy.double())
+    y.backward(gy.cuda())
+    e = _err(xg.grad, xd.grad)
+    print('dgrad err %.2e' % e)
+    assert e < TOL, 'dgrad: ' + _where(xg.grad, xd.grad, 'n,ci,y,x')
+    e = _err(cg.weight.grad, wd.grad)
+    print('wgrad err %.2e' % e)
+    assert e < 2e-5, 'wgrad: ' + _where(cg.weight.grad, wd.grad, 'co,ci,ky,kx')
+    assert _err(cg.bias.grad, bd.grad) < 1e-5
+
+
+def test_fused_input_relu_residual_and_its_backward():
+    """ResidualConvUnit pieces (midas_blocks.py:121-135): conv(relu(x)) + relu(res), gradient masks included."""
+    from dvd_hip import conv as C
+    torch.manual_seed(5)
+    N, Cc, H, W = 2, 64, 10, 18
+    x, res, gy = torch.randn(N, Cc, H, W), torch.randn(N, Cc, H, W), torch.randn(N, Cc, H, W)
+    conv = torch.nn.Conv2d(Cc, Cc, 3, padding=1)
+    xd, rd = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    want = F.conv2d(xd.relu(), wd, conv.bias.detach().double(), padding=1) + rd.relu()
+    want.backward(gy.double())
+    xg, rg = x.cuda().requires_grad_(True), res.cuda().requires_grad_(True)
+    cg = conv.cuda()
+    y = C.xconv2d(cg, xg, relu_in=True, residual=rg, res_relu=True)
+    y.backward(gy.cuda())
+    assert _err(y.detach(), want.detach()) < TOL
+    assert _err(xg.grad, xd.grad) < TOL and _err(rg.grad, rd.grad) < 1e-7
+    assert _err(cg.weight.grad, wd.grad) < 2e-5
+
+
+def test_packed_weights_follow_weight_updates():
+    from dvd_hip import conv as C, ops
+    torch.manual_seed(6)
+    conv = torch.nn.Conv2d(32, 32, 3, padding=1, bias=False).cuda()
+    x = torch.randn(1, 32, 8, 12).cuda()
+    y0 = C.xconv2d(conv, x)
+    with torch.no_grad():
+        conv.weight.mul_(2.0)                         # autograd-visible update
+    assert _err(C.xconv2d(conv, x).detach(), 2 * y0.detach().double().cpu()) < 1e-6
+    conv.weight.data.view(-1)[:] = conv.weight.data.view(-1) * 0.5      # update behind autograd's back ...
+    ops.WEIGHT_EPOCH[0] += 1                          # ... announced the way the fused Adam step does
+    assert _err(C.xconv2d(conv, x).detach(), y0.detach().double().cpu()) < 1e-6
+
+
+def test_decoder_size_is_deterministic():
+    """Same inputs, same bits (no atomics anywhere), at the size of the MiDaS decoder's largest level."""
+    from dvd_hip import conv as C
+    torch.manual_seed(7)
+    conv = torch.nn.Conv2d(256, 256, 3, padding=1).cuda()
+    x = torch.randn(2, 256, 96, 168, device='cuda').requires_grad_(True)
+    outs = []
+    for _ in range(2):
+        conv.weight.grad = None
+        x.grad = None
+        y = C.xconv2d(conv, x)
+        y.backward(torch.ones_like(y))
+        outs.append((y.detach().clone(), x.grad.clone(), conv.weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
