@@ -150,8 +150,8 @@ def main():
     ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (48 = the BASELINE configuration)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_steps', type=int, default=3, help='timed oracle steps of the cpu_baseline leg (after 1 warm-up)')
-    ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '0')),
-                    help='1: replay the depth net from HIP graphs (experimental); 0 (default): eager launches')
+    ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '1')),
+                    help='1 (default): replay the depth net from HIP graphs; 0: eager launches')
     ap.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
     a = ap.parse_args()
 

@@ -248,6 +248,14 @@ def xconv_packed(weight, transposed):
     if not w.is_contiguous():
         w = w.contiguous()
     Cout, Cin, KS, _ = w.shape
+    lib = _lib.load()
+    if torch.cuda.is_current_stream_capturing():
+        # HIP-graph capture: the pack launch must be PART of the graph (a replay runs no Python, and the weights
+        # change between replays), into a buffer of the graph's own pool -- never served from the cache
+        nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, int(transposed))
+        packed = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+        _lib.check(lib.dvd_xconv_pack(_p(w), _p(packed), Cout, Cin, KS, int(transposed), _stream()), 'dvd_xconv_pack')
+        return packed
     key = (w.data_ptr(), weight._version, ops.WEIGHT_EPOCH[0], tuple(w.shape))
     cache = getattr(weight, '_dvd_xpack', None)
     if cache is None:
@@ -256,7 +264,6 @@ def xconv_packed(weight, transposed):
     hit = cache.get(bool(transposed))
     if hit is not None and hit[0] == key:
         return hit[1]
-    lib = _lib.load()
     nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, int(transposed))
     if nbytes == 0:
         raise RuntimeError('xconv: unsupported weight shape %s' % (tuple(w.shape),))

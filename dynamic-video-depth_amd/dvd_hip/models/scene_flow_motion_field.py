@@ -63,11 +63,12 @@ class Model(NetInterface):
                             help='HBM ceiling for keeping the forward stashes of the whole batch alive so that the '
                                  'warp+loss kernel runs as ONE launch (falls back to one launch per chunk)')
         parser.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
-        parser.add_argument('--depth_graphs', type=int, default=0,
-                            help='1: capture the depth net per chunk shape in HIP graphs (forward, forward+backward) and '
-                                 'replay them (removes ~17 000 host-side launches per step; falls back to eager '
-                                 'execution if a capture fails); 0 (default): eager.  Experimental: measured 2.23 s vs '
-                                 '2.9 s per step on a host-bound box but 3.7 s vs 2.08 s on a GPU-bound one')
+        parser.add_argument('--depth_graphs', type=int, default=1,
+                            help='1 (default): capture the depth net per chunk shape in HIP graphs (forward, forward+backward) '
+                                 'and replay them: one launch per chunk instead of ~2 000, so the step does not depend on '
+                                 'the host cores (2.8 s -> 2.0 s per step on a slow-host box, equal on a fast one; replay is '
+                                 'bit-identical to eager execution, tests/test_30_full_step_gpu.py); falls back to eager '
+                                 'execution if a capture fails.  0: eager launches')
         return parser, set()
 
     # ------------------------------------------------------------------------------------
@@ -136,10 +137,10 @@ class Model(NetInterface):
         return self.net_depth(img, frame_ids.long() if frame_ids is not None else None)
 
     # -- HIP graphs for the depth net -------------------------------------------------------
-    # A MiDaS forward+backward of one chunk is ~1 500 kernel launches; 12 chunk passes per step make the
-    # step launch-bound on hosts with slower cores (rocprofv3: 2.14 s of kernels in a 2.7 s step on one
-    # box, 2.08 s wall on another).  EXPERIMENTAL, off by default (replay time varied between boxes, see
-    # --depth_graphs).  With --depth_graphs 1
+    # A MiDaS forward+backward of one chunk is ~2 000 kernel launches; 12 chunk passes per step make the
+    # step launch-bound on hosts with slower cores (rocprofv3: 1.95 s of kernels in a 2.8 s step on one
+    # box, 1.97 s wall on another).  With --depth_graphs 1 (default since the convolutions run on this
+    # package's own kernels: round 1's replay through MIOpen was erratic)
     # each chunk shape is captured once (forward-only graph for phase 1, forward+backward graph for
     # phase 3, static input / output / output-gradient buffers; parameter gradients accumulate in place
     # into the flat gradient buffer) and replayed; anything that cannot be captured falls back to eager.
@@ -153,6 +154,8 @@ class Model(NetInterface):
             return self._depth_graphs[key]
         entry = None
         try:
+            import gc
+            gc.collect()        # graphs of discarded models must not be destroyed while this capture is open
             static_in = img.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -191,7 +194,7 @@ class Model(NetInterface):
         return entry
 
     def _use_graphs(self, img, frame_ids):
-        return bool(getattr(self.opt, 'depth_graphs', False)) and (frame_ids is None or not self.opt.use_embedding)
+        return bool(getattr(self.opt, 'depth_graphs', 1)) and (frame_ids is None or not self.opt.use_embedding)
 
     def _depths_nograd(self, img, frame_ids):
         out = []
@@ -462,7 +465,7 @@ class Model(NetInterface):
             ops.scale_add(k.grad, self._sf_grad_main, scale_ptr=inv, b=k.grad)
         # the MLP gradient all-reduce overlaps the depth-net backward, except in a step that still has to
         # capture the depth net's forward+backward graph (no collective in flight during a capture)
-        capturing = (not warm and getattr(opt, 'depth_graphs', False)
+        capturing = (not warm and getattr(opt, 'depth_graphs', 1)
                      and self._graph_key('fb', inp.img_1[:max(1, int(opt.depth_chunk))]) not in self._depth_graphs)
         h_sf = None if capturing else k.all_reduce_grads(async_op=True)
 

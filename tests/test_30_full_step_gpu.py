@@ -239,9 +239,33 @@ def test_two_rank_data_parallel_step_equals_single_process():
     np.testing.assert_array_equal(res[0][3], res[1][3])
 
 
-@pytest.mark.skipif(not __import__('os').environ.get('DVD_TEST_DEPTH_GRAPHS'),
-                    reason='--depth_graphs is experimental and off by default (replay timing and MIOpen solver choice '
-                           'under capture vary between boxes, DESIGN.md section 7.1); opt in with DVD_TEST_DEPTH_GRAPHS=1')
+@pytest.mark.parametrize('name', ['fullstep_midas_b1_64x96_train', 'fullstep_hourglass_b2_32x48_train'])
+def test_replayed_graphs_follow_the_weights(name):
+    """After two optimisation steps (the weights moved), a REPLAY of the captured forward graph and of the captured
+    forward+backward graph must give what eager execution gives with the model's current weights: derived buffers
+    (fragment-ordered conv weights) are rebuilt inside the graphs, not frozen at capture time."""
+    gd = helpers.load_golden(name)
+    model, opt, batch = _build(gd, depth_graphs=True, depth_chunk=1, lr=1e-3)
+    for i in range(2):
+        model._train_on_batch(6, i, helpers.loader_batch(dict(batch)))
+    assert sum(v is not None for v in model._depth_graphs.values()) == 2, 'forward and forward+backward graphs'
+    img = batch['img_1'].cuda()
+    fid = batch['frame_id_1'].cuda() if not opt.midas else None
+    g_depth = torch.randn(img.shape[0], 1, img.shape[2], img.shape[3], device='cuda')
+    out = {}
+    for graphs in (True, False):
+        model.opt.depth_graphs = graphs
+        d = model._depths_nograd(img, fid)
+        model._flat_depth.zero_grad()
+        model._depth_backward(img, fid, g_depth)
+        torch.cuda.synchronize()
+        out[graphs] = (d.clone(), model._flat_depth.grad.clone())
+    d_err = float((out[True][0] - out[False][0]).abs().max() / out[False][0].abs().max())
+    g_err = float((out[True][1] - out[False][1]).abs().max() / out[False][1].abs().max())
+    print('replay vs eager after 2 steps: depth %.2e, gradient %.2e' % (d_err, g_err))
+    assert d_err < 1e-6 and g_err < 1e-5
+
+
 def test_depth_net_hip_graphs_equal_eager_execution():
     """--depth_graphs replays the depth net (forward, forward+backward per chunk) from captured HIP graphs:
     a step must give the logs and depth-net gradients of eager execution.  MIOpen's weight-gradient kernels
@@ -250,7 +274,7 @@ def test_depth_net_hip_graphs_equal_eager_execution():
     gd = helpers.load_golden('fullstep_midas_b1_64x96_train')
     outs = []
     for graphs in (False, False, True):
-        model, opt, batch = _build(gd, depth_graphs=graphs, depth_chunk=1)
+        model, opt, batch = _build(gd, depth_graphs=int(graphs), depth_chunk=1)
         log = model._train_on_batch(6, 0, helpers.loader_batch(dict(batch)))
         torch.cuda.synchronize()
         if graphs:
