@@ -105,6 +105,7 @@ SIGNATURES = {
     'dvd_xconv_fwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     'dvd_xwgrad_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 7 + [c_void_p]),
+    'dvd_flow_consistency_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'dvd_sf_mlp_bwd_dw': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_longlong, ctypes.POINTER(PtrArr5),
                                   ctypes.POINTER(PtrArr5), c_void_p]),
 }

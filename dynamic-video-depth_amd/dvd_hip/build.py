@@ -33,6 +33,7 @@ SOURCES = [
     ('bnrelu.hip', []),
     ('xconv.hip', []),
     ('xwgrad.hip', []),
+    ('consistency.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

@@ -27,7 +27,10 @@ Depth-net convolutions run on PyTorch-ROCm/MIOpen in this round (BASELINE config
 """
 import os
 import warnings
+from os import makedirs
+from os.path import join
 
+import numpy as np
 import torch
 
 from .. import configs, flat, ops, parallel
@@ -492,14 +495,55 @@ class Model(NetInterface):
         # overwrites 'loss' at :226)
         batch_log = {'size': opt.batch_size, 'loss': host[1] / mul, 'total_loss': host[1] / mul, 'flow_loss_1_2': host[2],
                      'disp_loss_1_2': host[3], 'sf_loss': host[4], 'acc_reg': acc_reg}
-        self._last = {'depth_1': depth_1, 'depth_2': depth_2, 'mask_sum': host[5]}
+        self._last = {'depth_1': depth_1, 'depth_2': depth_2, 'mask_sum': host[5], 'sf_all': sf_all, 'mseg': mseg}
+        self._export_train_visuals(epoch, batch_ind, batch)
         return batch_log
+
+    # -- the reference's `pred` dict and its export (scene_flow_motion_field.py:201-225, video_base.py:105-126) ----
+    def _export_train_visuals(self, epoch, batch_ind, batch):
+        opt = self.opt
+        every = getattr(opt, 'vis_every_train', 0)
+        if not every or np.mod(epoch, every) != 0:
+            return
+        indx = batch_ind if getattr(opt, 'vis_at_start', False) else getattr(opt, 'epoch_batches', 0) - batch_ind
+        if indx > getattr(opt, 'vis_batches_train', 0):
+            return
+        pred = {k: v.data.cpu().numpy() for k, v in self._predict_on_batch(is_train=True).items()}
+        outdir = join(self.full_logdir, 'visualize', 'epoch%04d_train' % epoch)
+        makedirs(outdir, exist_ok=True)
+        output = self.pack_output(pred, batch)
+        if self.global_rank == 0 and self.visualizer is not None:
+            self.visualizer.visualize(output, indx + (1000 * epoch), outdir)
+        np.savez(join(outdir, 'rank%04d_batch%04d' % (self.global_rank, batch_ind)), **output)
+
+    def pack_output(self, pred_all, batch):
+        """video_base.py:105-126, key for key."""
+        if 'pair_path' in batch:
+            batch_size = len(batch['pair_path'])
+        else:                                          # synthetic batches carry no paths
+            batch_size = int((batch['img'] if 'img' in batch else batch['img_1']).shape[0])
+        if 'img' not in batch:
+            img_1, img_2 = batch['img_1'].cpu().numpy(), batch['img_2'].cpu().numpy()
+        else:
+            img_1 = img_2 = batch['img']
+        output = {'batch_size': batch_size, 'img_1': img_1, 'img_2': img_2, **pred_all}
+        if 'img' not in batch:
+            output['flow_1_2'] = self._input.flow_1_2.cpu().numpy()
+            output['flow_2_1'] = self._input.flow_2_1.cpu().numpy()
+            if 'depth_pred_1' in batch:
+                output['depth_nn_1'] = batch['depth_pred_1'].cpu().numpy()
+        else:
+            for src, dst in (('depth_pred', 'depth_nn'), ('depth_mvs', 'depth_gt'), ('cam_c2w', 'cam_c2w'), ('K', 'K')):
+                if src in batch:
+                    output[dst] = batch[src].cpu().numpy()
+        output['pair_path'] = batch.get('pair_path', [])
+        return output
 
     # ------------------------------------------------------------------------------------
     def _predict_on_batch(self, is_train=True):
         """Inference path (is_train=False, :265-275): depth + unprojection + one MLP evaluation."""
         if is_train:
-            raise RuntimeError('the training forward is fused into _train_on_batch')
+            return self._train_pred()
         inp = self._input
         fid = inp.frame_id_1 if not self.opt.midas else None
         depth = self._depths_nograd(inp.img, fid)
@@ -510,13 +554,35 @@ class Model(NetInterface):
         self._mlp.forward(P, ts, 0.0, 1.0 / self.opt.sf_mag_div, sf_out=sf)
         return {'depth': depth, 'sf_1_2': sf}
 
+    def _train_pred(self):
+        """The reference's train-time `pred` dict (:243-264 + `sf_loss_pp` of :308), materialised on demand from the
+        state of the last `_train_on_batch` (the fused step itself never builds these thirteen surfaces): same keys,
+        shapes and values, forward only."""
+        if getattr(self, '_last', None) is None:
+            raise RuntimeError('the training forward is fused into _train_on_batch: run a step first')
+        inp, last = self._input, self._last
+        cams = {k: getattr(inp, k) for k in CAM_KEYS}
+        sf = last['sf_all']
+        if last['mseg'] is not None:
+            sf = ops.mul_mask(torch.empty_like(sf), sf, last['mseg'])
+        sflow = sf.permute(0, 2, 3, 1)[..., None, :].contiguous()
+        with torch.no_grad():
+            dflow = self.depth_flow(last['depth_1'], last['depth_2'], inp.flow_1_2, **cams)
+            pred = self.warp(last['depth_1'], last['depth_2'], inp.flow_1_2, inp.flow_2_1, sflow_1_2=sflow,
+                             sflow_2_1=sflow, **cams)
+        pred['sf_1_2'] = sf
+        pred['global_p1'] = dflow['global_p1'].squeeze(3).permute(0, 3, 1, 2)
+        pred['sf_by_dep_1_2'] = dflow['sf_by_depth']
+        pred['sf_loss_pp'] = torch.abs(dflow['sf_by_depth'].squeeze(3).permute(0, 3, 1, 2) - sf).sum(1)
+        return pred
+
     @staticmethod
     def depth2disp(depth):
         valid = (depth > 1e-2).float()
         return (1 / (depth + (1 - valid) * 1e-8)) * valid
 
     def _vali_on_batch(self, epoch, batch_idx, batch):
-        """Disparity MSE against the MVS depth (models/video_base.py:72-103)."""
+        """Disparity MSE against the MVS depth, optional export (models/video_base.py:72-103)."""
         self.eval()
         self.load_batch(batch)
         with torch.no_grad():
@@ -524,11 +590,36 @@ class Model(NetInterface):
             gt = batch['depth_mvs'].to(self.device)
             vali = gt > 1e-2
             loss = torch.nn.functional.mse_loss(self.depth2disp(pred['depth']) * vali, self.depth2disp(gt) * vali).item()
+        every = getattr(self.opt, 'vis_every_vali', 0)
+        if every and np.mod(epoch, every) == 0 and batch_idx < getattr(self.opt, 'vis_batches_vali', 0):
+            pred = {k: v.cpu().numpy() for k, v in pred.items()}
+            outdir = join(self.full_logdir, 'visualize', 'epoch%04d_vali' % epoch)
+            makedirs(outdir, exist_ok=True)
+            output = self.pack_output(pred, batch)
+            if self.global_rank == 0 and self.visualizer is not None:
+                self.visualizer.visualize(output, batch_idx + (1000 * epoch), outdir)
+            np.savez(join(outdir, 'rank%04d_batch%04d' % (self.global_rank, batch_idx)), **output)
         return {'size': batch['img'].shape[0], 'loss': loss}
 
-    def test_on_batch(self, batch_ind, batch):
+    def test_on_batch(self, batch_idx, batch):
+        """models/video_base.py:128-155: predict, pack, cache, write `<output_dir>/epoch<e>_test/batch%04d.npz`."""
+        if not hasattr(self, 'test_cache'):
+            self.test_cache = []
         self.eval()
         self.load_batch(batch)
         with torch.no_grad():
             pred = self._predict_on_batch(is_train=False)
-        return {k: v.cpu().numpy() for k, v in pred.items()}
+        if not hasattr(self, 'test_loss'):
+            self.test_loss = 0
+        pred = {k: v.cpu().numpy() for k, v in pred.items()}
+        ep = getattr(self.opt, 'epoch', 0)
+        outdir = join(getattr(self.opt, 'output_dir', self.full_logdir or '.'), 'epoch%s_test' % ('best' if ep < 0 else '%04d' % ep))
+        if not hasattr(self, 'outdir'):
+            self.outdir = outdir
+        makedirs(outdir, exist_ok=True)
+        output = self.pack_output(pred, batch)
+        self.test_cache.append(output.copy())
+        if self.global_rank == 0 and self.visualizer is not None:
+            self.visualizer.visualize(output, batch_idx, outdir)
+        np.savez(join(outdir, 'batch%04d' % batch_idx), **output)
+        return output

@@ -304,6 +304,17 @@ size_t dvd_xwgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int KS
 int dvd_xwgrad(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
                int Cout, int H, int W, int KS, int relu_in, dvd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Flow-consistency (occlusion) + out-of-bounds mask of one direction of a frame pair.
+ * Replaces scripts/preprocess/davis/generate_flows.py:57-82,139-148:
+ *   mask = clip([ || grid_sample(flow_a, (x,y)+flow_b, zeros padding, align_corners) + flow_b || > 1 ]
+ *               + [ (x,y)+flow_b outside the image ], 0, 1)
+ * mask_1 = f(flow_a = flow_1_2, flow_b = flow_2_1), mask_2 = f(flow_2_1, flow_1_2); flows [B,H,W,2], mask [B,H,W]
+ * in {0,1} (1 = occluded / leaves the image; the training masks are 1 - mask, generate_sequence_midas.py:144-147).
+ * Same fp32 operation order as the reference's numpy / ATen path: the integer masks are bit-identical. */
+int dvd_flow_consistency_mask(const float* flow_a, const float* flow_b, float* mask, int B, int H, int W,
+                              dvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,8 +46,17 @@ def _inference_batch(B, H, W, seed=3):
 def test_inference_path_matches_cpu():
     model, cpu_depth, cpu_sd = _model()
     batch = _inference_batch(2, 32, 48)
+    import os
+    import tempfile
+    model.opt.output_dir, model.opt.epoch = tempfile.mkdtemp(), 7
+    batch['pair_path'] = ['a', 'b']
     pred = model.test_on_batch(0, batch)
-    assert set(pred) == {'depth', 'sf_1_2'} and pred['depth'].shape == (2, 1, 32, 48) and pred['sf_1_2'].shape == (2, 3, 32, 48)
+    # video_base.py:105-155: packed output, cached and written as <output_dir>/epoch0007_test/batch0000.npz
+    assert {'batch_size', 'img_1', 'img_2', 'depth', 'sf_1_2', 'depth_gt', 'pair_path'} <= set(pred)
+    assert pred['batch_size'] == 2 and pred['depth'].shape == (2, 1, 32, 48) and pred['sf_1_2'].shape == (2, 3, 32, 48)
+    saved = np.load(os.path.join(model.opt.output_dir, 'epoch0007_test', 'batch0000.npz'))
+    np.testing.assert_array_equal(saved['depth'], pred['depth'])
+    assert len(model.test_cache) == 1 and model.outdir.endswith('epoch0007_test')
     with torch.no_grad():
         d = cpu_depth(batch['img'], batch['frame_id_1'].long())
         P = G.unproject(d, batch['R_1'], batch['t_1'], batch['K_inv']).squeeze(3).permute(0, 3, 1, 2)
@@ -97,3 +106,31 @@ def test_checkpoint_round_trip_restores_weights_and_adam_state(tmp_path):
     for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
         np.testing.assert_allclose(la[k], lb[k], rtol=1e-6, err_msg=k)
     assert float((a._flat_sf.flat - b._flat_sf.flat).abs().max()) <= 1e-6
+
+
+REFERENCE_PRED_KEYS = {'dflow_1_2', 'depth_image_1_2', 'depth_warp_1_2', 'depth_1', 'depth_2', 'scenef_1_2', 'global_p1',
+                       'staticflow_1_2', 'p1_camera_2', 'warped_p2_camera_2', 'sf_1_2', 'sf_by_dep_1_2', 'sf_loss_pp'}
+
+
+def test_train_time_pred_dict_and_visual_export(tmp_path):
+    """The reference materialises thirteen per-pixel surfaces every step and exports them with np.savez on the
+    visualisation batches (scene_flow_motion_field.py:201-225, 243-264).  The fused step does not build them; on
+    demand they must have the reference's keys and shapes and the oracle's values for this step's depths / weights."""
+    from dvd_hip import synthetic
+    from oracle import losses as L
+    model, _, cpu_sd = _model(seed=61, use_motion_seg=True, vis_every_train=1, vis_at_start=True, vis_batches_train=0,
+                              full_logdir=str(tmp_path))
+    batch = synthetic.make_batch(2, 32, 48, gap=2, seed=8)
+    model._train_on_batch(6, 0, helpers.loader_batch(dict(batch)))
+    pred = model._predict_on_batch(is_train=True)
+    assert set(pred) == REFERENCE_PRED_KEYS
+    opt = L.default_opt(use_motion_seg=True, midas=False)
+    want = L.predict_train(opt, cpu_sd, batch, model._last['depth_1'].cpu(), model._last['depth_2'].cpu())
+    want['sf_loss_pp'] = torch.abs(want['sf_by_dep_1_2'].squeeze(3).permute(0, 3, 1, 2) - want['sf_1_2']).sum(1)
+    for k in sorted(REFERENCE_PRED_KEYS):
+        got, ref = pred[k].cpu(), want[k].detach()
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-3, atol=2e-4, err_msg=k)
+    out = np.load(str(tmp_path / 'visualize' / 'epoch0006_train' / 'rank0000_batch0000.npz'))
+    assert REFERENCE_PRED_KEYS | {'batch_size', 'img_1', 'img_2', 'flow_1_2', 'flow_2_1'} <= set(out.files)
+    np.testing.assert_array_equal(out['dflow_1_2'], pred['dflow_1_2'].cpu().numpy())
