@@ -780,9 +780,8 @@ constexpr int kPreFloats = 64;
 constexpr int kpM3 = 0, kpM2 = 9, kpTV = 18, kpM4 = 21, kpR2 = 24, kpTQ = 27, kpKZ = 28, kpM1 = 31, kpT1 = 40,
               kpM5 = 43, kpT2 = 52, kpEAxy = 55, kpEBxy = 56, kpEAz = 57, kpEBz = 58, kpTsum = 59;
 
-__global__ __launch_bounds__(64) void warp_prepare_kernel(const WarpArgs a, float* __restrict__ pre) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
+// composite matrices + guard-band error model of pair b -> o[0..59] (one thread, double precision)
+__device__ void warp_prepare_pair(const WarpArgs& a, int b, float* __restrict__ o) {
   double Ki[9], R1[9], R2[9], R2T[9], K[9], t1[3], t2[3];
   for (int i = 0; i < 9; ++i) {
     Ki[i] = a.Ki[b * 9 + i];
@@ -804,7 +803,6 @@ __global__ __launch_bounds__(64) void warp_prepare_kernel(const WarpArgs a, floa
   mm(R2T, K, M2);
   mm(M1, M2, M3);
   mm(Ki, R2, M5);
-  float* o = pre + (size_t)b * kPreFloats;
   for (int i = 0; i < 9; ++i) {
     o[kpM3 + i] = (float)M3[i];
     o[kpM2 + i] = (float)M2[i];
@@ -857,6 +855,12 @@ __global__ __launch_bounds__(64) void warp_prepare_kernel(const WarpArgs a, floa
   o[kpEBz] = (float)(eps * kz * nq);
   o[kpTsum] = (float)(fabs(t1[0]) + fabs(t1[1]) + fabs(t1[2]) + fabs(t2[0]) + fabs(t2[1]) + fabs(t2[2]));
   for (int i = 60; i < kPreFloats; ++i) o[i] = 0.0f;
+}
+
+__global__ __launch_bounds__(64) void warp_prepare_kernel(const WarpArgs a, float* __restrict__ pre) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= a.B) return;
+  warp_prepare_pair(a, b, pre + (size_t)b * kPreFloats);
 }
 
 struct Pre {
@@ -1438,6 +1442,8 @@ __global__ __launch_bounds__(1024) void warp_finish_kernel(const float* __restri
   }
 }
 
+#include "warp_gen4.inc"
+
 __global__ void loss_finalize_kernel(const float* __restrict__ sums, float flow_mul, float disp_mul,
                                      int loss_on_sf, float* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1534,8 +1540,9 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.nty = p.nty;
   const int nblocks = p.ntx * p.nty * a.B;
   const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
-  // counter block (256 B): [0] overflow count, [16] fix-up count, [32..63] four Q31.32 fix-up sums
-  DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, 64, stream));
+  const int gen = env_int("DVD_WARP_GEN", 1);
+  // counter block (256 B): [0] overflow count, [1] finish ticket, [4] fix-up count, [8..15] four Q31.32 fix-up sums
+  if (gen != 4) DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, 64, stream));
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
   // generation 1 (default) = the reference's rounding sequence for every pixel; generation 3
   // (DVD_WARP_GEN=3) = guard-banded fast arithmetic + exact fix-up pass.  Measured at 48x384x672
@@ -1543,7 +1550,6 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   // against 147 us, but its extra prepare / fix-up launches and a slower scatter phase leave the
   // whole launch at 299 us against 260 us, so generation 1 stays the production kernel until the
   // slab round trip (the common 65 us + 33 us of both) is gone.
-  const int gen = env_int("DVD_WARP_GEN", 1);
   // 2 pixels per thread-step when that splits the tile evenly over the block and 4 does not
   constexpr bool kEven4 = ((TW / 4) * TH) % NT == 0, kEven2 = ((TW / 2) * TH) % NT == 0;
   const bool px2 = env_int("DVD_WARP_PX", (kEven2 && !kEven4) ? 2 : 4) == 2;
@@ -1552,6 +1558,47 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   fix.rec = reinterpret_cast<int2*>(ws + p.off_fix);
   fix.cap = (unsigned)(p.fix_cap > 0xffffffffULL ? 0xffffffffULL : p.fix_cap);
   unsigned long long* fix_sums = reinterpret_cast<unsigned long long*>(ta.ovf.count + 8);
+  if (gen == 4) {
+    float* pre = reinterpret_cast<float*>(ws + p.off_pre);
+    hipLaunchKernelGGL(warp_prep_kernel, dim3(a.B), dim3(64), 0, stream, a, pre, ta.ovf.count);
+    DVD_LAUNCH_OK();
+    const size_t lds4 = lds + (size_t)TH * kRowFloats * sizeof(float);
+    const int mode4 = env_int("DVD_WARP4_MODE", 0);
+#define DVD_TILED4_LAUNCH(G, S)                                                                           \
+  do {                                                                                                    \
+    auto k4 = mode4 == 1 ? warp_loss_tiled4_kernel<TW, TH, kR, NT, G, S, 2, false>                       \
+              : mode4 == 2 ? warp_loss_tiled4_kernel<TW, TH, kR, NT, G, S, 2, true>                       \
+                           : warp_loss_tiled4_kernel<TW, TH, kR, NT, G, S, 4, false>;                     \
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k4),                                     \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));               \
+    hipLaunchKernelGGL(k4, dim3(nblocks), dim3(NT), lds4, stream, a, ta, pre, fix);                       \
+  } while (0)
+    if (grads) {
+      if (shipped)
+        DVD_TILED4_LAUNCH(true, true);
+      else
+        DVD_TILED4_LAUNCH(true, false);
+    } else {
+      if (shipped)
+        DVD_TILED4_LAUNCH(false, true);
+      else
+        DVD_TILED4_LAUNCH(false, false);
+    }
+#undef DVD_TILED4_LAUNCH
+    DVD_LAUNCH_OK();
+    if (grads) {
+      const int qpr = (a.W + 3) / 4;
+      const int total_quads = qpr * a.H * a.B;
+      hipLaunchKernelGGL((combine_slabs4_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, stream,
+                         ta.slabs, pre, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads);
+      DVD_LAUNCH_OK();
+      hipLaunchKernelGGL(warp_finish4_kernel<true>, dim3(128), dim3(1024), 0, stream, a, ta.ovf, fix, ta.ovf.count, nblocks);
+    } else {
+      hipLaunchKernelGGL(warp_finish4_kernel<false>, dim3(16), dim3(1024), 0, stream, a, ta.ovf, fix, ta.ovf.count, nblocks);
+    }
+    DVD_LAUNCH_OK();
+    return DVD_OK;
+  }
   if (gen == 3) {
     float* pre = reinterpret_cast<float*>(ws + p.off_pre);
     hipLaunchKernelGGL(warp_prepare_kernel, dim3((a.B + 63) / 64), dim3(64), 0, stream, a, pre);

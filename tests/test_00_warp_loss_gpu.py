@@ -14,7 +14,7 @@ from oracle import losses as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['tiled', 'tile64x32', 'px4', 'direct', 'gen3', 'gen3_tile64x32'], autouse=True)
+@pytest.fixture(params=['tiled', 'tile64x32', 'px4', 'direct', 'gen3', 'gen3_tile64x32', 'gen4', 'gen4_tile64x32'], autouse=True)
 def warp_variant(request, monkeypatch):
     """Every case runs on the production tiled kernel (generation 1: the reference's rounding
     sequence for every pixel; auto tile shape), on the smallest tile shape (more tile seams /
@@ -31,6 +31,8 @@ def warp_variant(request, monkeypatch):
         monkeypatch.setenv('DVD_WARP_PX', '4')
     if request.param.startswith('gen3'):
         monkeypatch.setenv('DVD_WARP_GEN', '3')
+    if request.param.startswith('gen4'):
+        monkeypatch.setenv('DVD_WARP_GEN', '4')
     return request.param
 
 CAM_KEYS = ('R_1', 'R_2', 'R_1_T', 'R_2_T', 't_1', 't_2', 'K', 'K_inv')
@@ -252,15 +254,16 @@ def test_guard_banded_generation_matches_exact_generation_at_full_size(monkeypat
     cams = {k: batch[k] for k in CAM_KEYS}
     cfg = ops.warp_cfg(B, H, W, flow_mul=1.0, disp_mul=1.0)
     out = {}
-    for gen in ('1', '3'):
+    for gen in ('1', '3', '4'):
         for k in ('DVD_WARP_DIRECT', 'DVD_WARP_TILE', 'DVD_WARP_PX'):
             monkeypatch.delenv(k, raising=False)
         monkeypatch.setenv('DVD_WARP_GEN', gen)
         out[gen] = [t.clone() for t in ops.warp_loss_fused(cfg, d1, d2, batch['flow_1_2'], batch['mask_2'], sf, cams)]
-    s1, s3 = out['1'][0].cpu().numpy(), out['3'][0].cpu().numpy()
-    assert s1[0] == s3[0]
-    np.testing.assert_allclose(s3, s1, rtol=1e-5)
-    for name, a, b in zip(('g_depth_1', 'g_depth_2', 'g_sf'), out['1'][1:], out['3'][1:]):
-        scale = float(a.abs().max())
-        bad = ((a - b).abs() > 1e-4 * a.abs() + 1e-5 * scale).sum().item()
-        assert bad == 0, '%s: %d elements differ between generations' % (name, bad)
+    for g in ('3', '4'):
+        s1, s3 = out['1'][0].cpu().numpy(), out[g][0].cpu().numpy()
+        assert s1[0] == s3[0], g
+        np.testing.assert_allclose(s3, s1, rtol=1e-5)
+        for name, a, b in zip(('g_depth_1', 'g_depth_2', 'g_sf'), out['1'][1:], out[g][1:]):
+            scale = float(a.abs().max())
+            bad = ((a - b).abs() > 1e-4 * a.abs() + 1e-5 * scale).sum().item()
+            assert bad == 0, 'generation %s, %s: %d elements differ from generation 1' % (g, name, bad)
