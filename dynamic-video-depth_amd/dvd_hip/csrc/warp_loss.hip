@@ -25,8 +25,6 @@
 // index masks [depth_1<100], [W2.z<100], [I.z<1e-3] and the tap indices are
 // bit-identical to PyTorch's CPU path.  Build with -ffp-contract=off.
 
-#include <stdlib.h>
-
 #include "dvd_common.h"
 
 #ifndef DVD_WARP_PREFETCH
@@ -57,7 +55,6 @@ struct WarpArgs {
   int midas_mask, crit_l2, disp_mode, loss_on_sf;
   float flow_mul, disp_mul;
   float half_w, half_h, wmax, hmax;
-  int ablate;  // DVD_WARP_ABLATE bit mask, timing experiments only (1: no scatter, 2: no g stores, 4: no slab flush)
 };
 
 struct Cam {
@@ -283,7 +280,7 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
     h1 = DVD_FMA(uG0, c.R2[3], DVD_FMA(uG1, c.R2[4], uG2 * c.R2[5]));
     h2 += DVD_FMA(uG0, c.R2[6], DVD_FMA(uG1, c.R2[7], uG2 * c.R2[8]));
   }
-  if ((h0 != 0.0f || h1 != 0.0f || h2 != 0.0f) && !(a.ablate & 1)) {
+  if (h0 != 0.0f || h1 != 0.0f || h2 != 0.0f) {
     const float hb = DVD_FMA(h0, q0, DVD_FMA(h1, q1, h2 * q2));
     const float hx = DVD_FMA(h0, c.Ki[0], DVD_FMA(h1, c.Ki[1], h2 * c.Ki[2]));
     const float hy = DVD_FMA(h0, c.Ki[3], DVD_FMA(h1, c.Ki[4], h2 * c.Ki[5]));
@@ -422,10 +419,15 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
 // Blocks are numbered so that each XCD receives a contiguous run of tiles
 // (neighbouring tiles share depth_2 halo lines in that XCD's L2).
 
+// Window-overflow records go to kOvfLists separate lists (a block appends to list `block % kOvfLists`): returned
+// atomics on ONE word saturate at ~88 per microsecond on MI355X, which made a flow field that leaves the windows
+// (iid noise of 10 px) cost 8 ms; 256 counters on different cache lines take that to tens of microseconds.
+constexpr int kOvfLists = 256;
+constexpr int kOvfStride = 16;   // unsigned per counter: one 64-byte line each
 struct Overflow {
-  unsigned* count;
-  int2* rec;
-  unsigned cap;
+  unsigned* count;   // [kOvfLists * kOvfStride]
+  int2* rec;         // [kOvfLists][cap]
+  unsigned cap;      // records per list (sized so that no list can overflow)
 };
 
 // LDS accumulation is 64-bit fixed point (Q31.32): ds_add_u64 sustains ~6.5 lane-ops/clk/CU
@@ -437,12 +439,20 @@ constexpr float kFixScale = 4294967296.0f;          // 2^32
 constexpr float kFixInv = 1.0f / 4294967296.0f;
 constexpr float kFixMax = 1073741824.0f;            // 2^30
 
+// Q31.32 from a float with |v| < 2^30: hi = floor(v), lo = (v - floor(v)) * 2^32 (both exact).
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+  const float fl = floorf(v);
+  const unsigned lo = (unsigned)((v - fl) * kFixScale);
+  const unsigned hi = (unsigned)(int)fl;
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 template <int WW, int WH>
 struct TileIO {
   const float* d2b;          // depth_2 of this pair
   float* win;                // LDS [WH][WW]
   unsigned long long* accw;  // LDS [WH][WW], Q31.32
-  int W, wx0, wy0, pair_base;
+  int W, wx0, wy0, pair_base, list;
   float unit;                // accumulated values are multiplied by this at the end
   Overflow ovf;
   __device__ __forceinline__ bool inside(int x0, int y0) const {
@@ -463,13 +473,21 @@ struct TileIO {
       g.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
     }
   }
+  // (index, value) record for a tap the window cannot take; applied with global atomics after the slab combine.
+  // The lanes of the wave that are here together reserve their slots with ONE atomic on the shared counter
+  // (a flow field that leaves the windows used to serialise 30 M returned atomics on that counter: 8 ms).
   __device__ __forceinline__ void spill(int idx, float v) const {
-    const unsigned i = atomicAdd(ovf.count, 1u);
-    if (i < ovf.cap) ovf.rec[i] = make_int2(pair_base + idx, __float_as_int(v * unit));
+    const unsigned long long m = __ballot(1);
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    unsigned base = 0u;
+    if (lane == leader) base = atomicAdd(ovf.count + list * kOvfStride, (unsigned)__popcll(m));
+    base = __shfl(base, leader, 64);
+    const unsigned i = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (i < ovf.cap) ovf.rec[(size_t)list * ovf.cap + i] = make_int2(pair_base + idx, __float_as_int(v * unit));
   }
   __device__ __forceinline__ void add_fixed(unsigned long long* p, int idx, float v) const {
     if (fabsf(v) < kFixMax)
-      atomicAdd(p, (unsigned long long)(long long)(v * kFixScale));  // ds_add_u64
+      atomicAdd(p, to_fixed(v));  // ds_add_u64
     else
       spill(idx, v);
   }
@@ -493,6 +511,7 @@ struct TileIO {
 struct TileArgs {
   float* slabs;
   Overflow ovf;
+  const int2* offs;   // per pair: window offset (multiple of 4 in x), written by warp_prep_kernel
   int ntx, nty;
 };
 
@@ -530,7 +549,8 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   const int t = logical - b * tiles;
   const int tj = t / ta.ntx, ti = t - tj * ta.ntx;
   const int tx0 = ti * TW, ty0 = tj * TH;
-  const int wx0 = tx0 - R, wy0 = ty0 - R;
+  const int2 off = ta.offs[b];
+  const int wx0 = tx0 - R + off.x, wy0 = ty0 - R + off.y;
   Cam c;
   load_cam(a, b, c);
   // The 51 camera scalars are wave-uniform; left alone they all land in SGPRs and push the
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   }
   __syncthreads();
 
-  TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, a.disp_mul, ta.ovf};
+  TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, logical % kOvfLists, a.disp_mul, ta.ovf};
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   // ---- phase 1: the tile's pixels, PX per thread per step.  The inputs of step i+1 are requested before
   //      step i is evaluated: all waves of a block leave the barrier together, so without this every
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
         g1[i] = gs[1];
         g2[i] = gs[2];
       }
-      if (GRADS && !(a.ablate & 2)) {
+      if (GRADS) {
         float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
         if (wv) {
           *reinterpret_cast<vecf*>(a.g_d1 + base) = *reinterpret_cast<const vecf*>(gd1);
@@ -676,7 +696,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   }
   // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
   __syncthreads();
-  if (GRADS && !(a.ablate & 4)) {
+  if (GRADS) {
     float* slab = ta.slabs + (size_t)logical * (WW * WH);
     const float back = kFixInv * a.disp_mul;
     for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
@@ -702,635 +722,32 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
 }
 
 // ---------------------------------------------------------------------------
-// Helpers shared by the tiled kernels: unscaled exact division, fixed-point conversion,
-// branch-free sign, uniform-base addressing.
-// mag * sign(x), 0 when x == 0 (v_bfi + select)
-__device__ __forceinline__ float signed_mag(float mag, float x) {
-  return (x == 0.0f) ? 0.0f : __builtin_copysignf(mag, x);
-}
-
-// uniform base + 32-bit per-lane BYTE offset: lets the backend use the saddr+voffset addressing
-// form (no 64-bit VALU address arithmetic, one VGPR of address per lane)
-template <class T>
-__device__ __forceinline__ T ld_off(const float* base, unsigned byte_off) {
-  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-template <class T>
-__device__ __forceinline__ void st_off(float* base, unsigned byte_off, T v) {
-  *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
-}
-
-// Q31.32 from a float with |v| < 2^30: hi = floor(v), lo = (v - floor(v)) * 2^32 (both exact).
-__device__ __forceinline__ unsigned long long to_fixed(float v) {
-  const float fl = floorf(v);
-  const unsigned lo = (unsigned)((v - fl) * kFixScale);
-  const unsigned hi = (unsigned)(int)fl;
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-template <int WW, int WH>
-struct TileIO2 {
-  const float* d2b;
-  const float* win;
-  unsigned long long* accw;
-  int W, wx0, wy0, pair_base;
-  float unit;
-  Overflow ovf;
-  __device__ __forceinline__ void spill(int idx, float v) const {
-    if (v != 0.0f) {
-      const unsigned i = atomicAdd(ovf.count, 1u);
-      if (i < ovf.cap) ovf.rec[i] = make_int2(pair_base + idx, __float_as_int(v * unit));
-    }
+// One small launch before the tile kernel (it takes the place of the counter memset): zeroes the overflow counter
+// and chooses the window offset of every pair -- the pair's mean flow, sampled on an 8 x 8 grid, rounded (x to a
+// multiple of 4 so that window rows stay 16-byte aligned).  A coherent motion of tens of pixels (camera pan, the
+// frame gaps 2-4 of the shipped schedule) then lands inside the LDS windows instead of on the overflow path; mean
+// flows below 4 px keep the unshifted window.  Any offset is correct: it only moves where the on-chip window sits.
+__global__ __launch_bounds__(64) void warp_prep_kernel(const float* __restrict__ flow, int H, int W, int2* __restrict__ offs,
+                                                       unsigned* __restrict__ counters) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = b * 64 + lane; i < kOvfLists * kOvfStride; i += gridDim.x * 64) counters[i] = 0u;
+  const int gy = lane >> 3, gx = lane & 7;
+  const int y = (int)(((2 * gy + 1) * (long long)H) / 16), x = (int)(((2 * gx + 1) * (long long)W) / 16);
+  const float* f = flow + 2 * ((size_t)b * H * W + (size_t)y * W + x);
+  const float mx = wave_sum(f[0]) * (1.0f / 64.0f), my = wave_sum(f[1]) * (1.0f / 64.0f);
+  if (lane != 0) return;
+  int ox = 0, oy = 0;
+  if (fabsf(mx) >= 4.0f || fabsf(my) >= 4.0f) {
+    const float cx = fminf(fmaxf(mx, -(float)W), (float)W), cy = fminf(fmaxf(my, -(float)H), (float)H);   // (NaN -> bound)
+    ox = ((int)rintf(cx * 0.25f)) * 4;
+    oy = (int)rintf(cy);
   }
-};
-
-// ---------------------------------------------------------------------------
-// Tiled variant, third generation: guard-banded fast arithmetic (DVD_WARP_GEN=3; experimental, see launch_tiled).
-//
-// PMC on the first tiled kernel (profiles/r01_warp_loss_sq_counters.txt): 8.9e7 VALU wave
-// instructions per launch at 48x384x672 = 457 per pixel, VALU busy 63 % of the kernel time:
-// the kernel is bound by instruction issue, not by HBM.  Most of those instructions serve the
-// reference's exact rounding sequence ray -> p_cam -> P -> A -> Q -> I (five dependent 3x3
-// products, unfused), although bit-exactness is only REQUIRED where a value decides an index
-// or a mask: the tap indices, [I.z < 1e-3], [W2.z < 100], and the sign of
-// (dflow - flow) that the L1 sub-gradient takes.  So:
-//   * `warp_prepare_kernel` folds the camera block of every pair into composite matrices
-//     (computed in double): I = d1 * (c @ M3) + s @ M2 + tv, with c = (x, y, 1),
-//     M1 = K_inv R1, M2 = R2T K, M3 = M1 M2, tv = (t1 - t2) M2; p1_camera_2.z likewise from
-//     one row; the frame-2 warped point from (sum_k a_k c_k) @ (K_inv R2).  Per pixel that is
-//     ~35 FMAs instead of ~110 unfused operations, and the per-pixel live state shrinks.
-//   * every decision is taken on the fast value when it is outside a GUARD BAND around the
-//     threshold, sized from the operand magnitudes (error model in warp_prepare_kernel).  A
-//     pixel inside a band (about 1 in 1000) is NOT evaluated by the tile kernel at all: it
-//     contributes nothing there and its index goes to a fix-up list; `warp_post_kernel`
-//     (which also applies the window-overflow list) then evaluates exactly those pixels with the
-//     reference's exact sequence (the pixel<>() of the first generation) and adds their sums and
-//     gradients.  Masks, the valid-pixel count and the sub-gradient signs are therefore those of
-//     the exact kernels; everything else agrees within fp32 rounding (it was FAST arithmetic
-//     before, too).  Keeping the exact sequence out of the tile kernel is what makes it lean:
-//     inlined as a rare branch it cost 75 us of spills and divergence at 48x384x672.
-//   * the bilinear sampling position and weights keep the exact five-rounding sequence
-//     (tap indices), evaluated with the unscaled division of the second-generation kernel.
-
-#ifndef DVD_WARP3_PIN
-#define DVD_WARP3_PIN 0x3ffull   // bit g pins floats [3g, 3g+3) of the pair record into VGPRs
-#endif
-constexpr int kPreFloats = 64;
-// layout of one pair's record (floats)
-constexpr int kpM3 = 0, kpM2 = 9, kpTV = 18, kpM4 = 21, kpR2 = 24, kpTQ = 27, kpKZ = 28, kpM1 = 31, kpT1 = 40,
-              kpM5 = 43, kpT2 = 52, kpEAxy = 55, kpEBxy = 56, kpEAz = 57, kpEBz = 58, kpTsum = 59;
-
-// composite matrices + guard-band error model of pair b -> o[0..59] (one thread, double precision)
-__device__ void warp_prepare_pair(const WarpArgs& a, int b, float* __restrict__ o) {
-  double Ki[9], R1[9], R2[9], R2T[9], K[9], t1[3], t2[3];
-  for (int i = 0; i < 9; ++i) {
-    Ki[i] = a.Ki[b * 9 + i];
-    R1[i] = a.R1[b * 9 + i];
-    R2[i] = a.R2[b * 9 + i];
-    R2T[i] = a.R2T[b * 9 + i];
-    K[i] = a.K[b * 9 + i];
-  }
-  for (int i = 0; i < 3; ++i) {
-    t1[i] = a.t1[b * 3 + i];
-    t2[i] = a.t2[b * 3 + i];
-  }
-  auto mm = [](const double* A, const double* B, double* C) {
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
-  };
-  double M1[9], M2[9], M3[9], M5[9];
-  mm(Ki, R1, M1);
-  mm(R2T, K, M2);
-  mm(M1, M2, M3);
-  mm(Ki, R2, M5);
-  for (int i = 0; i < 9; ++i) {
-    o[kpM3 + i] = (float)M3[i];
-    o[kpM2 + i] = (float)M2[i];
-    o[kpM1 + i] = (float)M1[i];
-    o[kpM5 + i] = (float)M5[i];
-  }
-  double tq = 0.0;
-  for (int j = 0; j < 3; ++j) {
-    double tv = 0.0, m4 = 0.0;
-    for (int i = 0; i < 3; ++i) {
-      tv += (t1[i] - t2[i]) * M2[i * 3 + j];
-      m4 += M1[j * 3 + i] * R2T[i * 3 + 2];
-    }
-    o[kpTV + j] = (float)tv;
-    o[kpM4 + j] = (float)m4;
-    o[kpR2 + j] = (float)R2T[j * 3 + 2];
-    o[kpKZ + j] = (float)Ki[j * 3 + 2];
-    o[kpT1 + j] = (float)t1[j];
-    o[kpT2 + j] = (float)t2[j];
-    tq += (t1[j] - t2[j]) * R2T[j * 3 + 2];
-  }
-  o[kpTQ] = (float)tq;
-  // ---- error model of the guard bands.  Row-vector products: |v @ M|_1 <= |v|_1 * n(M),
-  // n(M) = max_i sum_j |M_ij|.  For every pixel of the pair
-  //   |ray|_1 <= rb = sum_j (W |Ki_0j| + H |Ki_1j| + |Ki_2j|),
-  //   |Q|_1  <= (|d1| rb n(R1) + |t1|_1 + |t2|_1 + |s|_1) n(R2T),   |I_j| <= |Q|_1 max_i |K_ij|.
-  // Both evaluation orders (the reference's and the composite one) are sums of at most ~20
-  // products of such magnitudes, so each is within 20 * 2^-24 * bound of the real value; the band
-  // is 2^-18 * bound (> 2 * 20 * 2^-24), i.e. conservative by construction.
-  auto nrm = [](const double* M) {
-    double n = 0.0;
-    for (int i = 0; i < 3; ++i) {
-      const double r = fabs(M[i * 3]) + fabs(M[i * 3 + 1]) + fabs(M[i * 3 + 2]);
-      n = r > n ? r : n;
-    }
-    return n;
-  };
-  double rb = 0.0;
-  for (int j = 0; j < 3; ++j) rb += a.W * fabs(Ki[j]) + a.H * fabs(Ki[3 + j]) + fabs(Ki[6 + j]);
-  auto colmax = [&](int j) {
-    const double m01 = fabs(K[j]) > fabs(K[3 + j]) ? fabs(K[j]) : fabs(K[3 + j]);
-    return m01 > fabs(K[6 + j]) ? m01 : fabs(K[6 + j]);
-  };
-  const double kxy = colmax(0) > colmax(1) ? colmax(0) : colmax(1), kz = colmax(2);
-  const double eps = 1.0 / 2097152.0;  // 2^-21
-  const double nq = nrm(R2T);
-  o[kpEAxy] = (float)(eps * kxy * nq * rb * nrm(R1));
-  o[kpEBxy] = (float)(eps * kxy * nq);
-  o[kpEAz] = (float)(eps * kz * nq * rb * nrm(R1));
-  o[kpEBz] = (float)(eps * kz * nq);
-  o[kpTsum] = (float)(fabs(t1[0]) + fabs(t1[1]) + fabs(t1[2]) + fabs(t2[0]) + fabs(t2[1]) + fabs(t2[2]));
-  for (int i = 60; i < kPreFloats; ++i) o[i] = 0.0f;
-}
-
-__global__ __launch_bounds__(64) void warp_prepare_kernel(const WarpArgs a, float* __restrict__ pre) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b >= a.B) return;
-  warp_prepare_pair(a, b, pre + (size_t)b * kPreFloats);
-}
-
-struct Pre {
-  float M3[9], M2[9], tv[3], m4[3], r2[3], tq, kz[3], M1[9], t1[3], M5[9], t2[3], eAxy, eBxy, eAz, eBz, tsum;
-};
-
-// The reference's exact I = (((d1 * (c @ Ki)) @ R1 + t1 + s) - t2) @ R2T @ K for one pixel, from the
-// raw camera block (only evaluated inside a guard band).
-// The reference's exact sequence for guard-band pixels lives in warp_post_kernel (below).
-__device__ __forceinline__ float sample_coord_x(float pix, float fl, float half, float rhalf, float maxv) {
-  float g = pix + fl;
-  g = div_exact1(g, half, rhalf);
-  g = g - 1.0f;
-  const float i = (g + 1.0f) * half;
-  return fminf(maxv, fmaxf(i, 0.0f));
-}
-
-struct RowConst {   // per image row: the y part of c @ M for the three composite matrices
-  float c3[3], c4, c1[3];
-};
-
-// One pixel, fast arithmetic + guard bands.  `k` = the pair's composite constants.
-template <bool GRADS, bool SHIPPED, int WW, int WH>
-__device__ __forceinline__ bool pixel_fast(const WarpArgs& a, const Pre& k, const TileIO2<WW, WH>& io,
-                                           float rhw, float rhh, const RowConst& rc, int y, int x, float d1,
-                                           float fx, float fy, float mk, float s0, float s1, float s2,
-                                           float acc[4], float& g_d1_out, float g_s_out[3]) {
-  const bool midas_mask = SHIPPED ? true : (a.midas_mask != 0);
-  const int disp_mode = SHIPPED ? 1 : a.disp_mode;
-  const bool loss_on_sf = SHIPPED ? false : (a.loss_on_sf != 0);
-  const float xf = (float)x, yf = (float)y;
-  // --- EXACT: sampling position, tap indices, bilinear weights
-  const float ix = sample_coord_x(xf, fx, a.half_w, rhw, a.wmax);
-  const float iy = sample_coord_x(yf, fy, a.half_h, rhh, a.hmax);
-  const float x0f = floorf(ix), y0f = floorf(iy);
-  const float ww = ix - x0f, we = 1.0f - ww;
-  const float wn = iy - y0f, ws = 1.0f - wn;
-  const float w_nw = ws * we, w_ne = ws * ww, w_sw = wn * we, w_se = wn * ww;
-  const int x0 = (int)x0f, y0 = (int)y0f;
-  const int lx = x0 - io.wx0, ly = y0 - io.wy0;
-  const bool inside = ((unsigned)lx < (unsigned)(WW - 1)) && ((unsigned)ly < (unsigned)(WH - 1));
-  const int cell = inside ? ly * WW + lx : 0;
-  float dnw, dne, dsw, dse;
-  {
-    const float* p = io.win + cell;
-    dnw = p[0];
-    dne = p[1];
-    dsw = p[WW];
-    dse = p[WW + 1];
-    if (!inside) {
-      DirectIO g{io.d2b, nullptr, io.W, 1.0f};
-      g.fetch(y0 * io.W + x0, x0, y0, (x0 + 1) < a.W, (y0 + 1) < a.H, dnw, dne, dsw, dse);
-    }
-  }
-  // --- frame-2 point warped to the pixel: sum_k a_k c_k with c_k = (x0+i, y0+j, 1)
-  const float a_nw = w_nw * dnw, a_ne = w_ne * dne, a_sw = w_sw * dsw, a_se = w_se * dse;
-  const float sE = a_ne + a_se, sS = a_sw + a_se, sA = (a_nw + a_ne) + sS;
-  const float vx = DVD_FMA(x0f, sA, sE), vy = DVD_FMA(y0f, sA, sS);
-  float W2z = DVD_FMA(vx, k.kz[0], DVD_FMA(vy, k.kz[1], sA * k.kz[2]));
-  const bool w2_lt = W2z < 100.0f;
-  // guard band of [W2.z < 100] (also catches NaN); the composite value is within 1e-3 of the reference's
-  bool unsure = midas_mask && !(fabsf(W2z - 100.0f) > 1.0f);
-  // --- reprojection of pixel 1 into image 2: I = d1 (c @ M3) + s @ M2 + tv
-  const float c30 = DVD_FMA(xf, k.M3[0], rc.c3[0]), c31 = DVD_FMA(xf, k.M3[1], rc.c3[1]),
-              c32 = DVD_FMA(xf, k.M3[2], rc.c3[2]);
-  const float c4 = DVD_FMA(xf, k.m4[0], rc.c4);
-  const float I0 = DVD_FMA(d1, c30, DVD_FMA(s0, k.M2[0], DVD_FMA(s1, k.M2[3], DVD_FMA(s2, k.M2[6], k.tv[0]))));
-  const float I1 = DVD_FMA(d1, c31, DVD_FMA(s0, k.M2[1], DVD_FMA(s1, k.M2[4], DVD_FMA(s2, k.M2[7], k.tv[1]))));
-  const float I2 = DVD_FMA(d1, c32, DVD_FMA(s0, k.M2[2], DVD_FMA(s1, k.M2[5], DVD_FMA(s2, k.M2[8], k.tv[2]))));
-  const float Q2 = DVD_FMA(d1, c4, DVD_FMA(s0, k.r2[0], DVD_FMA(s1, k.r2[1], DVD_FMA(s2, k.r2[2], k.tq))));
-  const float den = I2 + 1e-8f;
-  const float rden = __builtin_amdgcn_rcpf(den);
-  const bool behind = I2 < 1e-3f;
-  // the reference overwrites the projection of a behind-camera point by the pixel's own coordinates
-  const float u = behind ? xf : I0 * rden, v = behind ? yf : I1 * rden;
-  const float ex = (u - xf) - fx, ey = (v - yf) - fy;
-  {
-    // guard bands: |I_fast - I_ref| <= E (see warp_prepare_kernel)
-    const float smag = (fabsf(s0) + fabsf(s1)) + (fabsf(s2) + k.tsum);
-    const float ad1 = fabsf(d1);
-    const float Exy = DVD_FMA(ad1, k.eAxy, smag * k.eBxy), Ez = DVD_FMA(ad1, k.eAz, smag * k.eBz);
-    const float gu = DVD_FMA(fmaxf(fabsf(u), fabsf(v)), Ez, Exy) * fabsf(rden) * 1.25f;
-    const bool sure_behind = I2 < 1e-3f - Ez, sure_front = I2 > 1e-3f + Ez;
-    // the L1 sub-gradient takes sign(dflow - flow); the squared criterion of the warm phase does not
-    const bool signs_ok = a.crit_l2 || ((fabsf(ex) > gu) && (fabsf(ey) > gu));
-    unsure = unsure || !(sure_behind || (sure_front && signs_ok));   // NaNs land here too
-  }
-  if (unsure) mk = 0.0f;   // evaluated by warp_post_kernel instead: contributes nothing here
-  // --- sf_by_depth - sf = (sum_k a_k c_k) @ M5 + t2 - (d1 (c @ M1) + t1) - s
-  const float c10 = DVD_FMA(xf, k.M1[0], rc.c1[0]), c11 = DVD_FMA(xf, k.M1[1], rc.c1[1]),
-              c12 = DVD_FMA(xf, k.M1[2], rc.c1[2]);
-  const float f0 = DVD_FMA(vx, k.M5[0], DVD_FMA(vy, k.M5[3], DVD_FMA(sA, k.M5[6], k.t2[0]))) -
-                   (DVD_FMA(d1, c10, k.t1[0]) + s0);
-  const float f1 = DVD_FMA(vx, k.M5[1], DVD_FMA(vy, k.M5[4], DVD_FMA(sA, k.M5[7], k.t2[1]))) -
-                   (DVD_FMA(d1, c11, k.t1[1]) + s1);
-  const float f2 = DVD_FMA(vx, k.M5[2], DVD_FMA(vy, k.M5[5], DVD_FMA(sA, k.M5[8], k.t2[2]))) -
-                   (DVD_FMA(d1, c12, k.t1[2]) + s2);
-  // --- mask and per-pixel errors
-  float m = mk;
-  if (midas_mask) m = ((d1 < 100.0f) && w2_lt) ? m : 0.0f;   // mask_2 is {0,1}
-  const float flow_err = a.crit_l2 ? (ex * ex + ey * ey) : (fabsf(ex) + fabsf(ey));
-  float disp_err, rca = 0.0f, rcb = 0.0f, ediff = 0.0f;
-  if (disp_mode == 1) {
-    rca = __builtin_amdgcn_rcpf(fmaxf(Q2, 1e-3f));
-    rcb = __builtin_amdgcn_rcpf(fmaxf(W2z, 1e-3f));
-    ediff = rca - rcb;
-    disp_err = 100.0f * fabsf(ediff);
-  } else if (disp_mode == 2) {
-    const float ca = fmaxf(Q2, 1e-3f), cb = fmaxf(W2z, 1e-3f);
-    disp_err = fmaxf(ca, cb) * __builtin_amdgcn_rcpf(fminf(ca, cb)) - 1.0f;
-  } else {
-    disp_err = fabsf(Q2 - W2z);
-  }
-  const float sf_err = (fabsf(f0) + fabsf(f1)) + fabsf(f2);
-  acc[0] += m;
-  acc[1] = DVD_FMA(m, unsure ? 0.0f : flow_err, acc[1]);   // exactly nothing from a pixel left to the fix-up pass
-  acc[2] = DVD_FMA(m, unsure ? 0.0f : disp_err, acc[2]);
-  acc[3] = DVD_FMA(m, unsure ? 0.0f : sf_err, acc[3]);
-  if (!GRADS) return unsure;
-  // ------------------------------ backward (un-normalised), branch free ------------------
-  const float fm = behind ? 0.0f : a.flow_mul * m;
-  const float gu_ = a.crit_l2 ? fm * 2.0f * ex : signed_mag(fm, ex);
-  const float gv_ = a.crit_l2 ? fm * 2.0f * ey : signed_mag(fm, ey);
-  const float rd = behind ? 0.0f : rden;
-  const float gI0 = gu_ * rd, gI1 = gv_ * rd;
-  const float gI2 = -DVD_FMA(gu_, u, gv_ * v) * rd;
-  float gQ2 = 0.0f, uW2z = 0.0f, uG0 = 0.0f, uG1 = 0.0f, uG2 = 0.0f;
-  const float dm = a.disp_mul;
-  if (!loss_on_sf) {
-    if (disp_mode == 1) {
-      const float ue = signed_mag(m * 100.0f, ediff);
-      gQ2 = (Q2 >= 1e-3f) ? -(ue * dm) * (rca * rca) : 0.0f;
-      uW2z = (W2z >= 1e-3f) ? ue * (rcb * rcb) : 0.0f;
-    }   // !loss_on_sf implies --use_disp, i.e. disp_mode 1 (models/scene_flow_motion_field.py:310-319)
-  } else {
-    uG0 = signed_mag(m, f0);
-    uG1 = signed_mag(m, f1);
-    uG2 = signed_mag(m, f2);
-  }
-  g_s_out[0] = DVD_FMA(gI0, k.M2[0], DVD_FMA(gI1, k.M2[1], DVD_FMA(gI2, k.M2[2], DVD_FMA(gQ2, k.r2[0], -dm * uG0))));
-  g_s_out[1] = DVD_FMA(gI0, k.M2[3], DVD_FMA(gI1, k.M2[4], DVD_FMA(gI2, k.M2[5], DVD_FMA(gQ2, k.r2[1], -dm * uG1))));
-  g_s_out[2] = DVD_FMA(gI0, k.M2[6], DVD_FMA(gI1, k.M2[7], DVD_FMA(gI2, k.M2[8], DVD_FMA(gQ2, k.r2[2], -dm * uG2))));
-  float gd = DVD_FMA(gI0, c30, DVD_FMA(gI1, c31, DVD_FMA(gI2, c32, gQ2 * c4)));
-  if (loss_on_sf) gd = gd - dm * DVD_FMA(uG0, c10, DVD_FMA(uG1, c11, uG2 * c12));
-  g_d1_out = gd;
-  if (a.ablate & 1) return unsure;
-  // depth_2 taps (units of disp_mul): d/d(a_k) = H . c_k,  H = uG @ M5^T + uW2z * kz
-  float Hx = uW2z * k.kz[0], Hy = uW2z * k.kz[1], Hz = uW2z * k.kz[2];
-  if (loss_on_sf) {
-    Hx = DVD_FMA(uG0, k.M5[0], DVD_FMA(uG1, k.M5[1], DVD_FMA(uG2, k.M5[2], Hx)));
-    Hy = DVD_FMA(uG0, k.M5[3], DVD_FMA(uG1, k.M5[4], DVD_FMA(uG2, k.M5[5], Hy)));
-    Hz = DVD_FMA(uG0, k.M5[6], DVD_FMA(uG1, k.M5[7], DVD_FMA(uG2, k.M5[8], Hz)));
-  }
-  const float hb = DVD_FMA(x0f, Hx, DVD_FMA(y0f, Hy, Hz));
-  const float hbx = hb + Hx;
-  const float tn0 = w_nw * hb, tn1 = w_ne * hbx, ts0 = w_sw * (hb + Hy), ts1 = w_se * (hbx + Hy);
-  const float big = fmaxf(fmaxf(fabsf(tn0), fabsf(tn1)), fmaxf(fabsf(ts0), fabsf(ts1)));
-  const bool fast = inside && (big < kFixMax) && !unsure;
-  // out-of-image taps carry an exactly zero weight, and their window cells are never read back
-  unsigned long long* p = io.accw + cell;
-  atomicAdd(p, to_fixed(fast ? tn0 : 0.0f));
-  atomicAdd(p + 1, to_fixed(fast ? tn1 : 0.0f));
-  atomicAdd(p + WW, to_fixed(fast ? ts0 : 0.0f));
-  atomicAdd(p + WW + 1, to_fixed(fast ? ts1 : 0.0f));
-  if (!fast && !unsure) {   // rare: list of (index, value) applied after the slab combine
-    const int o_n = y0 * io.W + x0;
-    const bool in_e = (x0 + 1) < a.W, in_s = (y0 + 1) < a.H;
-    io.spill(o_n, tn0);
-    if (in_e) io.spill(o_n + 1, tn1);
-    if (in_s) io.spill(o_n + io.W, ts0);
-    if (in_e && in_s) io.spill(o_n + io.W + 1, ts1);
-  }
-  return unsure;
-}
-
-template <int TW, int TH, int R, int NT, bool GRADS, bool SHIPPED, int PX>
-__global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_loss_tiled3_kernel(
-    const WarpArgs a, const TileArgs ta, const float* __restrict__ pre, const Overflow fix) {
-  constexpr int WW = TW + 2 * R + 4;
-  constexpr int WH = TH + 2 * R + 1;
-  constexpr int QW = TW / PX;
-  typedef float vecf __attribute__((ext_vector_type(PX)));
-  static_assert(R % 4 == 0 && TW % 4 == 0, "tile geometry");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);
-  float* win = smem + 2 * WW * WH;
-
-  const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const int tiles = ta.ntx * ta.nty;
-  const int b = logical / tiles;
-  const int t = logical - b * tiles;
-  const int tj = t / ta.ntx, ti = t - tj * ta.ntx;
-  const int tx0 = ti * TW, ty0 = tj * TH;
-  const int wx0 = tx0 - R, wy0 = ty0 - R;
-  // composite camera constants of this pair: wave-uniform, held in VGPRs (60 scalars next to the
-  // kernel's pointers do not fit the SGPR file; as VALU operands VGPRs cost nothing extra)
-  Pre k;
-  {
-    const float* src = pre + (size_t)b * kPreFloats;
-    float t_[60];
-#pragma unroll
-    for (int i = 0; i < 60; ++i) {
-      t_[i] = src[i];
-      if ((DVD_WARP3_PIN >> (i / 3)) & 1) asm volatile("" : "+v"(t_[i]));
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      k.M3[i] = t_[kpM3 + i];
-      k.M2[i] = t_[kpM2 + i];
-      k.M1[i] = t_[kpM1 + i];
-      k.M5[i] = t_[kpM5 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      k.tv[i] = t_[kpTV + i];
-      k.m4[i] = t_[kpM4 + i];
-      k.r2[i] = t_[kpR2 + i];
-      k.kz[i] = t_[kpKZ + i];
-      k.t1[i] = t_[kpT1 + i];
-      k.t2[i] = t_[kpT2 + i];
-    }
-    k.tq = t_[kpTQ];
-    k.eAxy = t_[kpEAxy];
-    k.eBxy = t_[kpEBxy];
-    k.eAz = t_[kpEAz];
-    k.eBz = t_[kpEBz];
-    k.tsum = t_[kpTsum];
-  }
-  const float* d2b = a.d2 + (size_t)b * a.HW;
-
-  // ---- phase 0: fill the depth_2 window, clear the accumulator
-  const bool w4 = (a.W & 3) == 0;
-  for (int i = threadIdx.x; i < (WW / 4) * WH; i += NT) {
-    const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
-    const int iy = wy0 + wy, ixx = wx0 + wx;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iy >= 0 && iy < a.H) {
-      if (w4) {
-        if (ixx >= 0 && ixx < a.W) v = *reinterpret_cast<const float4*>(d2b + (size_t)iy * a.W + ixx);
-      } else {
-        const float* row = d2b + (size_t)iy * a.W;
-        if (ixx >= 0 && ixx < a.W) v.x = row[ixx];
-        if (ixx + 1 >= 0 && ixx + 1 < a.W) v.y = row[ixx + 1];
-        if (ixx + 2 >= 0 && ixx + 2 < a.W) v.z = row[ixx + 2];
-        if (ixx + 3 >= 0 && ixx + 3 < a.W) v.w = row[ixx + 3];
-      }
-    }
-    *reinterpret_cast<float4*>(win + wy * WW + wx) = v;
-    if (GRADS) {
-      uint4* z = reinterpret_cast<uint4*>(accw + wy * WW + wx);
-      z[0] = make_uint4(0u, 0u, 0u, 0u);
-      z[1] = make_uint4(0u, 0u, 0u, 0u);
-    }
-  }
-  __syncthreads();
-
-  const TileIO2<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, a.disp_mul, ta.ovf};
-  const float rhw = rcp_refined(a.half_w), rhh = rcp_refined(a.half_h);
-  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  const float* d1b = a.d1 + (size_t)b * a.HW;
-  const float* mkb = a.mask + (size_t)b * a.HW;
-  const float* flb = a.flow + 2 * (size_t)b * a.HW;
-  const float* sf0b = a.sf + (size_t)b * 3 * a.HW;
-  const float* sf1b = sf0b + a.HW;
-  const float* sf2b = sf1b + a.HW;
-  float* gd1b = a.g_d1 + (size_t)b * a.HW;
-  float* gs0b = a.g_sf + (size_t)b * 3 * a.HW;
-  float* gs1b = gs0b + a.HW;
-  float* gs2b = gs1b + a.HW;
-  // ---- phase 1: the tile's pixels, PX per thread per step; the inputs of step i+1 are requested
-  //      before step i is evaluated (all waves of a block leave the barrier together, so without
-  //      this every load latency of the block is exposed at the same time)
-  const bool wv = (a.W % PX) == 0;
-  struct In {
-    float d1[PX], mk[PX], fl[2 * PX], s0[PX], s1[PX], s2[PX];
-  };
-  auto locate = [&](int q, int& x, int& y) {
-    const int ly = q / QW, lx = (q - ly * QW) * PX;
-    y = ty0 + ly;
-    x = tx0 + lx;
-    return (q < QW * TH) && (y < a.H) && (x < a.W);
-  };
-  auto fetch = [&](int q, In& r) {
-    int x, y;
-    if (!locate(q, x, y)) return;
-    const unsigned p0 = (unsigned)(y * a.W + x);
-    const int nvalid = (a.W - x) < PX ? (a.W - x) : PX;
-    if (wv) {
-      const unsigned o4 = p0 * 4u;
-      *reinterpret_cast<vecf*>(r.d1) = ld_off<vecf>(d1b, o4);
-      *reinterpret_cast<vecf*>(r.mk) = ld_off<vecf>(mkb, o4);
-      *reinterpret_cast<vecf*>(r.fl) = ld_off<vecf>(flb, o4 * 2u);
-      *reinterpret_cast<vecf*>(r.fl + PX) = ld_off<vecf>(flb, o4 * 2u + 4u * PX);
-      *reinterpret_cast<vecf*>(r.s0) = ld_off<vecf>(sf0b, o4);
-      *reinterpret_cast<vecf*>(r.s1) = ld_off<vecf>(sf1b, o4);
-      *reinterpret_cast<vecf*>(r.s2) = ld_off<vecf>(sf2b, o4);
-    } else {
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        const bool ok = i < nvalid;
-        r.d1[i] = ok ? d1b[p0 + i] : 1.0f;
-        r.mk[i] = ok ? mkb[p0 + i] : 0.0f;
-        r.fl[2 * i] = ok ? flb[2 * (size_t)(p0 + i)] : 0.0f;
-        r.fl[2 * i + 1] = ok ? flb[2 * (size_t)(p0 + i) + 1] : 0.0f;
-        r.s0[i] = ok ? sf0b[p0 + i] : 0.0f;
-        r.s1[i] = ok ? sf1b[p0 + i] : 0.0f;
-        r.s2[i] = ok ? sf2b[p0 + i] : 0.0f;
-      }
-    }
-  };
-  In cur, nxt;
-  fetch(threadIdx.x, cur);
-  for (int q = threadIdx.x; q < QW * TH; q += NT) {
-    fetch(q + NT, nxt);
-    int x, y;
-    if (locate(q, x, y)) {
-      const unsigned p0 = (unsigned)(y * a.W + x);
-      const int nvalid = (a.W - x) < PX ? (a.W - x) : PX;
-      RowConst rc;
-      {
-        const float yf = (float)y;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          rc.c3[j] = DVD_FMA(yf, k.M3[3 + j], k.M3[6 + j]);
-          rc.c1[j] = DVD_FMA(yf, k.M1[3 + j], k.M1[6 + j]);
-        }
-        rc.c4 = DVD_FMA(yf, k.m4[1], k.m4[2]);
-      }
-      float gd1[PX], g0[PX], g1[PX], g2[PX];
-      unsigned unsure_bits = 0u;
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        float gs[3] = {0.0f, 0.0f, 0.0f};
-        gd1[i] = 0.0f;
-        if (i < nvalid) {
-          const bool un = pixel_fast<GRADS, SHIPPED, WW, WH>(a, k, io, rhw, rhh, rc, y, x + i, cur.d1[i], cur.fl[2 * i],
-                                                             cur.fl[2 * i + 1], cur.mk[i], cur.s0[i], cur.s1[i],
-                                                             cur.s2[i], acc, gd1[i], gs);
-          unsure_bits |= un ? (1u << i) : 0u;
-        }
-        g0[i] = gs[0];
-        g1[i] = gs[1];
-        g2[i] = gs[2];
-      }
-      if (unsure_bits) {   // about 1 pixel in 1000: left to warp_post_kernel
-#pragma unroll
-        for (int i = 0; i < PX; ++i) {
-          if (unsure_bits & (1u << i)) {
-            const unsigned slot = atomicAdd(fix.count, 1u);
-            if (slot < fix.cap) reinterpret_cast<int*>(fix.rec)[slot] = (int)(b * a.HW + p0 + i);
-          }
-        }
-      }
-      if (GRADS && !(a.ablate & 2)) {
-        if (wv) {
-          const unsigned o4 = p0 * 4u;
-          st_off<vecf>(gd1b, o4, *reinterpret_cast<const vecf*>(gd1));
-          st_off<vecf>(gs0b, o4, *reinterpret_cast<const vecf*>(g0));
-          st_off<vecf>(gs1b, o4, *reinterpret_cast<const vecf*>(g1));
-          st_off<vecf>(gs2b, o4, *reinterpret_cast<const vecf*>(g2));
-        } else {
-          for (int i = 0; i < nvalid; ++i) {
-            gd1b[p0 + i] = gd1[i];
-            gs0b[p0 + i] = g0[i];
-            gs1b[p0 + i] = g1[i];
-            gs2b[p0 + i] = g2[i];
-          }
-        }
-      }
-    }
-    cur = nxt;
-  }
-  // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
-  __syncthreads();
-  if (GRADS && !(a.ablate & 4)) {
-    float* slab = ta.slabs + (size_t)logical * (WW * WH);
-    const float back = kFixInv * a.disp_mul;
-    for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
-      const longlong2 lo = reinterpret_cast<const longlong2*>(accw)[2 * i];
-      const longlong2 hi = reinterpret_cast<const longlong2*>(accw)[2 * i + 1];
-      reinterpret_cast<float4*>(slab)[i] =
-          make_float4((float)lo.x * back, (float)lo.y * back, (float)hi.x * back, (float)hi.y * back);
-    }
-  }
-  float* red = win;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    const float v = wave_sum(acc[kk]);
-    if (lane == 0) red[wave * 4 + kk] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    float v = 0.0f;
-    for (int w = 0; w < NT / 64; ++w) v += red[w * 4 + threadIdx.x];
-    a.partial[(size_t)logical * 4 + threadIdx.x] = v;
-  }
-}
-
-// After the slab combine: (1) the window-overflow records, (2) the guard-band pixels of the
-// third-generation tile kernel, evaluated with the reference's exact sequence (pixel<>() of the
-// first generation on global memory); their four loss terms are accumulated in Q31.32 integers
-// (order independent) that reduce_partials_kernel adds to the block partials.
-struct FixIO {
-  const float* d2b;
-  float* gb;
-  int W;
-  float unit;
-  __device__ __forceinline__ void fetch(int o_n, int x0, int y0, bool in_e, bool in_s, float& dnw, float& dne,
-                                        float& dsw, float& dse) const {
-    DirectIO g{d2b, nullptr, W, 1.0f};
-    g.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
-  }
-  __device__ __forceinline__ void scatter(int o_n, int, int, bool in_e, bool in_s, float tnw, float tne, float tsw,
-                                          float tse) const {
-    unsafeAtomicAdd(gb + o_n, tnw * unit);
-    if (in_e) unsafeAtomicAdd(gb + o_n + 1, tne * unit);
-    if (in_s) unsafeAtomicAdd(gb + o_n + W, tsw * unit);
-    if (in_e && in_s) unsafeAtomicAdd(gb + o_n + W + 1, tse * unit);
-  }
-};
-
-template <bool GRADS>
-__global__ __launch_bounds__(256) void warp_post_kernel(const WarpArgs a, const Overflow ovf, const Overflow fix,
-                                                        unsigned long long* __restrict__ fix_sums) {
-  if (GRADS) {
-    unsigned n = *ovf.count;
-    if (n > ovf.cap) n = ovf.cap;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-      const int2 r = ovf.rec[i];
-      unsafeAtomicAdd(a.g_d2 + r.x, __int_as_float(r.y));
-    }
-  }
-  unsigned nf = *fix.count;
-  if (nf > fix.cap) nf = fix.cap;
-  unsigned long long tot[4] = {0ull, 0ull, 0ull, 0ull};
-  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nf; i += gridDim.x * 256) {
-    const int lin = reinterpret_cast<const int*>(fix.rec)[i];
-    const int b = lin / a.HW, p0 = lin - b * a.HW;
-    const int y = p0 / a.W, x = p0 - y * a.W;
-    Cam c;
-    load_cam(a, b, c);
-    FixIO io{a.d2 + (size_t)b * a.HW, GRADS ? a.g_d2 + (size_t)b * a.HW : nullptr, a.W, a.disp_mul};
-    const float* sfb = a.sf + (size_t)b * 3 * a.HW + p0;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gd1 = 0.0f, gs[3] = {0.0f, 0.0f, 0.0f};
-    pixel<GRADS, false>(a, c, io, y, x, a.d1[lin], a.flow[2 * (size_t)lin], a.flow[2 * (size_t)lin + 1], a.mask[lin],
-                        sfb[0], sfb[a.HW], sfb[2 * a.HW], acc, gd1, gs);
-    if (GRADS) {
-      float* gsb = a.g_sf + (size_t)b * 3 * a.HW + p0;
-      a.g_d1[lin] = gd1;
-      gsb[0] = gs[0];
-      gsb[a.HW] = gs[1];
-      gsb[2 * a.HW] = gs[2];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tot[j] += to_fixed(fminf(acc[j], kFixMax));
-  }
-  // integer sums: exact and order independent; one atomic per wave and term
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    unsigned long long v = tot[j];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v != 0ull) atomicAdd(fix_sums + j, v);
-  }
+  offs[b] = make_int2(ox, oy);
 }
 
 // g_depth_2[b,y,x] = sum over the tiles whose window covers (x,y), fixed order.
 template <int TW, int TH, int R>
-__global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ slabs,
+__global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ slabs, const int2* __restrict__ offs,
                                                             float* __restrict__ g_d2, int H, int W, int ntx,
                                                             int nty, int total_quads) {
   constexpr int WW = TW + 2 * R + 4;
@@ -1342,17 +759,19 @@ __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restr
   const int row = qid / qpr;
   const int x = (qid - row * qpr) * 4;
   const int b = row / H, y = row - b * H;
-  const int ti = x / TW, tj = y / TH;
+  const int2 off = offs[b];
+  const int xs = x - off.x, ys = y - off.y;          // coordinates in the pair's shifted tile grid
+  const int ti = xs >= 0 ? xs / TW : -((TW - 1 - xs) / TW), tj = ys >= 0 ? ys / TH : -((TH - 1 - ys) / TH);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int dj = -1; dj <= 1; ++dj) {
     const int j = tj + dj;
-    const int wy = y - (j * TH - R);
+    const int wy = ys - (j * TH - R);
     if (j < 0 || j >= nty || wy < 0 || wy >= WH) continue;
 #pragma unroll
     for (int di = -1; di <= 1; ++di) {
       const int i = ti + di;
-      const int wx = x - (i * TW - R);
+      const int wx = xs - (i * TW - R);
       if (i < 0 || i >= ntx || wx < 0 || wx + 3 >= WW) continue;
       const float4 v =
           *reinterpret_cast<const float4*>(slabs + ((size_t)(b * nty + j) * ntx + i) * (WW * WH) + wy * WW + wx);
@@ -1375,8 +794,7 @@ __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restr
 
 // Second stage: fixed-order sum of the per-block partials (deterministic).
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int n,
-                                                               float* __restrict__ sums,
-                                                               const unsigned long long* __restrict__ fix_sums) {
+                                                               float* __restrict__ sums) {
   __shared__ double sh[1024][4];
   double acc[4] = {0, 0, 0, 0};
   for (int i = threadIdx.x; i < n; i += 1024) {
@@ -1397,13 +815,11 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __re
     __syncthreads();
   }
   if (threadIdx.x < 4) {
-    double v = sh[0][threadIdx.x];
-    if (fix_sums) v += (double)(long long)fix_sums[threadIdx.x] * (1.0 / 4294967296.0);   // guard-band pixels (generation 3)
-    sums[threadIdx.x] = (float)v;
+    sums[threadIdx.x] = (float)sh[0][threadIdx.x];
   }
 }
 
-// Last launch of the generation-1 sequence: block 0 sums the per-tile partials (as reduce_partials_kernel),
+// Last launch of the tiled sequence: block 0 sums the per-tile partials (as reduce_partials_kernel),
 // the other blocks apply the window-overflow records with hardware fp32 atomics -- the two are independent,
 // so they share a launch.
 __global__ __launch_bounds__(1024) void warp_finish_kernel(const float* __restrict__ partial, int n,
@@ -1434,15 +850,16 @@ __global__ __launch_bounds__(1024) void warp_finish_kernel(const float* __restri
     return;
   }
   if (g_d2 == nullptr) return;
-  unsigned m = *count;
-  if (m > cap) m = cap;
-  for (unsigned i = (blockIdx.x - 1) * 1024 + threadIdx.x; i < m; i += (gridDim.x - 1) * 1024) {
-    const int2 r = rec[i];
-    unsafeAtomicAdd(g_d2 + r.x, __int_as_float(r.y));
+  for (int l = blockIdx.x - 1; l < kOvfLists; l += gridDim.x - 1) {
+    unsigned m = count[l * kOvfStride];
+    if (m > cap) m = cap;
+    const int2* lr = rec + (size_t)l * cap;
+    for (unsigned i = threadIdx.x; i < m; i += 1024) {
+      const int2 r = lr[i];
+      unsafeAtomicAdd(g_d2 + r.x, __int_as_float(r.y));
+    }
   }
 }
-
-#include "warp_gen4.inc"
 
 __global__ void loss_finalize_kernel(const float* __restrict__ sums, float flow_mul, float disp_mul,
                                      int loss_on_sf, float* __restrict__ out) {
@@ -1470,15 +887,16 @@ struct TileShape {
 static const TileShape kShapes[] = {{96, 32, 512}, {64, 48, 512}, {64, 32, 512}, {64, 32, 256}, {96, 32, 384}};
 constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
+// Variant selection: the production path is the tiled kernel with the auto-chosen tile shape.  The parity tests
+// also drive the other shapes, the 4-pixels-per-step mapping and the global-atomics reference variant through
+// dvd_warp_loss_select() -- a process-wide test hook, not an environment switch read on every call.
+static int g_variant = 0;   // 0 tiled, 1 direct (global gathers + hardware atomics)
+static int g_tile = -1;     // -1 auto, else index into kShapes
+static int g_px = 0;        // 0 auto, 2 or 4 pixels per thread-step
 
-// Least padded area wins; ties go to the earlier (larger) shape.  DVD_WARP_TILE=<index> overrides.
+// Least padded area wins; ties go to the earlier (larger) shape.
 static int choose_shape(int H, int W) {
-  const int forced = env_int("DVD_WARP_TILE", -1);
-  if (forced >= 0 && forced < kNumShapes) return forced;
+  if (g_tile >= 0 && g_tile < kNumShapes) return g_tile;
   int best = 0;
   long long best_area = -1;
   for (int i = 0; i < kNumShapes; ++i) {
@@ -1494,7 +912,7 @@ static int choose_shape(int H, int W) {
 
 struct Plan {
   int shape, ntx, nty, ww, wh;
-  size_t n_partials, off_count, off_pre, off_slabs, off_ovf, ovf_cap, off_fix, fix_cap, total;
+  size_t n_partials, off_count, off_offs, off_slabs, off_ovf, ovf_cap, total;
 };
 
 static Plan make_plan(int B, int H, int W) {
@@ -1511,19 +929,17 @@ static Plan make_plan(int B, int H, int W) {
   size_t off = p.n_partials * 4 * sizeof(float);
   off = (off + 255) & ~(size_t)255;
   p.off_count = off;
-  off += 256;
-  p.off_pre = off;
-  off += (size_t)B * kPreFloats * sizeof(float);
+  off += (size_t)kOvfLists * kOvfStride * sizeof(unsigned);
+  p.off_offs = off;
+  off += (size_t)B * sizeof(int2);
   off = (off + 255) & ~(size_t)255;
   p.off_slabs = off;
   off += tiles * (size_t)p.ww * p.wh * sizeof(float);
   off = (off + 255) & ~(size_t)255;
   p.off_ovf = off;
-  p.ovf_cap = (size_t)4 * B * H * W;  // every tap of every pixel: the list can never overflow
-  off += p.ovf_cap * sizeof(int2);
-  p.off_fix = off;
-  p.fix_cap = (size_t)B * H * W;       // guard-band pixel list of generation 3: one slot per pixel, cannot overflow
-  off += p.fix_cap * sizeof(int);
+  // per list: every tap of every pixel of the tiles that append to it -- no list can overflow
+  p.ovf_cap = ((tiles + kOvfLists - 1) / kOvfLists) * (size_t)t.tw * t.th * 4;
+  off += (size_t)kOvfLists * p.ovf_cap * sizeof(int2);
   p.total = off;
   return p;
 }
@@ -1536,93 +952,19 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.ovf.count = reinterpret_cast<unsigned*>(ws + p.off_count);
   ta.ovf.rec = reinterpret_cast<int2*>(ws + p.off_ovf);
   ta.ovf.cap = (unsigned)(p.ovf_cap > 0xffffffffULL ? 0xffffffffULL : p.ovf_cap);
+  int2* offs = reinterpret_cast<int2*>(ws + p.off_offs);
+  ta.offs = offs;
   ta.ntx = p.ntx;
   ta.nty = p.nty;
   const int nblocks = p.ntx * p.nty * a.B;
   const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
-  const int gen = env_int("DVD_WARP_GEN", 1);
-  // counter block (256 B): [0] overflow count, [1] finish ticket, [4] fix-up count, [8..15] four Q31.32 fix-up sums
-  if (gen != 4) DVD_HIP_OK(hipMemsetAsync(ta.ovf.count, 0, 64, stream));
+  // launch sequence: prep (counter + window offsets) -> tile kernel -> slab combine -> finish
+  hipLaunchKernelGGL(warp_prep_kernel, dim3(a.B), dim3(64), 0, stream, a.flow, a.H, a.W, offs, ta.ovf.count);
+  DVD_LAUNCH_OK();
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
-  // generation 1 (default) = the reference's rounding sequence for every pixel; generation 3
-  // (DVD_WARP_GEN=3) = guard-banded fast arithmetic + exact fix-up pass.  Measured at 48x384x672
-  // (profiles/r01_warp_loss_microbench.jsonl): generation 3 needs 121 us for loads + arithmetic
-  // against 147 us, but its extra prepare / fix-up launches and a slower scatter phase leave the
-  // whole launch at 299 us against 260 us, so generation 1 stays the production kernel until the
-  // slab round trip (the common 65 us + 33 us of both) is gone.
   // 2 pixels per thread-step when that splits the tile evenly over the block and 4 does not
   constexpr bool kEven4 = ((TW / 4) * TH) % NT == 0, kEven2 = ((TW / 2) * TH) % NT == 0;
-  const bool px2 = env_int("DVD_WARP_PX", (kEven2 && !kEven4) ? 2 : 4) == 2;
-  Overflow fix;
-  fix.count = ta.ovf.count + 4;
-  fix.rec = reinterpret_cast<int2*>(ws + p.off_fix);
-  fix.cap = (unsigned)(p.fix_cap > 0xffffffffULL ? 0xffffffffULL : p.fix_cap);
-  unsigned long long* fix_sums = reinterpret_cast<unsigned long long*>(ta.ovf.count + 8);
-  if (gen == 4) {
-    float* pre = reinterpret_cast<float*>(ws + p.off_pre);
-    hipLaunchKernelGGL(warp_prep_kernel, dim3(a.B), dim3(64), 0, stream, a, pre, ta.ovf.count);
-    DVD_LAUNCH_OK();
-    const size_t lds4 = lds + (size_t)TH * kRowFloats * sizeof(float);
-    const int mode4 = env_int("DVD_WARP4_MODE", 0);
-#define DVD_TILED4_LAUNCH(G, S)                                                                           \
-  do {                                                                                                    \
-    auto k4 = mode4 == 1 ? warp_loss_tiled4_kernel<TW, TH, kR, NT, G, S, 2, false>                       \
-              : mode4 == 2 ? warp_loss_tiled4_kernel<TW, TH, kR, NT, G, S, 2, true>                       \
-                           : warp_loss_tiled4_kernel<TW, TH, kR, NT, G, S, 4, false>;                     \
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k4),                                     \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));               \
-    hipLaunchKernelGGL(k4, dim3(nblocks), dim3(NT), lds4, stream, a, ta, pre, fix);                       \
-  } while (0)
-    if (grads) {
-      if (shipped)
-        DVD_TILED4_LAUNCH(true, true);
-      else
-        DVD_TILED4_LAUNCH(true, false);
-    } else {
-      if (shipped)
-        DVD_TILED4_LAUNCH(false, true);
-      else
-        DVD_TILED4_LAUNCH(false, false);
-    }
-#undef DVD_TILED4_LAUNCH
-    DVD_LAUNCH_OK();
-    if (grads) {
-      const int qpr = (a.W + 3) / 4;
-      const int total_quads = qpr * a.H * a.B;
-      hipLaunchKernelGGL((combine_slabs4_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, stream,
-                         ta.slabs, pre, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads);
-      DVD_LAUNCH_OK();
-      hipLaunchKernelGGL(warp_finish4_kernel<true>, dim3(128), dim3(1024), 0, stream, a, ta.ovf, fix, ta.ovf.count, nblocks);
-    } else {
-      hipLaunchKernelGGL(warp_finish4_kernel<false>, dim3(16), dim3(1024), 0, stream, a, ta.ovf, fix, ta.ovf.count, nblocks);
-    }
-    DVD_LAUNCH_OK();
-    return DVD_OK;
-  }
-  if (gen == 3) {
-    float* pre = reinterpret_cast<float*>(ws + p.off_pre);
-    hipLaunchKernelGGL(warp_prepare_kernel, dim3((a.B + 63) / 64), dim3(64), 0, stream, a, pre);
-    DVD_LAUNCH_OK();
-#define DVD_TILED3_LAUNCH(G, S)                                                                           \
-  do {                                                                                                    \
-    auto k3 = px2 ? warp_loss_tiled3_kernel<TW, TH, kR, NT, G, S, 2> : warp_loss_tiled3_kernel<TW, TH, kR, NT, G, S, 4>; \
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3),                                     \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-    hipLaunchKernelGGL(k3, dim3(nblocks), dim3(NT), lds, stream, a, ta, pre, fix);                        \
-  } while (0)
-    if (grads) {
-      if (shipped)
-        DVD_TILED3_LAUNCH(true, true);
-      else
-        DVD_TILED3_LAUNCH(true, false);
-    } else {
-      if (shipped)
-        DVD_TILED3_LAUNCH(false, true);
-      else
-        DVD_TILED3_LAUNCH(false, false);
-    }
-#undef DVD_TILED3_LAUNCH
-  } else {
+  const bool px2 = (g_px ? g_px : ((kEven2 && !kEven4) ? 2 : 4)) == 2;
 #define DVD_TILED_LAUNCH(G, S)                                                                            \
   do {                                                                                                    \
     auto k = px2 ? warp_loss_tiled_kernel<TW, TH, kR, NT, G, S, 2> : warp_loss_tiled_kernel<TW, TH, kR, NT, G, S, 4>; \
@@ -1630,40 +972,29 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);                                   \
   } while (0)
-    if (grads) {
-      if (shipped)
-        DVD_TILED_LAUNCH(true, true);
-      else
-        DVD_TILED_LAUNCH(true, false);
-    } else {
-      if (shipped)
-        DVD_TILED_LAUNCH(false, true);
-      else
-        DVD_TILED_LAUNCH(false, false);
-    }
-#undef DVD_TILED_LAUNCH
+  if (grads) {
+    if (shipped)
+      DVD_TILED_LAUNCH(true, true);
+    else
+      DVD_TILED_LAUNCH(true, false);
+  } else {
+    if (shipped)
+      DVD_TILED_LAUNCH(false, true);
+    else
+      DVD_TILED_LAUNCH(false, false);
   }
+#undef DVD_TILED_LAUNCH
   DVD_LAUNCH_OK();
   if (grads) {
     const int qpr = (a.W + 3) / 4;
     const int total_quads = qpr * a.H * a.B;
     hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, stream,
-                       ta.slabs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads);
+                       ta.slabs, (const int2*)offs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads);
     DVD_LAUNCH_OK();
   }
-  if (gen == 3) {
-    if (grads)
-      hipLaunchKernelGGL(warp_post_kernel<true>, dim3(128), dim3(256), 0, stream, a, ta.ovf, fix, fix_sums);
-    else
-      hipLaunchKernelGGL(warp_post_kernel<false>, dim3(128), dim3(256), 0, stream, a, ta.ovf, fix, fix_sums);
-    DVD_LAUNCH_OK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nblocks, a.sums,
-                       (const unsigned long long*)fix_sums);
-  } else {
-    // partial-sum reduction and overflow records in one launch
-    hipLaunchKernelGGL(warp_finish_kernel, dim3(grads ? 17 : 1), dim3(1024), 0, stream, a.partial, nblocks, a.sums,
-                       ta.ovf.count, ta.ovf.rec, ta.ovf.cap, grads ? a.g_d2 : (float*)nullptr);
-  }
+  // partial-sum reduction and overflow records in one launch
+  hipLaunchKernelGGL(warp_finish_kernel, dim3(grads ? 129 : 1), dim3(1024), 0, stream, a.partial, nblocks, a.sums,
+                     ta.ovf.count, ta.ovf.rec, ta.ovf.cap, grads ? a.g_d2 : (float*)nullptr);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -1722,12 +1053,11 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
   a.half_h = (float)((cfg->H - 1) / 2.0);
   a.wmax = (float)(cfg->W - 1);
   a.hmax = (float)(cfg->H - 1);
-  a.ablate = env_int("DVD_WARP_ABLATE", 0);
   const bool all16 = (((uintptr_t)depth_1 | (uintptr_t)depth_2 | (uintptr_t)flow_1_2 | (uintptr_t)mask_2 |
                        (uintptr_t)sf_1_2 | (uintptr_t)g_depth_1 | (uintptr_t)g_depth_2 | (uintptr_t)g_sf_1_2) &
                       15) == 0;
   DVD_REQUIRE(all16 || (cfg->W & 3) != 0, "warp_loss: tensors must be 16-byte aligned when W %% 4 == 0");
-  if (env_int("DVD_WARP_DIRECT", 0)) {
+  if (g_variant == 1) {
     // reference variant: global gathers + hardware atomics (kept for A/B runs and as a second implementation)
     const bool vec4 = (cfg->W % 4 == 0);
     const int nbx = blocks_x(HW, vec4 ? 4 : 1);
@@ -1745,8 +1075,7 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
         hipLaunchKernelGGL((warp_loss_kernel<1, false>), grid, block, 0, stream, a);
     }
     DVD_LAUNCH_OK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nbx * cfg->B, sums,
-                       (const unsigned long long*)nullptr);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, stream, a.partial, nbx * cfg->B, sums);
     DVD_LAUNCH_OK();
     return DVD_OK;
   }
@@ -1768,6 +1097,15 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
 }  // namespace dvd
 
 extern "C" {
+
+int dvd_warp_loss_select(int variant, int tile, int px) {
+  DVD_REQUIRE(variant >= 0 && variant <= 1 && tile >= -1 && tile < dvd::kNumShapes && (px == 0 || px == 2 || px == 4),
+              "warp_loss_select: variant %d tile %d px %d", variant, tile, px);
+  dvd::g_variant = variant;
+  dvd::g_tile = tile;
+  dvd::g_px = px;
+  return DVD_OK;
+}
 
 size_t dvd_warp_loss_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;

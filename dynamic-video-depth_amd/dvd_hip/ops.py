@@ -129,6 +129,13 @@ def warp_loss_fused(cfg, depth_1, depth_2, flow_1_2, mask_2, sf_1_2, cams, grads
     return sums, g1, g2, gs
 
 
+def warp_loss_select(variant='tiled', tile=-1, px=0):
+    """Test hook: run dvd_warp_loss_fused on another variant ('direct' = global gathers + hardware atomics), tile
+    shape or pixels-per-step mapping.  Process wide; call warp_loss_select() to restore the production path."""
+    lib = _lib.load()
+    _lib.check(lib.dvd_warp_loss_select({'tiled': 0, 'direct': 1}[variant], int(tile), int(px)), 'dvd_warp_loss_select')
+
+
 def loss_finalize(cfg, sums, out=None):
     """scalars[8]: [0]=1/(S0+1e-8) [1]=loss [2]=flow [3]=disp [4]=sf [5]=S0."""
     sums = _dev32(sums, 'sums')

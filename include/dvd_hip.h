@@ -103,6 +103,10 @@ typedef struct dvd_warp_cfg {
 } dvd_warp_cfg;
 
 size_t dvd_warp_loss_workspace_bytes(int B, int H, int W);
+/* Test hook (process wide; not an environment switch): variant 0 = tiled LDS kernel (production), 1 = reference
+ * variant with global gathers + hardware atomics; tile = -1 (auto) or an index of the tile-shape table;
+ * px = 0 (auto), 2 or 4 pixels per thread-step.  Every combination computes the same function. */
+int dvd_warp_loss_select(int variant, int tile, int px);
 int dvd_warp_loss_fused(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth_2,
                         const float* flow_1_2, const float* mask_2, const float* sf_1_2,
                         const dvd_cameras* cams, void* workspace, size_t workspace_bytes,

@@ -27,16 +27,20 @@ def main():
     ap.add_argument('--tile', type=int, default=-1, help='force tile shape index')
     ap.add_argument('--flow_sigma', type=float, default=3.0)
     ap.add_argument('--smooth_flow', action='store_true', help='constant flow per pair instead of iid noise')
+    ap.add_argument('--calm_border', type=int, default=0, help='zero the flow within this many pixels of the image border')
     a = ap.parse_args()
     B, H, W = a.B, a.H, a.W
-    if a.direct:
-        os.environ['DVD_WARP_DIRECT'] = '1'
-    if a.tile >= 0:
-        os.environ['DVD_WARP_TILE'] = str(a.tile)
+    ops.warp_loss_select(variant='direct' if a.direct else 'tiled', tile=a.tile)
     batch = synthetic.make_batch(B, H, W, device='cuda', with_images=False)
     batch['flow_1_2'] = batch['flow_1_2'] * (a.flow_sigma / 3.0)
     if a.smooth_flow:
         batch['flow_1_2'] = batch['flow_1_2'][:, :1, :1].expand(B, H, W, 2).contiguous()
+    if a.calm_border:
+        c = a.calm_border
+        batch['flow_1_2'][:, :c] = 0
+        batch['flow_1_2'][:, -c:] = 0
+        batch['flow_1_2'][:, :, :c] = 0
+        batch['flow_1_2'][:, :, -c:] = 0
     d1, d2 = synthetic.make_depths(B, H, W, device='cuda')
     sf = synthetic.make_scene_flow(B, H, W, device='cuda')
     cams = {k: batch[k] for k in CAM_KEYS}
