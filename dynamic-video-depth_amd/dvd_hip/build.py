@@ -33,6 +33,7 @@ SOURCES = [
     ('bnrelu.hip', []),
     ('xconv.hip', []),
     ('xwgrad.hip', []),
+    ('xwgrad3.hip', []),
     ('consistency.hip', ['-ffp-contract=off']),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',

@@ -326,6 +326,16 @@ class _XConv(torch.autograd.Function):
 def xconv_wgrad(x, gy, wshape, relu_in):
     """dW[co][ci][tap] = sum_{n,p} gy[n][co][p] * act(x)[n][ci][p + tap]."""
     lib = _lib.load()
+    if wshape[2] in (1, 3) and not _os.environ.get('DVD_NO_XWGRAD3'):      # split-bf16 MFMA (csrc/xwgrad3.hip)
+        N, Cin, H, W = x.shape
+        Cout = wshape[0]
+        gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+        size_fn, fn, name = ((lib.dvd_xwgrad3_workspace_bytes, lib.dvd_xwgrad3, 'dvd_xwgrad3') if wshape[2] == 3 else
+                             (lib.dvd_xwgrad1s_workspace_bytes, lib.dvd_xwgrad1s, 'dvd_xwgrad1s'))
+        ws = _workspace(size_fn(N, Cin, Cout, H, W), x.device)
+        _lib.check(fn(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W, int(bool(relu_in)),
+                      _stream()), name)
+        return gw
     if wshape[2] in (1, 3) and not _os.environ.get('DVD_NO_XWGRAD'):
         N, Cin, H, W = x.shape
         Cout, _, KS, _ = wshape

@@ -1,0 +1,440 @@
+// Backward-weight of the dense 3x3 stride-1 "same" convolutions on the bf16 matrix cores with fp32-class
+// accuracy (the three-term bf16 split of csrc/xconv.hip: six partial products per fp32 product, fp32
+// accumulation), deterministic (no atomics):
+//   dW[co][ci][ky][kx] = sum_{n, r, c} gy[n][co][r][c] * act(x)[n][ci][r + ky - 1][c + kx - 1]
+//
+// What it replaces (reference, /root/reference): the autograd weight gradient of the 3x3 nn.Conv2d of the MiDaS
+// decoder (third_party/midas_blocks.py:102-168, MiDaS.py:186-195); MIOpen's igemm_wrw (atomics, 113 TF/s) and the
+// exact-fp32 kernel of csrc/xwgrad.hip (86 TF/s: the fp32 MFMA rate is the ceiling there).
+//
+// Mapping.  GEMM M = output channel, N = input channel, K = pixels.  v_mfma_f32_32x32x16_bf16: lane l holds
+// A[co = l&31][8 consecutive pixels, run (l>>5)] = gy and B[the same 8 pixels shifted by the tap][ci = l&31] = x.
+// Pixels are contiguous in NCHW, so both operands are read as 16-byte runs along x; the run of tap kx = 1 is a
+// cell of the LDS row, the runs of kx = 0 / 2 start one pixel earlier / later and are assembled from the cell and
+// one dword of its neighbour with v_alignbit_b32 (five of them give both shifted fragments of a term).
+// A block owns 64 output x 64 input channels and walks DOWN a 64-pixel-wide column strip of an image, one row
+// per step: the gy row (64 channels x 64 pixels) and ONE new x row (64 channels x 80 pixels: the strip, one
+// 8-pixel cell left and right) are staged per step -- the three x rows a step needs live in a rolling buffer --
+// split into the three bf16 terms on the way in; the next step's rows are requested before the MFMAs of the
+// current one.  Wave (pm, pn, ky) of the 12 keeps the three accumulators of kernel row ky for its 32 x 32 pair.
+// Every block writes its partial sums; xwgrad3_reduce_kernel adds them in slice order.
+#include "dvd_common.h"
+
+namespace dvd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void w3_split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  const f32x2 v = {a, b};
+  const bf16x2 hb = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
+  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
+  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+
+struct Wg3Args {
+  const float* __restrict__ x;
+  const float* __restrict__ gy;
+  float* __restrict__ partial;   // [S][9][Cout][Cin]
+  int N, Cin, Cout, H, W;
+  int nstrips, RS, nrseg, S;     // column strips per image, rows per work item, row segments per image, slices
+  int relu_in;
+};
+
+constexpr int kW3Strip = 64;                  // pixels per row step
+constexpr int kW3GPitch = 128 + 16;           // bytes per gy row in LDS (64 bf16 + pad: conflict-free 16-byte reads across rows)
+constexpr int kW3XPitch = 160 + 16;           // bytes per x row in LDS (80 bf16 + pad)
+constexpr int kW3CB = 64;                     // channels per block, both operands
+constexpr int kW3NT = 768;                    // 12 waves: 2 x 2 tile pairs x 3 kernel rows
+
+__global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  // sG [term 3][co 64][kW3GPitch], sX [term 3][ci 64][slot 3][kW3XPitch]
+  unsigned char* sG = smem3;
+  unsigned char* sX = smem3 + 3 * kW3CB * kW3GPitch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ky = wave % 3, pn = (wave / 3) & 1, pm = wave / 6;
+  const int co0 = blockIdx.z * kW3CB, ci0 = blockIdx.y * kW3CB;
+  const size_t plane = (size_t)a.H * a.W;
+  const int items = a.N * a.nstrips * a.nrseg;
+
+  // staging assignment: a thread stages 4 consecutive pixels of one channel row.
+  //   gy row: 64 channels x 16 quads = 1024 quads;  x row: 64 channels x 20 quads = 1280 quads  -> 3 per thread
+  constexpr int GQ = kW3CB * 16, XQ = kW3CB * 20, NQ = (GQ + XQ + kW3NT - 1) / kW3NT;
+  float4 stg[NQ];
+  auto stage_load = [&](int n, int c0, int r, bool with_g) {   // gy row r (if with_g) and x row r + 1
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = i * kW3NT + tid;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < GQ) {
+        const int ch = q >> 4, px = c0 + ((q & 15) << 2);
+        if (with_g && (co0 + ch) < a.Cout && r < a.H) {
+          const float* p = a.gy + ((size_t)n * a.Cout + co0 + ch) * plane + (size_t)r * a.W;
+          if (px + 3 < a.W && ((a.W & 3) == 0)) {
+            v = *reinterpret_cast<const float4*>(p + px);
+          } else {
+            if (px < a.W) v.x = p[px];
+            if (px + 1 < a.W) v.y = p[px + 1];
+            if (px + 2 < a.W) v.z = p[px + 2];
+            if (px + 3 < a.W) v.w = p[px + 3];
+          }
+        }
+      } else if (q < GQ + XQ) {
+        const int qq = q - GQ;
+        const int ch = qq / 20, px = c0 - 8 + ((qq - ch * 20) << 2);
+        const int row = r + 1;
+        if ((ci0 + ch) < a.Cin && row >= 0 && row < a.H) {
+          const float* p = a.x + ((size_t)n * a.Cin + ci0 + ch) * plane + (size_t)row * a.W;
+          if (px >= 0 && px + 3 < a.W && ((a.W & 3) == 0)) {
+            v = *reinterpret_cast<const float4*>(p + px);
+          } else {
+            if (px >= 0 && px < a.W) v.x = p[px];
+            if (px + 1 >= 0 && px + 1 < a.W) v.y = p[px + 1];
+            if (px + 2 >= 0 && px + 2 < a.W) v.z = p[px + 2];
+            if (px + 3 >= 0 && px + 3 < a.W) v.w = p[px + 3];
+          }
+          if (a.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        }
+      }
+      stg[i] = v;
+    }
+  };
+  auto stage_store = [&](int xslot) {      // split and write: 4 pixels = 8 bytes per term
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = i * kW3NT + tid;
+      if (q >= GQ + XQ) continue;
+      unsigned h0, m0, l0, h1, m1, l1;
+      w3_split_pair(stg[i].x, stg[i].y, h0, m0, l0);
+      w3_split_pair(stg[i].z, stg[i].w, h1, m1, l1);
+      unsigned char* dst;
+      int tstride;
+      if (q < GQ) {
+        dst = sG + (q >> 4) * kW3GPitch + ((q & 15) << 3);
+        tstride = kW3CB * kW3GPitch;
+      } else {
+        const int qq = q - GQ, ch = qq / 20;
+        dst = sX + (ch * 3 + xslot) * kW3XPitch + ((qq - ch * 20) << 3);
+        tstride = kW3CB * 3 * kW3XPitch;
+      }
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(dst + 2 * tstride) = make_uint2(l0, l1);
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[k] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int half = lane >> 5;
+  const unsigned char* ga = sG + (pm * 32 + (lane & 31)) * kW3GPitch + half * 16;
+  const unsigned char* xa = sX + ((pn * 32 + (lane & 31)) * 3) * kW3XPitch + 16 + half * 16;   // cell 1 + half of slot 0
+
+  for (int item = blockIdx.x; item < items; item += a.S) {
+    const int n = item / (a.nstrips * a.nrseg);
+    const int rem = item - n * (a.nstrips * a.nrseg);
+    const int strip = rem / a.nrseg, seg = rem - strip * a.nrseg;
+    const int c0 = strip * kW3Strip, r0 = seg * a.RS;
+    const int r1 = (r0 + a.RS) < a.H ? (r0 + a.RS) : a.H;
+    // x rows r0 - 1 and r0 into their slots ((row + 3) % 3), then the loop stages row r + 1 with gy row r
+    __syncthreads();                               // the previous item's MFMAs have read their operands
+    stage_load(n, c0, r0 - 2, false);
+    stage_store((r0 - 1 + 3) % 3);
+    stage_load(n, c0, r0 - 1, false);
+    stage_store(r0 % 3);
+    stage_load(n, c0, r0, true);
+    for (int r = r0; r < r1; ++r) {
+      __syncthreads();                             // step r - 1 is done with the gy row and with slot (r + 1) % 3
+      stage_store((r + 1) % 3);
+      __syncthreads();
+      if (r + 1 < r1) stage_load(n, c0, r + 1, true);
+      const int slot = (r - 1 + ky + 3) % 3;       // x row r - 1 + ky
+      const unsigned char* xr = xa + slot * kW3XPitch;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {                // four K steps of 16 pixels
+        bf16x8 A[3], B[3][3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ga + t * (kW3CB * kW3GPitch) + s * 32));
+          const unsigned char* xc = xr + t * (kW3CB * 3 * kW3XPitch) + s * 32;
+          const u32x4 cur = *reinterpret_cast<const u32x4*>(xc);
+          const unsigned prev3 = *reinterpret_cast<const unsigned*>(xc - 4);
+          const unsigned next0 = *reinterpret_cast<const unsigned*>(xc + 16);
+          const unsigned t0 = __builtin_amdgcn_alignbit(cur.x, prev3, 16), t1 = __builtin_amdgcn_alignbit(cur.y, cur.x, 16),
+                         t2 = __builtin_amdgcn_alignbit(cur.z, cur.y, 16), t3 = __builtin_amdgcn_alignbit(cur.w, cur.z, 16),
+                         t4 = __builtin_amdgcn_alignbit(next0, cur.w, 16);
+          B[0][t] = __builtin_bit_cast(bf16x8, (u32x4){t0, t1, t2, t3});   // kx = 0: pixels shifted by -1
+          B[1][t] = __builtin_bit_cast(bf16x8, cur);                        // kx = 1
+          B[2][t] = __builtin_bit_cast(bf16x8, (u32x4){t1, t2, t3, t4});   // kx = 2: shifted by +1
+        }
+#define DVD_W3TERM(SA, SB)                                                                                  \
+  _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[kx] =                                                \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], B[kx][SB], acc[kx], 0, 0, 0);
+        DVD_W3TERM(2, 0)
+        DVD_W3TERM(0, 2)
+        DVD_W3TERM(1, 1)
+        DVD_W3TERM(1, 0)
+        DVD_W3TERM(0, 1)
+        DVD_W3TERM(0, 0)
+#undef DVD_W3TERM
+      }
+    }
+  }
+  // partial[s][tap][co][ci]
+  float* dst = a.partial + (size_t)blockIdx.x * 9 * a.Cout * a.Cin;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int tap = ky * 3 + kx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + pm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ci = ci0 + pn * 32 + (lane & 31);
+      if (co < a.Cout && ci < a.Cin) dst[((size_t)tap * a.Cout + co) * a.Cin + ci] = acc[kx][r];
+    }
+  }
+}
+
+// gw[co][ci][tap] = sum_s partial[s][tap][co][ci], ascending s (two interleaved chains)
+__global__ __launch_bounds__(256) void xwgrad3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int S,
+                                                             int T, int Cout, int Cin) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // over [tap][co][ci]
+  const long long per = (long long)T * Cout * Cin;
+  if (i >= per) return;
+  float s0 = 0.0f, s1 = 0.0f;
+  int s = 0;
+  for (; s + 1 < S; s += 2) {
+    s0 += partial[(size_t)s * per + i];
+    s1 += partial[(size_t)(s + 1) * per + i];
+  }
+  if (s < S) s0 += partial[(size_t)s * per + i];
+  const int ci = (int)(i % Cin);
+  const int co = (int)((i / Cin) % Cout);
+  const int tap = (int)(i / ((long long)Cin * Cout));
+  gw[((size_t)co * Cin + ci) * T + tap] = s0 + s1;
+}
+
+// ---- 1x1: dW[co][ci] = sum_{n, p} gy[n][co][p] * act(x)[n][ci][p] -- a plain "NT" GEMM with K = pixels contiguous in
+// both operands.  A block owns 128 x 128 channels (8 waves: 4 x 2, one output-channel tile x two input-channel tiles
+// each) and walks over chunks of 32 consecutive pixels of the flattened images; two blocks share a CU so that one
+// block's staging (load, split, LDS write, barrier) overlaps the other's MFMAs.
+constexpr int kW1Chunk = 32;
+constexpr int kW1Pitch = 64 + 16;             // bytes per channel row in LDS (32 bf16 + pad)
+constexpr int kW1CB = 128;
+constexpr int kW1NT = 512;
+
+__global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  unsigned char* sG = smem3;                               // [term 3][co 128][kW1Pitch]
+  unsigned char* sX = smem3 + 3 * kW1CB * kW1Pitch;        // [term 3][ci 128][kW1Pitch]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pn = wave & 1, pm = wave >> 1;
+  const int co0 = blockIdx.z * kW1CB, ci0 = blockIdx.y * kW1CB;
+  const int HW = a.H * a.W;
+  const size_t plane = (size_t)HW;
+  const int cpi = (HW + kW1Chunk - 1) / kW1Chunk;          // chunks per image
+  const int items = a.N * cpi;
+  // staging: 128 channels x 8 quads per operand = 2048 quads -> 4 per thread (2 gy + 2 x)
+  float4 stg[4];
+  auto stage_load = [&](int item) {
+    const int n = item / cpi, p0 = (item - n * cpi) * kW1Chunk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = (i & 1) * kW1NT + tid;                 // 0 .. 1023
+      const int ch = q >> 3, px = p0 + ((q & 7) << 2);
+      const bool isx = i >= 2;
+      const int C = isx ? a.Cin : a.Cout, c = (isx ? ci0 : co0) + ch;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) {
+        const float* p = (isx ? a.x : a.gy) + ((size_t)n * C + c) * plane;
+        if (px + 3 < HW && ((HW & 3) == 0)) {
+          v = *reinterpret_cast<const float4*>(p + px);
+        } else {
+          if (px < HW) v.x = p[px];
+          if (px + 1 < HW) v.y = p[px + 1];
+          if (px + 2 < HW) v.z = p[px + 2];
+          if (px + 3 < HW) v.w = p[px + 3];
+        }
+        if (isx && a.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      }
+      stg[i] = v;
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = (i & 1) * kW1NT + tid;
+      unsigned h0, m0, l0, h1, m1, l1;
+      w3_split_pair(stg[i].x, stg[i].y, h0, m0, l0);
+      w3_split_pair(stg[i].z, stg[i].w, h1, m1, l1);
+      unsigned char* dst = (i >= 2 ? sX : sG) + (q >> 3) * kW1Pitch + ((q & 7) << 3);
+      constexpr int tstride = kW1CB * kW1Pitch;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(dst + 2 * tstride) = make_uint2(l0, l1);
+    }
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) acc[k] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int half = lane >> 5;
+  const unsigned char* ga = sG + (pm * 32 + (lane & 31)) * kW1Pitch + half * 16;
+  const unsigned char* xa = sX + (pn * 64 + (lane & 31)) * kW1Pitch + half * 16;
+
+  int item = blockIdx.x;
+  if (item < items) stage_load(item);
+  for (; item < items; item += a.S) {
+    __syncthreads();
+    stage_store();
+    __syncthreads();
+    if (item + a.S < items) stage_load(item + a.S);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 A[3], B[2][3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ga + t * (kW1CB * kW1Pitch) + s * 32));
+        B[0][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xa + t * (kW1CB * kW1Pitch) + s * 32));
+        B[1][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xa + 32 * kW1Pitch + t * (kW1CB * kW1Pitch) + s * 32));
+      }
+#define DVD_W1TERM(SA, SB)                                                                                \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] =                                                  \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], B[j][SB], acc[j], 0, 0, 0);
+      DVD_W1TERM(2, 0)
+      DVD_W1TERM(0, 2)
+      DVD_W1TERM(1, 1)
+      DVD_W1TERM(1, 0)
+      DVD_W1TERM(0, 1)
+      DVD_W1TERM(0, 0)
+#undef DVD_W1TERM
+    }
+  }
+  float* dst = a.partial + (size_t)blockIdx.x * a.Cout * a.Cin;       // partial[s][co][ci]
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + pm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ci = ci0 + pn * 64 + j * 32 + (lane & 31);
+      if (co < a.Cout && ci < a.Cin) dst[(size_t)co * a.Cin + ci] = acc[j][r];
+    }
+}
+
+struct Wg3Plan {
+  int nstrips, RS, nrseg, S, nco, nci;
+  size_t lds;
+};
+static void wg3_plan(int N, int Cin, int Cout, int H, int W, Wg3Plan& p) {
+  p.nco = (Cout + kW3CB - 1) / kW3CB;
+  p.nci = (Cin + kW3CB - 1) / kW3CB;
+  p.nstrips = (W + kW3Strip - 1) / kW3Strip;
+  const int pairs = p.nco * p.nci;
+  // one block per CU is resident: a whole number of rounds over the 256 CUs, each block a few work items long
+  int S = pairs >= 256 ? 1 : (512 + pairs - 1) / pairs;
+  // rows per item: enough items to feed S slices evenly (>= 4 per slice), at least 8 rows (2 warm-up rows per item)
+  int RS = H;
+  while (RS > 8 && (long long)N * p.nstrips * ((H + RS - 1) / RS) < 4LL * S) RS = (RS + 1) / 2;
+  p.RS = RS;
+  p.nrseg = (H + RS - 1) / RS;
+  const long long items = (long long)N * p.nstrips * p.nrseg;
+  if (S > items) S = (int)items;
+  p.S = S;
+  p.lds = (size_t)3 * kW3CB * kW3GPitch + (size_t)3 * kW3CB * 3 * kW3XPitch;
+}
+
+}  // namespace dvd
+
+extern "C" {
+
+size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  dvd::Wg3Plan p;
+  dvd::wg3_plan(N, Cin, Cout, H, W, p);
+  return (size_t)p.S * 9 * Cout * Cin * sizeof(float);
+}
+
+int dvd_xwgrad3(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
+                int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
+  DVD_REQUIRE(x && gy && gw && workspace, "xwgrad3: null pointer");
+  DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgrad3: bad shape");
+  DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgrad3: image too large for 32-bit offsets");
+  dvd::Wg3Plan p;
+  dvd::wg3_plan(N, Cin, Cout, H, W, p);
+  const size_t need = (size_t)p.S * 9 * Cout * Cin * sizeof(float);
+  if (workspace_bytes < need) {
+    dvd::set_error("xwgrad3: workspace %zu < %zu bytes", workspace_bytes, need);
+    return DVD_ENOSPC;
+  }
+  DVD_REQUIRE(p.nco <= 65535 && p.nci <= 65535, "xwgrad3: too many channel blocks");
+  dvd::Wg3Args a;
+  a.x = x;
+  a.gy = gy;
+  a.partial = static_cast<float*>(workspace);
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.nstrips = p.nstrips; a.RS = p.RS; a.nrseg = p.nrseg; a.S = p.S;
+  a.relu_in = relu_in ? 1 : 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)p.lds));
+  hipLaunchKernelGGL(dvd::xwgrad3_kernel, dim3(p.S, p.nci, p.nco), dim3(dvd::kW3NT), p.lds, s, a);
+  DVD_LAUNCH_OK();
+  const long long per = (long long)9 * Cout * Cin;
+  hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
+                     static_cast<const float*>(workspace), gw, p.S, 9, Cout, Cin);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  const int pairs = ((Cout + dvd::kW1CB - 1) / dvd::kW1CB) * ((Cin + dvd::kW1CB - 1) / dvd::kW1CB);
+  const int S = pairs >= 512 ? 1 : (1024 + pairs - 1) / pairs;
+  return (size_t)S * Cout * Cin * sizeof(float);
+}
+
+int dvd_xwgrad1s(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
+                 int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
+  DVD_REQUIRE(x && gy && gw && workspace, "xwgrad1s: null pointer");
+  DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgrad1s: bad shape");
+  DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgrad1s: image too large for 32-bit offsets");
+  const int nco = (Cout + dvd::kW1CB - 1) / dvd::kW1CB, nci = (Cin + dvd::kW1CB - 1) / dvd::kW1CB;
+  const int pairs = nco * nci;
+  // two blocks per CU are resident: whole rounds over 512 slots
+  int S = pairs >= 512 ? 1 : (1024 + pairs - 1) / pairs;
+  const long long items = (long long)N * ((H * W + dvd::kW1Chunk - 1) / dvd::kW1Chunk);
+  if (S > items) S = (int)items;
+  const size_t need = (size_t)S * Cout * Cin * sizeof(float);
+  if (workspace_bytes < need) {
+    dvd::set_error("xwgrad1s: workspace %zu < %zu bytes", workspace_bytes, need);
+    return DVD_ENOSPC;
+  }
+  DVD_REQUIRE(nco <= 65535 && nci <= 65535, "xwgrad1s: too many channel blocks");
+  dvd::Wg3Args a;
+  a.x = x;
+  a.gy = gy;
+  a.partial = static_cast<float*>(workspace);
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.nstrips = 0; a.RS = 0; a.nrseg = 0; a.S = S;
+  a.relu_in = relu_in ? 1 : 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)2 * 3 * dvd::kW1CB * dvd::kW1Pitch;
+  DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+  hipLaunchKernelGGL(dvd::xwgrad1s_kernel, dim3(S, nci, nco), dim3(dvd::kW1NT), lds, s, a);
+  DVD_LAUNCH_OK();
+  const long long per = (long long)Cout * Cin;
+  hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
+                     static_cast<const float*>(workspace), gw, S, 1, Cout, Cin);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+}  // extern "C"

@@ -308,6 +308,16 @@ size_t dvd_xwgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int KS
 int dvd_xwgrad(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
                int Cout, int H, int W, int KS, int relu_in, dvd_stream_t stream);
 
+/* The 3x3 case on the bf16 matrix cores with the three-term split of dvd_xconv_fwd (fp32-class accuracy,
+ * deterministic; csrc/xwgrad3.hip): what the MiDaS decoder's weight gradients run on. */
+size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W);
+int dvd_xwgrad3(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
+                int Cout, int H, int W, int relu_in, dvd_stream_t stream);
+/* ... and the 1x1 case (ResNeXt bottleneck convolutions), same arithmetic: a K-contiguous "NT" GEMM over the pixels. */
+size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W);
+int dvd_xwgrad1s(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
+                 int Cout, int H, int W, int relu_in, dvd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Flow-consistency (occlusion) + out-of-bounds mask of one direction of a frame pair.
  * Replaces scripts/preprocess/davis/generate_flows.py:57-82,139-148:
