@@ -101,13 +101,13 @@ SIGNATURES = {
                                           c_void_p]),
     'dvd_gconv3x3_c32_bwd_weight': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int,
                                             c_int, c_int, c_void_p]),
-    'dvd_xconv_packed_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
-    'dvd_xconv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    'dvd_xconv_fwd': (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
-    'dvd_xwgrad3_workspace_bytes': (c_size_t, [c_int] * 5),
+    'dvd_xconv_packed_bytes': (c_size_t, [c_int] * 5),
+    'dvd_xconv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_xconv_fwd': (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
+    'dvd_xwgrad3_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad1s_workspace_bytes': (c_size_t, [c_int] * 5),
     'dvd_xwgrad1s': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 6 + [c_void_p]),
-    'dvd_xwgrad3': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 6 + [c_void_p]),
+    'dvd_xwgrad3': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     'dvd_xwgrad_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     'dvd_flow_consistency_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -239,8 +239,8 @@ class GroupedConv3x3C8(nn.Conv2d):
 # ---------------------------------------------------------------------------------------
 # Dense stride-1 convolutions on the split-bf16 MFMA kernels (csrc/xconv.hip)
 
-def xconv_packed(weight, transposed):
-    """Fragment-ordered, pre-split copy of a conv weight [Cout,Cin,k,k].  The copy hangs on the weight
+def xconv_packed(weight, transposed, groups=1):
+    """Fragment-ordered, pre-split copy of a conv weight [Cout,Cin/groups,k,k].  The copy hangs on the weight
     tensor OBJECT (not on its address: allocators reuse addresses) and is rebuilt when the weight changed:
     new storage, autograd version counter, or an optimiser step of the fused Adam (ops.WEIGHT_EPOCH)."""
     from . import ops
@@ -248,13 +248,14 @@ def xconv_packed(weight, transposed):
     if not w.is_contiguous():
         w = w.contiguous()
     Cout, Cin, KS, _ = w.shape
+    Cin *= groups
     lib = _lib.load()
     if torch.cuda.is_current_stream_capturing():
         # HIP-graph capture: the pack launch must be PART of the graph (a replay runs no Python, and the weights
         # change between replays), into a buffer of the graph's own pool -- never served from the cache
-        nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, int(transposed))
+        nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, groups, int(transposed))
         packed = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-        _lib.check(lib.dvd_xconv_pack(_p(w), _p(packed), Cout, Cin, KS, int(transposed), _stream()), 'dvd_xconv_pack')
+        _lib.check(lib.dvd_xconv_pack(_p(w), _p(packed), Cout, Cin, KS, groups, int(transposed), _stream()), 'dvd_xconv_pack')
         return packed
     key = (w.data_ptr(), weight._version, ops.WEIGHT_EPOCH[0], tuple(w.shape))
     cache = getattr(weight, '_dvd_xpack', None)
@@ -264,24 +265,24 @@ def xconv_packed(weight, transposed):
     hit = cache.get(bool(transposed))
     if hit is not None and hit[0] == key:
         return hit[1]
-    nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, int(transposed))
+    nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, groups, int(transposed))
     if nbytes == 0:
         raise RuntimeError('xconv: unsupported weight shape %s' % (tuple(w.shape),))
     packed = hit[1] if (hit is not None and hit[1].numel() == nbytes) else torch.empty(nbytes, device=w.device,
                                                                                        dtype=torch.uint8)
-    _lib.check(lib.dvd_xconv_pack(_p(w), _p(packed), Cout, Cin, KS, int(transposed), _stream()), 'dvd_xconv_pack')
+    _lib.check(lib.dvd_xconv_pack(_p(w), _p(packed), Cout, Cin, KS, groups, int(transposed), _stream()), 'dvd_xconv_pack')
     cache[bool(transposed)] = (key, packed)
     return packed
 
 
 def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, relu_in=False, relu_out=False,
-               res_relu=False):
+               res_relu=False, groups=1):
     N, Cin, H, W = x.shape
     y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
     flags = int(bool(relu_in)) | (int(bool(relu_out)) << 1) | (int(bool(res_relu)) << 2)
     lib = _lib.load()
     _lib.check(lib.dvd_xconv_fwd(_p(x), _p(packed), _p(bias), _p(residual), _p(mask_src), _p(y), N, Cin, Cout, H, W, KS,
-                                 flags, _stream()), 'dvd_xconv_fwd')
+                                 groups, flags, _stream()), 'dvd_xconv_fwd')
     return y
 
 
@@ -291,50 +292,64 @@ class _XConv(torch.autograd.Function):
     csrc/xwgrad.hip (deterministic)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, relu_in, res_relu):
+    def forward(ctx, x, weight, bias, residual, relu_in, res_relu, groups=1):
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
         Cout, _, KS, _ = weight.shape
-        y = _xconv_run(x, xconv_packed(weight, False), Cout, KS, bias=bias, residual=residual, relu_in=relu_in,
-                       res_relu=res_relu)
+        y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=bias, residual=residual, relu_in=relu_in,
+                       res_relu=res_relu, groups=groups)
         ctx.save_for_backward(x, residual if res_relu else None)
         ctx.wparam = weight          # the tensor object that carries the packed copies
-        ctx.cfg = (bool(relu_in), bool(res_relu), bias is not None, residual is not None)
+        ctx.cfg = (bool(relu_in), bool(res_relu), bias is not None, residual is not None, groups)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, residual = ctx.saved_tensors
         weight = ctx.wparam
-        relu_in, res_relu, has_bias, has_res = ctx.cfg
+        relu_in, res_relu, has_bias, has_res, groups = ctx.cfg
         gy = gy.contiguous()
         Cout, Cin, KS, _ = weight.shape
         need = ctx.needs_input_grad
         gx = gw = gb = gr = None
         if need[0]:
-            gx = _xconv_run(gy, xconv_packed(weight, True), Cin, KS, mask_src=x if relu_in else None)
+            gx = _xconv_run(gy, xconv_packed(weight, True, groups), Cin * groups, KS, mask_src=x if relu_in else None,
+                            groups=groups)
         if need[1]:
-            gw = xconv_wgrad(x, gy, weight.shape, relu_in)
+            gw = xconv_wgrad(x, gy, weight.shape, relu_in, groups)
         if has_bias and need[2]:
             gb = gy.sum((0, 2, 3))
         if has_res and need[3]:
             gr = gy * (residual > 0).to(gy.dtype) if res_relu else gy
-        return gx, gw, gb, gr, None, None
+        return gx, gw, gb, gr, None, None, None
 
 
-def xconv_wgrad(x, gy, wshape, relu_in):
+def xconv_wgrad(x, gy, wshape, relu_in, groups=1):
     """dW[co][ci][tap] = sum_{n,p} gy[n][co][p] * act(x)[n][ci][p + tap]."""
     lib = _lib.load()
+    if groups > 1:                                                          # grouped: 3x3 only (ResNeXt stage 4)
+        if wshape[2] != 3:
+            raise RuntimeError('xconv: grouped weight gradient exists for 3x3 kernels only')
+        N, Cin, H, W = x.shape
+        gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+        ws = _workspace(lib.dvd_xwgrad3_workspace_bytes(N, Cin, wshape[0], H, W, groups), x.device)
+        _lib.check(lib.dvd_xwgrad3(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, wshape[0], H, W,
+                                   groups, int(bool(relu_in)), _stream()), 'dvd_xwgrad3')
+        return gw
     if wshape[2] in (1, 3) and not _os.environ.get('DVD_NO_XWGRAD3'):      # split-bf16 MFMA (csrc/xwgrad3.hip)
         N, Cin, H, W = x.shape
         Cout = wshape[0]
         gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
-        size_fn, fn, name = ((lib.dvd_xwgrad3_workspace_bytes, lib.dvd_xwgrad3, 'dvd_xwgrad3') if wshape[2] == 3 else
-                             (lib.dvd_xwgrad1s_workspace_bytes, lib.dvd_xwgrad1s, 'dvd_xwgrad1s'))
-        ws = _workspace(size_fn(N, Cin, Cout, H, W), x.device)
-        _lib.check(fn(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W, int(bool(relu_in)),
-                      _stream()), name)
+        ws_bytes = (lib.dvd_xwgrad3_workspace_bytes(N, Cin, Cout, H, W, 1) if wshape[2] == 3 else
+                    lib.dvd_xwgrad1s_workspace_bytes(N, Cin, Cout, H, W))
+        ws = _workspace(ws_bytes, x.device)
+        if wshape[2] == 3:
+            _lib.check(lib.dvd_xwgrad3(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W, 1,
+                                       int(bool(relu_in)), _stream()), 'dvd_xwgrad3')
+        else:
+            _lib.check(lib.dvd_xwgrad1s(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W,
+                                        int(bool(relu_in)), _stream()), 'dvd_xwgrad1s')
         return gw
     if wshape[2] in (1, 3) and not _os.environ.get('DVD_NO_XWGRAD'):
         N, Cin, H, W = x.shape
@@ -354,7 +369,8 @@ def xconv_wgrad(x, gy, wshape, relu_in):
 
 def xconv_supported(conv, x):
     k = conv.kernel_size
-    return (x.is_cuda and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and conv.groups == 1 and
+    return (x.is_cuda and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and
+            (conv.groups == 1 or (k[0] == 3 and conv.in_channels // conv.groups >= 32)) and
             k[0] == k[1] and k[0] % 2 == 1 and k[0] <= 11 and tuple(conv.stride) == (1, 1) and
             tuple(conv.dilation) == (1, 1) and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and
             conv.padding_mode == 'zeros' and not _os.environ.get('DVD_NO_XCONV'))
@@ -365,7 +381,7 @@ def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False):
     GPU fp32 tensors of a dense stride-1 'same' convolution run on the HIP kernels; CPU tensors (the oracle /
     golden-fixture generator instantiates these modules on the CPU) take the ATen ops the reference uses."""
     if xconv_supported(conv, x):
-        return _XConv.apply(x, conv.weight, conv.bias, residual, relu_in, res_relu)
+        return _XConv.apply(x, conv.weight, conv.bias, residual, relu_in, res_relu, conv.groups)
     if x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and tuple(conv.stride) == (1, 1) and \
             not _os.environ.get('DVD_NO_XCONV'):
         raise RuntimeError('xconv2d: convolution %r is not covered by the HIP kernels' % (conv,))
@@ -376,13 +392,21 @@ def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False):
 
 
 class XConv2d(nn.Conv2d):
-    """Drop-in nn.Conv2d (same parameters / state_dict keys) whose dense stride-1 'same' case runs on the HIP
-    kernels; a strided 1x1 convolution without padding (the ResNeXt down-sampling shortcut) is the 1x1 kernel on
-    the sub-sampled input.  Anything else, and CPU tensors, take ATen."""
+    """Drop-in nn.Conv2d (same parameters / state_dict keys) whose stride-1 'same' case (dense, or grouped 3x3 with
+    at least 32 channels per group) runs on the HIP kernels; a strided 1x1 convolution without padding (the ResNeXt
+    down-sampling shortcut) is the 1x1 kernel on the sub-sampled input, a strided 3x3 'same' convolution is the
+    stride-1 kernel's output sub-sampled.  Anything else, and CPU tensors, take ATen."""
 
     def forward(self, x):
         if xconv_supported(self, x):
-            return _XConv.apply(x, self.weight, self.bias, None, False, False)
+            return _XConv.apply(x, self.weight, self.bias, None, False, False, self.groups)
+        k, st = self.kernel_size, self.stride
+        if (x.is_cuda and x.dtype == torch.float32 and k == (3, 3) and st[0] == st[1] and st[0] > 1 and
+                tuple(self.padding) == (1, 1) and tuple(self.dilation) == (1, 1) and
+                (self.groups == 1 or self.in_channels // self.groups >= 32) and not _os.environ.get('DVD_NO_XCONV')):
+            # out[i][j] of a stride-s 'same' 3x3 convolution is out1[s*i][s*j] of the stride-1 one
+            y = _XConv.apply(x, self.weight, self.bias, None, False, False, self.groups)
+            return y[:, :, ::st[0], ::st[0]].contiguous()
         if (x.is_cuda and x.dtype == torch.float32 and self.kernel_size == (1, 1) and self.groups == 1 and
                 tuple(self.padding) == (0, 0) and self.stride[0] == self.stride[1] and self.stride[0] > 1 and
                 not _os.environ.get('DVD_NO_XCONV')):

@@ -69,16 +69,19 @@ __device__ __forceinline__ void split8(const float v[8], uint4& h, uint4& m, uin
 //   forward:    A[m][k] = w[co = m][ci = k][tap]
 //   transposed: A[m][k] = w[co = k][ci = m][T - 1 - tap]      (backward-data: roles swapped, taps flipped)
 // rows m >= M and columns k >= K are zero (M, K are padded to the block / K-step granularity).
+// Grouped convolutions: Cout / Cin are per group, w is [G * Cout][Cin][T]; group g's fragments follow group g - 1's.
 __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
-                                                         int Cin, int T, int transposed, int mtiles, int nkc) {
+                                                         int Cin, int T, int transposed, int mtiles, int nkc, int G) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)mtiles * nkc * T * 64;
+  const long long total = (long long)G * mtiles * nkc * T * 64;
   if (idx >= total) return;
   const int lane = (int)(idx & 63);
   const long long f = idx >> 6;
   const int tap = (int)(f % T);
   const int kc = (int)((f / T) % nkc);
-  const int mt = (int)(f / T / nkc);
+  const int mtg = (int)(f / T / nkc);
+  const int g = mtg / mtiles, mt = mtg - g * mtiles;
+  w += (size_t)g * Cout * Cin * T;
   const int m = mt * 32 + (lane & 31);
   const int k0 = kc * 16 + 8 * (lane >> 5);
   const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
@@ -107,7 +110,8 @@ struct XArgs {
   const float* __restrict__ res;
   const float* __restrict__ mask_src;
   float* __restrict__ y;
-  int N, Cin, Cout, H, W;   // Cin = real K, Cout = real M of this launch
+  int N, Cin, Cout, H, W;   // Cin = real K, Cout = real M of this launch, PER GROUP
+  int G, mbpg, mtiles;      // groups, channel blocks per group, packed 32-row tiles per group
   int KS, pad, T;
   int TR, TC, P, ntr, ntc, NV;
   int nkc, npos, nfi;     // nfi: B staging items per thread (FI == 0 kernels loop over them at run time)
@@ -133,10 +137,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
   const int wm = wave / WN, wn = wave - wm * WN;
   const int tr = blockIdx.x / a.ntc, tc = blockIdx.x - tr * a.ntc;
   const int r0 = tr * a.TR, c0 = tc * a.TC;
-  const int mt0 = blockIdx.y * MT;
+  const int grp = blockIdx.y / a.mbpg;                 // group of a grouped convolution (0 for dense)
+  const int mt0 = (blockIdx.y - grp * a.mbpg) * MT;
   const int n = blockIdx.z;
   const size_t plane = (size_t)a.H * a.W;
-  const float* xn = a.x + (size_t)n * a.Cin * plane;
+  const float* xn = a.x + ((size_t)n * a.G + grp) * a.Cin * plane;
   const int npos = a.npos, P = a.P, T = a.T, KS = a.KS;
   const int nkt = a.nkc * T;
 
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
     const int j = i * NT + tid;
     const int jj = j < AU ? j : 0;
     const int mtl = jj / 192, rem = jj - mtl * 192;
-    asrc[i] = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(mt0 + mtl) * nkt) * 192 + rem;
+    asrc[i] = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(grp * a.mtiles + mt0 + mtl) * nkt) * 192 + rem;
   }
   struct ARegs {
     u32x4 v[AI];
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
   //      from the image's base: the host checks Cout * H * W < 2^31)
   const int TRv = (a.H - r0) < a.TR ? (a.H - r0) : a.TR;
   const int TCv = (a.W - c0) < a.TC ? (a.W - c0) : a.TC;
-  const size_t ibase = (size_t)n * a.Cout * plane;
+  const size_t ibase = ((size_t)n * a.G + grp) * a.Cout * plane;     // this group's channels of image n
   float* __restrict__ yb = a.y + ibase;
   const int iplane = (int)plane;
 #pragma unroll
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = cob + (r & 3) + 8 * (r >> 2);
-          v[r] += a.bias[co < a.Cout ? co : a.Cout - 1];
+          v[r] += a.bias[grp * a.Cout + (co < a.Cout ? co : a.Cout - 1)];
         }
       }
       if (a.res) {
@@ -485,33 +490,43 @@ static int xconv_mtiles(int M) {
 
 extern "C" {
 
-size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int transposed) {
-  if (Cout <= 0 || Cin <= 0 || KS <= 0 || !(KS & 1)) return 0;
-  const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
-  return (size_t)dvd::xconv_mtiles(M) * ((K + 15) / 16) * KS * KS * 3 * 64 * sizeof(uint4);
+// Channel counts in this ABI are TOTALS; a grouped convolution (groups > 1) has Cin / groups inputs and
+// Cout / groups outputs per group and a weight [Cout][Cin / groups][k][k], like nn.Conv2d.
+size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int groups, int transposed) {
+  if (Cout <= 0 || Cin <= 0 || KS <= 0 || !(KS & 1) || groups <= 0 || Cout % groups || Cin % groups) return 0;
+  const int co = Cout / groups, ci = Cin / groups;
+  const int M = transposed ? ci : co, K = transposed ? co : ci;
+  return (size_t)groups * dvd::xconv_mtiles(M) * ((K + 15) / 16) * KS * KS * 3 * 64 * sizeof(uint4);
 }
 
-int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int transposed, dvd_stream_t stream) {
+int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed, dvd_stream_t stream) {
   DVD_REQUIRE(w && packed, "xconv_pack: null pointer");
-  DVD_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && (KS & 1) && KS <= 11, "xconv_pack: bad shape Cout=%d Cin=%d KS=%d", Cout, Cin, KS);
-  const int M = transposed ? Cin : Cout, K = transposed ? Cout : Cin;
+  DVD_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && (KS & 1) && KS <= 11 && groups > 0 && Cout % groups == 0 && Cin % groups == 0,
+              "xconv_pack: bad shape Cout=%d Cin=%d KS=%d groups=%d", Cout, Cin, KS, groups);
+  const int co = Cout / groups, ci = Cin / groups;
+  const int M = transposed ? ci : co, K = transposed ? co : ci;
   const int mtiles = dvd::xconv_mtiles(M), nkc = (K + 15) / 16, T = KS * KS;
-  const long long total = (long long)mtiles * nkc * T * 64;
+  const long long total = (long long)groups * mtiles * nkc * T * 64;
   hipLaunchKernelGGL(dvd::xconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), w, static_cast<uint4*>(packed), Cout, Cin, T, transposed ? 1 : 0,
-                     mtiles, nkc);
+                     static_cast<hipStream_t>(stream), w, static_cast<uint4*>(packed), co, ci, T, transposed ? 1 : 0,
+                     mtiles, nkc, groups);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
 
 int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
-                  float* y, int N, int Cin, int Cout, int H, int W, int KS, int flags, dvd_stream_t stream) {
+                  float* y, int N, int Cin_total, int Cout_total, int H, int W, int KS, int groups, int flags,
+                  dvd_stream_t stream) {
   DVD_REQUIRE(x && packed && y, "xconv: null pointer");
-  DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xconv: bad shape N=%d Cin=%d Cout=%d H=%d W=%d", N, Cin,
-              Cout, H, W);
+  DVD_REQUIRE(N > 0 && Cin_total > 0 && Cout_total > 0 && H > 0 && W > 0, "xconv: bad shape N=%d Cin=%d Cout=%d H=%d W=%d", N,
+              Cin_total, Cout_total, H, W);
+  DVD_REQUIRE(groups > 0 && Cin_total % groups == 0 && Cout_total % groups == 0, "xconv: %d groups do not divide the channels",
+              groups);
   DVD_REQUIRE(KS > 0 && (KS & 1) && KS <= 11, "xconv: kernel size %d (odd sizes up to 11)", KS);
   DVD_REQUIRE(N <= 65535, "xconv: too many images for the grid");
-  DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xconv: image too large for 32-bit offsets");
+  DVD_REQUIRE((long long)H * W * (long long)(Cin_total > Cout_total ? Cin_total : Cout_total) < (1ll << 31),
+              "xconv: image too large for 32-bit offsets");
+  const int Cin = Cin_total / groups, Cout = Cout_total / groups;
   const dvd::XCfg c = dvd::pick_cfg(Cout);
   int Hh = H, Ww = W;
   if (KS == 1) {           // no spatial structure: one row of H * W positions
@@ -528,13 +543,15 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   a.mask_src = mask_src;
   a.y = y;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = Hh; a.W = Ww;
+  a.G = groups; a.mtiles = dvd::xconv_mtiles(Cout);
   a.KS = KS; a.pad = KS / 2; a.T = KS * KS;
   a.TR = t.TR; a.TC = t.TC; a.P = t.P; a.ntr = t.ntr; a.ntc = t.ntc; a.NV = t.NV;
   a.nkc = (Cin + 15) / 16; a.npos = t.npos; a.nfi = t.FI;
   a.relu_in = flags & 1; a.relu_out = (flags >> 1) & 1; a.res_relu = (flags >> 2) & 1;
   const int mblocks = (Cout + c.blockM() - 1) / c.blockM();
-  DVD_REQUIRE(mblocks <= 65535, "xconv: too many channel blocks");
-  const dim3 grid(t.ntr * t.ntc, mblocks, N);
+  a.mbpg = mblocks;
+  DVD_REQUIRE((long long)mblocks * groups <= 65535, "xconv: too many channel blocks");
+  const dim3 grid(t.ntr * t.ntc, mblocks * groups, N);
   const size_t lds = t.lds;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2>(a, t.FI, grid, lds, s);

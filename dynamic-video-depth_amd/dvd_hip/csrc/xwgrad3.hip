@@ -44,7 +44,8 @@ struct Wg3Args {
   const float* __restrict__ x;
   const float* __restrict__ gy;
   float* __restrict__ partial;   // [S][9][Cout][Cin]
-  int N, Cin, Cout, H, W;
+  int N, Cin, Cout, H, W;        // Cin / Cout per group
+  int G, nco;                    // groups, output-channel blocks per group
   int nstrips, RS, nrseg, S;     // column strips per image, rows per work item, row segments per image, slices
   int relu_in;
 };
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   unsigned char* sX = smem3 + 3 * kW3CB * kW3GPitch;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ky = wave % 3, pn = (wave / 3) & 1, pm = wave / 6;
-  const int co0 = blockIdx.z * kW3CB, ci0 = blockIdx.y * kW3CB;
+  const int grp = blockIdx.z / a.nco;                      // group of a grouped convolution (0 for dense)
+  const int co0 = (blockIdx.z - grp * a.nco) * kW3CB, ci0 = blockIdx.y * kW3CB;
   const size_t plane = (size_t)a.H * a.W;
   const int items = a.N * a.nstrips * a.nrseg;
 
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       if (q < GQ) {
         const int ch = q >> 4, px = c0 + ((q & 15) << 2);
         if (with_g && (co0 + ch) < a.Cout && r < a.H) {
-          const float* p = a.gy + ((size_t)n * a.Cout + co0 + ch) * plane + (size_t)r * a.W;
+          const float* p = a.gy + (((size_t)n * a.G + grp) * a.Cout + co0 + ch) * plane + (size_t)r * a.W;
           if (px + 3 < a.W && ((a.W & 3) == 0)) {
             v = *reinterpret_cast<const float4*>(p + px);
           } else {
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
         const int ch = qq / 20, px = c0 - 8 + ((qq - ch * 20) << 2);
         const int row = r + 1;
         if ((ci0 + ch) < a.Cin && row >= 0 && row < a.H) {
-          const float* p = a.x + ((size_t)n * a.Cin + ci0 + ch) * plane + (size_t)row * a.W;
+          const float* p = a.x + (((size_t)n * a.G + grp) * a.Cin + ci0 + ch) * plane + (size_t)row * a.W;
           if (px >= 0 && px + 3 < a.W && ((a.W & 3) == 0)) {
             v = *reinterpret_cast<const float4*>(p + px);
           } else {
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       }
     }
   }
-  // partial[s][tap][co][ci]
-  float* dst = a.partial + (size_t)blockIdx.x * 9 * a.Cout * a.Cin;
+  // partial[s][tap][G * Cout][Cin]
+  float* dst = a.partial + (size_t)blockIdx.x * 9 * a.G * a.Cout * a.Cin;
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
     const int tap = ky * 3 + kx;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + pm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int ci = ci0 + pn * 32 + (lane & 31);
-      if (co < a.Cout && ci < a.Cin) dst[((size_t)tap * a.Cout + co) * a.Cin + ci] = acc[kx][r];
+      if (co < a.Cout && ci < a.Cin) dst[((size_t)tap * a.G * a.Cout + grp * a.Cout + co) * a.Cin + ci] = acc[kx][r];
     }
   }
 }
@@ -332,11 +334,11 @@ struct Wg3Plan {
   int nstrips, RS, nrseg, S, nco, nci;
   size_t lds;
 };
-static void wg3_plan(int N, int Cin, int Cout, int H, int W, Wg3Plan& p) {
+static void wg3_plan(int N, int Cin, int Cout, int H, int W, int G, Wg3Plan& p) {   // Cin / Cout per group
   p.nco = (Cout + kW3CB - 1) / kW3CB;
   p.nci = (Cin + kW3CB - 1) / kW3CB;
   p.nstrips = (W + kW3Strip - 1) / kW3Strip;
-  const int pairs = p.nco * p.nci;
+  const int pairs = p.nco * p.nci * G;
   // one block per CU is resident: a whole number of rounds over the 256 CUs, each block a few work items long
   int S = pairs >= 256 ? 1 : (512 + pairs - 1) / pairs;
   // rows per item: enough items to feed S slices evenly (>= 4 per slice), at least 8 rows (2 warm-up rows per item)
@@ -354,41 +356,45 @@ static void wg3_plan(int N, int Cin, int Cout, int H, int W, Wg3Plan& p) {
 
 extern "C" {
 
-size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
-  if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W, int groups) {
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cin % groups || Cout % groups) return 0;
   dvd::Wg3Plan p;
-  dvd::wg3_plan(N, Cin, Cout, H, W, p);
-  return (size_t)p.S * 9 * Cout * Cin * sizeof(float);
+  dvd::wg3_plan(N, Cin / groups, Cout / groups, H, W, groups, p);
+  return (size_t)p.S * 9 * Cout * (Cin / groups) * sizeof(float);
 }
 
-int dvd_xwgrad3(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
-                int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
+int dvd_xwgrad3(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin_total,
+                int Cout_total, int H, int W, int groups, int relu_in, dvd_stream_t stream) {
   DVD_REQUIRE(x && gy && gw && workspace, "xwgrad3: null pointer");
-  DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgrad3: bad shape");
-  DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgrad3: image too large for 32-bit offsets");
+  DVD_REQUIRE(N > 0 && Cin_total > 0 && Cout_total > 0 && H > 0 && W > 0, "xwgrad3: bad shape");
+  DVD_REQUIRE(groups > 0 && Cin_total % groups == 0 && Cout_total % groups == 0, "xwgrad3: %d groups do not divide the channels", groups);
+  DVD_REQUIRE((long long)H * W * (long long)(Cin_total > Cout_total ? Cin_total : Cout_total) < (1ll << 31),
+              "xwgrad3: image too large for 32-bit offsets");
+  const int Cin = Cin_total / groups, Cout = Cout_total / groups;
   dvd::Wg3Plan p;
-  dvd::wg3_plan(N, Cin, Cout, H, W, p);
-  const size_t need = (size_t)p.S * 9 * Cout * Cin * sizeof(float);
+  dvd::wg3_plan(N, Cin, Cout, H, W, groups, p);
+  const size_t need = (size_t)p.S * 9 * Cout_total * Cin * sizeof(float);
   if (workspace_bytes < need) {
     dvd::set_error("xwgrad3: workspace %zu < %zu bytes", workspace_bytes, need);
     return DVD_ENOSPC;
   }
-  DVD_REQUIRE(p.nco <= 65535 && p.nci <= 65535, "xwgrad3: too many channel blocks");
+  DVD_REQUIRE((long long)p.nco * groups <= 65535 && p.nci <= 65535, "xwgrad3: too many channel blocks");
   dvd::Wg3Args a;
   a.x = x;
   a.gy = gy;
   a.partial = static_cast<float*>(workspace);
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.G = groups; a.nco = p.nco;
   a.nstrips = p.nstrips; a.RS = p.RS; a.nrseg = p.nrseg; a.S = p.S;
   a.relu_in = relu_in ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)p.lds));
-  hipLaunchKernelGGL(dvd::xwgrad3_kernel, dim3(p.S, p.nci, p.nco), dim3(dvd::kW3NT), p.lds, s, a);
+  hipLaunchKernelGGL(dvd::xwgrad3_kernel, dim3(p.S, p.nci, p.nco * groups), dim3(dvd::kW3NT), p.lds, s, a);
   DVD_LAUNCH_OK();
-  const long long per = (long long)9 * Cout * Cin;
+  const long long per = (long long)9 * Cout_total * Cin;
   hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
-                     static_cast<const float*>(workspace), gw, p.S, 9, Cout, Cin);
+                     static_cast<const float*>(workspace), gw, p.S, 9, Cout_total, Cin);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -422,6 +428,7 @@ int dvd_xwgrad1s(const float* x, const float* gy, float* gw, void* workspace, si
   a.gy = gy;
   a.partial = static_cast<float*>(workspace);
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.G = 1; a.nco = nco;
   a.nstrips = 0; a.RS = 0; a.nrseg = 0; a.S = S;
   a.relu_in = relu_in ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -297,10 +297,12 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
  *         bit1: act_out = ReLU, bit2: res' = relu(residual) instead of residual;
  *   bias [Cout], residual / mask_src [N,Cout,H,W] may be NULL.  mask_src is the ReLU mask of the
  *   backward-data pass (gx = dgrad(gy) * [x > 0]). */
-size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int transposed);
-int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int transposed, dvd_stream_t stream);
+/* Channel counts are totals; groups > 1 = grouped convolution with weight [Cout][Cin / groups][k][k] (nn.Conv2d's
+ * layout): the 64-channels-per-group 3x3 convolutions of ResNeXt stage 4 run here with groups = 32. */
+size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int groups, int transposed);
+int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed, dvd_stream_t stream);
 int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
-                  float* y, int N, int Cin, int Cout, int H, int W, int KS, int flags, dvd_stream_t stream);
+                  float* y, int N, int Cin, int Cout, int H, int W, int KS, int groups, int flags, dvd_stream_t stream);
 /* Backward-weight of the same convolutions (k = 1 and 3), exact fp32 MFMA, deterministic two-stage sum
  * (csrc/xwgrad.hip): gw[Cout,Cin,k,k] = sum_{n,p} gy[n,co,p] * act(x)[n,ci,p + tap], act = ReLU if relu_in.
  * Replaces the autograd weight gradient of the nn.Conv2d named above (MIOpen accumulates it with atomics). */
@@ -310,9 +312,9 @@ int dvd_xwgrad(const float* x, const float* gy, float* gw, void* workspace, size
 
 /* The 3x3 case on the bf16 matrix cores with the three-term split of dvd_xconv_fwd (fp32-class accuracy,
  * deterministic; csrc/xwgrad3.hip): what the MiDaS decoder's weight gradients run on. */
-size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W);
+size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W, int groups);
 int dvd_xwgrad3(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
-                int Cout, int H, int W, int relu_in, dvd_stream_t stream);
+                int Cout, int H, int W, int groups, int relu_in, dvd_stream_t stream);
 /* ... and the 1x1 case (ResNeXt bottleneck convolutions), same arithmetic: a K-contiguous "NT" GEMM over the pixels. */
 size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W);
 int dvd_xwgrad1s(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,

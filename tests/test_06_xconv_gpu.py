@@ -117,6 +117,38 @@ def test_forward_and_input_gradient(N, Cin, Cout, H, W, KS):
     assert _err(cg.bias.grad, bd.grad) < 1e-5
 
 
+GROUPED = [
+    # N, C, groups, H, W, stride
+    (2, 2048, 32, 6, 11, 1),         # ResNeXt-101 32x8d stage 4 (64 channels per group)
+    (1, 2048, 32, 12, 21, 2),        # its stride-2 entry
+    (1, 1024, 32, 13, 23, 2),        # stage 3's stride-2 entry (32 per group), odd image
+    (2, 96, 3, 9, 14, 1),            # group counts / sizes that are multiples of nothing much
+]
+
+
+@pytest.mark.parametrize('N,Cc,G,H,W,stride', GROUPED)
+def test_grouped_3x3(N, Cc, G, H, W, stride):
+    """Grouped 3x3 convolutions of the ResNeXt encoder (torchvision resnet.py Bottleneck.conv2 as MiDaS.py:186-195 runs
+    it): forward, input gradient and weight gradient against float64 autograd."""
+    from dvd_hip import conv as C
+    torch.manual_seed(Cc + G + stride)
+    x, conv = torch.randn(N, Cc, H, W), torch.nn.Conv2d(Cc, Cc, 3, stride=stride, padding=1, groups=G, bias=False)
+    xd = x.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    want = F.conv2d(xd, wd, None, stride=stride, padding=1, groups=G)
+    gy = torch.randn_like(want, dtype=torch.float32)
+    want.backward(gy.double())
+    cg = C.XConv2d(Cc, Cc, 3, stride=stride, padding=1, groups=G, bias=False).cuda()
+    cg.load_state_dict(conv.state_dict())
+    xg = x.cuda().requires_grad_(True)
+    y = cg(xg)
+    assert y.shape == want.shape
+    assert _err(y.detach(), want.detach()) < TOL, _where(y.detach(), want.detach(), 'n,co,y,x')
+    y.backward(gy.cuda())
+    assert _err(xg.grad, xd.grad) < TOL, 'dgrad: ' + _where(xg.grad, xd.grad, 'n,ci,y,x')
+    assert _err(cg.weight.grad, wd.grad) < 2e-5, 'wgrad: ' + _where(cg.weight.grad, wd.grad, 'co,ci,ky,kx')
+
+
 def test_fused_input_relu_residual_and_its_backward():
     """ResidualConvUnit pieces (midas_blocks.py:121-135): conv(relu(x)) + relu(res), gradient masks included."""
     from dvd_hip import conv as C
