@@ -1,4 +1,5 @@
-// Fused scene-flow field MLP for gfx950 (MI355X): forward, backward-dX chain, backward-dW.
+// Fused scene-flow field MLP for gfx950 (MI355X): forward, backward-dX chain, backward-dW, on the bf16
+// matrix cores with fp32-class accuracy.
 //
 // What it replaces (reference, /root/reference):
 //   networks/sceneflow_field.py:43-53   SceneFlowFieldNet.forward
@@ -8,48 +9,70 @@
 // and the autograd backward of all of it.  The unfused reference saves 11 168 B per
 // pixel-evaluation for backward and launches ~80 kernels per evaluation.
 //
-// Roofline: fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF peak, bit-exact fp32 FMA chains).
-// 593 408 FLOP per pixel forward, 2x that backward.
+// Arithmetic (same as csrc/xconv.hip).  gfx950 runs fp32 MFMAs at the vector rate (157 TF), 1/16 of the bf16
+// matrix rate, so every fp32 operand is split exactly into three bf16 terms x = h + m + l (24 significant bits) and a
+// product is the six largest of the nine partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+// about one ulp more error per product than an fp32 FMA chain, at 16/6 = 2.7x the fp32 MFMA rate.  The first
+// generation of this file (fp32 MFMAs, 121 / 94 / 91 TF/s forward / dX / dW) is in the history.
 //
-// Structure (all three kernels): a 256-thread workgroup (4 waves, one per SIMD, two
-// workgroups per CU) owns a tile of 64 pixels.
-//   * Activations live in LDS as X[kq][m] float4 = channels 4kq..4kq+3 of pixel m
-//     ("k-quad major").  One ds_read_b128 per lane feeds FOUR MFMA k-steps of a
-//     32-pixel column tile, and the MFMA result registers (4 consecutive output channels
-//     of one pixel per lane) go back with one ds_write_b128 - both conflict free.
-//   * Weights never touch LDS: they are pre-packed (dvd_sf_mlp_pack) in MFMA fragment
-//     order so that a lane's operands for four k-steps are one 16-byte global load; the
-//     1.2 MB of packed weights stay in each XCD's 4 MB L2.
-//   * forward: wave w computes output channels [64w, 64w+64) for all 64 pixels
-//     (2x2 tiles of 32x32, 64 accumulator registers), layer after layer in place.
-//   * backward dX: same loop with the transposed packing, multiplied by LeakyReLU'
-//     (sign of the stashed activation); writes the pre-activation gradients G_l.
-//   * backward dW: dW_l = G_l H_{l-1}^T contracts over PIXELS.  Both operands are read
-//     straight from the stash in the layout above, where a lane's 16-byte load holds
-//     four channels of one pixel = four MFMA row(col) tiles; a wave keeps a 128x128
-//     block of dW_l in 256 accumulator registers across all of its tiles and adds it to
-//     global memory once.
+// 593 408 FLOP per pixel forward, the same again for dX and for dW.
 //
-// The forward writes the embedding and the five hidden activations to the stash
-// (5 664 B per pixel, streamed while the MFMAs run): at fp32-MFMA rates re-reading them
-// is cheaper than recomputing the forward in the backward pass (+33 % MFMA work).
+// Forward and dX: a 512-thread workgroup (8 waves, two per SIMD, one workgroup per CU) owns a tile of 64 pixels.
+//   * Activations live in LDS already split: X[term][k-octet][pixel] cells of 8 bf16 (96 KB).  A lane's B fragment
+//     of one K step (16 channels) is one ds_read_b128 per term; 32 consecutive pixels = 32 consecutive cells.
+//   * Weights never touch LDS: dvd_sf_mlp_pack writes them split and in fragment order (both orientations,
+//     3.5 MB, resident in each XCD's 4 MB L2); a lane's A fragment is one 16-byte global load per term.
+//   * Wave w computes output channels [32w, 32w+32) for all 64 pixels (1x2 tiles of 32x32), layer after layer in
+//     place: 12 MFMAs per K step against 3 global + 6 LDS fragment loads.
+//   * The epilogue (bias, LeakyReLU, split, LDS write) also streams the fp32 activation to the stash as
+//     [channel][64 pixels] rows -- the K-contiguous operand layout of the dW GEMM -- and one SIGN BIT per unit:
+//     the dX chain needs LeakyReLU' only, so it reads 4 bytes per lane and layer instead of the activations.
+//   * The 256 -> 3 output layer is folded into the last epilogue (per-lane partial dot products of the fp32
+//     values, reduced over the waves through LDS in fixed order).
+// dW: dW_l = G_l H_{l-1}^T contracts over PIXELS.  A 512-thread workgroup owns the whole 256 x 256 matrix of one
+//   layer for a run of tiles (each operand is read from HBM exactly once): per 16-pixel chunk 512 channel rows are
+//   loaded as fp32, split and written to a double-buffered LDS stage while the MFMAs of the previous chunk run
+//   (one barrier per chunk); wave (wr, wc) keeps rows [64wr,+64) x columns [128wc,+128) in 128 accumulators.
+//   Per-workgroup partial matrices go to a workspace at the end of `gstash` and are summed in fixed order by a
+//   second kernel: the weight gradients are bitwise reproducible (the first generation used float atomics).
 
 #include "dvd_common.h"
 
 namespace dvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of it stay in registers
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kTM = 64;      // pixels per tile
-constexpr int kWidth = 256;  // hidden width (scene_flow_motion_field.py:107)
-constexpr int kKQ = kWidth / 4;
-constexpr int kHidden = 5;   // layers with LeakyReLU: convs.0 .. convs.4
+constexpr int kTM = 64;        // pixels per tile
+constexpr int kWidth = 256;    // hidden width (scene_flow_motion_field.py:107)
+constexpr int kHidden = 5;     // layers with LeakyReLU: convs.0 .. convs.4
+constexpr int kNT = 512;       // threads per workgroup (forward, dX, dW)
 constexpr float kSlope = 0.2f;
+constexpr int kTermStride = 32 * kTM * 16;   // bytes between the split terms of X: [32 k-octets][64 pixels][16 B]
+constexpr int kXBytes = 3 * kTermStride;     // 98 304
+
+// (a, b) -> three dwords of two bf16 each: a in the low half, b in the high half
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  const f32x2 v = {a, b};
+  const bf16x2 hb = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
+  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
+  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
 
 struct Geometry {
   int n_freq_xyz, n_freq_t, time_dependent;
-  int c_in, c_in_pad, kb0, kq0;  // input channels, padded to 8, k-blocks, k-quads
-  int t_base, xyz_base;          // channel of t / of x in the input layer
+  int c_in, c_in16;      // input channels, padded to the K step
+  int ks0, rt0;          // K steps of the input layer, row tiles of W_0^T
+  int t_base, xyz_base;  // channel of t / of x in the input layer
 };
 
 static Geometry make_geometry(const dvd_mlp_desc* d) {
@@ -59,89 +82,185 @@ static Geometry make_geometry(const dvd_mlp_desc* d) {
   g.time_dependent = d->time_dependent;
   const int ct = d->time_dependent ? 1 + 2 * d->n_freq_t : 0;
   g.c_in = ct + 3 + 6 * d->n_freq_xyz;
-  g.c_in_pad = (g.c_in + 7) & ~7;
-  g.kb0 = g.c_in_pad / 8;
-  g.kq0 = g.c_in_pad / 4;
+  g.c_in16 = (g.c_in + 15) & ~15;
+  g.ks0 = g.c_in16 / 16;
+  g.rt0 = (g.c_in + 31) / 32;
   g.t_base = 0;
   g.xyz_base = ct;
   return g;
 }
 
-// ---- packed weight buffer (floats) -------------------------------------------------
+// ---- packed weight buffer ----------------------------------------------------------------
+// fragments: [(row tile * nk + K step) * 3 + term][64 lanes] x 16 bytes; lane l holds A[32 rt + (l&31)][16 kc + 8 (l>>5) .. +7]
+//   forward  layer l: A[m][k] = W_l[out = m][in = k]    8 row tiles, nk = K_l / 16
+//   backward layer l: A[m][k] = W_l[out = k][in = m]    ceil(K_l / 32) row tiles, 16 K steps
+// then fp32: W_5 [3][256], biases.
 struct PackLayout {
-  size_t fwd[kHidden];  // [8 nt][KB_l][64 lanes][4]
-  size_t bwd[kHidden];  // [KT_l][32][64][4]      (W^T, for the dX chain)
-  size_t w5, bias[6];
-  int kb[kHidden], kt[kHidden];
-  size_t total;
+  size_t fwd[kHidden], bwd[kHidden];   // offsets in 16-byte units
+  int nk[kHidden], rtb[kHidden];
+  size_t w5, bias[6];                  // offsets in floats
+  size_t total_bytes;
 };
 
 static PackLayout make_pack_layout(const Geometry& g) {
   PackLayout L;
   size_t off = 0;
   for (int l = 0; l < kHidden; ++l) {
-    L.kb[l] = l == 0 ? g.kb0 : kWidth / 8;
-    L.kt[l] = l == 0 ? (g.c_in_pad + 31) / 32 : kWidth / 32;
+    L.nk[l] = l == 0 ? g.ks0 : kWidth / 16;
+    L.rtb[l] = l == 0 ? g.rt0 : kWidth / 32;
     L.fwd[l] = off;
-    off += (size_t)8 * L.kb[l] * 256;
+    off += (size_t)8 * L.nk[l] * 192;
     L.bwd[l] = off;
-    off += (size_t)L.kt[l] * 32 * 256;
+    off += (size_t)L.rtb[l] * 16 * 192;
   }
-  L.w5 = off;
-  off += 3 * kWidth;
+  size_t f = off * 4;
+  L.w5 = f;
+  f += 3 * kWidth;
   for (int l = 0; l < 6; ++l) {
-    L.bias[l] = off;
-    off += l < 5 ? kWidth : 4;
+    L.bias[l] = f;
+    f += l < 5 ? kWidth : 4;
   }
-  L.total = off;
+  L.total_bytes = f * 4;
   return L;
 }
 
 struct PackArgs {
   const float* W[6];
   const float* b[6];
-  float* out;
+  void* out;
   PackLayout L;
   int c_in;
 };
 
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const PackArgs a) {
-  const int l = blockIdx.y;
+  const int job = blockIdx.y;   // 0..4 forward layer, 5..9 backward layer, 10 fp32 tail
   const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (l < kHidden) {
-    const int K = l == 0 ? a.c_in : kWidth;  // true fan-in; padded positions get 0
-    const float* W = a.W[l];
-    const int kb = a.L.kb[l], kt = a.L.kt[l];
-    const int nf = 8 * kb * 256;
-    if (gid < nf) {
-      const int s = gid & 3, lane = (gid >> 2) & 63, G = (gid >> 8) % kb, nt = (gid >> 8) / kb;
-      const int n = 32 * nt + (lane & 31), k = 8 * G + 4 * (lane >> 5) + s;
-      a.out[a.L.fwd[l] + gid] = k < K ? W[(size_t)n * K + k] : 0.0f;
+  float* outf = static_cast<float*>(a.out);
+  if (job == 10) {
+    if (gid < 3 * kWidth) outf[a.L.w5 + gid] = a.W[5][gid];
+    if (gid < 4) outf[a.L.bias[5] + gid] = gid < 3 ? a.b[5][gid] : 0.0f;
+    for (int l = 0; l < kHidden; ++l)
+      if (gid < kWidth) outf[a.L.bias[l] + gid] = a.b[l][gid];
+    return;
+  }
+  const bool bwd = job >= kHidden;
+  const int l = bwd ? job - kHidden : job;
+  const int Kin = l == 0 ? a.c_in : kWidth;          // true fan-in of layer l (row length of W_l)
+  const int nk = bwd ? 16 : a.L.nk[l], nrt = bwd ? a.L.rtb[l] : 8;
+  if (gid >= nrt * nk * 64) return;
+  const int lane = gid & 63, f = gid >> 6, kc = f % nk, rt = f / nk;
+  const int m = 32 * rt + (lane & 31), k0 = 16 * kc + 8 * (lane >> 5);
+  const float* W = a.W[l];
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = k0 + e;
+    float val = 0.0f;
+    if (!bwd) {
+      if (k < Kin) val = W[(size_t)m * Kin + k];       // m < 256 always
+    } else {
+      if (m < Kin) val = W[(size_t)k * Kin + m];       // k < 256 always
     }
-    const int nb = kt * 32 * 256;
-    if (gid < nb) {
-      const int s = gid & 3, lane = (gid >> 2) & 63, G = (gid >> 8) & 31, t = gid >> 13;
-      const int n = 8 * G + 4 * (lane >> 5) + s, k = 32 * t + (lane & 31);
-      a.out[a.L.bwd[l] + gid] = k < K ? W[(size_t)n * K + k] : 0.0f;
-    }
-    if (gid < kWidth) a.out[a.L.bias[l] + gid] = a.b[l][gid];
-  } else {
-    if (gid < 3 * kWidth) a.out[a.L.w5 + gid] = a.W[5][gid];
-    if (gid < 4) a.out[a.L.bias[5] + gid] = gid < 3 ? a.b[5][gid] : 0.0f;
+    v[e] = val;
+  }
+  unsigned hw[4], mw[4], lw[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hw[e], mw[e], lw[e]);
+  const u32x4 h = {hw[0], hw[1], hw[2], hw[3]}, mm = {mw[0], mw[1], mw[2], mw[3]}, lo = {lw[0], lw[1], lw[2], lw[3]};
+  u32x4* dst = static_cast<u32x4*>(a.out) + (bwd ? a.L.bwd[l] : a.L.fwd[l]) + (size_t)f * 192 + lane;
+  dst[0] = h;
+  dst[64] = mm;
+  dst[128] = lo;
+}
+
+// ---- stash layouts (floats per tile) -------------------------------------------------------
+// stash : embedding [c_in16][64], h_0 .. h_4 [256][64] each, sign words [5][512] (one bit per unit of the lane's
+//         32 outputs of that layer, bit = 16 ct + r)
+// gstash: pre-activation gradients G_0 .. G_4 [256][64] each; after all tiles: the dW workspace
+__host__ __device__ inline size_t stash_floats_per_tile(int c_in16) {
+  return (size_t)(c_in16 + kHidden * kWidth) * kTM + (size_t)kHidden * kNT;
+}
+__host__ __device__ inline size_t stash_h_off(int c_in16, int l) { return (size_t)(c_in16 + l * kWidth) * kTM; }   // h_l
+__host__ __device__ inline size_t stash_sign_off(int c_in16, int l) {
+  return (size_t)(c_in16 + kHidden * kWidth) * kTM + (size_t)l * kNT;
+}
+__host__ __device__ inline size_t gstash_floats_per_tile() { return (size_t)kHidden * kWidth * kTM; }
+constexpr int kDwSlices = 51;                                  // workgroups per layer (5 x 51 = 255 of 256 CUs)
+constexpr size_t kDwPartial = (size_t)kWidth * kWidth + kWidth;   // floats per workgroup: dW block + row sums
+
+// ---- the GEMM core of forward and dX ---------------------------------------------------------
+// acc[ct] += A (this wave's 32 rows, fragments streamed from global / L2) x B (X in LDS, column tile ct) over nk K steps.
+// Ap = fragment base of the wave's row tile + lane; Xl = LDS base of X + (lane>>5) * 1024 + (lane&31) * 16.
+__device__ __forceinline__ void load_frags(const u32x4* __restrict__ Ap, const unsigned char* Xl, int kc, u32x4 (&A)[3],
+                                           u32x4 (&B)[2][3]) {
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    A[t] = Ap[(size_t)kc * 192 + t * 64];
+    B[0][t] = *reinterpret_cast<const u32x4*>(Xl + t * kTermStride + kc * 2048);
+    B[1][t] = *reinterpret_cast<const u32x4*>(Xl + t * kTermStride + kc * 2048 + 512);
   }
 }
 
-// ---- stash layout --------------------------------------------------------------------
-// per tile: float4 cells [kq0][64] (embedding) then 5 x [64][64] (hidden activations)
-__host__ __device__ inline size_t stash_cells_per_tile(int kq0) { return (size_t)kq0 * kTM + (size_t)kHidden * kKQ * kTM; }
-__host__ __device__ inline size_t stash_layer_off(int kq0, int slot) {  // slot 0 = embedding, 1..5 = h0..h4
-  return slot == 0 ? 0 : (size_t)kq0 * kTM + (size_t)(slot - 1) * kKQ * kTM;
+__device__ __forceinline__ void mfma_step(const u32x4 (&A)[3], const u32x4 (&B)[2][3], f32x16 (&acc)[2]) {
+#define DVD_MLP_TERM(SA, SB)                                                                               \
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[SA]),                      \
+                                                   __builtin_bit_cast(bf16x8, B[0][SB]), acc[0], 0, 0, 0); \
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[SA]),                      \
+                                                   __builtin_bit_cast(bf16x8, B[1][SB]), acc[1], 0, 0, 0);
+  DVD_MLP_TERM(2, 0)   // smallest partial products first
+  DVD_MLP_TERM(0, 2)
+  DVD_MLP_TERM(1, 1)
+  DVD_MLP_TERM(1, 0)
+  DVD_MLP_TERM(0, 1)
+  DVD_MLP_TERM(0, 0)
+#undef DVD_MLP_TERM
 }
-// gstash per tile: 5 x [64][64] cells (pre-activation gradients of layers 0..4) + [64] cells (g_z5, 3 used)
-__host__ __device__ inline size_t gstash_cells_per_tile() { return (size_t)kHidden * kKQ * kTM + kTM; }
 
+__device__ __forceinline__ void gemm_rows32(const u32x4* __restrict__ Ap, int nk, const unsigned char* Xl, f32x16 (&acc)[2]) {
+  // two fragment sets, ping-pong: the loads of step kc+1 are issued before the MFMAs of step kc.  The scheduling
+  // barriers keep them there (the scheduler otherwise sinks the loads to their first use and every K step waits a
+  // full L2 round trip); steps past the end re-read the last one (no conditional loads).
+  u32x4 A0[3], B0[2][3], A1[3], B1[2][3];
+  load_frags(Ap, Xl, 0, A0, B0);
+  int kc = 0;
+#pragma unroll 1
+  for (; kc + 1 < nk; kc += 2) {
+    load_frags(Ap, Xl, kc + 1, A1, B1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(A0, B0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(Ap, Xl, kc + 2 < nk ? kc + 2 : nk - 1, A0, B0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(A1, B1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (kc < nk) mfma_step(A0, B0, acc);   // odd nk: set 0 already holds the last step
+}
+
+__device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+}
+
+// Four consecutive channels (n4 .. n4+3, the half `hh` of k-octet ko) of pixel m -> the three split terms in X.
+__device__ __forceinline__ void store_split4(unsigned char* X, int ko, int m, int hh, float v0, float v1, float v2, float v3) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  split_pair(v0, v1, h0, m0, l0);
+  split_pair(v2, v3, h1, m1, l1);
+  unsigned char* dst = X + (ko * kTM + m) * 16 + hh * 8;
+  *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+  *reinterpret_cast<u32x2*>(dst + kTermStride) = (u32x2){m0, m1};
+  *reinterpret_cast<u32x2*>(dst + 2 * kTermStride) = (u32x2){l0, l1};
+}
+
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, kSlope * v); }
+
+// ==========================================================================================
+// forward
 struct FwdArgs {
-  const float* packed;
+  const void* packed;
   const float* p;
   const float* t;
   const float* freqs_xyz;
@@ -149,7 +268,7 @@ struct FwdArgs {
   float* sf_out;
   float* p_next;
   float* acc;
-  float4* stash;
+  float* stash;
   PackLayout L;
   Geometry g;
   long long n_pix;
@@ -157,24 +276,34 @@ struct FwdArgs {
   float t_offset, out_scale;
 };
 
-__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, kSlope * v); }
+// LDS: X | psm [4][64] | w5 [3][256] + bias5 [4] | red [8][3][64]
+constexpr size_t kFwdLds = (size_t)kXBytes + 4 * kTM * 4 + (3 * kWidth + 4) * 4 + 8 * 3 * kTM * 4;
 
-// Input embedding of one tile into X (k-quad major) ; psm = [4][64] floats: x,y,z,t of the pixels.
-__device__ __forceinline__ void build_embedding(const Geometry& g, const float* __restrict__ fx,
-                                                const float* __restrict__ ft, const float* psm, float* Xf) {
-  const int m = threadIdx.x & 63, part = threadIdx.x >> 6;
-  auto put = [&](int ch, float v) { Xf[((ch >> 2) * kTM + m) * 4 + (ch & 3)] = v; };
+// Input embedding of one tile: split into X, fp32 to the stash.  psm = [4][64] floats: x, y, z, t of the pixels.
+template <bool STASH>
+__device__ __forceinline__ void build_embedding(const Geometry& g, const float* __restrict__ fx, const float* __restrict__ ft,
+                                                const float* psm, unsigned char* X, float* st_emb) {
+  const int m = threadIdx.x & 63, part = threadIdx.x >> 6;   // 8 parts
+  auto put = [&](int ch, float v) {
+    unsigned h, mm, l;
+    split_pair(v, 0.0f, h, mm, l);
+    unsigned char* dst = X + ((ch >> 3) * kTM + m) * 16 + (ch & 7) * 2;
+    *reinterpret_cast<unsigned short*>(dst) = (unsigned short)h;
+    *reinterpret_cast<unsigned short*>(dst + kTermStride) = (unsigned short)mm;
+    *reinterpret_cast<unsigned short*>(dst + 2 * kTermStride) = (unsigned short)l;
+    if (STASH) st_emb[(size_t)ch * kTM + m] = v;
+  };
   const float x0 = psm[m], x1 = psm[kTM + m], x2 = psm[2 * kTM + m], tt = psm[3 * kTM + m];
   if (part == 0) {
     if (g.time_dependent) put(g.t_base, tt);
     put(g.xyz_base + 0, x0);
     put(g.xyz_base + 1, x1);
     put(g.xyz_base + 2, x2);
-    for (int ch = g.c_in; ch < g.c_in_pad; ++ch) put(ch, 0.0f);
+    for (int ch = g.c_in; ch < g.c_in16; ++ch) put(ch, 0.0f);
   }
   const int nt = g.n_freq_t, nx = g.n_freq_xyz;
   const int items = nt + 3 * nx;
-  for (int e = part; e < items; e += 4) {
+  for (int e = part; e < items; e += 8) {
     float arg;
     int ch_cos, ch_sin;
     if (e < nt) {
@@ -194,173 +323,119 @@ __device__ __forceinline__ void build_embedding(const Geometry& g, const float* 
   }
 }
 
-// One dense layer on the tile: acc[nt][mt] += A(packed weights) x B(X in LDS) over KB k-blocks of 8.
-// Wave w owns row tiles 2w, 2w+1 of the packed matrix.
-__device__ __forceinline__ void gemm_tile(const float4* __restrict__ Wp, int KB, int rowtile0, const float4* X4,
-                                          int lane, f32x16 acc[2][2]) {
-  const int j = lane & 31, h = lane >> 5;
-  const float4* A0 = Wp + (size_t)(rowtile0 + 0) * KB * 64 + lane;
-  const float4* A1 = Wp + (size_t)(rowtile0 + 1) * KB * 64 + lane;
-  const float4* B0 = X4 + h * kTM + j;
-  float4 a0 = A0[0], a1 = A1[0], b0 = B0[0], b1 = B0[32];
-#pragma unroll 1
-  for (int G = 0; G < KB; ++G) {
-    float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-    if (G + 1 < KB) {
-      na0 = A0[(size_t)(G + 1) * 64];
-      na1 = A1[(size_t)(G + 1) * 64];
-      nb0 = B0[(size_t)(G + 1) * 2 * kTM];
-      nb1 = B0[(size_t)(G + 1) * 2 * kTM + 32];
-    }
-#define DVD_STEP(S)                                                                       \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.S, b0.S, acc[0][0], 0, 0, 0);       \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.S, b1.S, acc[0][1], 0, 0, 0);       \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.S, b0.S, acc[1][0], 0, 0, 0);       \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.S, b1.S, acc[1][1], 0, 0, 0);
-    DVD_STEP(x)
-    DVD_STEP(y)
-    DVD_STEP(z)
-    DVD_STEP(w)
-#undef DVD_STEP
-    a0 = na0;
-    a1 = na1;
-    b0 = nb0;
-    b1 = nb1;
-  }
-}
-
-// Same with a single row tile (acc[0][*] only).
-__device__ __forceinline__ void gemm_tile_single(const float4* __restrict__ Wp, int KB, int rowtile, const float4* X4,
-                                                 int lane, f32x16 acc[2][2]) {
-  const int j = lane & 31, h = lane >> 5;
-  const float4* A0 = Wp + (size_t)rowtile * KB * 64 + lane;
-  const float4* B0 = X4 + h * kTM + j;
-  float4 a0 = A0[0], b0 = B0[0], b1 = B0[32];
-#pragma unroll 1
-  for (int G = 0; G < KB; ++G) {
-    float4 na0 = a0, nb0 = b0, nb1 = b1;
-    if (G + 1 < KB) {
-      na0 = A0[(size_t)(G + 1) * 64];
-      nb0 = B0[(size_t)(G + 1) * 2 * kTM];
-      nb1 = B0[(size_t)(G + 1) * 2 * kTM + 32];
-    }
-#define DVD_STEP(S)                                                                 \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.S, b0.S, acc[0][0], 0, 0, 0); \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.S, b1.S, acc[0][1], 0, 0, 0);
-    DVD_STEP(x)
-    DVD_STEP(y)
-    DVD_STEP(z)
-    DVD_STEP(w)
-#undef DVD_STEP
-    a0 = na0;
-    b0 = nb0;
-    b1 = nb1;
-  }
-}
-
-__device__ __forceinline__ void zero_acc(f32x16 acc[2][2]) {
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-}
-
 template <bool STASH>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(const FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float4* X4 = reinterpret_cast<float4*>(smem);  // [64 kq][64 m]
-  float* Xf = smem;
-  float* psm = smem + kKQ * kTM * 4;             // [4][64]
-  float* w5 = psm + 4 * kTM;                     // [3][256] + bias5[4]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+__global__ __launch_bounds__(kNT) void mlp_fwd_kernel(const FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* X = smem;
+  float* psm = reinterpret_cast<float*>(smem + kXBytes);   // [4][64]
+  float* w5 = psm + 4 * kTM;                               // [3][256] + bias5[4]
+  float* red = w5 + 3 * kWidth + 4;                        // [8 waves][3][64]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
-  for (int i = tid; i < 3 * kWidth + 4; i += 256) w5[i] = a.packed[a.L.w5 + (i < 3 * kWidth ? i : (a.L.bias[5] - a.L.w5) + (i - 3 * kWidth))];
-  const float4* P4 = reinterpret_cast<const float4*>(a.packed);
+  const float* pf = static_cast<const float*>(a.packed);
+  const u32x4* P4 = static_cast<const u32x4*>(a.packed);
+  for (int i = tid; i < 3 * kWidth + 4; i += kNT) w5[i] = pf[i < 3 * kWidth ? a.L.w5 + i : a.L.bias[5] + (i - 3 * kWidth)];
+  const unsigned char* Xl = X + hh * 1024 + j * 16;
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long n0 = (long long)tile * kTM;
-    __syncthreads();  // previous tile's readers are done with X / psm
-    {  // pixel inputs: thread (c = w, m = lane)
+    __syncthreads();  // previous tile's readers are done with X / psm / red
+    if (tid < 4 * kTM) {  // pixel inputs: thread (c = tid >> 6, m = lane)
+      const int c = tid >> 6;
       const long long n = n0 + lane;
       float v = 0.0f;
       if (n < a.n_pix) {
         const long long b = n / a.pix_per_img, hw = n - b * a.pix_per_img;
-        if (w < 3)
-          v = a.p[(b * 3 + w) * a.pix_per_img + hw];
+        if (c < 3)
+          v = a.p[(b * 3 + c) * a.pix_per_img + hw];
         else
           v = a.t ? a.t[n] + a.t_offset : 0.0f;
       }
-      psm[w * kTM + lane] = v;
+      psm[c * kTM + lane] = v;
     }
     __syncthreads();
-    build_embedding(a.g, a.freqs_xyz, a.freqs_t, psm, Xf);
+    float* st = STASH ? a.stash + (size_t)tile * stash_floats_per_tile(a.g.c_in16) : nullptr;
+    build_embedding<STASH>(a.g, a.freqs_xyz, a.freqs_t, psm, X, st);
     __syncthreads();
-    float4* st = STASH ? a.stash + (size_t)tile * stash_cells_per_tile(a.g.kq0) : nullptr;
-    if (STASH)
-      for (int i = tid; i < a.g.kq0 * kTM; i += 256) st[i] = X4[i];
 
 #pragma unroll 1
     for (int l = 0; l < kHidden; ++l) {
-      f32x16 acc[2][2];
-      zero_acc(acc);
-      gemm_tile(P4 + a.L.fwd[l] / 4, a.L.kb[l], 2 * w, X4, lane, acc);
-      __syncthreads();  // every wave has finished reading this layer's input
-      const float* bias = a.packed + a.L.bias[l];
-      float4* sl = STASH ? st + stash_layer_off(a.g.kq0, l + 1) : nullptr;
+      f32x16 acc[2];
+      zero2(acc);
+      const int nk = a.L.nk[l];
+      const float* bias = pf + a.L.bias[l];
+      float4 bvq[4];   // requested before the GEMM: an L2 round trip each if loaded where they are used
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int q = 0; q < 4; ++q) bvq[q] = *reinterpret_cast<const float4*>(bias + 32 * w + 8 * q + 4 * hh);
+      gemm_rows32(P4 + a.L.fwd[l] + (size_t)w * nk * 192 + lane, nk, Xl, acc);
+      __syncthreads();  // every wave has finished reading this layer's input
+      float* sh = STASH ? st + stash_h_off(a.g.c_in16, l) : nullptr;
+      unsigned sw = 0;
+      float po[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n4 = 64 * w + 32 * nt + 8 * q + 4 * hh;  // first of 4 consecutive output channels
-          const float4 bv = *reinterpret_cast<const float4*>(bias + n4);
+          const int n4 = 32 * w + 8 * q + 4 * hh;  // first of 4 consecutive output channels
+          const float4 bv = bvq[q];
+          const float v0 = lrelu(acc[ct][4 * q + 0] + bv.x), v1 = lrelu(acc[ct][4 * q + 1] + bv.y);
+          const float v2 = lrelu(acc[ct][4 * q + 2] + bv.z), v3 = lrelu(acc[ct][4 * q + 3] + bv.w);
+          const int m = 32 * ct + j;
+          if (l < kHidden - 1) store_split4(X, 4 * w + q, m, hh, v0, v1, v2, v3);   // the next layer's input
+          if (STASH) {
+            float* sp = sh + (size_t)n4 * kTM + m;
+            sp[0] = v0;
+            sp[kTM] = v1;
+            sp[2 * kTM] = v2;
+            sp[3 * kTM] = v3;
+            const int b0 = 16 * ct + 4 * q;
+            sw |= (v0 > 0.f ? 1u : 0u) << b0 | (v1 > 0.f ? 1u : 0u) << (b0 + 1) | (v2 > 0.f ? 1u : 0u) << (b0 + 2) |
+                  (v3 > 0.f ? 1u : 0u) << (b0 + 3);
+          }
+          if (l == kHidden - 1) {   // 256 -> 3 output layer: this lane's share of the dot products
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            float4 v;
-            v.x = lrelu(acc[nt][mt][4 * q + 0] + bv.x);
-            v.y = lrelu(acc[nt][mt][4 * q + 1] + bv.y);
-            v.z = lrelu(acc[nt][mt][4 * q + 2] + bv.z);
-            v.w = lrelu(acc[nt][mt][4 * q + 3] + bv.w);
-            const int cell = (n4 >> 2) * kTM + 32 * mt + j;
-            X4[cell] = v;
-            if (STASH) sl[cell] = v;
+            for (int c = 0; c < 3; ++c) {
+              const float4 ww = *reinterpret_cast<const float4*>(w5 + c * kWidth + n4);
+              po[c][ct] = __builtin_fmaf(v0, ww.x, __builtin_fmaf(v1, ww.y, __builtin_fmaf(v2, ww.z, __builtin_fmaf(v3, ww.w, po[c][ct]))));
+            }
           }
         }
+      if (STASH) reinterpret_cast<unsigned*>(st + stash_sign_off(a.g.c_in16, l))[tid] = sw;
+      if (l == kHidden - 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const float v = po[c][ct] + __shfl_xor(po[c][ct], 32, 64);
+            if (hh == 0) red[(w * 3 + c) * kTM + 32 * ct + j] = v;
+          }
+      }
       __syncthreads();
     }
-    // output layer 256 -> 3 on the VALU: thread (c = w, m = lane), waves 0..2
-    if (w < 3) {
-      const float* wr = w5 + w * kWidth;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 8
-      for (int kq = 0; kq < kKQ; ++kq) {
-        const float4 x = X4[kq * kTM + lane];
-        const float4 ww = *reinterpret_cast<const float4*>(wr + 4 * kq);
-        s0 = __builtin_fmaf(x.x, ww.x, s0);
-        s1 = __builtin_fmaf(x.y, ww.y, s1);
-        s2 = __builtin_fmaf(x.z, ww.z, s2);
-        s3 = __builtin_fmaf(x.w, ww.w, s3);
-      }
-      const float sf = (((s0 + s1) + (s2 + s3)) + w5[3 * kWidth + w]) * a.out_scale;
+    if (tid < 3 * kTM) {  // thread (c, m): sum the 8 waves' shares in fixed order
+      const int c = tid >> 6;
+      float s = 0.0f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) s += red[(ww * 3 + c) * kTM + lane];
+      const float sf = (s + w5[3 * kWidth + c]) * a.out_scale;
       const long long n = n0 + lane;
       if (n < a.n_pix) {
         const long long b = n / a.pix_per_img, hw = n - b * a.pix_per_img;
-        const size_t o = (size_t)((b * 3 + w) * a.pix_per_img + hw);
+        const size_t o = (size_t)((b * 3 + c) * a.pix_per_img + hw);
         if (a.sf_out) a.sf_out[o] = sf;
-        if (a.p_next) a.p_next[o] = psm[w * kTM + lane] + sf;
+        if (a.p_next) a.p_next[o] = psm[c * kTM + lane] + sf;
         if (a.acc) a.acc[o] += sf;
       }
     }
   }
 }
 
-// ======================================================================================
+// ==========================================================================================
 // backward, dX chain
 struct BwdArgs {
-  const float* packed;
-  const float4* stash;
-  float4* gstash;
+  const void* packed;
+  const float* stash;
+  float* gstash;
   const float* g_out1;
   const float* g_out2;
   const float* scale_ptr;
@@ -376,260 +451,339 @@ struct BwdArgs {
   float out_scale, gscale;
 };
 
-__global__ __launch_bounds__(256, 2) void mlp_bwd_dx_kernel(const BwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float4* X4 = reinterpret_cast<float4*>(smem);  // gradient tile, k-quad major
-  float* Xf = smem;
-  float* gz5 = smem + kKQ * kTM * 4;             // [4][64]: g of the 3 outputs (already * out_scale)
-  float* w5 = gz5 + 4 * kTM;                     // [3][256]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// LDS: X (gradient tile, split; at the end fp32 g_in [<= 256][64]) | gz5 [4][64] | w5 [3][256]
+constexpr size_t kBwdLds = (size_t)kXBytes + 4 * kTM * 4 + 3 * kWidth * 4;
+
+__global__ __launch_bounds__(kNT) void mlp_bwd_dx_kernel(const BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* X = smem;
+  float* Xf = reinterpret_cast<float*>(smem);
+  float* gz5 = reinterpret_cast<float*>(smem + kXBytes);   // [4][64]: g of the 3 outputs (already * out_scale)
+  float* w5 = gz5 + 4 * kTM;                               // [3][256]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
-  for (int i = tid; i < 3 * kWidth; i += 256) w5[i] = a.packed[a.L.w5 + i];
-  const float4* P4 = reinterpret_cast<const float4*>(a.packed);
+  const float* pf = static_cast<const float*>(a.packed);
+  const u32x4* P4 = static_cast<const u32x4*>(a.packed);
+  for (int i = tid; i < 3 * kWidth; i += kNT) w5[i] = pf[a.L.w5 + i];
   const float s1 = a.gscale * (a.scale_ptr ? a.scale_ptr[0] : 1.0f);
-  // last-layer weight/bias gradient, accumulated over this block's tiles:
-  // thread t owns k-quad kq = t>>2 and pixels (t&3)*16 .. +15
-  float dw5[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const unsigned char* Xl = X + hh * 1024 + j * 16;
+  // last layer's parameter gradients, accumulated over this workgroup's tiles: dw5[c][i] belongs to channel
+  // 32 w + 8 (i >> 2) + 4 hh + (i & 3) (summed over this lane's pixels; over the 32 lanes j at the end)
+  float dw5[3][16];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dw5[c][i] = 0.0f;
   float db5 = 0.0f;
+  const size_t spt = stash_floats_per_tile(a.g.c_in16), gpt = gstash_floats_per_tile();
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long n0 = (long long)tile * kTM;
-    const float4* st = a.stash + (size_t)tile * stash_cells_per_tile(a.g.kq0);
-    float4* gs = a.gstash + (size_t)tile * gstash_cells_per_tile();
+    const float* st = a.stash + (size_t)tile * spt;
+    float* gs = a.gstash + (size_t)tile * gpt;
     __syncthreads();
-    if (w < 3) {  // g_z5[c][m]
+    if (tid < 4 * kTM) {  // g_z5[c][m]
+      const int c = tid >> 6;
       const long long n = n0 + lane;
       float v = 0.0f;
-      if (n < a.n_pix) {
+      if (c < 3 && n < a.n_pix) {
         const long long b = n / a.pix_per_img, hw = n - b * a.pix_per_img;
-        const size_t o = (size_t)((b * 3 + w) * a.pix_per_img + hw);
+        const size_t o = (size_t)((b * 3 + c) * a.pix_per_img + hw);
         v = s1 * a.g_out1[o];
         if (a.g_out2) v += a.g_out2[o];
         v *= a.out_scale;
       }
-      gz5[w * kTM + lane] = v;
+      gz5[c * kTM + lane] = v;
       db5 += v;
-    } else {
-      gz5[3 * kTM + lane] = 0.0f;
     }
     __syncthreads();
-    {  // layer 5 (256 -> 3): g_h4 = W5^T g_z5, masked by LeakyReLU'(h4); dW5 += g_z5 h4^T
-      const int kq = tid >> 2, mb = (tid & 3) * 16;
-      const float4* h4 = st + stash_layer_off(a.g.kq0, 5) + kq * kTM;
-      float4* g4 = gs + (size_t)4 * kKQ * kTM + kq * kTM;
-      const float4 wa = *reinterpret_cast<const float4*>(w5 + 4 * kq);
-      const float4 wb = *reinterpret_cast<const float4*>(w5 + kWidth + 4 * kq);
-      const float4 wc = *reinterpret_cast<const float4*>(w5 + 2 * kWidth + 4 * kq);
-#pragma unroll 4
-      for (int i = 0; i < 16; ++i) {
-        const int m = mb + i;
-        const float4 hv = h4[m];
+    {  // layer 5 (256 -> 3): g_z4 = (W5^T g_z5) * LeakyReLU'(h4); dW5 += g_z5 h4^T -- in the epilogue mapping
+      const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4))[tid];
+      const float* h4 = st + stash_h_off(a.g.c_in16, 4);
+      float* g4 = gs + (size_t)4 * kWidth * kTM;
+#pragma unroll 1
+      for (int ct = 0; ct < 2; ++ct) {
+        const int m = 32 * ct + j;
         const float ga = gz5[m], gb = gz5[kTM + m], gc = gz5[2 * kTM + m];
-        float4 v;
-        v.x = (ga * wa.x + gb * wb.x + gc * wc.x) * (hv.x > 0.f ? 1.f : kSlope);
-        v.y = (ga * wa.y + gb * wb.y + gc * wc.y) * (hv.y > 0.f ? 1.f : kSlope);
-        v.z = (ga * wa.z + gb * wb.z + gc * wc.z) * (hv.z > 0.f ? 1.f : kSlope);
-        v.w = (ga * wa.w + gb * wb.w + gc * wc.w) * (hv.w > 0.f ? 1.f : kSlope);
-        X4[kq * kTM + m] = v;
-        g4[m] = v;
-        dw5[0][0] = __builtin_fmaf(ga, hv.x, dw5[0][0]);
-        dw5[0][1] = __builtin_fmaf(ga, hv.y, dw5[0][1]);
-        dw5[0][2] = __builtin_fmaf(ga, hv.z, dw5[0][2]);
-        dw5[0][3] = __builtin_fmaf(ga, hv.w, dw5[0][3]);
-        dw5[1][0] = __builtin_fmaf(gb, hv.x, dw5[1][0]);
-        dw5[1][1] = __builtin_fmaf(gb, hv.y, dw5[1][1]);
-        dw5[1][2] = __builtin_fmaf(gb, hv.z, dw5[1][2]);
-        dw5[1][3] = __builtin_fmaf(gb, hv.w, dw5[1][3]);
-        dw5[2][0] = __builtin_fmaf(gc, hv.x, dw5[2][0]);
-        dw5[2][1] = __builtin_fmaf(gc, hv.y, dw5[2][1]);
-        dw5[2][2] = __builtin_fmaf(gc, hv.z, dw5[2][2]);
-        dw5[2][3] = __builtin_fmaf(gc, hv.w, dw5[2][3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n4 = 32 * w + 8 * q + 4 * hh;
+          const float4 wa = *reinterpret_cast<const float4*>(w5 + n4);
+          const float4 wb = *reinterpret_cast<const float4*>(w5 + kWidth + n4);
+          const float4 wc = *reinterpret_cast<const float4*>(w5 + 2 * kWidth + n4);
+          const float war[4] = {wa.x, wa.y, wa.z, wa.w}, wbr[4] = {wb.x, wb.y, wb.z, wb.w}, wcr[4] = {wc.x, wc.y, wc.z, wc.w};
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float hv = h4[(size_t)(n4 + e) * kTM + m];
+            const bool pos = (sw >> (16 * ct + 4 * q + e)) & 1u;
+            v[e] = (ga * war[e] + gb * wbr[e] + gc * wcr[e]) * (pos ? 1.0f : kSlope);
+            g4[(size_t)(n4 + e) * kTM + m] = v[e];
+            dw5[0][4 * q + e] = __builtin_fmaf(ga, hv, dw5[0][4 * q + e]);
+            dw5[1][4 * q + e] = __builtin_fmaf(gb, hv, dw5[1][4 * q + e]);
+            dw5[2][4 * q + e] = __builtin_fmaf(gc, hv, dw5[2][4 * q + e]);
+          }
+          store_split4(X, 4 * w + q, m, hh, v[0], v[1], v[2], v[3]);
+        }
       }
-      if (tid < kTM) gs[(size_t)kHidden * kKQ * kTM + tid] = make_float4(gz5[tid], gz5[kTM + tid], gz5[2 * kTM + tid], 0.f);
     }
     __syncthreads();
     // layers 4..1: g_z_{l-1} = (W_l^T g_z_l) * LeakyReLU'(h_{l-1})
 #pragma unroll 1
     for (int l = 4; l >= 1; --l) {
-      f32x16 acc[2][2];
-      zero_acc(acc);
-      gemm_tile(P4 + a.L.bwd[l] / 4, 32, 2 * w, X4, lane, acc);
+      f32x16 acc[2];
+      zero2(acc);
+      const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, l - 1))[tid];
+      gemm_rows32(P4 + a.L.bwd[l] + (size_t)w * 16 * 192 + lane, 16, Xl, acc);
       __syncthreads();
-      const float4* hprev = st + stash_layer_off(a.g.kq0, l);  // h_{l-1}
-      float4* gl = gs + (size_t)(l - 1) * kKQ * kTM;
+      float* gl = gs + (size_t)(l - 1) * kWidth * kTM;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n4 = 64 * w + 32 * nt + 8 * q + 4 * hh;
+          const int n4 = 32 * w + 8 * q + 4 * hh, m = 32 * ct + j;
+          float v[4];
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const int cell = (n4 >> 2) * kTM + 32 * mt + j;
-            const float4 hv = hprev[cell];
-            float4 v;
-            v.x = acc[nt][mt][4 * q + 0] * (hv.x > 0.f ? 1.f : kSlope);
-            v.y = acc[nt][mt][4 * q + 1] * (hv.y > 0.f ? 1.f : kSlope);
-            v.z = acc[nt][mt][4 * q + 2] * (hv.z > 0.f ? 1.f : kSlope);
-            v.w = acc[nt][mt][4 * q + 3] * (hv.w > 0.f ? 1.f : kSlope);
-            X4[cell] = v;
-            gl[cell] = v;
+          for (int e = 0; e < 4; ++e) {
+            const bool pos = (sw >> (16 * ct + 4 * q + e)) & 1u;
+            v[e] = acc[ct][4 * q + e] * (pos ? 1.0f : kSlope);
+            gl[(size_t)(n4 + e) * kTM + m] = v[e];
           }
+          store_split4(X, 4 * w + q, m, hh, v[0], v[1], v[2], v[3]);
         }
       __syncthreads();
     }
-    // layer 0: g_in = W_0^T g_z0  (c_in_pad <= 256 rows = at most 8 row tiles: wave w takes tiles 2w, 2w+1)
+    // layer 0: g_in = W_0^T g_z0  (c_in <= 256 rows = rt0 <= 8 row tiles, wave w takes tile w), as fp32 [channel][64]
     {
-      const int KT = a.L.kt[0], rt = 2 * w;
-      const bool has0 = rt < KT, has1 = rt + 1 < KT;
-      f32x16 acc[2][2];
-      zero_acc(acc);
-      const float4* Wp = P4 + a.L.bwd[0] / 4;
-      if (has1)
-        gemm_tile(Wp, 32, rt, X4, lane, acc);
-      else if (has0)
-        gemm_tile_single(Wp, 32, rt, X4, lane, acc);
+      f32x16 acc[2];
+      zero2(acc);
+      if (w < a.g.rt0) gemm_rows32(P4 + a.L.bwd[0] + (size_t)w * 16 * 192 + lane, 16, Xl, acc);
       __syncthreads();  // all waves finished reading g_z0
+      if (w < a.g.rt0) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        if (nt == 0 ? !has0 : !has1) continue;
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int k4 = 32 * (rt + nt) + 8 * q + 4 * hh;
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            X4[(k4 >> 2) * kTM + 32 * mt + j] = make_float4(acc[nt][mt][4 * q + 0], acc[nt][mt][4 * q + 1],
-                                                            acc[nt][mt][4 * q + 2], acc[nt][mt][4 * q + 3]);
-        }
+          for (int r = 0; r < 16; ++r) Xf[(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3)) * kTM + 32 * ct + j] = acc[ct][r];
       }
       __syncthreads();
     }
-    // embedding backward -> g_p[c][m]:  thread (c = w, m = lane), waves 0..2
-    if (w < 3) {
+    // embedding backward -> g_p[c][m]:  thread (c, m), waves 0..2
+    if (tid < 3 * kTM) {
+      const int c = tid >> 6;
       const int nx = a.g.n_freq_xyz, xb = a.g.xyz_base;
-      auto gin = [&](int ch) { return Xf[((ch >> 2) * kTM + lane) * 4 + (ch & 3)]; };
-      const float* ef = reinterpret_cast<const float*>(st);  // embedding cells, same indexing
-      auto emb = [&](int ch) { return ef[((ch >> 2) * kTM + lane) * 4 + (ch & 3)]; };
-      float gx = gin(xb + w);
+      auto gin = [&](int ch) { return Xf[ch * kTM + lane]; };
+      auto emb = [&](int ch) { return st[(size_t)ch * kTM + lane]; };
+      float gx = gin(xb + c);
       for (int i = 0; i < nx; ++i) {
-        const int cc = xb + 3 + 3 * i + w, cs = xb + 3 + 3 * nx + 3 * i + w;
+        const int cc = xb + 3 + 3 * i + c, cs = xb + 3 + 3 * nx + 3 * i + c;
         // d cos(f x)/dx = -f sin(f x) ; d sin(f x)/dx = f cos(f x)
         gx = __builtin_fmaf(a.freqs_xyz[i], __builtin_fmaf(emb(cc), gin(cs), -emb(cs) * gin(cc)), gx);
       }
       const long long n = n0 + lane;
       if (n < a.n_pix) {
         const long long b = n / a.pix_per_img, hw = n - b * a.pix_per_img;
-        const size_t o = (size_t)((b * 3 + w) * a.pix_per_img + hw);
+        const size_t o = (size_t)((b * 3 + c) * a.pix_per_img + hw);
         if (a.g_p_add) gx += a.g_p_add[o];
         a.g_p[o] = gx;
       }
     }
   }
   // flush the last layer's parameter gradients
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = dw5[c][i];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      if (j == 0) unsafeAtomicAdd(a.gW5 + c * kWidth + 32 * w + 8 * (i >> 2) + 4 * hh + (i & 3), v);
+    }
   {
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = dw5[c][e];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        if ((tid & 3) == 0) unsafeAtomicAdd(a.gW5 + c * kWidth + 4 * (tid >> 2) + e, v);
-      }
     const float v = wave_sum(db5);
     if (lane == 0 && w < 3) unsafeAtomicAdd(a.gb5 + w, v);
   }
 }
 
-// ======================================================================================
-// backward, dW:  dW_l[n][k] += sum_pixels G_l[n][m] H_{l-1}[k][m]
+// ==========================================================================================
+// backward, dW:  dW_l[n][k] = sum_pixels G_l[n][m] H_{l-1}[k][m]   (H_{-1} = the embedding)
 struct DwArgs {
-  const float4* stash;
-  const float4* gstash;
-  float* gW[kHidden];
-  float* gb[kHidden];
+  const float* stash;
+  const float* gstash;
+  float* partial;      // [5][S][kDwPartial]
   Geometry g;
-  int n_tiles, tiles_per_block;
+  int n_tiles, S;
 };
 
-// One layer for a run of tiles.  Wave (wr, wc) owns rows [128wr, +128) x cols [128wc, +128):
-// accumulator tile (c, c') holds rows 4i+c (i = 0..31) and cols 4j+c'.
-template <bool FIRST>
-__device__ __forceinline__ void dw_layer(const DwArgs& a, int layer, int tile0, int tile1, int lane, int wr, int wc,
-                                         f32x16 (&acc)[4][4], float (&rs)[4]) {
-  const int i = lane & 31, h = lane >> 5;
-  const int kq_cols = FIRST ? a.g.kq0 : kKQ;     // valid k-quads of H_{l-1}
-  const int jq = 32 * wc + i;                    // this lane's k-quad of the B operand
-  const bool bvalid = jq < kq_cols;
-  const size_t spt = stash_cells_per_tile(a.g.kq0), gpt = gstash_cells_per_tile();
-  for (int tile = tile0; tile < tile1; ++tile) {
-    const float4* G = a.gstash + (size_t)tile * gpt + (size_t)layer * kKQ * kTM + (size_t)(32 * wr + i) * kTM;
-    const float4* H = a.stash + (size_t)tile * spt + stash_layer_off(a.g.kq0, layer) + (size_t)jq * kTM;
-#pragma unroll 2
-    for (int mb = 0; mb < kTM; mb += 8) {
-      float4 av[4], bv[4];
+constexpr int kDwPitch = 48;                       // bytes per channel row of a 16-pixel chunk in LDS (32 + 16 pad)
+constexpr int kDwTerm = 256 * kDwPitch;            // 12 288: one split term of one operand
+constexpr int kDwBuf = 2 * 3 * kDwTerm;            // 73 728: G terms, then H terms
+constexpr size_t kDwLds = 2 * (size_t)kDwBuf;      // double buffered
+
+// FULL: every H row and every column tile is live (layers 1..4) -- no predicates in the chunk loop
+template <bool FULL>
+__device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;               // rows [64 wr, +64), columns [128 wc, +128)
+  const int i32 = lane & 31, hh = lane >> 5;
+  const int layer = blockIdx.y, s = blockIdx.x;
+  const int t0 = (int)((long long)a.n_tiles * s / a.S), t1 = (int)((long long)a.n_tiles * (s + 1) / a.S);
+  const int n_it = (t1 - t0) * 4;                  // 16-pixel chunks
+  const int hrows = FULL ? kWidth : a.g.c_in16;
+  const int nct = FULL ? 4 : ((a.g.c_in16 + 31) / 32 - 4 * wc);   // column tiles of this wave that hold anything
+  const size_t spt = stash_floats_per_tile(a.g.c_in16), gpt = gstash_floats_per_tile();
+  const size_t hoff = layer == 0 ? 0 : stash_h_off(a.g.c_in16, layer - 1);
+  const size_t goff = (size_t)layer * kWidth * kTM;
+
+  f32x16 acc[2][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        av[s] = G[mb + 4 * h + s];
-        bv[s] = bvalid ? H[mb + 4 * h + s] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+  for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float ar[4] = {av[s].x, av[s].y, av[s].z, av[s].w};
-        const float br[4] = {bv[s].x, bv[s].y, bv[s].z, bv[s].w};
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          rs[c] += ar[c];
+      for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.0f;
+  float rs[2] = {0.f, 0.f};                        // row sums of G (bias gradient): rows (tid >> 2) and 128 + (tid >> 2)
+
+  // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread; q = i * 512 + tid, row = q >> 2, quad = q & 3.
+  // Two register sets: the chunk loaded during step `it` is split and stored during step it + 1 and consumed by the
+  // MFMAs of step it + 2, so no wave ever waits for HBM.
+  float4 sg0[4], sg1[4];
+  auto stage_load = [&](int it, float4 (&sg)[4]) {
+    const int tile = t0 + (it >> 2), chunk = it & 3;
 #pragma unroll
-          for (int d = 0; d < 4; ++d) acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[c], br[d], acc[c][d], 0, 0, 0);
-        }
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 128 + (tid >> 2), quad = tid & 3;
+      const bool isH = i >= 2;
+      const int r = row & 255;
+      const bool valid = FULL || !isH || r < hrows;
+      const float* src = isH ? a.stash + (size_t)tile * spt + hoff + (size_t)(valid ? r : 0) * kTM
+                             : a.gstash + (size_t)tile * gpt + goff + (size_t)r * kTM;
+      const float4 v = *reinterpret_cast<const float4*>(src + chunk * 16 + quad * 4);
+      sg[i] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage_store = [&](int buf, const float4 (&sg)[4], bool count) {
+    unsigned char* base = smem + buf * kDwBuf;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 128 + (tid >> 2), quad = tid & 3;
+      if (i < 2) rs[i] += count ? (sg[i].x + sg[i].y) + (sg[i].z + sg[i].w) : 0.0f;
+      unsigned h0, m0, l0, h1, m1, l1;
+      split_pair(sg[i].x, sg[i].y, h0, m0, l0);
+      split_pair(sg[i].z, sg[i].w, h1, m1, l1);
+      unsigned char* dst = base + (i >= 2 ? 3 * kDwTerm : 0) + (row & 255) * kDwPitch + quad * 8;
+      *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
+      *reinterpret_cast<u32x2*>(dst + kDwTerm) = (u32x2){m0, m1};
+      *reinterpret_cast<u32x2*>(dst + 2 * kDwTerm) = (u32x2){l0, l1};
+    }
+  };
+  auto mfma_chunk = [&](int buf) {
+    const unsigned char* gb = smem + buf * kDwBuf + (64 * wr + i32) * kDwPitch + hh * 16;
+    const unsigned char* hb = smem + buf * kDwBuf + 3 * kDwTerm + (128 * wc + i32) * kDwPitch + hh * 16;
+    u32x4 A[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) A[r][t] = *reinterpret_cast<const u32x4*>(gb + t * kDwTerm + r * 32 * kDwPitch);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (FULL || c < nct) {
+        u32x4 B[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) B[t] = *reinterpret_cast<const u32x4*>(hb + t * kDwTerm + c * 32 * kDwPitch);
+#define DVD_DW_TERM(SA, SB)                                                                                       \
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(              \
+      __builtin_bit_cast(bf16x8, A[r][SA]), __builtin_bit_cast(bf16x8, B[SB]), acc[r][c], 0, 0, 0);
+        DVD_DW_TERM(2, 0)
+        DVD_DW_TERM(0, 2)
+        DVD_DW_TERM(1, 1)
+        DVD_DW_TERM(1, 0)
+        DVD_DW_TERM(0, 1)
+        DVD_DW_TERM(0, 0)
+#undef DVD_DW_TERM
       }
     }
+  };
+
+  // n_it is a multiple of 4 (whole tiles), so the chunk loop runs in pairs with the two register sets / LDS buffers
+  // in fixed roles.  One barrier per chunk: buffer b is complete, and every wave is done reading buffer b ^ 1.
+  const int last = n_it - 1;
+  stage_load(0, sg0);
+  stage_store(0, sg0, true);
+  stage_load(1 < last ? 1 : last, sg0);
+#pragma unroll 1
+  for (int it = 0; it < n_it; it += 2) {
+    __syncthreads();
+    stage_load(it + 2 < last ? it + 2 : last, sg1);
+    __builtin_amdgcn_sched_barrier(0);   // the loads stay above the MFMAs
+    mfma_chunk(0);
+    stage_store(1, sg0, true);           // chunk it + 1 (always exists)
+    __syncthreads();
+    stage_load(it + 3 < last ? it + 3 : last, sg0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_chunk(1);
+    // chunk it + 2; past the end this rewrites the idle buffer with the last chunk, not counted in the row sums
+    // (a conditional store would drag its loads into the branch, behind the MFMAs)
+    stage_store(0, sg1, it + 2 < n_it);
+  }
+  // this workgroup's partial matrix: element r of acc[rr][c] in lane l is row 64 wr + 32 rr + (r&3) + 8 (r>>2) + 4 (l>>5),
+  // column 128 wc + 32 c + (l&31)
+  float* dst = a.partial + ((size_t)layer * a.S + s) * kDwPartial;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 64 * wr + 32 * rr + (r & 3) + 8 * (r >> 2) + 4 * hh, k = 128 * wc + 32 * c + i32;
+        dst[(size_t)n * kWidth + k] = acc[rr][c][r];
+      }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float v = rs[i];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    if ((tid & 3) == 0) dst[(size_t)kWidth * kWidth + i * 128 + (tid >> 2)] = v;
   }
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_bwd_dw_kernel(const DwArgs a) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wr = w >> 1, wc = w & 1;
-  const int tile0 = blockIdx.x * a.tiles_per_block;
-  int tile1 = tile0 + a.tiles_per_block;
-  if (tile1 > a.n_tiles) tile1 = a.n_tiles;
-  if (tile0 >= tile1) return;
-  const int layer = blockIdx.y;  // 0..4
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.0f;
-  float rs[4] = {0.f, 0.f, 0.f, 0.f};
-  if (layer == 0)
-    dw_layer<true>(a, layer, tile0, tile1, lane, wr, wc, acc, rs);
+__global__ __launch_bounds__(kNT) void mlp_bwd_dw_kernel(const DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (blockIdx.y == 0)
+    dw_body<false>(a, smem);
   else
-    dw_layer<false>(a, layer, tile0, tile1, lane, wr, wc, acc, rs);
-  // flush: element r of acc[c][d] in lane l is row 4*i' + c, col 4*j' + d with
-  // i' = (r&3) + 8(r>>2) + 4(l>>5), j' = l&31  (within this wave's 128x128 block)
-  const int K = layer == 0 ? a.g.c_in : kWidth;
-  float* gW = a.gW[layer];
-  const int jp = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ip = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int n = 128 * wr + 4 * ip + c, k = 128 * wc + 4 * jp + d;
-        if (k < K) unsafeAtomicAdd(gW + (size_t)n * K + k, acc[c][d][r]);
-      }
-  if (wc == 0) {
-    const int i = lane & 31;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float v = rs[c];
-      v += __shfl_xor(v, 32, 64);
-      if (hh == 0) unsafeAtomicAdd(a.gb[layer] + 128 * wr + 4 * i + c, v);
-    }
+    dw_body<true>(a, smem);
+}
+
+// gW_l[n][k] += sum_s partial[l][s][n][k] (ascending s), gb_l[n] += sum_s rowsum[l][s][n]
+struct DwReduceArgs {
+  const float* partial;
+  float* gW[kHidden];
+  float* gb[kHidden];
+  int S, c_in;
+};
+
+__global__ __launch_bounds__(256) void mlp_dw_reduce_kernel(const DwReduceArgs a) {
+  const int layer = blockIdx.y;
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // over [256][256] + [256]
+  if (idx >= (int)kDwPartial) return;
+  const float* p = a.partial + (size_t)layer * a.S * kDwPartial + idx;
+  float s0 = 0.0f, s1 = 0.0f;
+  int s = 0;
+  for (; s + 1 < a.S; s += 2) {
+    s0 += p[(size_t)s * kDwPartial];
+    s1 += p[(size_t)(s + 1) * kDwPartial];
+  }
+  if (s < a.S) s0 += p[(size_t)s * kDwPartial];
+  const float v = s0 + s1;
+  if (idx < kWidth * kWidth) {
+    const int K = layer == 0 ? a.c_in : kWidth;
+    const int n = idx >> 8, k = idx & 255;
+    if (k < K) a.gW[layer][(size_t)n * K + k] += v;
+  } else {
+    a.gb[layer][idx - kWidth * kWidth] += v;
   }
 }
 
@@ -642,7 +796,13 @@ static int check_desc(const dvd_mlp_desc* d) {
   return DVD_OK;
 }
 
-constexpr size_t kFwdLds = (size_t)kKQ * kTM * 16 + 4 * kTM * 4 + (3 * kWidth + 4) * 4;
+static int dw_slices(int n_tiles) { return n_tiles < kDwSlices ? n_tiles : kDwSlices; }
+
+static int persistent_grid(int n_tiles) {
+  int cus = dvd_device_cu_count();
+  if (cus <= 0) cus = 256;
+  return n_tiles < cus ? n_tiles : cus;   // one 512-thread workgroup (96 KB of LDS) per CU
+}
 
 }  // namespace dvd
 
@@ -652,19 +812,19 @@ int dvd_sf_mlp_in_channels(const dvd_mlp_desc* d) { return d ? dvd::make_geometr
 
 size_t dvd_sf_mlp_packed_bytes(const dvd_mlp_desc* d) {
   if (!d) return 0;
-  return dvd::make_pack_layout(dvd::make_geometry(d)).total * sizeof(float);
+  return dvd::make_pack_layout(dvd::make_geometry(d)).total_bytes;
 }
 
 size_t dvd_sf_mlp_stash_bytes(const dvd_mlp_desc* d, long long n_pix) {
   if (!d || n_pix <= 0) return 0;
   const long long tiles = (n_pix + dvd::kTM - 1) / dvd::kTM;
-  return (size_t)tiles * dvd::stash_cells_per_tile(dvd::make_geometry(d).kq0) * 16;
+  return (size_t)tiles * dvd::stash_floats_per_tile(dvd::make_geometry(d).c_in16) * 4;
 }
 
 size_t dvd_sf_mlp_gstash_bytes(long long n_pix) {
   if (n_pix <= 0) return 0;
   const long long tiles = (n_pix + dvd::kTM - 1) / dvd::kTM;
-  return (size_t)tiles * dvd::gstash_cells_per_tile() * 16;
+  return ((size_t)tiles * dvd::gstash_floats_per_tile() + (size_t)dvd::kHidden * dvd::kDwSlices * dvd::kDwPartial) * 4;
 }
 
 int dvd_sf_mlp_pack(const dvd_mlp_desc* d, const float* const W[6], const float* const b[6], void* packed,
@@ -679,10 +839,12 @@ int dvd_sf_mlp_pack(const dvd_mlp_desc* d, const float* const W[6], const float*
     a.b[l] = b[l];
   }
   const Geometry g = make_geometry(d);
-  a.out = static_cast<float*>(packed);
+  DVD_REQUIRE(g.c_in <= kWidth, "sf_mlp_pack: input layer wider than 256 channels");
+  a.out = packed;
   a.L = make_pack_layout(g);
   a.c_in = g.c_in;
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3(256, 6), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  // the largest job has 8 row tiles x 16 K steps x 64 lanes = 8192 threads
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(32, 11), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -699,8 +861,9 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   DVD_REQUIRE(n_pix < (1LL << 31) * 16, "sf_mlp_fwd: too many pixels");
   FwdArgs a;
   a.g = make_geometry(d);
+  DVD_REQUIRE(a.g.c_in <= kWidth, "sf_mlp_fwd: input layer wider than 256 channels");
   a.L = make_pack_layout(a.g);
-  a.packed = static_cast<const float*>(packed);
+  a.packed = packed;
   a.p = p;
   a.t = d->time_dependent ? t : nullptr;
   a.freqs_xyz = d->freqs_xyz;
@@ -708,24 +871,22 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   a.sf_out = sf_out;
   a.p_next = p_next;
   a.acc = acc;
-  a.stash = static_cast<float4*>(stash);
+  a.stash = static_cast<float*>(stash);
   a.n_pix = n_pix;
   a.pix_per_img = pix_per_img;
   a.n_tiles = (int)((n_pix + kTM - 1) / kTM);
   a.t_offset = t_offset;
   a.out_scale = out_scale;
-  int cus = dvd_device_cu_count();
-  if (cus <= 0) cus = 256;
-  const int grid = a.n_tiles < 2 * cus ? a.n_tiles : 2 * cus;
+  const int grid = persistent_grid(a.n_tiles);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (stash) {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
-    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(256), kFwdLds, s, a);
+    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kNT), kFwdLds, s, a);
   } else {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
-    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(256), kFwdLds, s, a);
+    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kNT), kFwdLds, s, a);
   }
   DVD_LAUNCH_OK();
   return DVD_OK;
@@ -741,11 +902,11 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
   DVD_REQUIRE(n_pix > 0 && pix_per_img > 0 && n_pix % pix_per_img == 0, "sf_mlp_bwd_dx: bad sizes");
   BwdArgs a;
   a.g = make_geometry(d);
+  DVD_REQUIRE(a.g.c_in <= kWidth, "sf_mlp_bwd_dx: input layer wider than 256 channels");
   a.L = make_pack_layout(a.g);
-  DVD_REQUIRE(a.L.kt[0] <= 8, "sf_mlp_bwd_dx: input layer wider than 256 channels");
-  a.packed = static_cast<const float*>(packed);
-  a.stash = static_cast<const float4*>(stash);
-  a.gstash = static_cast<float4*>(gstash);
+  a.packed = packed;
+  a.stash = static_cast<const float*>(stash);
+  a.gstash = static_cast<float*>(gstash);
   a.g_out1 = g_out1;
   a.g_out2 = g_out2;
   a.scale_ptr = scale_ptr;
@@ -759,38 +920,41 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
   a.n_tiles = (int)((n_pix + kTM - 1) / kTM);
   a.out_scale = out_scale;
   a.gscale = gscale;
-  int cus = dvd_device_cu_count();
-  if (cus <= 0) cus = 256;
-  const int grid = a.n_tiles < 2 * cus ? a.n_tiles : 2 * cus;
+  const int grid = persistent_grid(a.n_tiles);
   DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
-  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(256), kFwdLds, static_cast<hipStream_t>(stream), a);
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
+  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(kNT), kBwdLds, static_cast<hipStream_t>(stream), a);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
 
-int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, const void* gstash, long long n_pix,
-                      float* const gW[5], float* const gb[5], dvd_stream_t stream) {
+int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, void* gstash, long long n_pix, float* const gW[5],
+                      float* const gb[5], dvd_stream_t stream) {
   using namespace dvd;
   if (int e = check_desc(d)) return e;
   DVD_REQUIRE(stash && gstash && gW && gb && n_pix > 0, "sf_mlp_bwd_dw: null pointer / size");
   DwArgs a;
   a.g = make_geometry(d);
-  a.stash = static_cast<const float4*>(stash);
-  a.gstash = static_cast<const float4*>(gstash);
+  a.stash = static_cast<const float*>(stash);
+  a.gstash = static_cast<const float*>(gstash);
+  a.n_tiles = (int)((n_pix + kTM - 1) / kTM);
+  a.S = dw_slices(a.n_tiles);
+  a.partial = static_cast<float*>(gstash) + (size_t)a.n_tiles * gstash_floats_per_tile();
+  DwReduceArgs r;
   for (int l = 0; l < kHidden; ++l) {
     DVD_REQUIRE(gW[l] && gb[l], "sf_mlp_bwd_dw: null gradient %d", l);
-    a.gW[l] = gW[l];
-    a.gb[l] = gb[l];
+    r.gW[l] = gW[l];
+    r.gb[l] = gb[l];
   }
-  a.n_tiles = (int)((n_pix + kTM - 1) / kTM);
-  int cus = dvd_device_cu_count();
-  if (cus <= 0) cus = 256;
-  // one workgroup (4 waves x 256 accumulators) per CU per layer; 5 layers share the CUs in turn
-  int blocks = a.n_tiles < cus ? a.n_tiles : cus;
-  a.tiles_per_block = (a.n_tiles + blocks - 1) / blocks;
-  blocks = (a.n_tiles + a.tiles_per_block - 1) / a.tiles_per_block;
-  hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3(blocks, kHidden), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  r.partial = a.partial;
+  r.S = a.S;
+  r.c_in = a.g.c_in;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kDwLds));
+  hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3(a.S, kHidden), dim3(kNT), kDwLds, s, a);
+  DVD_LAUNCH_OK();
+  hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((unsigned)((kDwPartial + 255) / 256), kHidden), dim3(256), 0, s, r);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

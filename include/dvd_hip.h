@@ -123,7 +123,7 @@ int dvd_loss_finalize(const dvd_warp_cfg* cfg, const float* sums, float* scalars
                       dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * Scene-flow field MLP (fused, fp32 MFMA).
+ * Scene-flow field MLP (fused; bf16 matrix cores on three-term split operands = fp32-class accuracy).
  * Replaces SceneFlowFieldNet.forward (networks/sceneflow_field.py:43-53):
  *   PeriodicEmbed of t and xyz (networks/blocks.py:19-34), 1x1 conv C_in->256,
  *   4 x (256->256), each + LeakyReLU(0.2), then 256->3 (blocks.py:50-102),
@@ -137,8 +137,9 @@ int dvd_loss_finalize(const dvd_warp_cfg* cfg, const float* sums, float* scalars
  * Weights are the reference state_dict tensors convs.{0..5}.conv.{weight,bias}
  * (weight [out,in] row-major); dvd_sf_mlp_pack re-orders them into MFMA
  * fragment order (both orientations) inside `packed`.
- * `stash` (forward, optional) receives the embedding and the five hidden
- * activations, 5.53 KB per pixel; the backward kernels consume it. */
+ * `stash` (forward, optional) receives the embedding, the five hidden
+ * activations (fp32, [channel][64 pixels] rows per tile) and one sign bit per
+ * hidden unit, 5.72 KB per pixel; the backward kernels consume it. */
 typedef struct dvd_mlp_desc {
   int n_freq_xyz;      /* 16 */
   int n_freq_t;        /* 16; ignored if !time_dependent */
@@ -168,9 +169,10 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
                       const float* g_out1, float gscale, const float* scale_ptr, const float* g_out2,
                       const float* g_p_add, long long n_pix, int pix_per_img, float* g_p, void* gstash,
                       float* gW5, float* gb5, dvd_stream_t stream);
-/* dW_l += G_l . H_{l-1}^T and db_l += rowsum(G_l) for l = 0..4 (accumulating, atomics),
- * gW[l] in the reference layout [out,in]. */
-int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, const void* gstash, long long n_pix,
+/* dW_l += G_l . H_{l-1}^T and db_l += rowsum(G_l) for l = 0..4 (accumulating; per-workgroup partial
+ * matrices in the tail of `gstash`, summed in fixed order: bitwise reproducible), gW[l] in the
+ * reference layout [out,in]. */
+int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, void* gstash, long long n_pix,
                       float* const gW[5], float* const gb[5], dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
