@@ -187,6 +187,10 @@ class GroupedConv3x3C32(nn.Conv2d):
         super().__init__(channels, channels, 3, stride=1, padding=1, groups=channels // 32, bias=False)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and not _os.environ.get('DVD_GCONV32'):
+            # the grouped split-bf16 kernels (csrc/xconv.hip, csrc/xwgrad3.hip): 0.097 ms forward / 0.37 ms backward per
+            # 16-image call at [1024, 24, 42] against 0.156 / 0.42 ms of the fp32-MFMA kernels (tools/microbench_gx.py)
+            return _XConv.apply(x, self.weight, None, None, False, False, self.groups)
         return gconv3x3_c32(x, self.weight)
 
 
@@ -213,6 +217,8 @@ class GroupedConv3x3C16(nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32 and not _os.environ.get('DVD_NO_C16'):
+            if not _os.environ.get('DVD_GCONV32'):
+                return _XConv.apply(x, _pair_groups_of_16(self.weight), None, None, False, False, self.groups // 2)
             return gconv3x3_c32(x, _pair_groups_of_16(self.weight))
         return F.conv2d(x, self.weight, None, 1, 1, 1, self.groups)
 
