@@ -118,33 +118,22 @@ struct XArgs {
   int relu_in, relu_out, res_relu;
 };
 
-// One block = WM x WN CONSUMER waves, each TM x TN tiles of 32 x 32, plus two PRODUCER waves.
-//   * producers stage the activations: the haloed tile of a CHUNK of 16 * KCH input channels is read from HBM as fp32,
-//     split and written to a double-buffered LDS stage that serves all k x k taps of the chunk -- one barrier per
-//     chunk (9 K steps for a 3x3 kernel).  They issue every HBM load of the block, so the consumers' in-order
-//     vmcnt queue holds nothing slower than an L2 hit.
-//   * consumers never touch HBM before the epilogue: every wave streams its TM x 3 weight fragments per K step from
-//     L2 into registers one K step ahead of the MFMAs that use them (ping-pong register sets), reads the B fragments
-//     of the tap from LDS and issues 6 * TM * TN MFMAs.
-//   Two blocks share a CU, so one block's barrier / epilogue overlaps the other's MFMAs.
-// (Third generation of this loop.  The first staged the weights through LDS as well and needed a barrier every K step
-// -- 24 MFMAs per wave between barriers, matrix pipe 60 % busy, 165 TF/s on the decoder's 3x3; the second streamed the
-// weights from L2 but kept the staging in the MFMA waves: each chunk's HBM loads sat in front of the next weight
-// fragments in the in-order load queue and stalled the pipe once per chunk, 151 TF/s.)
-constexpr int kXProd = 128;                      // producer threads per block
-template <int TM, int TN, int WM, int WN, int FIT, int KCH>
-__global__ __launch_bounds__(64 * WM * WN + kXProd, 3) void xconv_kernel(const XArgs a) {
-  constexpr int NC = 64 * WM * WN;               // consumer threads
-  constexpr int NT = kXProd;                     // staging threads
-  constexpr bool kDirect = FIT == 0;             // big halos (k >= 5): stage item by item
+// One block = WM x WN waves, each wave TM x TN tiles of 32 x 32; A and B double buffered in LDS, one barrier per
+// K step (16 channels x one tap); two blocks share a CU, so one block's staging / barrier / epilogue overlaps
+// the other's MFMAs.
+template <int TM, int TN, int WM, int WN, int FIT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr bool kDirect = FIT == 0;             // big halos (k >= 5): stage without the register prefetch
   constexpr int FI = kDirect ? 1 : FIT;
   constexpr int MT = WM * TM;                    // 32-channel tiles per block
-  constexpr int NCG = 2 * KCH;                   // channel groups of 8 per chunk
+  constexpr int AU = MT * 3 * 64;                // uint4 per A stage (all tiles, three terms)
+  constexpr int AI = (AU + NT - 1) / NT;         // staging loads per thread
+  constexpr int AS = AI * NT;                    // LDS cells per A stage (>= AU)
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-  u32x4* sB = smem;                              // [2][term 3][channel group NCG][npos]
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const bool producer = wave >= WM * WN;         // wave-uniform
-  const int tid = producer ? (int)threadIdx.x - NC : (int)threadIdx.x;   // index within the role
+  u32x4* sA = smem;                              // [2][AS] : [MT][3][64] + padding
+  u32x4* sB = smem + 2 * AS;                     // [2][term 3][channel group 2][npos]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int tr = blockIdx.x / a.ntc, tc = blockIdx.x - tr * a.ntc;
   const int r0 = tr * a.TR, c0 = tc * a.TC;
@@ -154,34 +143,32 @@ __global__ __launch_bounds__(64 * WM * WN + kXProd, 3) void xconv_kernel(const X
   const size_t plane = (size_t)a.H * a.W;
   const float* xn = a.x + ((size_t)n * a.G + grp) * a.Cin * plane;
   const int npos = a.npos, P = a.P, T = a.T, KS = a.KS;
-  const int nkt = a.nkc * T;                           // K steps
-  const int nch = (a.nkc + KCH - 1) / KCH;             // chunks
-  const int spc = T * KCH;                             // K steps per chunk
+  const int nkt = a.nkc * T;
 
-  // ---- B staging (producer waves; tid = 0 .. 127): item = channel group * NV + position of the haloed tile.  Every
-  //      thread runs every staging step unconditionally (no divergent branches around loads: hipcc would serialise
-  //      them with vmcnt(0) waits and park the staging registers in scratch): items beyond the tile load a valid
+  // ---- B staging bookkeeping: item = channel group * NV + position of the haloed tile.  Every thread runs
+  //      every staging step unconditionally (no divergent branches around loads: hipcc would serialise them
+  //      with vmcnt(0) waits and park the staging registers in scratch): items beyond the tile load a valid
   //      dummy address and store to the spare cell npos - 1 of the first plane.
   int goff[FI], lidx[FI], cig8[FI];
   bool gok[FI];
 #pragma unroll
   for (int it = 0; it < FI; ++it) {
     const int item = it * NT + tid;
-    const bool live = item < NCG * a.NV;
-    const int cig = live ? item / a.NV : 0;
-    const int p = live ? item - cig * a.NV : 0;
+    const int cig = item >= a.NV ? 1 : 0;
+    const int p = item - cig * a.NV;
     const int rr = p / P, cc = p - rr * P;
     const int row = r0 - a.pad + rr, col = c0 - a.pad + cc;
+    const bool live = item < 2 * a.NV;
     gok[it] = live && row >= 0 && row < a.H && col >= 0 && col < a.W;
     goff[it] = gok[it] ? (row * a.W + col) : 0;
     lidx[it] = live ? (cig * npos + p) : (npos - 1);
-    cig8[it] = cig * 8;
+    cig8[it] = live ? cig * 8 : 0;
   }
   float raw[FI][8];
-  auto load_raw = [&](int chunk) {
+  auto load_raw = [&](int kc) {
 #pragma unroll
     for (int it = 0; it < FI; ++it) {
-      const int ch0 = chunk * (16 * KCH) + cig8[it];
+      const int ch0 = kc * 16 + cig8[it];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int ch = (ch0 + e) < a.Cin ? (ch0 + e) : (a.Cin - 1);
@@ -189,11 +176,11 @@ __global__ __launch_bounds__(64 * WM * WN + kXProd, 3) void xconv_kernel(const X
       }
     }
   };
-  auto split_write = [&](int buf, int chunk) {
-    u32x4* dst = sB + buf * 3 * NCG * npos;
+  auto split_write = [&](int buf, int kc) {
+    u32x4* dst = sB + buf * 6 * npos;
 #pragma unroll
     for (int it = 0; it < FI; ++it) {
-      const int ch0 = chunk * (16 * KCH) + cig8[it];
+      const int ch0 = kc * 16 + cig8[it];
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -203,24 +190,24 @@ __global__ __launch_bounds__(64 * WM * WN + kXProd, 3) void xconv_kernel(const X
       uint4 h, m, l;
       split8(v, h, m, l);
       dst[lidx[it]] = (u32x4){h.x, h.y, h.z, h.w};
-      dst[NCG * npos + lidx[it]] = (u32x4){m.x, m.y, m.z, m.w};
-      dst[2 * NCG * npos + lidx[it]] = (u32x4){l.x, l.y, l.z, l.w};
+      dst[2 * npos + lidx[it]] = (u32x4){m.x, m.y, m.z, m.w};
+      dst[4 * npos + lidx[it]] = (u32x4){l.x, l.y, l.z, l.w};
     }
   };
 
   // direct staging (kDirect): load, split and store item by item, nothing kept in registers across the MFMAs
-  auto stage_direct = [&](int buf, int chunk) {
-    u32x4* dst = sB + buf * 3 * NCG * npos;
+  auto stage_direct = [&](int buf, int kc) {
+    u32x4* dst = sB + buf * 6 * npos;
     for (int it = 0; it < a.nfi; ++it) {
       const int item = it * NT + tid;
-      const bool live = item < NCG * a.NV;
-      const int cig = live ? item / a.NV : 0;
-      const int p = live ? item - cig * a.NV : 0;
+      const int cig = item >= a.NV ? 1 : 0;
+      const int p = item - cig * a.NV;
       const int rr = p / P, cc = p - rr * P;
       const int row = r0 - a.pad + rr, col = c0 - a.pad + cc;
+      const bool live = item < 2 * a.NV;
       const bool ok = live && row >= 0 && row < a.H && col >= 0 && col < a.W;
       const int go = ok ? (row * a.W + col) : 0;
-      const int ch0 = chunk * (16 * KCH) + cig * 8;
+      const int ch0 = kc * 16 + (live ? cig * 8 : 0);
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -236,44 +223,31 @@ __global__ __launch_bounds__(64 * WM * WN + kXProd, 3) void xconv_kernel(const X
       split8(v, h, m, l);
       const int li = live ? (cig * npos + p) : (npos - 1);
       dst[li] = (u32x4){h.x, h.y, h.z, h.w};
-      dst[NCG * npos + li] = (u32x4){m.x, m.y, m.z, m.w};
-      dst[2 * NCG * npos + li] = (u32x4){l.x, l.y, l.z, l.w};
+      dst[2 * npos + li] = (u32x4){m.x, m.y, m.z, m.w};
+      dst[4 * npos + li] = (u32x4){l.x, l.y, l.z, l.w};
     }
   };
 
-  if (producer) {
-    // chunk c + 1 is split into the idle buffer while the consumers work on chunk c; its raw values were requested a
-    // chunk earlier (k >= 5: item by item, the chunks are long enough)
-    if (kDirect) {
-      stage_direct(0, 0);
-    } else {
-      load_raw(0);
-      split_write(0, 0);
-      load_raw(nch > 1 ? 1 : 0);
-    }
-#pragma unroll 1
-    for (int c = 0; c < nch; ++c) {
-      __syncthreads();                               // buffer c & 1 complete; every consumer is done with the other one
-      if (kDirect) {
-        if (c + 1 < nch) stage_direct((c + 1) & 1, c + 1);
-      } else {
-        split_write((c + 1) & 1, c + 1);             // (a spare write after the last chunk is harmless)
-        load_raw(c + 2 < nch ? c + 2 : c);
-      }
-    }
-    return;
+  // ---- A staging: the block's AU uint4 of K step kt are MT pieces of 192 uint4 in the packed buffer; the
+  //      LDS stage is padded to AI * NT cells so that every thread loads and stores unconditionally
+  const u32x4* asrc[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int j = i * NT + tid;
+    const int jj = j < AU ? j : 0;
+    const int mtl = jj / 192, rem = jj - mtl * 192;
+    asrc[i] = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(grp * a.mtiles + mt0 + mtl) * nkt) * 192 + rem;
   }
-
-  // ---- A fragments: tile tm of this wave, K step s, term t at ap[tm][s * 192 + t * 64]
-  const u32x4* ap[TM];
+  struct ARegs {
+    u32x4 v[AI];
+  };
+  auto load_a = [&](ARegs& r, int kt) {
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
-    ap[tm] = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(grp * a.mtiles + mt0 + wm * TM + tm) * nkt) * 192 + lane;
-  auto load_A = [&](u32x4 (&A)[TM][3], int s) {
+    for (int i = 0; i < AI; ++i) r.v[i] = asrc[i][(size_t)kt * 192];
+  };
+  auto write_a = [&](const ARegs& r, int buf) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int t = 0; t < 3; ++t) A[tm][t] = ap[tm][(size_t)s * 192 + t * 64];
+    for (int i = 0; i < AI; ++i) sA[buf * AS + i * NT + tid] = r.v[i];
   };
 
   f32x16 acc[TM][TN];
@@ -286,29 +260,34 @@ __global__ __launch_bounds__(64 * WM * WN + kXProd, 3) void xconv_kernel(const X
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) qb[tn] = (wn * TN + tn) * 32 + (lane & 31);
   const int bl = (lane >> 5) * npos;
+  const int al = (wm * TM) * 192 + lane;
 
-  u32x4 A0[TM][3], A1[TM][3];
-  load_A(A0, 0);
-
-  // Order inside a K step: (first step of a chunk: barrier) | request A(s + 1) | B fragments of step s from LDS |
-  // 6 * TM * TN MFMAs, small terms first, the TM * TN accumulators interleaved so that consecutive MFMAs are
-  // independent.  The scheduling barriers keep the A loads above the MFMAs (the scheduler otherwise sinks them to
-  // their first use and every K step waits an L2 round trip).
-  int chunk = 0, sc = 0, kcl = 0, ky = 0, kx = 0;
-  auto half = [&](const u32x4 (&Ac)[TM][3], u32x4 (&An)[TM][3], int s) {
-    const bool first = sc == 0;                      // block-uniform
-    if (first) __syncthreads();                      // this chunk's B buffer is complete, the other one is free
-    load_A(An, s + 1 < nkt ? s + 1 : s);
-    const u32x4* Bc = sB + (chunk & 1) * 3 * NCG * npos + 2 * kcl * npos + bl + ky * P + kx;
-    bf16x8 fb[TN][3];
+  // Order inside a K step: barrier | fragments of step kt from LDS | 6 * TM * TN MFMAs | stage A(kt + 1)
+  // (requested two steps ago) into the other A buffer, request A(kt + 3) | on the last tap of a chunk: split
+  // the raw values of the next chunk into the other B buffer, request the chunk after it.  The waits for
+  // global data sit BEHIND the wave's own MFMAs, so the matrix pipe works while they resolve (first version:
+  // staging at the top of the step -- every step waited an L2 round trip before its first MFMA, pipe 60 % busy).
+  struct Frag {
+    bf16x8 a[TM][3], b[TN][3];
+  };
+  auto read_frags = [&](Frag& f, int abuf, int kc, int off) {
+    const u32x4* Ac = sA + abuf * AS + al;
+    const u32x4* Bc = sB + (kc & 1) * 6 * npos + bl + off;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) f.a[tm][s] = __builtin_bit_cast(bf16x8, Ac[(tm * 3 + s) * 64]);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) fb[tn][t] = __builtin_bit_cast(bf16x8, Bc[t * NCG * npos + qb[tn]]);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int s = 0; s < 3; ++s) f.b[tn][s] = __builtin_bit_cast(bf16x8, Bc[s * 2 * npos + qb[tn]]);
+  };
+  auto mfmas = [&](const Frag& f) {
+    // six partial products, small terms first; the TM * TN accumulators are interleaved so that consecutive
+    // MFMAs are independent
 #define DVD_XTERM(SA, SB)                                                                             \
   _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) \
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Ac[tm][SA]), fb[tn][SB], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[tm][SA], f.b[tn][SB], acc[tm][tn], 0, 0, 0);
     DVD_XTERM(2, 0)
     DVD_XTERM(0, 2)
     DVD_XTERM(1, 1)
@@ -316,28 +295,47 @@ __global__ __launch_bounds__(64 * WM * WN + kXProd, 3) void xconv_kernel(const X
     DVD_XTERM(0, 1)
     DVD_XTERM(0, 0)
 #undef DVD_XTERM
-    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: A(0), B(0) staged; A(1), A(2) and raw(1) in flight
+  ARegs ra, rb;
+  load_a(ra, 0);
+  if (!kDirect) load_raw(0);
+  write_a(ra, 0);
+  load_a(rb, nkt > 1 ? 1 : 0);                     // set of odd steps
+  load_a(ra, nkt > 2 ? 2 : 0);                     // set of even steps
+  if (kDirect) {
+    stage_direct(0, 0);
+  } else {
+    split_write(0, 0);
+    load_raw(a.nkc > 1 ? 1 : 0);
+  }
+
+  int kc = 0, ky = 0, kx = 0;
+  auto step = [&](int kt, ARegs& rn) {             // rn holds A(kt + 1)
+    __syncthreads();
+    Frag f;
+    read_frags(f, kt & 1, kc, ky * P + kx);
+    mfmas(f);
+    write_a(rn, (kt + 1) & 1);                      // (a spare write after the last step is harmless)
+    load_a(rn, kt + 3 < nkt ? kt + 3 : kt);
     if (++kx == KS) {
       kx = 0;
-      if (++ky == KS) {
+      if (++ky == KS) {                             // last tap of the chunk (block-uniform)
         ky = 0;
-        ++kcl;
+        if (kDirect) {
+          if (kc + 1 < a.nkc) stage_direct((kc + 1) & 1, kc + 1);
+        } else {
+          split_write((kc + 1) & 1, kc + 1);
+          load_raw(kc + 2 < a.nkc ? kc + 2 : kc);
+        }
+        ++kc;
       }
     }
-    if (++sc == spc) {
-      sc = 0;
-      kcl = 0;
-      ++chunk;
-    }
   };
-  {
-    int s = 0;
-#pragma unroll 1
-    for (; s + 1 < nkt; s += 2) {
-      half(A0, A1, s);
-      half(A1, A0, s + 1);
-    }
-    if (s < nkt) half(A0, A1, s);
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(kt, rb);
+    if (kt + 1 < nkt) step(kt + 1, ra);
   }
 
   // ---- epilogue (uniform branches only; the optional operands are loaded in batches of 16; 32-bit offsets
@@ -417,18 +415,22 @@ static XCfg pick_cfg(int M) {
   return {2, 2, 2, 2};                  // 128 x 128
 }
 constexpr int kXLdsBudget = 78 * 1024;    // two blocks per CU
-constexpr int kXMaxFI = 4;       // register-prefetched staging; larger halos use the direct-staging kernels
-constexpr int kXMaxFIDirect = 64;
+constexpr int kXMaxFI = 3;       // register-prefetched staging; larger halos use the direct-staging kernels
+constexpr int kXMaxFIDirect = 16;
 
 struct XTile {
   int TR, TC, P, ntr, ntc, NV, npos, FI;
   size_t lds;
 };
-static size_t xconv_lds(int kch, int npos) { return (size_t)12 * kch * npos * sizeof(uint4); }
+static size_t xconv_lds(const XCfg& c, int npos) {
+  const int AU = c.WM * c.TM * 192, NT = c.NT();
+  const int AS = (AU + NT - 1) / NT * NT;
+  return ((size_t)2 * AS + (size_t)12 * npos) * sizeof(uint4);
+}
 // Tile of the image per block: TR x TC outputs, TR * (TC + 2 pad) <= NQ positions; choose the split of the
 // width that wastes the fewest positions, subject to the LDS budget and the staging-iteration bound.
-static bool pick_tile_budget(int H, int W, int KS, const XCfg& c, int kch, XTile& best, int budget) {
-  const int pad = KS / 2, NQ = c.NQ(), NT = kXProd;
+static bool pick_tile_budget(int H, int W, int KS, const XCfg& c, XTile& best, int budget) {
+  const int pad = KS / 2, NQ = c.NQ(), NT = c.NT();
   double best_eff = -1.0;
   for (int nct = 1; nct <= W; ++nct) {
     const int TC = (W + nct - 1) / nct;
@@ -436,20 +438,20 @@ static bool pick_tile_budget(int H, int W, int KS, const XCfg& c, int kch, XTile
     if (P > NQ) continue;
     const int ntc = (W + TC - 1) / TC;
     const int npos = NQ + (KS - 1) * (P + 1) + 1;        // + the spare cell of the staging code
-    if (xconv_lds(kch, npos) > (size_t)budget) continue;
+    if (xconv_lds(c, npos) > (size_t)budget) continue;
     int trmax = NQ / P;
     if (trmax > H) trmax = H;
     for (int tr0 = trmax; tr0 >= 1; --tr0) {
       const int ntr = (H + tr0 - 1) / tr0;
       const int TR = (H + ntr - 1) / ntr;               // even out the rows
       const int NV = (TR + 2 * pad) * P;
-      const int FI = (2 * kch * NV + NT - 1) / NT;
+      const int FI = (2 * NV + NT - 1) / NT;
       if (FI > kXMaxFIDirect) continue;
       // useful positions per computed position, minus what the halo costs in staging work
       const double eff = (double)H * W / ((double)ntr * ntc * NQ) - 0.02 * (double)NV / (TR * TC) - 1e-6 * nct;
       if (eff > best_eff) {
         best_eff = eff;
-        best = {TR, TC, P, ntr, ntc, NV, npos, FI, xconv_lds(kch, npos)};
+        best = {TR, TC, P, ntr, ntc, NV, npos, FI, xconv_lds(c, npos)};
       }
       break;                                             // smaller TR only lowers the efficiency
     }
@@ -458,25 +460,24 @@ static bool pick_tile_budget(int H, int W, int KS, const XCfg& c, int kch, XTile
   return best_eff > -1.0;
 }
 
-static bool pick_tile(int H, int W, int KS, const XCfg& c, int kch, XTile& best) {
+static bool pick_tile(int H, int W, int KS, const XCfg& c, XTile& best) {
   // two blocks per CU where the haloed tile allows it, one block (big kernels: k >= 7) otherwise
-  return pick_tile_budget(H, W, KS, c, kch, best, kXLdsBudget) || pick_tile_budget(H, W, KS, c, kch, best, 156 * 1024);
+  return pick_tile_budget(H, W, KS, c, best, kXLdsBudget) || pick_tile_budget(H, W, KS, c, best, 156 * 1024);
 }
 
-template <int TM, int TN, int WM, int WN, int KCH>
+template <int TM, int TN, int WM, int WN>
 static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t s) {
   auto go = [&](auto kern) -> int {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN + kXProd), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
     DVD_LAUNCH_OK();
     return DVD_OK;
   };
   switch (FI) {
-    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1, KCH>);
-    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2, KCH>);
-    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3, KCH>);
-    case 4: return go(xconv_kernel<TM, TN, WM, WN, 4, KCH>);
-    default: return go(xconv_kernel<TM, TN, WM, WN, 0, KCH>);
+    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1>);
+    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2>);
+    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3>);
+    default: return go(xconv_kernel<TM, TN, WM, WN, 0>);
   }
 }
 
@@ -532,11 +533,8 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
     Hh = 1;
     Ww = H * W;
   }
-  // 1x1 kernels have one K step per 16 channels: chunks of 32 channels halve their barriers (128 x 128 blocks only:
-  // the 256-position blocks would need more staging registers than the prefetching producers have)
-  const int kch = (KS == 1 && c.WM == 2 && Cin > 16) ? 2 : 1;
   dvd::XTile t;
-  DVD_REQUIRE(dvd::pick_tile(Hh, Ww, KS, c, kch, t), "xconv: no tile of a %dx%d image with a %dx%d kernel fits the LDS", H, W, KS, KS);
+  DVD_REQUIRE(dvd::pick_tile(Hh, Ww, KS, c, t), "xconv: no tile of a %dx%d image with a %dx%d kernel fits the LDS", H, W, KS, KS);
   dvd::XArgs a;
   a.x = x;
   a.wp = static_cast<const uint4*>(packed);
@@ -556,9 +554,9 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   const dim3 grid(t.ntr * t.ntc, mblocks * groups, N);
   const size_t lds = t.lds;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (c.WM == 2) return kch == 2 ? dvd::launch_fi<2, 2, 2, 2, 2>(a, t.FI, grid, lds, s) : dvd::launch_fi<2, 2, 2, 2, 1>(a, t.FI, grid, lds, s);
-  if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4, 1>(a, t.FI, grid, lds, s);
-  return dvd::launch_fi<1, 2, 1, 4, 1>(a, t.FI, grid, lds, s);
+  if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2>(a, t.FI, grid, lds, s);
+  if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4>(a, t.FI, grid, lds, s);
+  return dvd::launch_fi<1, 2, 1, 4>(a, t.FI, grid, lds, s);
 }
 
 }  // extern "C"
