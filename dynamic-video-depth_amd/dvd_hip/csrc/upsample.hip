@@ -40,38 +40,48 @@ __device__ __forceinline__ void src_index(const Axis& a, int dst, int& i0, int& 
   w0 = 1.0f - w1;
 }
 
+// Thread block = 64 quads x 4 row groups; a thread produces 4 adjacent output pixels of kRows consecutive rows, so the
+// column indices / weights are computed once per kRows rows (the kernel is VALU-bound otherwise: ~150 instructions per
+// 16-byte store); row index = plane * n_out_y + oy, 32-bit arithmetic only (the first version decomposed a 64-bit linear
+// index with three 64-bit divisions per thread and ran at 0.9 TB/s).
+constexpr int kRows = 4;
 __global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                    Axis ay, Axis ax, long long planes) {
-  const int quads = (ax.n_out + 3) >> 2;
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = planes * ay.n_out * quads;
-  if (gid >= total) return;
-  const int q = (int)(gid % quads);
-  const long long r = gid / quads;
-  const int oy = (int)(r % ay.n_out);
-  const long long p = r / ay.n_out;
-  int y0, y1;
-  float wy0, wy1;
-  src_index(ay, oy, y0, y1, wy0, wy1);
-  const float* r0 = x + (p * ay.n_in + y0) * ax.n_in;
-  const float* r1 = x + (p * ay.n_in + y1) * ax.n_in;
-  float o[4];
+                                                                    Axis ay, Axis ax, unsigned rows) {
+  const unsigned quads = (unsigned)(ax.n_out + 3) >> 2;
+  const unsigned q = blockIdx.y * 64 + threadIdx.x;
+  const unsigned rb = (blockIdx.x * 4 + threadIdx.y) * kRows;
+  if (q >= quads || rb >= rows) return;
+  int x0[4], x1[4];
+  float wx0[4], wx1[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int ox = q * 4 + j;
-    int x0, x1;
-    float wx0, wx1;
-    src_index(ax, ox < ax.n_out ? ox : ax.n_out - 1, x0, x1, wx0, wx1);
-    // ATen: w_y0 * (w_x0 * a + w_x1 * b) + w_y1 * (w_x0 * c + w_x1 * d)
-    o[j] = wy0 * (wx0 * r0[x0] + wx1 * r0[x1]) + wy1 * (wx0 * r1[x0] + wx1 * r1[x1]);
+    const int ox = (int)q * 4 + j;
+    src_index(ax, ox < ax.n_out ? ox : ax.n_out - 1, x0[j], x1[j], wx0[j], wx1[j]);
   }
-  float* dst = y + (p * ay.n_out + oy) * ax.n_out + q * 4;
-  if ((ax.n_out & 3) == 0) {
-    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-  } else {
+  const bool vec = (ax.n_out & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (q * 4 + j < ax.n_out) dst[j] = o[j];
+  for (int k = 0; k < kRows; ++k) {
+    const unsigned r = rb + k;
+    if (r >= rows) break;
+    const unsigned p = r / (unsigned)ay.n_out;
+    const int oy = (int)(r - p * (unsigned)ay.n_out);
+    int y0, y1;
+    float wy0, wy1;
+    src_index(ay, oy, y0, y1, wy0, wy1);
+    const float* r0 = x + ((size_t)p * ay.n_in + y0) * ax.n_in;
+    const float* r1 = x + ((size_t)p * ay.n_in + y1) * ax.n_in;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)   // ATen: w_y0 * (w_x0 * a + w_x1 * b) + w_y1 * (w_x0 * c + w_x1 * d)
+      o[j] = wy0 * (wx0[j] * r0[x0[j]] + wx1[j] * r0[x1[j]]) + wy1 * (wx0[j] * r1[x0[j]] + wx1[j] * r1[x1[j]]);
+    float* dst = y + (size_t)r * ax.n_out + q * 4;
+    if (vec) {
+      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((int)q * 4 + j < ax.n_out) dst[j] = o[j];
+    }
   }
 }
 
@@ -79,7 +89,8 @@ __global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float*
 // around i/scale: a bracket of kCand candidates from `lo` on covers it for scale >= 1/3; every
 // candidate is then tested exactly (weight 0 if it does not touch i), so the bracket only has to
 // be wide enough, never tight.
-constexpr int kCand = 8;
+// A bracket of k candidates from lo = floor(L) covers it when frac(L) + 2 / scale <= k: k = 6 for scale >= 0.4 (the x2
+// up-sampling of the decoder, either align_corners flavour), k = 8 for scale >= 1/3.
 __device__ __forceinline__ int dst_lo(const Axis& a, int i) {
   if (a.scale <= 0.0f) return 0;
   const float inv = 1.0f / a.scale;
@@ -87,7 +98,8 @@ __device__ __forceinline__ int dst_lo(const Axis& a, int i) {
   const int lo = (int)floorf(l);
   return lo < 0 ? 0 : lo;
 }
-__device__ __forceinline__ void axis_weights(const Axis& a, int i, int lo, float w[kCand]) {
+template <int kCand>
+__device__ __forceinline__ void axis_weights(const Axis& a, int i, int lo, float (&w)[kCand]) {
 #pragma unroll
   for (int k = 0; k < kCand; ++k) {
     const int o = lo + k;
@@ -99,32 +111,41 @@ __device__ __forceinline__ void axis_weights(const Axis& a, int i, int lo, float
   }
 }
 
+// Thread block = 64 input columns x 4 row groups of kRows input rows (the column bracket and its weights are computed
+// once per thread); row index = plane * n_in_y + iy.
+template <int kCand>
 __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                                    Axis ay, Axis ax, long long planes) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = planes * ay.n_in * ax.n_in;
-  if (gid >= total) return;
-  const int ix = (int)(gid % ax.n_in);
-  const long long r = gid / ax.n_in;
-  const int iy = (int)(r % ay.n_in);
-  const long long p = r / ay.n_in;
-  const int ylo = dst_lo(ay, iy), xlo = dst_lo(ax, ix);
-  float wy[kCand], wx[kCand];
-  axis_weights(ay, iy, ylo, wy);
-  axis_weights(ax, ix, xlo, wx);
-  const float* g = gy + p * ay.n_out * ax.n_out;
-  float acc = 0.0f;
+                                                                    Axis ay, Axis ax, unsigned rows) {
+  const unsigned ixu = blockIdx.y * 64 + threadIdx.x;
+  const unsigned rb = (blockIdx.x * 4 + threadIdx.y) * kRows;
+  if (ixu >= (unsigned)ax.n_in || rb >= rows) return;
+  const int ix = (int)ixu;
+  const int xlo = dst_lo(ax, ix);
+  float wx[kCand];
+  axis_weights<kCand>(ax, ix, xlo, wx);
+#pragma unroll 1
+  for (int k = 0; k < kRows; ++k) {
+    const unsigned r = rb + k;
+    if (r >= rows) break;
+    const unsigned p = r / (unsigned)ay.n_in;
+    const int iy = (int)(r - p * (unsigned)ay.n_in);
+    const int ylo = dst_lo(ay, iy);
+    float wy[kCand];
+    axis_weights<kCand>(ay, iy, ylo, wy);
+    const float* g = gy + (size_t)p * ay.n_out * ax.n_out;
+    float acc = 0.0f;
 #pragma unroll
-  for (int a = 0; a < kCand; ++a) {
-    if (wy[a] == 0.0f) continue;
-    const float* grow = g + (long long)(ylo + a) * ax.n_out + xlo;
-    float row = 0.0f;
+    for (int a = 0; a < kCand; ++a) {
+      if (wy[a] == 0.0f) continue;
+      const float* grow = g + (size_t)(ylo + a) * ax.n_out + xlo;
+      float row = 0.0f;
 #pragma unroll
-    for (int b = 0; b < kCand; ++b)
-      if (wx[b] != 0.0f) row = __builtin_fmaf(wx[b], grow[b], row);
-    acc = __builtin_fmaf(wy[a], row, acc);
+      for (int b = 0; b < kCand; ++b)
+        if (wx[b] != 0.0f) row = __builtin_fmaf(wx[b], grow[b], row);
+      acc = __builtin_fmaf(wy[a], row, acc);
+    }
+    gx[(size_t)r * ax.n_in + ix] = acc;
   }
-  gx[gid] = acc;
 }
 
 static Axis make_axis(int n_in, int n_out, int align) {
@@ -148,10 +169,12 @@ int dvd_upsample_bilinear_fwd(const float* x, float* y, long long planes, int H_
   DVD_REQUIRE(x && y, "upsample fwd: null pointer");
   DVD_REQUIRE(planes > 0 && H_in > 0 && W_in > 0 && H_out > 0 && W_out > 0, "upsample fwd: bad shape");
   const dvd::Axis ay = dvd::make_axis(H_in, H_out, align_corners), ax = dvd::make_axis(W_in, W_out, align_corners);
-  const long long total = planes * H_out * ((W_out + 3) / 4);
-  DVD_REQUIRE((total + 255) / 256 < (1LL << 31), "upsample fwd: grid too large");
-  hipLaunchKernelGGL(dvd::upsample_bilinear_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, y, ay, ax, planes);
+  const long long rows = planes * H_out;
+  DVD_REQUIRE(rows < (1LL << 32) - 4, "upsample fwd: too many rows");
+  const unsigned quads = (unsigned)(W_out + 3) / 4;
+  DVD_REQUIRE((quads + 63) / 64 <= 65535, "upsample fwd: rows too wide");
+  hipLaunchKernelGGL(dvd::upsample_bilinear_fwd_kernel, dim3((unsigned)((rows + 4 * dvd::kRows - 1) / (4 * dvd::kRows)), (quads + 63) / 64),
+                     dim3(64, 4), 0, static_cast<hipStream_t>(stream), x, y, ay, ax, (unsigned)rows);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -161,10 +184,18 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
   DVD_REQUIRE(gy && gx, "upsample bwd: null pointer");
   DVD_REQUIRE(planes > 0 && H_in > 0 && W_in > 0 && H_out > 0 && W_out > 0, "upsample bwd: bad shape");
   const dvd::Axis ay = dvd::make_axis(H_in, H_out, align_corners), ax = dvd::make_axis(W_in, W_out, align_corners);
-  const long long total = planes * H_in * W_in;
-  DVD_REQUIRE((total + 255) / 256 < (1LL << 31), "upsample bwd: grid too large");
-  hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), gy, gx, ay, ax, planes);
+  const long long rows = planes * H_in;
+  DVD_REQUIRE(rows < (1LL << 32) - 4, "upsample bwd: too many rows");
+  DVD_REQUIRE(((unsigned)W_in + 63) / 64 <= 65535, "upsample bwd: rows too wide");
+  // the candidate bracket must cover every output that reads an input pixel (or simply all outputs of a short axis)
+  const auto covered = [](const dvd::Axis& a, int k, float smin) { return a.scale >= smin || a.n_out <= k; };
+  DVD_REQUIRE(covered(ay, 8, 1.0f / 3.0f) && covered(ax, 8, 1.0f / 3.0f), "upsample bwd: up-sampling factors above 3 are not covered");
+  const dim3 grid((unsigned)((rows + 4 * dvd::kRows - 1) / (4 * dvd::kRows)), ((unsigned)W_in + 63) / 64);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (covered(ay, 6, 0.4f) && covered(ax, 6, 0.4f))
+    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<6>, grid, dim3(64, 4), 0, s, gy, gx, ay, ax, (unsigned)rows);
+  else
+    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<8>, grid, dim3(64, 4), 0, s, gy, gx, ay, ax, (unsigned)rows);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

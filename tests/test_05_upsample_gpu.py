@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('align', [True, False])
-@pytest.mark.parametrize('N,C,H,W', [(2, 3, 12, 21), (1, 8, 24, 42), (2, 4, 5, 7), (1, 2, 1, 9), (1, 16, 48, 84)])
+@pytest.mark.parametrize('N,C,H,W', [(2, 3, 12, 21), (1, 8, 24, 42), (2, 4, 5, 7), (1, 2, 1, 9), (1, 16, 48, 84),
+                                     (1, 2, 70, 150), (3, 1, 6, 131)])
 def test_matches_torch_cpu(N, C, H, W, align):
     from dvd_hip.conv import upsample_bilinear2x
     g = torch.Generator().manual_seed(H * 100 + W)
