@@ -72,6 +72,9 @@ class Model(NetInterface):
                                  'the host cores (2.8 s -> 2.0 s per step on a slow-host box, equal on a fast one; replay is '
                                  'bit-identical to eager execution, tests/test_30_full_step_gpu.py); falls back to eager '
                                  'execution if a capture fails.  0: eager launches')
+        parser.add_argument('--grad_buckets', type=int, default=4,
+                            help='data parallel: the depth-net gradient (421 MB for MiDaS) is all-reduced as this many large '
+                                 'buckets in flight at once, the Adam launch of a bucket overlapping the reduction of the next')
         return parser, set()
 
     # ------------------------------------------------------------------------------------
@@ -481,8 +484,9 @@ class Model(NetInterface):
             g_d2 = ops.scale_add(g_d2_main, g_d2_main, scale_ptr=inv)
             self._depth_backward(inp.img_1, fid1, g_d1)
             self._depth_backward(inp.img_2, fid2, g_d2)
-            self._flat_depth.all_reduce_grads()
-            self._flat_depth.adam_step()
+            # 421 MB (MiDaS) in --grad_buckets large all-reduces, each bucket's Adam launch overlapping the next
+            # bucket's reduction
+            self._flat_depth.all_reduce_and_adam_step(getattr(opt, 'grad_buckets', 4))
         if capturing:
             k.all_reduce_grads()
         if h_sf is not None:

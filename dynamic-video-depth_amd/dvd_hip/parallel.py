@@ -60,6 +60,29 @@ def all_reduce_sum_async_(t):
     return None
 
 
+def bucket_bounds(numel, n_buckets, align=1024):
+    """Boundaries of `n_buckets` contiguous, `align`-element aligned slices of a flat buffer.  A function of the
+    buffer size only, so every rank issues the same collectives in the same order."""
+    n_buckets = max(1, min(int(n_buckets), (numel + align - 1) // align))
+    per = -(-numel // n_buckets)
+    per = -(-per // align) * align
+    bounds = [min(i * per, numel) for i in range(n_buckets + 1)]
+    bounds[-1] = numel
+    return [(lo, hi) for lo, hi in zip(bounds[:-1], bounds[1:]) if hi > lo]
+
+
+def all_reduce_sum_buckets_async_(flat, n_buckets):
+    """Sum-all-reduce of a flat buffer as a few large messages in flight at once: returns [(lo, hi, work)] in issue
+    order.  The caller waits for bucket i and consumes flat[lo:hi] (the optimiser step of that slice) while the
+    later buckets are still on the links; xGMI is point-to-point, so the buckets stay large (>= 100 MB for the
+    421 MB MiDaS gradient) -- what is bought is the overlap of the reduction with its consumer, not message size."""
+    out = []
+    for lo, hi in bucket_bounds(flat.numel(), n_buckets):
+        work = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True) if is_distributed() else None
+        out.append((lo, hi, work))
+    return out
+
+
 def agree_on_step_plan(device, needs_late_normaliser, n_pairs):
     """Makes the collective schedule of a step independent of rank-local data.
 

@@ -194,3 +194,43 @@ def test_ranks_agree_on_one_collective_schedule():
         assert p.exitcode == 0
     assert res[0] == res[1] == [(True, 88), (False, 96)]
     assert parallel.agree_on_step_plan(torch.device('cpu'), True, 5) == (True, 5)       # no process group: local values
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend='gloo')
+    try:
+        g = torch.Generator().manual_seed(7 + rank)
+        flat = torch.randn(10 * 1024 + 37, generator=g)
+        want = flat.clone()
+        dist.all_reduce(want)
+        pending = parallel.all_reduce_sum_buckets_async_(flat, 4)
+        seen = []
+        for lo, hi, work in pending:            # consume bucket by bucket, as the optimiser does
+            work.wait()
+            seen.append((lo, hi, bool(torch.equal(flat[lo:hi], want[lo:hi]))))
+        q.put((rank, seen, bool(torch.equal(flat, want))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_gradient_all_reduce_equals_one_all_reduce():
+    """The depth-net gradient goes out as a few large buckets in flight at once (flat.FlatNet.all_reduce_and_adam_step);
+    same sums as one all-reduce, same bucket schedule on every rank."""
+    assert parallel.bucket_bounds(10, 4, align=4) == [(0, 4), (4, 8), (8, 10)]
+    assert parallel.bucket_bounds(105362945, 4)[-1][1] == 105362945 and len(parallel.bucket_bounds(105362945, 4)) == 4
+    assert parallel.bucket_bounds(100, 8) == [(0, 100)]                      # smaller than one aligned bucket
+    ctx = mp.get_context('spawn')
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, s0, ok0), (r1, s1, ok1) = sorted(res)
+    assert ok0 and ok1 and s0 == s1 and len(s0) == 4 and all(ok for _, _, ok in s0)
+    assert s0[0][0] == 0 and s0[-1][1] == 10 * 1024 + 37 and all(a[1] == b[0] for a, b in zip(s0, s0[1:]))
