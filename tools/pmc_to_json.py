@@ -32,7 +32,7 @@ def main():
     out = {'workload': '48 pairs x 384 x 672 (one dvd_warp_loss_fused launch sequence)',
            'hbm_bytes_per_launch': total, 'algorithmic_bytes_per_launch': 48 * 384 * 672 * 52,
            'corrections': 'FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), KiB -> bytes', 'kernels': kernels,
-           'source': src}
+           'source': src, 'collected': sys.argv[3] if len(sys.argv) > 3 else 'rocprofv3 --pmc passes'}
     json.dump(out, open(dst, 'w'), indent=1)
     print(json.dumps({k: out[k] for k in ('hbm_bytes_per_launch', 'algorithmic_bytes_per_launch')}))
 
