@@ -53,6 +53,12 @@ class FlatNet(object):
         for p in self.params:
             p.grad = None
 
+    def reattach_grads(self):
+        """`.grad` of every parameter = its view of the flat buffer again (after a detach that was not absorbed)."""
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
     def absorb_grads(self):
         views, fresh = [], []
         for p, o in zip(self.params, self.offsets):

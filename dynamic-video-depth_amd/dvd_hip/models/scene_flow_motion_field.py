@@ -172,9 +172,11 @@ class Model(NetInterface):
                         with torch.no_grad():
                             self._depth_forward(static_in, fid)
                     else:
+                        self._flat_depth.detach_grads()
                         with torch.enable_grad():
                             d = self._depth_forward(static_in, fid)
                         d.backward(torch.zeros_like(d))
+                        self._flat_depth.absorb_grads()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             # thread_local: calls made by other threads (the RCCL watchdog polling its events) do not invalidate
@@ -186,15 +188,21 @@ class Model(NetInterface):
                 entry = (graph, static_in, static_out, None)
             else:
                 static_g = torch.zeros(img.shape[0], 1, img.shape[2], img.shape[3], device=img.device)
+                # parameter gradients: the engine hands over fresh tensors (no pre-attached .grad) and ONE multi-tensor add
+                # per chunk, captured with the rest, folds them into the flat buffer -- ~620 tiny accumulate kernels
+                # per replay otherwise
+                self._flat_depth.detach_grads()
                 with torch.cuda.graph(graph, **mode):
                     with torch.enable_grad():
                         static_out = self._depth_forward(static_in, fid)
                     static_out.backward(static_g)
+                    self._flat_depth.absorb_grads()
                 entry = (graph, static_in, static_out, static_g)
                 self._flat_depth.grad.copy_(grad_backup)   # warm-up / capture passes used zero output gradients
         except Exception as e:                             # noqa: BLE001 -- capture is an optimisation only
             warnings.warn('depth-net HIP graph capture failed (%s); running eagerly' % (str(e).splitlines()[0],))
             torch.cuda.synchronize()
+            self._flat_depth.reattach_grads()
             entry = None
         self._depth_graphs[key] = entry
         return entry
