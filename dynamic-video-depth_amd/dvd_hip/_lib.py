@@ -43,6 +43,11 @@ class MlpDesc(ctypes.Structure):
 
 
 c_longlong = ctypes.c_longlong
+
+
+class BnParams(ctypes.Structure):           # struct dvd_bn_params
+    _fields_ = [('gamma', c_void_p), ('beta', c_void_p), ('mean', c_void_p), ('var', c_void_p), ('eps', ctypes.c_float)]
+
 PtrArr6 = c_void_p * 6
 PtrArr5 = c_void_p * 5
 
@@ -103,7 +108,10 @@ SIGNATURES = {
                                             c_int, c_int, c_void_p]),
     'dvd_xconv_packed_bytes': (c_size_t, [c_int] * 5),
     'dvd_xconv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    'dvd_xconv_fwd': (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p]),
+    'dvd_xconv_fwd': (c_int, [c_void_p] * 5 + [ctypes.POINTER(BnParams), c_void_p] + [c_int] * 8 + [c_void_p]),
+    'dvd_xconv_pack_scaled': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                      c_void_p]),
+    'dvd_convbn_finalize': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'dvd_xwgrad3_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad1s_workspace_bytes': (c_size_t, [c_int] * 5),
     'dvd_xwgrad1s': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 6 + [c_void_p]),

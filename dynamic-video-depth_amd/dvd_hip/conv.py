@@ -245,6 +245,36 @@ class GroupedConv3x3C8(nn.Conv2d):
 # ---------------------------------------------------------------------------------------
 # Dense stride-1 convolutions on the split-bf16 MFMA kernels (csrc/xconv.hip)
 
+def xconv_packed_scaled(weight, groups, gamma, var, eps):
+    """Transposed packing with row co scaled by gamma[co] / sqrt(var[co] + eps): backward-data through a fused BatchNorm.
+    Cached on the weight like xconv_packed; the key also follows gamma (optimiser steps) and the running variance."""
+    from . import ops
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    Cout, Cin, KS, _ = w.shape
+    Cin *= groups
+    lib = _lib.load()
+    nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, groups, 1)
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (w.data_ptr(), weight._version, ops.WEIGHT_EPOCH[0], tuple(w.shape),
+           None if gamma is None else (gamma.data_ptr(), gamma._version), var.data_ptr(), var._version, float(eps))
+    cache = getattr(weight, '_dvd_xpack', None)
+    if cache is None and not capturing:
+        cache = {}
+        weight._dvd_xpack = cache
+    hit = cache.get('Ts') if cache is not None else None
+    if not capturing and hit is not None and hit[0] == key:
+        return hit[1]
+    packed = hit[1] if (not capturing and hit is not None and hit[1].numel() == nbytes) else \
+        torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    _lib.check(lib.dvd_xconv_pack_scaled(_p(w), _p(packed), Cout, Cin, KS, groups, 1, _p(gamma), _p(var), float(eps), _stream()),
+               'dvd_xconv_pack_scaled')
+    if not capturing:
+        cache['Ts'] = (key, packed)
+    return packed
+
+
 def xconv_packed(weight, transposed, groups=1):
     """Fragment-ordered, pre-split copy of a conv weight [Cout,Cin/groups,k,k].  The copy hangs on the weight
     tensor OBJECT (not on its address: allocators reuse addresses) and is rebuilt when the weight changed:
@@ -282,12 +312,18 @@ def xconv_packed(weight, transposed, groups=1):
 
 
 def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, relu_in=False, relu_out=False,
-               res_relu=False, groups=1):
+               res_relu=False, groups=1, bn=None):
+    """bn = (gamma | None, beta | None, mean, var, eps): eval-mode BatchNorm of the output, fused into the epilogue."""
     N, Cin, H, W = x.shape
     y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
     flags = int(bool(relu_in)) | (int(bool(relu_out)) << 1) | (int(bool(res_relu)) << 2)
     lib = _lib.load()
-    _lib.check(lib.dvd_xconv_fwd(_p(x), _p(packed), _p(bias), _p(residual), _p(mask_src), _p(y), N, Cin, Cout, H, W, KS,
+    bnp = None
+    if bn is not None:
+        g, b, m, v, eps = bn
+        bnp = ctypes.byref(_lib.BnParams(g.data_ptr() if g is not None else None, b.data_ptr() if b is not None else None,
+                                         m.data_ptr(), v.data_ptr(), float(eps)))
+    _lib.check(lib.dvd_xconv_fwd(_p(x), _p(packed), _p(bias), _p(residual), _p(mask_src), bnp, _p(y), N, Cin, Cout, H, W, KS,
                                  groups, flags, _stream()), 'dvd_xconv_fwd')
     return y
 
@@ -371,6 +407,76 @@ def xconv_wgrad(x, gy, wshape, relu_in, groups=1):
     KS = wshape[2]
     return torch.ops.aten.convolution_backward(gy, xin, torch.empty(wshape, device=x.device), None, [1, 1],
                                                [KS // 2, KS // 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+
+
+class _XConvBn(torch.autograd.Function):
+    """y = act(bn_eval(conv2d(x, w) + cbias) (+ residual)): the convolution kernel's epilogue applies the BatchNorm, so
+    the pre-BN tensor is never written.  Backward: one pass masks the output gradient (g = gy * [y > 0]) and sums it per
+    channel (dbeta); backward-data runs on g with the weights packed transposed AND scaled by gamma * rstd; backward-weight
+    runs on g unscaled, and a tiny kernel derives dW, dgamma and the conv-bias gradient from it (csrc/bnrelu.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, cbias, gamma, beta, mean, var, eps, residual, relu, groups):
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        Cout, _, KS, _ = weight.shape
+        y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=cbias, residual=residual, relu_out=relu,
+                       groups=groups, bn=(gamma, beta, mean, var, eps))
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, var, cbias)
+        ctx.wparam = weight
+        ctx.cfg = (float(eps), bool(relu), residual is not None, groups)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, mean, var, cbias = ctx.saved_tensors
+        weight = ctx.wparam
+        eps, relu, has_res, groups = ctx.cfg
+        gy = gy.contiguous()
+        Cout, Cing, KS, _ = weight.shape
+        N, _, H, W = gy.shape
+        need = ctx.needs_input_grad
+        lib = _lib.load()
+        # masked gradient + per-channel sums
+        dbeta = torch.empty(Cout, device=gy.device, dtype=torch.float32)
+        g = torch.empty_like(gy) if relu else gy
+        ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, Cout, H * W), gy.device)
+        _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y), None, _p(var), _p(mean), _p(var), eps, None, _p(g) if relu else None,
+                                      None, _p(dbeta), _p(ws), ctypes.c_size_t(ws.numel()), N, Cout, H * W, int(relu),
+                                      _stream()), 'dvd_bnrelu_bwd')
+        gx = gw = gcb = gg = None
+        if need[0]:
+            gx = _xconv_run(g, xconv_packed_scaled(weight, groups, gamma, var, eps), Cing * groups, KS, groups=groups)
+        if need[1] or (gamma is not None and need[3]) or (cbias is not None and need[2]):
+            gw = xconv_wgrad(x, g, weight.shape, False, groups)
+            gg = torch.empty_like(gamma) if gamma is not None else None
+            gcb = torch.empty_like(cbias) if cbias is not None else None
+            _lib.check(lib.dvd_convbn_finalize(_p(weight.detach()), _p(gw), _p(dbeta), _p(gamma), _p(mean), _p(var), eps,
+                                               _p(cbias), Cout, Cing * KS * KS, _p(gg), _p(gcb), _stream()),
+                       'dvd_convbn_finalize')
+        return gx, gw, gcb, gg, (dbeta if need[4] else None), None, None, None, (g if has_res else None), None, None
+
+
+def conv_bn_act(conv, bn, x, residual=None, relu=True):
+    """relu(bn(conv(x)) (+ residual)) for an nn.Conv2d followed by an eval-mode nn.BatchNorm2d.  Convolutions the xconv
+    kernels cover run as ONE launch (BatchNorm, residual and ReLU in the epilogue); everything else (CPU tensors,
+    training-mode statistics, the 8/16-per-group and strided 3x3 convolutions) is conv(x) followed by the fused
+    BatchNorm+ReLU kernel / the ATen ops."""
+    if (x.is_cuda and x.dtype == torch.float32 and not bn.training and bn.track_running_stats and
+            isinstance(conv, nn.Conv2d) and not _os.environ.get('DVD_NO_BNFUSE')):
+        xin = None
+        if xconv_supported(conv, x):
+            xin = x
+        elif (conv.kernel_size == (1, 1) and conv.groups == 1 and tuple(conv.padding) == (0, 0) and
+              conv.stride[0] == conv.stride[1] and conv.stride[0] > 1 and conv.weight.dtype == torch.float32 and
+              not _os.environ.get('DVD_NO_XCONV')):
+            xin = x[:, :, ::conv.stride[0], ::conv.stride[0]].contiguous()
+        if xin is not None:
+            gamma, beta = (bn.weight, bn.bias) if bn.affine else (None, None)
+            return _XConvBn.apply(xin, conv.weight, conv.bias, gamma, beta, bn.running_mean, bn.running_var, bn.eps,
+                                  residual, relu, conv.groups)
+    return bn_eval_relu(bn, conv(x), residual=residual, relu=relu)
 
 
 def xconv_supported(conv, x):

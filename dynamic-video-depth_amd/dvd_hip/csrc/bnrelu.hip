@@ -90,10 +90,12 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
         g.z = o.z > 0.0f ? g.z : 0.0f;
         g.w = o.w > 0.0f ? g.w : 0.0f;
       }
-      const float4 v = *reinterpret_cast<const float4*>(x + base + i);
       sg += (g.x + g.y) + (g.z + g.w);
-      sgx = __builtin_fmaf(g.x, v.x - mu,
-                           __builtin_fmaf(g.y, v.y - mu, __builtin_fmaf(g.z, v.z - mu, __builtin_fmaf(g.w, v.w - mu, sgx))));
+      if (x) {
+        const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+        sgx = __builtin_fmaf(g.x, v.x - mu,
+                             __builtin_fmaf(g.y, v.y - mu, __builtin_fmaf(g.z, v.z - mu, __builtin_fmaf(g.w, v.w - mu, sgx))));
+      }
       if (gres) *reinterpret_cast<float4*>(gres + base + i) = g;
       if (gx) *reinterpret_cast<float4*>(gx + base + i) = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
     }
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
       float g = gy[base + i];
       if (relu) g = y[base + i] > 0.0f ? g : 0.0f;
       sg += g;
-      sgx = __builtin_fmaf(g, x[base + i] - mu, sgx);
+      if (x) sgx = __builtin_fmaf(g, x[base + i] - mu, sgx);
       if (gres) gres[base + i] = g;
       if (gx) gx[base + i] = g * s;
     }
@@ -138,6 +140,36 @@ __global__ __launch_bounds__(64) void bnrelu_param_grad_kernel(const float2* __r
   if (ggamma) ggamma[c] = (float)(sgx / sqrt((double)var[c] + (double)eps));
 }
 
+// Convolution + fused eval-mode BatchNorm, backward bookkeeping of one site.  The weight-gradient kernels ran on the
+// UNSCALED masked gradient g = gy * [y > 0]:  dWu[co][k] = sum g[co] x[k].  With z = W x + cb (pre-BN), s = gamma * rstd:
+//   dW[co][k]  = s[co] * dWu[co][k]
+//   dgamma[co] = sum g * (z - mean) * rstd = rstd * (sum_k W[co][k] dWu[co][k] + (cb[co] - mean[co]) * dbeta[co])
+//   dcb[co]    = s[co] * dbeta[co]
+// One 64-thread block per output channel, fixed-order sums (deterministic).
+__global__ __launch_bounds__(64) void convbn_finalize_kernel(const float* __restrict__ W, float* __restrict__ dW,
+                                                             const float* __restrict__ dbeta, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                             const float* __restrict__ cbias, int K, float* __restrict__ dgamma,
+                                                             float* __restrict__ dcbias) {
+  const int co = blockIdx.x, lane = threadIdx.x;
+  const float rstd = 1.0f / sqrtf(var[co] + eps);
+  const float s = (gamma ? gamma[co] : 1.0f) * rstd;
+  const float* w = W + (size_t)co * K;
+  float* d = dW + (size_t)co * K;
+  float acc = 0.0f;
+  for (int k = lane; k < K; k += 64) {
+    const float u = d[k];
+    acc = __builtin_fmaf(w[k], u, acc);
+    d[k] = u * s;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float db = dbeta[co];
+    if (dgamma) dgamma[co] = rstd * (acc + ((cbias ? cbias[co] : 0.0f) - mean[co]) * db);
+    if (dcbias) dcbias[co] = s * db;
+  }
+}
+
 }  // namespace dvd
 
 extern "C" {
@@ -164,7 +196,8 @@ size_t dvd_bnrelu_bwd_workspace_bytes(int N, int C, int HW) {
 int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* mean,
                    const float* var, float eps, float* gx, float* g_residual, float* g_gamma, float* g_beta,
                    void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu, dvd_stream_t stream) {
-  DVD_REQUIRE(gy && x && gamma && mean && var && workspace, "bnrelu bwd: null pointer");
+  DVD_REQUIRE(gy && gamma && mean && var && workspace, "bnrelu bwd: null pointer");
+  DVD_REQUIRE(x || !g_gamma, "bnrelu bwd: the gamma gradient needs the BatchNorm input");
   DVD_REQUIRE(!relu || y, "bnrelu bwd: the ReLU mask needs the forward output");
   DVD_REQUIRE(N > 0 && C > 0 && HW > 0, "bnrelu bwd: bad shape");
   if (workspace_bytes < dvd_bnrelu_bwd_workspace_bytes(N, C, HW)) {
@@ -183,6 +216,16 @@ int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float*
                        static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, N * chunks);
     DVD_LAUNCH_OK();
   }
+  return DVD_OK;
+}
+
+int dvd_convbn_finalize(const float* W, float* dW, const float* dbeta, const float* gamma, const float* mean, const float* var,
+                        float eps, const float* conv_bias, int Cout, int K, float* dgamma, float* dconv_bias, dvd_stream_t stream) {
+  DVD_REQUIRE(W && dW && dbeta && mean && var, "convbn_finalize: null pointer");
+  DVD_REQUIRE(Cout > 0 && K > 0, "convbn_finalize: bad shape");
+  hipLaunchKernelGGL(dvd::convbn_finalize_kernel, dim3(Cout), dim3(64), 0, static_cast<hipStream_t>(stream), W, dW, dbeta, gamma,
+                     mean, var, eps, conv_bias, K, dgamma, dconv_bias);
+  DVD_LAUNCH_OK();
   return DVD_OK;
 }
 

@@ -70,8 +70,12 @@ __device__ __forceinline__ void split8(const float v[8], uint4& h, uint4& m, uin
 //   transposed: A[m][k] = w[co = k][ci = m][T - 1 - tap]      (backward-data: roles swapped, taps flipped)
 // rows m >= M and columns k >= K are zero (M, K are padded to the block / K-step granularity).
 // Grouped convolutions: Cout / Cin are per group, w is [G * Cout][Cin][T]; group g's fragments follow group g - 1's.
+// sc_gamma / sc_var (optional): every weight of output channel co is multiplied by gamma[co] / sqrt(var[co] + eps) (gamma
+// null = 1) -- the backward-data pass of a convolution whose eval-mode BatchNorm is fused into its epilogue.
 __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
-                                                         int Cin, int T, int transposed, int mtiles, int nkc, int G) {
+                                                         int Cin, int T, int transposed, int mtiles, int nkc, int G,
+                                                         const float* __restrict__ sc_gamma, const float* __restrict__ sc_var,
+                                                         float sc_eps) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)G * mtiles * nkc * T * 64;
   if (idx >= total) return;
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict
     if (m < M && k < K) {
       const int co = transposed ? k : m, ci = transposed ? m : k, tp = transposed ? T - 1 - tap : tap;
       val = w[((size_t)co * Cin + ci) * T + tp];
+      if (sc_var) val *= (sc_gamma ? sc_gamma[g * Cout + co] : 1.0f) / sqrtf(sc_var[g * Cout + co] + sc_eps);
     }
     v[e] = val;
   }
@@ -109,6 +114,11 @@ struct XArgs {
   const float* __restrict__ bias;
   const float* __restrict__ res;
   const float* __restrict__ mask_src;
+  const float* __restrict__ bn_gamma;   // fused eval-mode BatchNorm of the output (bn_var != null): gamma / beta may be null
+  const float* __restrict__ bn_beta;
+  const float* __restrict__ bn_mean;
+  const float* __restrict__ bn_var;
+  float bn_eps;
   float* __restrict__ y;
   int N, Cin, Cout, H, W;   // Cin = real K, Cout = real M of this launch, PER GROUP
   int G, mbpg, mtiles;      // groups, channel blocks per group, packed 32-row tiles per group
@@ -345,6 +355,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
   const size_t ibase = ((size_t)n * a.G + grp) * a.Cout * plane;     // this group's channels of image n
   float* __restrict__ yb = a.y + ibase;
   const int iplane = (int)plane;
+  // fused eval-mode BatchNorm: y = (z - mean) / sqrt(var + eps) * gamma + beta as z * s + (beta - mean * s), the formula of
+  // csrc/bnrelu.hip.  Lane j computes s and the shift of channel 32 * tile + j ONCE (IEEE sqrt and division: 16 channels
+  // per lane and tile evaluated in place cost more than the MFMAs of a 1x1 convolution); the 16 channels a lane's
+  // accumulators belong to are fetched from those lanes where they are applied (keeping them in registers tripled the
+  // kernel's VGPR count and cost the 1x1 kernels their third block per CU).
+  float my_sc[TM], my_sh[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    my_sc[tm] = 1.0f;
+    my_sh[tm] = 0.0f;
+    if (a.bn_var) {
+      const int co = (mt0 + wm * TM + tm) * 32 + (lane & 31);
+      const int cg = grp * a.Cout + (co < a.Cout ? co : a.Cout - 1);
+      my_sc[tm] = (a.bn_gamma ? a.bn_gamma[cg] : 1.0f) / sqrtf(a.bn_var[cg] + a.bn_eps);
+      my_sh[tm] = (a.bn_beta ? a.bn_beta[cg] : 0.0f) - a.bn_mean[cg] * my_sc[tm];
+    }
+  }
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int q = qb[tn];
@@ -365,6 +392,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int co = cob + (r & 3) + 8 * (r >> 2);
           v[r] += a.bias[grp * a.Cout + (co < a.Cout ? co : a.Cout - 1)];
+        }
+      }
+      if (a.bn_var) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int src = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          v[r] = __builtin_fmaf(v[r], __shfl(my_sc[tm], src, 64), __shfl(my_sh[tm], src, 64));
         }
       }
       if (a.res) {
@@ -499,7 +533,8 @@ size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int groups, int transpo
   return (size_t)groups * dvd::xconv_mtiles(M) * ((K + 15) / 16) * KS * KS * 3 * 64 * sizeof(uint4);
 }
 
-int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed, dvd_stream_t stream) {
+static int xconv_pack_impl(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed,
+                           const float* gamma, const float* var, float eps, dvd_stream_t stream) {
   DVD_REQUIRE(w && packed, "xconv_pack: null pointer");
   DVD_REQUIRE(Cout > 0 && Cin > 0 && KS > 0 && (KS & 1) && KS <= 11 && groups > 0 && Cout % groups == 0 && Cin % groups == 0,
               "xconv_pack: bad shape Cout=%d Cin=%d KS=%d groups=%d", Cout, Cin, KS, groups);
@@ -509,14 +544,24 @@ int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int 
   const long long total = (long long)groups * mtiles * nkc * T * 64;
   hipLaunchKernelGGL(dvd::xconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, static_cast<uint4*>(packed), co, ci, T, transposed ? 1 : 0,
-                     mtiles, nkc, groups);
+                     mtiles, nkc, groups, gamma, var, eps);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
 
+int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed, dvd_stream_t stream) {
+  return xconv_pack_impl(w, packed, Cout, Cin, KS, groups, transposed, nullptr, nullptr, 0.0f, stream);
+}
+
+int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed,
+                          const float* bn_gamma, const float* bn_var, float bn_eps, dvd_stream_t stream) {
+  DVD_REQUIRE(bn_var, "xconv_pack_scaled: null variance");
+  return xconv_pack_impl(w, packed, Cout, Cin, KS, groups, transposed, bn_gamma, bn_var, bn_eps, stream);
+}
+
 int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
-                  float* y, int N, int Cin_total, int Cout_total, int H, int W, int KS, int groups, int flags,
-                  dvd_stream_t stream) {
+                  const dvd_bn_params* bn, float* y, int N, int Cin_total, int Cout_total, int H, int W, int KS, int groups,
+                  int flags, dvd_stream_t stream) {
   DVD_REQUIRE(x && packed && y, "xconv: null pointer");
   DVD_REQUIRE(N > 0 && Cin_total > 0 && Cout_total > 0 && H > 0 && W > 0, "xconv: bad shape N=%d Cin=%d Cout=%d H=%d W=%d", N,
               Cin_total, Cout_total, H, W);
@@ -541,6 +586,12 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   a.bias = bias;
   a.res = residual;
   a.mask_src = mask_src;
+  a.bn_gamma = bn ? bn->gamma : nullptr;
+  a.bn_beta = bn ? bn->beta : nullptr;
+  a.bn_mean = bn ? bn->mean : nullptr;
+  a.bn_var = bn ? bn->var : nullptr;
+  a.bn_eps = bn ? bn->eps : 0.0f;
+  DVD_REQUIRE(!bn || (bn->mean && bn->var), "xconv: BatchNorm statistics missing");
   a.y = y;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = Hh; a.W = Ww;
   a.G = groups; a.mtiles = dvd::xconv_mtiles(Cout);

@@ -303,8 +303,28 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
  * layout): the 64-channels-per-group 3x3 convolutions of ResNeXt stage 4 run here with groups = 32. */
 size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int groups, int transposed);
 int dvd_xconv_pack(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed, dvd_stream_t stream);
+/* Eval-mode BatchNorm of the convolution's output fused into the epilogue (the depth nets are always in eval mode while
+ * training, models/scene_flow_motion_field.py:157,168):  y = act((conv(x) + bias - mean) / sqrt(var + eps) * gamma + beta
+ * + residual).  gamma / beta null = BatchNorm2d(affine=False) (hourglass.py:21-57).  bn null = no BatchNorm. */
+typedef struct dvd_bn_params {
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float eps;
+} dvd_bn_params;
 int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
-                  float* y, int N, int Cin, int Cout, int H, int W, int KS, int groups, int flags, dvd_stream_t stream);
+                  const dvd_bn_params* bn, float* y, int N, int Cin, int Cout, int H, int W, int KS, int groups, int flags,
+                  dvd_stream_t stream);
+/* Transposed / forward packing with every weight of output channel co scaled by gamma[co] / sqrt(var[co] + eps): the
+ * backward-data pass through a fused BatchNorm is dvd_xconv_fwd on the masked, UNSCALED output gradient. */
+int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed,
+                          const float* bn_gamma, const float* bn_var, float bn_eps, dvd_stream_t stream);
+/* After the weight-gradient kernel ran on the unscaled masked gradient (dW holds dWu [Cout][K]): scales dW in place and
+ * derives the BatchNorm-gamma and convolution-bias gradients (csrc/bnrelu.hip); dbeta = per-channel sum of the masked
+ * gradient (dvd_bnrelu_bwd with x = null). */
+int dvd_convbn_finalize(const float* W, float* dW, const float* dbeta, const float* gamma, const float* mean, const float* var,
+                        float eps, const float* conv_bias, int Cout, int K, float* dgamma, float* dconv_bias, dvd_stream_t stream);
 /* Backward-weight of the same convolutions (k = 1 and 3), exact fp32 MFMA, deterministic two-stage sum
  * (csrc/xwgrad.hip): gw[Cout,Cin,k,k] = sum_{n,p} gy[n,co,p] * act(x)[n,ci,p + tap], act = ReLU if relu_in.
  * Replaces the autograd weight gradient of the nn.Conv2d named above (MIOpen accumulates it with atomics). */

@@ -198,3 +198,69 @@ def test_decoder_size_is_deterministic():
         outs.append((y.detach().clone(), x.grad.clone(), conv.weight.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+BN_CASES = [
+    # Cin, Cout, k, groups, stride, affine, conv_bias, residual, relu, H, W
+    (64, 256, 1, 1, 1, True, False, True, True, 12, 21),       # bottleneck conv3 + bn3 + skip + ReLU
+    (256, 64, 1, 1, 1, True, False, False, True, 12, 21),      # conv1 + bn1 + ReLU
+    (128, 128, 3, 4, 1, True, False, False, True, 9, 14),      # grouped conv2 (32 per group) + bn2 + ReLU
+    (64, 128, 1, 1, 2, True, False, False, False, 12, 22),     # down-sampling shortcut: strided 1x1 + BN, no ReLU
+    (48, 32, 5, 1, 1, False, True, False, True, 11, 13),       # hourglass inception branch: conv bias, BatchNorm2d(affine=False)
+]
+
+
+@pytest.mark.parametrize('Cin,Cout,k,groups,stride,affine,cbias,with_res,relu,H,W', BN_CASES)
+def test_convolution_with_fused_batchnorm(Cin, Cout, k, groups, stride, affine, cbias, with_res, relu, H, W):
+    """conv -> eval-mode BatchNorm (-> + residual) (-> ReLU) as one launch (conv.conv_bn_act; torchvision Bottleneck as
+    third_party/midas_blocks.py:35-50 runs it, hourglass.py:21-57): output and ALL gradients (input, weight, conv bias,
+    gamma, beta, residual) against float64 autograd of the unfused ops."""
+    from dvd_hip import conv as C
+    torch.manual_seed(Cin + Cout + k)
+    N = 2
+    conv = torch.nn.Conv2d(Cin, Cout, k, stride=stride, padding=0 if stride > 1 else k // 2, groups=groups, bias=cbias)
+    bn = torch.nn.BatchNorm2d(Cout, affine=affine).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.3, 2.0)
+        if affine:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.3)
+    x = torch.randn(N, Cin, H, W)
+    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    res = torch.randn(N, Cout, Ho, Wo) if with_res else None
+    gy = torch.randn(N, Cout, Ho, Wo)
+    # float64 reference
+    xd = x.double().requires_grad_(True)
+    gamma_d = bn.weight.detach().double().requires_grad_(True) if affine else None
+    beta_d = bn.bias.detach().double().requires_grad_(True) if affine else None
+    wd = conv.weight.detach().double().requires_grad_(True)
+    cbd = conv.bias.detach().double().requires_grad_(True) if cbias else None
+    z = F.conv2d(xd, wd, cbd, stride=stride, padding=conv.padding, groups=groups)
+    yd = F.batch_norm(z, bn.running_mean.double(), bn.running_var.double(), gamma_d, beta_d, False, 0.0, bn.eps)
+    rd = res.double().requires_grad_(True) if with_res else None
+    if with_res:
+        yd = yd + rd
+    if relu:
+        yd = yd.relu()
+    yd.backward(gy.double())
+    # fused path
+    conv_g = (C.XConv2d(Cin, Cout, k, stride=stride, padding=conv.padding, groups=groups, bias=cbias)).cuda()
+    conv_g.load_state_dict(conv.state_dict())
+    bn_g = torch.nn.BatchNorm2d(Cout, affine=affine).cuda().eval()
+    bn_g.load_state_dict(bn.state_dict())
+    xg = x.cuda().requires_grad_(True)
+    rg = res.cuda().requires_grad_(True) if with_res else None
+    y = C.conv_bn_act(conv_g, bn_g, xg, residual=rg, relu=relu)
+    assert y.grad_fn is not None and 'XConvBn' in type(y.grad_fn).__name__, 'the fused path must be taken'
+    y.backward(gy.cuda())
+    assert _err(y.detach(), yd.detach()) < 2 * TOL, _where(y.detach(), yd.detach(), 'n,c,y,x')
+    assert _err(xg.grad, xd.grad) < 2 * TOL, 'dgrad: ' + _where(xg.grad, xd.grad, 'n,c,y,x')
+    assert _err(conv_g.weight.grad, wd.grad) < 2e-5, 'wgrad'
+    if cbias:
+        assert _err(conv_g.bias.grad, cbd.grad) < 2e-5, 'conv bias grad'
+    if affine:
+        assert _err(bn_g.weight.grad, gamma_d.grad) < 2e-5, 'gamma grad'
+        assert _err(bn_g.bias.grad, beta_d.grad) < 2e-5, 'beta grad'
+    if with_res:
+        assert _err(rg.grad, rd.grad) < 1e-7, 'residual grad'
