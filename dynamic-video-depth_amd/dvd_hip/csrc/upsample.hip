@@ -40,7 +40,7 @@ __device__ __forceinline__ void src_index(const Axis& a, int dst, int& i0, int& 
   w0 = 1.0f - w1;
 }
 
-// Thread block = 64 quads x 4 row groups; a thread produces 4 adjacent output pixels of kRows consecutive rows, so the
+// Linear index over (row group, quad); a thread produces 4 adjacent output pixels of kRows consecutive rows, so the
 // column indices / weights are computed once per kRows rows (the kernel is VALU-bound otherwise: ~150 instructions per
 // 16-byte store); row index = plane * n_out_y + oy, 32-bit arithmetic only (the first version decomposed a 64-bit linear
 // index with three 64-bit divisions per thread and ran at 0.9 TB/s).
@@ -48,9 +48,11 @@ constexpr int kRows = 4;
 __global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                     Axis ay, Axis ax, unsigned rows) {
   const unsigned quads = (unsigned)(ax.n_out + 3) >> 2;
-  const unsigned q = blockIdx.y * 64 + threadIdx.x;
-  const unsigned rb = (blockIdx.x * 4 + threadIdx.y) * kRows;
-  if (q >= quads || rb >= rows) return;
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;          // (row group, quad), quads fastest: no idle lanes in
+  const unsigned rg = idx / quads;                               // rows that are not a multiple of 64 quads wide
+  const unsigned q = idx - rg * quads;
+  const unsigned rb = rg * kRows;
+  if (rb >= rows) return;
   int x0[4], x1[4];
   float wx0[4], wx1[4];
 #pragma unroll
@@ -111,14 +113,16 @@ __device__ __forceinline__ void axis_weights(const Axis& a, int i, int lo, float
   }
 }
 
-// Thread block = 64 input columns x 4 row groups of kRows input rows (the column bracket and its weights are computed
-// once per thread); row index = plane * n_in_y + iy.
+// Linear index over (row group of kRows input rows, input column): the column bracket and its weights are computed once
+// per thread; row index = plane * n_in_y + iy.
 template <int kCand>
 __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                     Axis ay, Axis ax, unsigned rows) {
-  const unsigned ixu = blockIdx.y * 64 + threadIdx.x;
-  const unsigned rb = (blockIdx.x * 4 + threadIdx.y) * kRows;
-  if (ixu >= (unsigned)ax.n_in || rb >= rows) return;
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;          // (row group, input column), columns fastest
+  const unsigned rg = idx / (unsigned)ax.n_in;
+  const unsigned ixu = idx - rg * (unsigned)ax.n_in;
+  const unsigned rb = rg * kRows;
+  if (rb >= rows) return;
   const int ix = (int)ixu;
   const int xlo = dst_lo(ax, ix);
   float wx[kCand];
@@ -172,9 +176,10 @@ int dvd_upsample_bilinear_fwd(const float* x, float* y, long long planes, int H_
   const long long rows = planes * H_out;
   DVD_REQUIRE(rows < (1LL << 32) - 4, "upsample fwd: too many rows");
   const unsigned quads = (unsigned)(W_out + 3) / 4;
-  DVD_REQUIRE((quads + 63) / 64 <= 65535, "upsample fwd: rows too wide");
-  hipLaunchKernelGGL(dvd::upsample_bilinear_fwd_kernel, dim3((unsigned)((rows + 4 * dvd::kRows - 1) / (4 * dvd::kRows)), (quads + 63) / 64),
-                     dim3(64, 4), 0, static_cast<hipStream_t>(stream), x, y, ay, ax, (unsigned)rows);
+  const long long total = (rows + dvd::kRows - 1) / dvd::kRows * quads;
+  DVD_REQUIRE(total < (1LL << 32) - 256, "upsample fwd: too large");
+  hipLaunchKernelGGL(dvd::upsample_bilinear_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, y, ay, ax, (unsigned)rows);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -186,16 +191,17 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
   const dvd::Axis ay = dvd::make_axis(H_in, H_out, align_corners), ax = dvd::make_axis(W_in, W_out, align_corners);
   const long long rows = planes * H_in;
   DVD_REQUIRE(rows < (1LL << 32) - 4, "upsample bwd: too many rows");
-  DVD_REQUIRE(((unsigned)W_in + 63) / 64 <= 65535, "upsample bwd: rows too wide");
+  const long long total = (rows + dvd::kRows - 1) / dvd::kRows * W_in;
+  DVD_REQUIRE(total < (1LL << 32) - 256, "upsample bwd: too large");
   // the candidate bracket must cover every output that reads an input pixel (or simply all outputs of a short axis)
   const auto covered = [](const dvd::Axis& a, int k, float smin) { return a.scale >= smin || a.n_out <= k; };
   DVD_REQUIRE(covered(ay, 8, 1.0f / 3.0f) && covered(ax, 8, 1.0f / 3.0f), "upsample bwd: up-sampling factors above 3 are not covered");
-  const dim3 grid((unsigned)((rows + 4 * dvd::kRows - 1) / (4 * dvd::kRows)), ((unsigned)W_in + 63) / 64);
+  const dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (covered(ay, 6, 0.4f) && covered(ax, 6, 0.4f))
-    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<6>, grid, dim3(64, 4), 0, s, gy, gx, ay, ax, (unsigned)rows);
+    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<6>, grid, dim3(256), 0, s, gy, gx, ay, ax, (unsigned)rows);
   else
-    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<8>, grid, dim3(64, 4), 0, s, gy, gx, ay, ax, (unsigned)rows);
+    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<8>, grid, dim3(256), 0, s, gy, gx, ay, ax, (unsigned)rows);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
