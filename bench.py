@@ -233,6 +233,8 @@ def main():
                                'non-warm phase with acceleration regulariser' % (H, W, a.pairs, GAP),
                    'pairs_per_gpu': a.pairs, 'height': H, 'width': W, 'parallelism': 'dp%d over frame pairs' % world},
         'pairs_per_s': world * a.pairs * a.steps / dt, 'feed': a.feed, 'graph_setup_steps': setup_steps,
+        'hbm_peak_allocated_GB': torch.cuda.max_memory_allocated(device) / 2 ** 30,
+        'hbm_peak_reserved_GB': torch.cuda.max_memory_reserved(device) / 2 ** 30,
         'last_loss': log['loss'],
     }
     if warp is not None:

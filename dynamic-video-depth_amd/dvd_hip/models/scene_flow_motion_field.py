@@ -72,6 +72,11 @@ class Model(NetInterface):
                                  'the host cores (2.8 s -> 2.0 s per step on a slow-host box, equal on a fast one; replay is '
                                  'bit-identical to eager execution, tests/test_30_full_step_gpu.py); falls back to eager '
                                  'execution if a capture fails.  0: eager launches')
+        parser.add_argument('--depth_keep_gb', type=float, default=150.0,
+                            help='HBM budget for keeping the depth net\'s autograd state of a step alive between its forward '
+                                 '(phase 1) and its backward (phase 3), chunk by chunk, in HIP graphs: a kept chunk is not '
+                                 'recomputed (MiDaS at 384x672: 1 GB per image, 95 GB for 48 pairs).  Chunks beyond the budget, '
+                                 'or beyond what the MLP stashes leave free, take the no-graph forward + recompute path')
         parser.add_argument('--grad_buckets', type=int, default=4,
                             help='data parallel: the depth-net gradient (421 MB for MiDaS) is all-reduced as this many large '
                                  'buckets in flight at once, the Adam launch of a bucket overlapping the reduction of the next')
@@ -115,6 +120,7 @@ class Model(NetInterface):
         self._flat_depth = self._flat_sf = None     # created by .to(device)
         self._optimizers = []
         self._depth_graphs = {}
+        self._keep_bytes = 0         # HBM held by kept-activation graph slots
         self.warm = False
 
     # flat parameter buffers + fused Adam replace the two torch.optim.Adam objects (:113-115)
@@ -207,6 +213,79 @@ class Model(NetInterface):
         self._depth_graphs[key] = entry
         return entry
 
+    # -- kept activations -----------------------------------------------------------------------
+    # With this package's kernels a MiDaS forward keeps ~1 GB of autograd state per 384x672 image (round 1, through
+    # MIOpen/ATen: 3 GB), so the state of ALL chunks of a 48-pair step (95 GB) fits next to the MLP stashes: phase 1 runs
+    # every chunk's forward WITH its graph state into a slot of its own (forward graph + backward graph on one private
+    # memory pool), phase 3 replays the slot's backward graph -- the forward is computed once per step instead of twice.
+    def _keep_slot(self, slot, chunk, fid, reserve_bytes):
+        key = ('keep', slot, tuple(chunk.shape), bool(self.opt.midas))
+        if key in self._depth_graphs:
+            return self._depth_graphs[key]
+        entry = None
+        est = int(chunk.shape[0] * chunk.shape[2] * chunk.shape[3] * 4400 + 1.5 * 2 ** 30)    # ~4.1 KB / pixel + packed weights
+        free, total = torch.cuda.mem_get_info(chunk.device)
+        free += torch.cuda.memory_reserved(chunk.device) - torch.cuda.memory_allocated(chunk.device)   # cached, reusable
+        budget = float(getattr(self.opt, 'depth_keep_gb', 150.0)) * 2 ** 30
+        if self._keep_bytes + est > budget or free - est < reserve_bytes + 0.06 * total:
+            self._depth_graphs[key] = None
+            return None
+        try:
+            import gc
+            gc.collect()
+            static_in = chunk.clone()
+            grad_backup = self._flat_depth.grad.clone()
+            if not any(k[0] == 'keep' and v is not None for k, v in self._depth_graphs.items()):
+                side = torch.cuda.Stream()                 # warm-up outside the capture (allocator, handles), once
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._flat_depth.detach_grads()
+                        with torch.enable_grad():
+                            d = self._depth_forward(static_in, fid)
+                        d.backward(torch.zeros_like(d))
+                        self._flat_depth.absorb_grads()
+                        del d
+                torch.cuda.current_stream().wait_stream(side)
+            before = torch.cuda.memory_allocated(chunk.device)
+            mode = dict(capture_error_mode='thread_local')
+            pool = torch.cuda.graph_pool_handle()
+            g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_f, pool=pool, **mode):
+                with torch.enable_grad():
+                    static_out = self._depth_forward(static_in, fid)
+            static_g = torch.zeros(chunk.shape[0], 1, chunk.shape[2], chunk.shape[3], device=chunk.device)
+            self._flat_depth.detach_grads()
+            with torch.cuda.graph(g_b, pool=pool, **mode):
+                static_out.backward(static_g)
+                self._flat_depth.absorb_grads()
+            self._flat_depth.grad.copy_(grad_backup)
+            self._keep_bytes += max(0, torch.cuda.memory_allocated(chunk.device) - before)
+            entry = (g_f, g_b, static_in, static_out, static_g)
+        except Exception as e:                             # noqa: BLE001 -- an optimisation only
+            warnings.warn('keeping the depth net\'s activations in HIP graphs failed (%s); recomputing' % (str(e).splitlines()[0],))
+            torch.cuda.synchronize()
+            self._flat_depth.reattach_grads()
+            entry = None
+        self._depth_graphs[key] = entry
+        return entry
+
+    def _depths_keep(self, img, frame_ids, slot0, reserve_bytes):
+        """Depth maps of phase 1 with the autograd state of as many chunks as fit kept for phase 3."""
+        out = []
+        c = max(1, int(self.opt.depth_chunk))
+        for ci, b0 in enumerate(range(0, img.shape[0], c)):
+            fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
+            chunk = img[b0:b0 + c]
+            e = self._keep_slot(slot0 + ci, chunk, fid, reserve_bytes) if self._use_graphs(chunk, fid) else None
+            if e is not None:
+                e[2].copy_(chunk)
+                e[0].replay()
+                out.append(e[3].detach().clone())
+            else:
+                out.append(self._depths_nograd(chunk, fid))
+        return torch.cat(out, 0).contiguous()
+
     def _use_graphs(self, img, frame_ids):
         return bool(getattr(self.opt, 'depth_graphs', 1)) and (frame_ids is None or not self.opt.use_embedding)
 
@@ -226,11 +305,16 @@ class Model(NetInterface):
                     out.append(self._depth_forward(chunk, fid))
         return torch.cat(out, 0).contiguous()
 
-    def _depth_backward(self, img, frame_ids, g_depth):
+    def _depth_backward(self, img, frame_ids, g_depth, slot0=None):
         c = max(1, int(self.opt.depth_chunk))
-        for b0 in range(0, img.shape[0], c):
+        for ci, b0 in enumerate(range(0, img.shape[0], c)):
             fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
             chunk = img[b0:b0 + c]
+            kept = None if slot0 is None else self._depth_graphs.get(('keep', slot0 + ci, tuple(chunk.shape), bool(self.opt.midas)))
+            if kept is not None:                        # the forward of phase 1 left this chunk's graph state in its slot
+                kept[4].copy_(g_depth[b0:b0 + c])
+                kept[1].replay()
+                continue
             g = self._capture_depth_graph('fb', chunk, fid) if self._use_graphs(chunk, fid) else None
             if g is not None:
                 g[1].copy_(chunk)
@@ -289,12 +373,22 @@ class Model(NetInterface):
         fid1 = inp.frame_id_1 if not opt.midas else None
         fid2 = inp.frame_id_2 if not opt.midas else None
 
-        # ---- phase 1: depth maps, no autograd graph
-        depth_1 = self._depths_nograd(inp.img_1, fid1)
-        depth_2 = self._depths_nograd(inp.img_2, fid2)
+        # ---- phase 1: depth maps; the autograd state of as many chunks as fit stays alive for phase 3 (kept slots),
+        #      the rest is a no-graph forward that phase 3 recomputes
+        do_reg = opt.interp_steps > 0 and (not warm or opt.warm_reg) and opt.acc_mul > 0
+        n_slots = -(-B // max(1, int(opt.depth_chunk)))
+        if warm or not getattr(opt, 'depth_graphs', 1) or float(getattr(opt, 'depth_keep_gb', 150.0)) <= 0:
+            depth_1 = self._depths_nograd(inp.img_1, fid1)
+            depth_2 = self._depths_nograd(inp.img_2, fid2)
+        else:
+            Bc0 = self._pairs_per_chunk(B, HW, steps, do_reg)
+            stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
+            mlp_need = min(B * steps * stash + Bc0 * (gstash + (2 * stash if do_reg else 0)),
+                           float(getattr(opt, 'mlp_whole_batch_gb', 160.0)) * 2 ** 30) + 24 * B * HW * 4
+            depth_1 = self._depths_keep(inp.img_1, fid1, 0, mlp_need)
+            depth_2 = self._depths_keep(inp.img_2, fid2, n_slots, mlp_need)
 
         # ---- phase 2: geometry + scene-flow MLP + losses, forward and backward, in HIP
-        do_reg = opt.interp_steps > 0 and (not warm or opt.warm_reg) and opt.acc_mul > 0
         mul = steps if opt.weight_steps else 1
         disp_mode = 1 if opt.use_disp else (2 if opt.use_disp_ratio else 0)
         sums = torch.zeros(8, device=dev)            # [S0..S3, sum|sf1-sf0|, 0, 0, 0]
@@ -479,8 +573,11 @@ class Model(NetInterface):
             ops.scale_add(k.grad, self._sf_grad_main, scale_ptr=inv, b=k.grad)
         # the MLP gradient all-reduce overlaps the depth-net backward, except in a step that still has to
         # capture the depth net's forward+backward graph (no collective in flight during a capture)
-        capturing = (not warm and getattr(opt, 'depth_graphs', 1)
-                     and self._graph_key('fb', inp.img_1[:max(1, int(opt.depth_chunk))]) not in self._depth_graphs)
+        c0 = inp.img_1[:max(1, int(opt.depth_chunk))]
+        recompute = any(self._depth_graphs.get(('keep', sl, tuple(c0.shape), bool(opt.midas))) is None
+                        for sl in range(2 * n_slots))          # some chunk of phase 3 takes the forward+backward graph
+        capturing = (not warm and getattr(opt, 'depth_graphs', 1) and recompute
+                     and self._graph_key('fb', c0) not in self._depth_graphs)
         h_sf = None if capturing else k.all_reduce_grads(async_op=True)
 
         # ---- phase 3: depth-net backward from the depth gradients
@@ -490,8 +587,8 @@ class Model(NetInterface):
             else:
                 g_d1 = ops.scale_add(g_d1_main, g_d1_main, scale_ptr=inv, b=g_d1_reg)
             g_d2 = ops.scale_add(g_d2_main, g_d2_main, scale_ptr=inv)
-            self._depth_backward(inp.img_1, fid1, g_d1)
-            self._depth_backward(inp.img_2, fid2, g_d2)
+            self._depth_backward(inp.img_1, fid1, g_d1, slot0=0)
+            self._depth_backward(inp.img_2, fid2, g_d2, slot0=n_slots)
             # 421 MB (MiDaS) in --grad_buckets large all-reduces, each bucket's Adam launch overlapping the next
             # bucket's reduction
             self._flat_depth.all_reduce_and_adam_step(getattr(opt, 'grad_buckets', 4))

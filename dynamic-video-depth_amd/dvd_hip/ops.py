@@ -81,6 +81,11 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
+    if torch.cuda.is_current_stream_capturing():
+        # an allocation made while a HIP graph is being captured lives in THAT graph's private pool: it must stay private
+        # to the graph (a cached one would outlive the pool -- a memory-access fault in whichever model reused it after
+        # the first model's graphs were destroyed)
+        return torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:

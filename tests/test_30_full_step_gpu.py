@@ -239,25 +239,32 @@ def test_two_rank_data_parallel_step_equals_single_process():
     np.testing.assert_array_equal(res[0][3], res[1][3])
 
 
+@pytest.mark.parametrize('keep_gb', [150.0, 0.0])
 @pytest.mark.parametrize('name', ['fullstep_midas_b1_64x96_train', 'fullstep_hourglass_b2_32x48_train'])
-def test_replayed_graphs_follow_the_weights(name):
-    """After two optimisation steps (the weights moved), a REPLAY of the captured forward graph and of the captured
-    forward+backward graph must give what eager execution gives with the model's current weights: derived buffers
-    (fragment-ordered conv weights) are rebuilt inside the graphs, not frozen at capture time."""
+def test_replayed_graphs_follow_the_weights(name, keep_gb):
+    """After two optimisation steps (the weights moved), a REPLAY of the captured graphs must give what eager execution
+    gives with the model's current weights: derived buffers (fragment-ordered conv weights) are rebuilt inside the
+    graphs, not frozen at capture time.  keep_gb > 0: the kept-activation slots (forward graph in phase 1, backward graph
+    in phase 3); keep_gb = 0: the no-graph forward + forward/backward recompute graphs."""
     gd = helpers.load_golden(name)
-    model, opt, batch = _build(gd, depth_graphs=True, depth_chunk=1, lr=1e-3)
+    model, opt, batch = _build(gd, depth_graphs=True, depth_chunk=1, lr=1e-3, depth_keep_gb=keep_gb)
     for i in range(2):
         model._train_on_batch(6, i, helpers.loader_batch(dict(batch)))
-    assert sum(v is not None for v in model._depth_graphs.values()) == 2, 'forward and forward+backward graphs'
+    live = {k[0] for k, v in model._depth_graphs.items() if v is not None}
+    assert live == ({'keep'} if keep_gb else {'f', 'fb'}), live
     img = batch['img_1'].cuda()
     fid = batch['frame_id_1'].cuda() if not opt.midas else None
     g_depth = torch.randn(img.shape[0], 1, img.shape[2], img.shape[3], device='cuda')
     out = {}
     for graphs in (True, False):
         model.opt.depth_graphs = graphs
-        d = model._depths_nograd(img, fid)
         model._flat_depth.zero_grad()
-        model._depth_backward(img, fid, g_depth)
+        if graphs and keep_gb:
+            d = model._depths_keep(img, fid, 0, 0)
+            model._depth_backward(img, fid, g_depth, slot0=0)
+        else:
+            d = model._depths_nograd(img, fid)
+            model._depth_backward(img, fid, g_depth)
         torch.cuda.synchronize()
         out[graphs] = (d.clone(), model._flat_depth.grad.clone())
     d_err = float((out[True][0] - out[False][0]).abs().max() / out[False][0].abs().max())
@@ -266,19 +273,22 @@ def test_replayed_graphs_follow_the_weights(name):
     assert d_err < 1e-6 and g_err < 1e-5
 
 
-def test_depth_net_hip_graphs_equal_eager_execution():
-    """--depth_graphs replays the depth net (forward, forward+backward per chunk) from captured HIP graphs:
+@pytest.mark.parametrize('keep_gb', [150.0, 0.0])
+def test_depth_net_hip_graphs_equal_eager_execution(keep_gb):
+    """--depth_graphs replays the depth net from captured HIP graphs -- kept-activation slots (forward graph in phase 1,
+    backward graph in phase 3; keep_gb > 0) or no-graph forward + forward/backward recompute graphs (keep_gb = 0):
     a step must give the logs and depth-net gradients of eager execution.  MIOpen's weight-gradient kernels
     accumulate with atomics, so two EAGER runs already differ at rounding level; the graph run must be within
     a few times that noise (a capture bug -- a missing or doubled chunk -- would be O(1))."""
     gd = helpers.load_golden('fullstep_midas_b1_64x96_train')
     outs = []
     for graphs in (False, False, True):
-        model, opt, batch = _build(gd, depth_graphs=int(graphs), depth_chunk=1)
+        model, opt, batch = _build(gd, depth_graphs=int(graphs), depth_chunk=1, depth_keep_gb=keep_gb)
         log = model._train_on_batch(6, 0, helpers.loader_batch(dict(batch)))
         torch.cuda.synchronize()
         if graphs:
-            assert sum(v is not None for v in model._depth_graphs.values()) == 2, 'forward and forward+backward graphs'
+            live = sorted(k[0] for k, v in model._depth_graphs.items() if v is not None)
+            assert live == (['keep', 'keep'] if keep_gb else ['f', 'fb']), live
             log2 = model._train_on_batch(6, 1, helpers.loader_batch(dict(batch)))      # replays only
             assert np.isfinite(log2['loss'])
         outs.append((log, model._flat_depth.grad.clone() if not graphs else None, model))
@@ -286,7 +296,7 @@ def test_depth_net_hip_graphs_equal_eager_execution():
     for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
         np.testing.assert_allclose(lc[k], la[k], rtol=1e-5, atol=1e-9, err_msg=k)
     # gradients of the FIRST step of a fresh graph model (same weights as the eager models)
-    mg, _, batch = _build(gd, depth_graphs=True, depth_chunk=1)
+    mg, _, batch = _build(gd, depth_graphs=True, depth_chunk=1, depth_keep_gb=keep_gb)
     mg.opt.lr = 0.0
     mg._flat_depth.lr = 0.0
     mg._train_on_batch(6, 0, helpers.loader_batch(dict(batch)))
