@@ -227,7 +227,7 @@ class Model(NetInterface):
         free, total = torch.cuda.mem_get_info(chunk.device)
         free += torch.cuda.memory_reserved(chunk.device) - torch.cuda.memory_allocated(chunk.device)   # cached, reusable
         budget = float(getattr(self.opt, 'depth_keep_gb', 150.0)) * 2 ** 30
-        if self._keep_bytes + est > budget or free - est < reserve_bytes + 0.06 * total:
+        if self._keep_bytes + est > budget or free - est < reserve_bytes + 0.08 * total:      # what the MLP stashes will need + 8 % head room
             self._depth_graphs[key] = None
             return None
         try:
