@@ -15,6 +15,7 @@ os.environ.setdefault('MIOPEN_LOG_LEVEL', '1')
 from dvd_hip import conv as C  # noqa: E402
 
 SHAPES = [  # N, Cin, Cout, H, W, KS
+    (16, 2048, 256, 12, 21, 3), (16, 1024, 256, 24, 42, 3), (16, 512, 256, 48, 84, 3), (16, 128, 32, 384, 672, 3),
     (16, 256, 256, 96, 168, 3), (16, 256, 256, 48, 84, 3), (16, 256, 128, 192, 336, 3), (8, 128, 32, 384, 672, 3),
     (16, 256, 256, 96, 168, 1), (16, 1024, 256, 24, 42, 1), (16, 256, 1024, 24, 42, 1), (16, 512, 2048, 12, 21, 1),
 ]
@@ -36,7 +37,9 @@ def timeit(fn, iters):
 def main():
     only = sys.argv[1:]
     shapes = SHAPES[:int(os.environ.get('XCONV_NSHAPES', len(SHAPES)))]
+    nmul = int(os.environ.get('XCONV_NMUL', '1'))            # 3: the 48-image chunks of the bench
     for (N, Cin, Cout, H, W, KS) in shapes:
+        N *= nmul
         torch.manual_seed(0)
         x = torch.randn(N, Cin, H, W, device='cuda')
         conv = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2).cuda()
