@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # diagnostic, not a test: which hidden units flip LeakyReLU sign between devices
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'dynamic-video-depth_amd'))
 from oracle import sceneflow_mlp as M
 from dvd_hip.networks.sceneflow_field import SceneFlowFieldNet

@@ -30,7 +30,7 @@ def _close(got, want, rel, name, max_outliers=0):
     pre-activation within fp32 noise of zero (about one per 2.5e6 units on these
     inputs) can take slope 1 on one device and 0.2 on the other; that perturbs the
     input gradient of that ONE pixel (3 elements) and, through it, every weight
-    gradient by a fraction of a percent.  Verified with tools/debug/mlp_err.py."""
+    gradient by a fraction of a percent.  Verified with tests/debug_mlp_err.py."""
     want = np.asarray(want)
     got = np.asarray(got).reshape(want.shape)
     scale = max(np.abs(want).max(), 1e-30)
