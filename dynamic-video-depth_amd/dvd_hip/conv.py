@@ -22,6 +22,19 @@ from torch import nn
 from . import _lib
 from .ops import _p, _stream, _workspace
 
+# Same-box A/B measurement switches (previous-generation kernels / MIOpen against the kernels in use), read ONCE at
+# import from DVD_AB="gconv32,no_bnfuse,...".  Not product configuration: every default is the fastest measured path.
+#   gconv32     32-per-group 3x3 on round 1's fp32-MFMA kernels (csrc/gconv32.hip) instead of the grouped xconv path
+#   no_c16      16-per-group 3x3 on MIOpen instead of paired groups on the 32-per-group kernels
+#   no_xwgrad3  weight gradients on the exact-fp32 MFMA kernel (csrc/xwgrad.hip);  no_xwgrad: on MIOpen
+#   no_bnfuse   BatchNorm (+ residual, ReLU) as a separate pass after the convolution
+#   no_xconv    dense convolutions on MIOpen
+AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv')}
+for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
+    if _k not in AB:
+        raise RuntimeError('DVD_AB: unknown switch %r (known: %s)' % (_k, ', '.join(sorted(AB))))
+    AB[_k] = True
+
 
 class _BnRelu(torch.autograd.Function):
     """y = relu(bn_eval(x) (+ residual)); see csrc/bnrelu.hip."""
@@ -187,7 +200,7 @@ class GroupedConv3x3C32(nn.Conv2d):
         super().__init__(channels, channels, 3, stride=1, padding=1, groups=channels // 32, bias=False)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and not _os.environ.get('DVD_GCONV32'):
+        if x.is_cuda and x.dtype == torch.float32 and not AB['gconv32']:
             # the grouped split-bf16 kernels (csrc/xconv.hip, csrc/xwgrad3.hip): 0.097 ms forward / 0.37 ms backward per
             # 16-image call at [1024, 24, 42] against 0.156 / 0.42 ms of the fp32-MFMA kernels (tools/microbench_gx.py)
             return _XConv.apply(x, self.weight, None, None, False, False, self.groups)
@@ -216,8 +229,8 @@ class GroupedConv3x3C16(nn.Conv2d):
         super().__init__(channels, channels, 3, stride=1, padding=1, groups=channels // 16, bias=False)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and not _os.environ.get('DVD_NO_C16'):
-            if not _os.environ.get('DVD_GCONV32'):
+        if x.is_cuda and x.dtype == torch.float32 and not AB['no_c16']:
+            if not AB['gconv32']:
                 return _XConv.apply(x, _pair_groups_of_16(self.weight), None, None, False, False, self.groups // 2)
             return gconv3x3_c32(x, _pair_groups_of_16(self.weight))
         return F.conv2d(x, self.weight, None, 1, 1, 1, self.groups)
@@ -379,7 +392,7 @@ def xconv_wgrad(x, gy, wshape, relu_in, groups=1):
         _lib.check(lib.dvd_xwgrad3(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, wshape[0], H, W,
                                    groups, int(bool(relu_in)), _stream()), 'dvd_xwgrad3')
         return gw
-    if wshape[2] in (1, 3) and not _os.environ.get('DVD_NO_XWGRAD3'):      # split-bf16 MFMA (csrc/xwgrad3.hip)
+    if wshape[2] in (1, 3) and not AB['no_xwgrad3']:      # split-bf16 MFMA (csrc/xwgrad3.hip)
         N, Cin, H, W = x.shape
         Cout = wshape[0]
         gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
@@ -393,7 +406,7 @@ def xconv_wgrad(x, gy, wshape, relu_in, groups=1):
             _lib.check(lib.dvd_xwgrad1s(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W,
                                         int(bool(relu_in)), _stream()), 'dvd_xwgrad1s')
         return gw
-    if wshape[2] in (1, 3) and not _os.environ.get('DVD_NO_XWGRAD'):
+    if wshape[2] in (1, 3) and not AB['no_xwgrad']:
         N, Cin, H, W = x.shape
         Cout, _, KS, _ = wshape
         gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
@@ -464,13 +477,13 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True):
     training-mode statistics, the 8/16-per-group and strided 3x3 convolutions) is conv(x) followed by the fused
     BatchNorm+ReLU kernel / the ATen ops."""
     if (x.is_cuda and x.dtype == torch.float32 and not bn.training and bn.track_running_stats and
-            isinstance(conv, nn.Conv2d) and not _os.environ.get('DVD_NO_BNFUSE')):
+            isinstance(conv, nn.Conv2d) and not AB['no_bnfuse']):
         xin = None
         if xconv_supported(conv, x):
             xin = x
         elif (conv.kernel_size == (1, 1) and conv.groups == 1 and tuple(conv.padding) == (0, 0) and
               conv.stride[0] == conv.stride[1] and conv.stride[0] > 1 and conv.weight.dtype == torch.float32 and
-              not _os.environ.get('DVD_NO_XCONV')):
+              not AB['no_xconv']):
             xin = x[:, :, ::conv.stride[0], ::conv.stride[0]].contiguous()
         if xin is not None:
             gamma, beta = (bn.weight, bn.bias) if bn.affine else (None, None)
@@ -485,7 +498,7 @@ def xconv_supported(conv, x):
             (conv.groups == 1 or (k[0] == 3 and conv.in_channels // conv.groups >= 32)) and
             k[0] == k[1] and k[0] % 2 == 1 and k[0] <= 11 and tuple(conv.stride) == (1, 1) and
             tuple(conv.dilation) == (1, 1) and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and
-            conv.padding_mode == 'zeros' and not _os.environ.get('DVD_NO_XCONV'))
+            conv.padding_mode == 'zeros' and not AB['no_xconv'])
 
 
 def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False):
@@ -495,7 +508,7 @@ def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False):
     if xconv_supported(conv, x):
         return _XConv.apply(x, conv.weight, conv.bias, residual, relu_in, res_relu, conv.groups)
     if x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and tuple(conv.stride) == (1, 1) and \
-            not _os.environ.get('DVD_NO_XCONV'):
+            not AB['no_xconv']:
         raise RuntimeError('xconv2d: convolution %r is not covered by the HIP kernels' % (conv,))
     y = conv(F.relu(x) if relu_in else x)
     if residual is not None:
@@ -515,13 +528,13 @@ class XConv2d(nn.Conv2d):
         k, st = self.kernel_size, self.stride
         if (x.is_cuda and x.dtype == torch.float32 and k == (3, 3) and st[0] == st[1] and st[0] > 1 and
                 tuple(self.padding) == (1, 1) and tuple(self.dilation) == (1, 1) and
-                (self.groups == 1 or self.in_channels // self.groups >= 32) and not _os.environ.get('DVD_NO_XCONV')):
+                (self.groups == 1 or self.in_channels // self.groups >= 32) and not AB['no_xconv']):
             # out[i][j] of a stride-s 'same' 3x3 convolution is out1[s*i][s*j] of the stride-1 one
             y = _XConv.apply(x, self.weight, self.bias, None, False, False, self.groups)
             return y[:, :, ::st[0], ::st[0]].contiguous()
         if (x.is_cuda and x.dtype == torch.float32 and self.kernel_size == (1, 1) and self.groups == 1 and
                 tuple(self.padding) == (0, 0) and self.stride[0] == self.stride[1] and self.stride[0] > 1 and
-                not _os.environ.get('DVD_NO_XCONV')):
+                not AB['no_xconv']):
             st = self.stride[0]
             return _XConv.apply(x[:, :, ::st, ::st].contiguous(), self.weight, self.bias, None, False, False)
         return super().forward(x)

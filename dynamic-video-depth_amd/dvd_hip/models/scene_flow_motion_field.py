@@ -321,14 +321,11 @@ class Model(NetInterface):
                 g[3].copy_(g_depth[b0:b0 + c])
                 g[0].replay()
                 continue
-            multi = not os.environ.get('DVD_NO_FOREACH_ACCUM')      # (switch kept for same-box A/B runs)
-            if multi:
-                self._flat_depth.detach_grads()      # one multi-tensor accumulation per chunk instead of ~620 adds
+            self._flat_depth.detach_grads()          # one multi-tensor accumulation per chunk instead of ~620 adds
             with torch.enable_grad():
                 d = self._depth_forward(chunk, fid)
             d.backward(g_depth[b0:b0 + c])
-            if multi:
-                self._flat_depth.absorb_grads()
+            self._flat_depth.absorb_grads()
 
     def _integer_steps(self, batch_or_input):
         """Euler steps of this batch = round(mean(ts2 - ts1) / time_step) (:248-250), recomputed every step:
