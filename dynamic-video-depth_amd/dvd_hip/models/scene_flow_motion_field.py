@@ -26,6 +26,7 @@ What is different is HOW a step runs.  The reference builds one autograd graph o
 Depth-net convolutions run on PyTorch-ROCm/MIOpen in this round (BASELINE config 2).
 """
 import os
+import sys
 import warnings
 from os import makedirs
 from os.path import join
@@ -121,6 +122,8 @@ class Model(NetInterface):
         self._optimizers = []
         self._depth_graphs = {}
         self._keep_bytes = 0         # HBM held by kept-activation graph slots
+        self._keep_per_px = 0.0      # measured bytes per image pixel of a captured slot
+        self._pool_bytes = 0         # HBM reserved by the private pools of all captured graphs
         self.warm = False
 
     # flat parameter buffers + fused Adam replace the two torch.optim.Adam objects (:113-115)
@@ -205,6 +208,7 @@ class Model(NetInterface):
                     self._flat_depth.absorb_grads()
                 entry = (graph, static_in, static_out, static_g)
                 self._flat_depth.grad.copy_(grad_backup)   # warm-up / capture passes used zero output gradients
+            self._pool_bytes += self._pool_size(graph.pool(), img.device)
         except Exception as e:                             # noqa: BLE001 -- capture is an optimisation only
             warnings.warn('depth-net HIP graph capture failed (%s); running eagerly' % (str(e).splitlines()[0],))
             torch.cuda.synchronize()
@@ -218,16 +222,25 @@ class Model(NetInterface):
     # MIOpen/ATen: 3 GB), so the state of ALL chunks of a 48-pair step (95 GB) fits next to the MLP stashes: phase 1 runs
     # every chunk's forward WITH its graph state into a slot of its own (forward graph + backward graph on one private
     # memory pool), phase 3 replays the slot's backward graph -- the forward is computed once per step instead of twice.
-    def _keep_slot(self, slot, chunk, fid, reserve_bytes):
+    def _keep_slot(self, slot, chunk, fid, reserve_bytes, last_and_all_kept=False):
         key = ('keep', slot, tuple(chunk.shape), bool(self.opt.midas))
         if key in self._depth_graphs:
             return self._depth_graphs[key]
         entry = None
-        est = int(chunk.shape[0] * chunk.shape[2] * chunk.shape[3] * 4400 + 1.5 * 2 ** 30)    # ~4.1 KB / pixel + packed weights
-        free, total = torch.cuda.mem_get_info(chunk.device)
-        free += torch.cuda.memory_reserved(chunk.device) - torch.cuda.memory_allocated(chunk.device)   # cached, reusable
+        # bytes a slot will hold: measured on the slots captured so far (per image and pixel), a-priori figure (MiDaS with
+        # fused epilogues: ~4.1 KB per pixel) for the first one, + packed weights
+        n_px = chunk.shape[0] * chunk.shape[2] * chunk.shape[3]
+        est = int(n_px * max(4400.0, self._keep_per_px) + 1.5 * 2 ** 30)
+        free, total = self._free_hbm(chunk.device)
         budget = float(getattr(self.opt, 'depth_keep_gb', 150.0)) * 2 ** 30
-        if self._keep_bytes + est > budget or free - est < reserve_bytes + 0.08 * total:      # what the MLP stashes will need + 8 % head room
+        # room that must stay free: the MLP stashes of phase 2 + 8 % head room + (unless this is the last slot of a step
+        # whose other slots are all kept) the pool of the forward+backward recompute graph a non-kept chunk will need
+        spare = 0 if last_and_all_kept else est
+        if os.environ.get('DVD_KEEP_DEBUG'):
+            print('keep slot %d: est %.1f GB, free %.1f, reserve %.1f + %.1f + spare %.1f, kept so far %.1f, pools %.1f' % (
+                slot, est / 2 ** 30, free / 2 ** 30, reserve_bytes / 2 ** 30, 0.08 * total / 2 ** 30, spare / 2 ** 30,
+                self._keep_bytes / 2 ** 30, self._pool_bytes / 2 ** 30), file=sys.stderr, flush=True)
+        if self._keep_bytes + est > budget or free - est < reserve_bytes + 0.08 * total + spare:
             self._depth_graphs[key] = None
             return None
         try:
@@ -247,7 +260,6 @@ class Model(NetInterface):
                         self._flat_depth.absorb_grads()
                         del d
                 torch.cuda.current_stream().wait_stream(side)
-            before = torch.cuda.memory_allocated(chunk.device)
             mode = dict(capture_error_mode='thread_local')
             pool = torch.cuda.graph_pool_handle()
             g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -260,8 +272,11 @@ class Model(NetInterface):
                 static_out.backward(static_g)
                 self._flat_depth.absorb_grads()
             self._flat_depth.grad.copy_(grad_backup)
-            self._keep_bytes += max(0, torch.cuda.memory_allocated(chunk.device) - before)
-            entry = (g_f, g_b, static_in, static_out, static_g)
+            used = self._pool_size(pool, chunk.device)
+            self._keep_bytes += used
+            self._pool_bytes += used
+            self._keep_per_px = max(self._keep_per_px, used / float(n_px))
+            entry = (g_f, g_b, static_in, static_out, static_g, used)
         except Exception as e:                             # noqa: BLE001 -- an optimisation only
             warnings.warn('keeping the depth net\'s activations in HIP graphs failed (%s); recomputing' % (str(e).splitlines()[0],))
             torch.cuda.synchronize()
@@ -270,14 +285,49 @@ class Model(NetInterface):
         self._depth_graphs[key] = entry
         return entry
 
-    def _depths_keep(self, img, frame_ids, slot0, reserve_bytes):
+    @staticmethod
+    def _pool_size(pool_id, device):
+        """Bytes of the caching allocator's segments that belong to a graph's private pool (the reserved-bytes counter does
+        not tell: a new pool may be carved from memory the process had reserved before)."""
+        pid = tuple(pool_id)
+        return sum(seg['total_size'] for seg in torch.cuda.memory_snapshot()
+                   if tuple(seg.get('segment_pool_id', (0, 0))) == pid and seg.get('device', device.index) == device.index)
+
+    def _free_hbm(self, device):
+        """(bytes available to ordinary allocations: free on the device + cached by the allocator, total bytes).  The
+        private pools of captured graphs are reserved but not `allocated` once the capture's temporaries are released, and
+        they are NOT reusable: they are subtracted."""
+        free, total = torch.cuda.mem_get_info(device)
+        cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device) - self._pool_bytes
+        return free + max(0, cached), total
+
+    def _trim_keep_slots(self, device, need_bytes):
+        """After phase 1: if the slots left less than phase 2 needs (a first slot larger than its a-priori estimate),
+        give the newest slots back -- their chunks take the recompute path in phase 3, the step stays correct."""
+        free, total = self._free_hbm(device)
+        if os.environ.get('DVD_KEEP_DEBUG'):
+            print('after phase 1: free %.1f GB, phase 2 needs %.1f, pools %.1f' % (free / 2 ** 30, need_bytes / 2 ** 30,
+                                                                               self._pool_bytes / 2 ** 30), file=sys.stderr, flush=True)
+        kept = [k for k, v in self._depth_graphs.items() if k[0] == 'keep' and v is not None]
+        while kept and free < need_bytes + 0.04 * total:
+            key = kept.pop()
+            self._keep_bytes -= self._depth_graphs[key][5]
+            self._pool_bytes -= self._depth_graphs[key][5]
+            self._depth_graphs[key] = None
+            import gc
+            gc.collect()
+            free, total = self._free_hbm(device)
+
+    def _depths_keep(self, img, frame_ids, slot0, reserve_bytes, n_slots_total):
         """Depth maps of phase 1 with the autograd state of as many chunks as fit kept for phase 3."""
         out = []
         c = max(1, int(self.opt.depth_chunk))
         for ci, b0 in enumerate(range(0, img.shape[0], c)):
             fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
             chunk = img[b0:b0 + c]
-            e = self._keep_slot(slot0 + ci, chunk, fid, reserve_bytes) if self._use_graphs(chunk, fid) else None
+            others_kept = all(v is not None for k, v in self._depth_graphs.items() if k[0] == 'keep') and \
+                sum(1 for k in self._depth_graphs if k[0] == 'keep') == n_slots_total - 1
+            e = self._keep_slot(slot0 + ci, chunk, fid, reserve_bytes, others_kept) if self._use_graphs(chunk, fid) else None
             if e is not None:
                 e[2].copy_(chunk)
                 e[0].replay()
@@ -382,8 +432,9 @@ class Model(NetInterface):
             stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
             mlp_need = min(B * steps * stash + Bc0 * (gstash + (2 * stash if do_reg else 0)),
                            float(getattr(opt, 'mlp_whole_batch_gb', 160.0)) * 2 ** 30) + 24 * B * HW * 4
-            depth_1 = self._depths_keep(inp.img_1, fid1, 0, mlp_need)
-            depth_2 = self._depths_keep(inp.img_2, fid2, n_slots, mlp_need)
+            depth_1 = self._depths_keep(inp.img_1, fid1, 0, mlp_need, 2 * n_slots)
+            depth_2 = self._depths_keep(inp.img_2, fid2, n_slots, mlp_need, 2 * n_slots)
+            self._trim_keep_slots(dev, mlp_need)
 
         # ---- phase 2: geometry + scene-flow MLP + losses, forward and backward, in HIP
         mul = steps if opt.weight_steps else 1

@@ -260,7 +260,7 @@ def test_replayed_graphs_follow_the_weights(name, keep_gb):
         model.opt.depth_graphs = graphs
         model._flat_depth.zero_grad()
         if graphs and keep_gb:
-            d = model._depths_keep(img, fid, 0, 0)
+            d = model._depths_keep(img, fid, 0, 0, 2)
             model._depth_backward(img, fid, g_depth, slot0=0)
         else:
             d = model._depths_nograd(img, fid)
