@@ -237,6 +237,7 @@ def main():
         'pairs_per_s': world * a.pairs * a.steps / dt, 'feed': a.feed, 'graph_setup_steps': setup_steps,
         'hbm_peak_allocated_GB': torch.cuda.max_memory_allocated(device) / 2 ** 30,
         'hbm_peak_reserved_GB': torch.cuda.max_memory_reserved(device) / 2 ** 30,
+        'hbm_graph_pools_GB': getattr(model, '_pool_bytes', 0) / 2 ** 30,      # kept depth-net activations + graph temporaries
         'last_loss': log['loss'],
     }
     if warp is not None:
