@@ -44,6 +44,14 @@ from .netinterface import NetInterface
 CAM_KEYS = ops.CAM_KEYS
 
 
+def keep_slot_fits(est, free, total, reserve, spare, kept, budget):
+    """May one more kept-activation slot of `est` bytes be captured?  `free` = HBM available to ordinary allocations,
+    `reserve` = what phase 2 (the MLP stashes) will allocate, `spare` = room for the recompute graph of a chunk that is not
+    kept (0 if this slot completes the step), `kept` = bytes already held by slots, `budget` = --depth_keep_gb.
+    8 % of the device stays free as head room (allocator fragmentation, RCCL buffers)."""
+    return kept + est <= budget and free - est >= reserve + 0.08 * total + spare
+
+
 class Model(NetInterface):
     @classmethod
     def add_arguments(cls, parser):
@@ -240,7 +248,7 @@ class Model(NetInterface):
             print('keep slot %d: est %.1f GB, free %.1f, reserve %.1f + %.1f + spare %.1f, kept so far %.1f, pools %.1f' % (
                 slot, est / 2 ** 30, free / 2 ** 30, reserve_bytes / 2 ** 30, 0.08 * total / 2 ** 30, spare / 2 ** 30,
                 self._keep_bytes / 2 ** 30, self._pool_bytes / 2 ** 30), file=sys.stderr, flush=True)
-        if self._keep_bytes + est > budget or free - est < reserve_bytes + 0.08 * total + spare:
+        if not keep_slot_fits(est, free, total, reserve_bytes, spare, self._keep_bytes, budget):
             self._depth_graphs[key] = None
             return None
         try:

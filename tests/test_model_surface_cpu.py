@@ -69,3 +69,17 @@ def test_attribute_contract_after_construction():
         m.to(torch.device('cpu'))
     with pytest.raises(NotImplementedError):
         Model(SimpleNamespace(**dict(o, use_cnn=True)), None)
+
+
+def test_kept_activation_slot_planning_arithmetic():
+    """models.scene_flow_motion_field.keep_slot_fits with the numbers of the bench (288 GB device, MLP stashes 130 GB):
+    two 58 GB slots fit, a third does not; with 82 GB slots (no BatchNorm fusion) only the first fits; the
+    --depth_keep_gb budget caps regardless of free memory."""
+    from dvd_hip.models.scene_flow_motion_field import keep_slot_fits
+    G = 2 ** 30
+    total, reserve = 288 * G, 130 * G
+    assert keep_slot_fits(52 * G, 285 * G, total, reserve, 52 * G, 0, 150 * G)                 # first slot, a-priori size
+    assert keep_slot_fits(60 * G, 225 * G, total, reserve, 0, 58 * G, 150 * G)                 # second (last) slot, measured size
+    assert not keep_slot_fits(60 * G, 166 * G, total, reserve, 60 * G, 116 * G, 300 * G)       # a third would starve phase 2
+    assert not keep_slot_fits(84 * G, 200 * G, total, reserve, 0, 82 * G, 150 * G)             # 82 GB slots: the second does not fit
+    assert not keep_slot_fits(60 * G, 285 * G, total, 0, 0, 116 * G, 150 * G)                  # budget
