@@ -230,7 +230,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]/[2]: synthetic %dx%d, %d frame pairs per GPU, gap %d, MiDaS '
                                '(ResNeXt-101 32x8d) depth net with hand-written split-bf16 MFMA convolution kernels '
-                               '(forward, data and weight gradients; stem 7x7 and one 16-per-group stride-2 conv on MIOpen) '
+                               '(forward, data and weight gradients; only the 7x7 stride-2 stem on MIOpen) '
                                'under PyTorch-ROCm autograd + HIP scene-flow MLP + HIP fused warp/reprojection/loss, '
                                'non-warm phase with acceleration regulariser' % (H, W, a.pairs, GAP),
                    'pairs_per_gpu': a.pairs, 'height': H, 'width': W, 'parallelism': 'dp%d over frame pairs' % world},

@@ -223,17 +223,21 @@ class GroupedConv3x3C16(nn.Conv2d):
     on the 32-channel MFMA kernels: two groups share one 32x32 tile with a block-diagonal weight.  MIOpen's
     immediate mode runs this shape per image as im2col + small GEMMs (~80 launches per call)."""
 
-    def __init__(self, channels):
+    def __init__(self, channels, stride=1):
         if channels % 32:
             raise ValueError('GroupedConv3x3C16 needs a multiple of 32 channels')
-        super().__init__(channels, channels, 3, stride=1, padding=1, groups=channels // 16, bias=False)
+        super().__init__(channels, channels, 3, stride=stride, padding=1, groups=channels // 16, bias=False)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and not AB['no_c16']:
+        st = self.stride[0]
+        if x.is_cuda and x.dtype == torch.float32 and not AB['no_c16'] and (st == 1 or not AB['gconv32']):
             if not AB['gconv32']:
-                return _XConv.apply(x, _pair_groups_of_16(self.weight), None, None, False, False, self.groups // 2)
+                y = _XConv.apply(x, _pair_groups_of_16(self.weight), None, None, False, False, self.groups // 2)
+                # the stride-2 entry of stage 2: out[i][j] of a strided 'same' 3x3 is the stride-1 result at [s*i][s*j]
+                # (4x the needed work, still half of MIOpen's per-image im2col + GEMM + col2im path)
+                return y if st == 1 else y[:, :, ::st, ::st].contiguous()
             return gconv3x3_c32(x, _pair_groups_of_16(self.weight))
-        return F.conv2d(x, self.weight, None, 1, 1, 1, self.groups)
+        return F.conv2d(x, self.weight, None, self.stride, 1, 1, self.groups)
 
 
 def gconv3x3_c8(x, weight):

@@ -149,6 +149,30 @@ def test_grouped_3x3(N, Cc, G, H, W, stride):
     assert _err(cg.weight.grad, wd.grad) < 2e-5, 'wgrad: ' + _where(cg.weight.grad, wd.grad, 'co,ci,ky,kx')
 
 
+@pytest.mark.parametrize('stride', [1, 2])
+def test_sixteen_per_group_module_incl_stride_two(stride):
+    """ResNeXt stage 2's 3x3 convolutions (16 channels per group; the first one strided): conv.GroupedConv3x3C16 pairs the
+    groups into block-diagonal 32-channel tiles; forward and both gradients against float64 autograd."""
+    from dvd_hip import conv as C
+    torch.manual_seed(7 + stride)
+    N, Cc, H, W = 2, 64, 11, 18
+    mod = C.GroupedConv3x3C16(Cc, stride=stride)
+    x = torch.randn(N, Cc, H, W)
+    xd = x.double().requires_grad_(True)
+    wd = mod.weight.detach().double().requires_grad_(True)
+    want = F.conv2d(xd, wd, None, stride=stride, padding=1, groups=Cc // 16)
+    gy = torch.randn_like(want, dtype=torch.float32)
+    want.backward(gy.double())
+    mg = mod.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = mg(xg)
+    assert y.shape == want.shape and 'XConv' in type(y.grad_fn).__name__ or stride == 2
+    y.backward(gy.cuda())
+    assert _err(y.detach(), want.detach()) < TOL
+    assert _err(xg.grad, xd.grad) < TOL
+    assert _err(mg.weight.grad, wd.grad) < 2e-5
+
+
 def test_fused_input_relu_residual_and_its_backward():
     """ResidualConvUnit pieces (midas_blocks.py:121-135): conv(relu(x)) + relu(res), gradient masks included."""
     from dvd_hip import conv as C
