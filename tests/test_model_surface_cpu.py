@@ -83,3 +83,18 @@ def test_kept_activation_slot_planning_arithmetic():
     assert not keep_slot_fits(60 * G, 166 * G, total, reserve, 60 * G, 116 * G, 300 * G)       # a third would starve phase 2
     assert not keep_slot_fits(84 * G, 200 * G, total, reserve, 0, 82 * G, 150 * G)             # 82 GB slots: the second does not fit
     assert not keep_slot_fits(60 * G, 285 * G, total, 0, 0, 116 * G, 150 * G)                  # budget
+
+
+def test_grouped_conv_modules_on_cpu_are_plain_convolutions():
+    """The depth-net modules run on the CPU through the ATen ops the reference uses (the golden-fixture generator and the
+    oracle instantiate them there): the 16-per-group module, strided or not, is nn.Conv2d with the same parameters."""
+    import torch
+    from dvd_hip import conv as C
+    torch.manual_seed(0)
+    for stride in (1, 2):
+        m = C.GroupedConv3x3C16(64, stride=stride)
+        ref = torch.nn.Conv2d(64, 64, 3, stride=stride, padding=1, groups=4, bias=False)
+        ref.load_state_dict(m.state_dict())
+        x = torch.randn(2, 64, 9, 14)
+        assert torch.equal(m(x), ref(x))
+    assert set(C.AB) == {'gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv'} and not any(C.AB.values())
