@@ -473,7 +473,15 @@ class Model(NetInterface):
         whole = Bc < B and self._whole_batch_fits(B, Bc, HW, steps, do_reg)
         # ranks may hold different batch sizes / frame gaps: agree on the schedule (early or late normaliser)
         # and on the size of the global batch before the first data-dependent collective
-        late, n_global = parallel.agree_on_step_plan(dev, not (whole or Bc >= B), B)
+        # (also agreed across ranks: does ANY rank still have to capture a depth-net graph in phase 3 -- a chunk that is not
+        #  kept and has no recompute graph yet?  Then every rank keeps the MLP-gradient all-reduce out of flight until after
+        #  phase 3, so the order of collectives is the same everywhere)
+        c0 = inp.img_1[:max(1, int(opt.depth_chunk))]
+        recompute = any(self._depth_graphs.get(('keep', sl, tuple(c0.shape), bool(opt.midas))) is None
+                        for sl in range(2 * n_slots))
+        may_capture = bool(not warm and getattr(opt, 'depth_graphs', 1) and recompute
+                           and self._graph_key('fb', c0) not in self._depth_graphs)
+        late, n_global, capturing = parallel.agree_on_step_plan(dev, not (whole or Bc >= B), B, may_capture)
         early_norm = not late
         reg_coef = opt.acc_mul / (3.0 * n_global * HW + 1e-6)
         chunks = [(b0, min(B, b0 + Bc)) for b0 in range(0, B, Bc)]
@@ -629,11 +637,6 @@ class Model(NetInterface):
             ops.scale_add(k.grad, self._sf_grad_main, scale_ptr=inv, b=k.grad)
         # the MLP gradient all-reduce overlaps the depth-net backward, except in a step that still has to
         # capture the depth net's forward+backward graph (no collective in flight during a capture)
-        c0 = inp.img_1[:max(1, int(opt.depth_chunk))]
-        recompute = any(self._depth_graphs.get(('keep', sl, tuple(c0.shape), bool(opt.midas))) is None
-                        for sl in range(2 * n_slots))          # some chunk of phase 3 takes the forward+backward graph
-        capturing = (not warm and getattr(opt, 'depth_graphs', 1) and recompute
-                     and self._graph_key('fb', c0) not in self._depth_graphs)
         h_sf = None if capturing else k.all_reduce_grads(async_op=True)
 
         # ---- phase 3: depth-net backward from the depth gradients

@@ -83,19 +83,23 @@ def all_reduce_sum_buckets_async_(flat, n_buckets):
     return out
 
 
-def agree_on_step_plan(device, needs_late_normaliser, n_pairs):
+def agree_on_step_plan(device, needs_late_normaliser, n_pairs, may_capture=None):
     """Makes the collective schedule of a step independent of rank-local data.
 
     Whether a rank can keep the whole batch's MLP stashes alive (and so all-reduces the loss sums
-    BEFORE its MLP backward) depends on its own batch size and frame gap; ranks that decided
-    differently would issue mismatched collectives.  One 2-element sum all-reduce at the start of the
-    step settles it: returns (any rank needs the late normaliser, pairs in the global batch)."""
+    BEFORE its MLP backward) depends on its own batch size and frame gap; whether it still has to capture a depth-net HIP
+    graph in phase 3 (and therefore keeps the MLP-gradient all-reduce out of flight until afterwards) depends on its own
+    memory situation; ranks that decided differently would issue mismatched collectives.  One small sum all-reduce
+    settles both: returns (any rank needs the late normaliser, pairs in the global batch[, any rank may capture])."""
     if not is_distributed():
-        return bool(needs_late_normaliser), int(n_pairs)
-    v = torch.tensor([1.0 if needs_late_normaliser else 0.0, float(n_pairs)], device=device, dtype=torch.float64)
+        out = (bool(needs_late_normaliser), int(n_pairs))
+        return out if may_capture is None else out + (bool(may_capture),)
+    v = torch.tensor([1.0 if needs_late_normaliser else 0.0, float(n_pairs), 1.0 if may_capture else 0.0], device=device,
+                     dtype=torch.float64)
     dist.all_reduce(v, op=dist.ReduceOp.SUM)
-    late, total = v.tolist()
-    return late > 0.5, int(round(total))
+    late, total, cap = v.tolist()
+    out = (late > 0.5, int(round(total)))
+    return out if may_capture is None else out + (cap > 0.5,)
 
 
 def broadcast_(t, src=0):

@@ -176,6 +176,8 @@ def _plan_worker(rank, world, port, q):
         out.append(parallel.agree_on_step_plan(torch.device('cpu'), rank == 1, 48 if rank == 0 else 40))
         # step 2: both can
         out.append(parallel.agree_on_step_plan(torch.device('cpu'), False, 48))
+        # step 3: only rank 0 still has a depth-net graph to capture in phase 3 -> both keep the collective out of flight
+        out.append(parallel.agree_on_step_plan(torch.device('cpu'), False, 48, may_capture=(rank == 0)))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -192,7 +194,8 @@ def test_ranks_agree_on_one_collective_schedule():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res[0] == res[1] == [(True, 88), (False, 96)]
+    assert res[0] == res[1] == [(True, 88), (False, 96), (False, 96, True)]
+    assert parallel.agree_on_step_plan(torch.device('cpu'), False, 5, may_capture=False) == (False, 5, False)
     assert parallel.agree_on_step_plan(torch.device('cpu'), True, 5) == (True, 5)       # no process group: local values
 
 
