@@ -4,7 +4,9 @@ module level and cannot be imported here):
   get_oob_mask        :57-68
   backward_flow_warp  :71-82    (F.grid_sample with the default 'zeros' padding, align_corners=True)
   mask_k              :139-148  clip([||warp + flow|| > 1] + oob, 0, 1), stored as uint8
-parity unpinned against published vectors (the reference ships none); pinned to the reference's formulas line by line.
+Pinned: tests/golden/flow_masks.npz holds the masks the reference's OWN functions / statements produce (cut out of
+the script with `ast` and executed unmodified: tests/ref_exec.py, tests/golden/make_golden.py); this restatement is
+bit-identical to them on every case (tests/test_oracle_vs_golden.py, tests/test_reference_interop_cpu.py).
 """
 import numpy as np
 import torch

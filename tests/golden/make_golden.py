@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = '/root/reference'
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(ROOT, 'dynamic-video-depth_amd'))
+sys.path.insert(0, ROOT)          # oracle/ (the independent ResNeXt restatement)
 
 from dvd_hip import synthetic  # noqa: E402  (pure-torch input generator, no HIP needed)
 
@@ -196,8 +197,9 @@ def case_step(name, B, H, W, gap, behind, seed, warm, **opt_over):
 
 def case_full_step(name, midas, B, H, W, gap, epoch, seed, over=None):
     """The REAL reference Model._train_on_batch (models/scene_flow_motion_field.py:152-227)
-    on CPU: depth net (hourglass, or MiDaS with the locally defined ResNeXt encoder since
-    torch.hub is unreachable) + scene-flow MLP + warp + losses + both backward passes + Adam."""
+    on CPU: depth net (hourglass, or MiDaS whose `torch.hub.load` call -- unreachable here --
+    returns oracle/resnext.py's independent restatement of torchvision's ResNeXt-101 32x8d; the reference's own
+    `_make_pretrained_resnext101_wsl` / `_make_resnet_backbone` then run unmodified) + scene-flow MLP + warp + losses + both backward passes + Adam."""
     import tempfile
     import unittest.mock as mock
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -207,7 +209,7 @@ def case_full_step(name, midas, B, H, W, gap, epoch, seed, over=None):
     import third_party.MiDaS as RM
     import visualize.html_visualizer as HV
     from models.scene_flow_motion_field import Model
-    from dvd_hip.third_party.MiDaS import make_resnext101_32x8d_backbone
+    from oracle import resnext          # independent restatement of torchvision's ResNeXt-101 32x8d (NOT the product's)
     o = dict(helpers.FULL_STEP_OPT)
     o.update(midas=midas, full_logdir=tempfile.mkdtemp())
     o.update(over or {})
@@ -221,7 +223,7 @@ def case_full_step(name, midas, B, H, W, gap, epoch, seed, over=None):
             return None
     real_load = torch.load
     with mock.patch.object(HV, 'Pool', lambda n: None), \
-            mock.patch.object(RB, '_make_pretrained_resnext101_wsl', lambda use_pretrained: make_resnext101_32x8d_backbone()), \
+            mock.patch.object(torch.hub, 'load', lambda repo, entry, *a, **k: resnext.resnext101_32x8d()), \
             mock.patch.object(RM.BaseModel, 'load', lambda self, path: None), \
             mock.patch.object(torch, 'load', lambda path, *a, **k: RH.HourglassModel().state_dict()
                               if 'pretrained_depth_ckpt' in str(path) else real_load(path, *a, **k)):
@@ -265,8 +267,34 @@ def case_full_step(name, midas, B, H, W, gap, epoch, seed, over=None):
     print('wrote', name, {k: float(v) for k, v in log.items()})
 
 
+def case_flow_masks(name):
+    """Occlusion / out-of-bounds masks: `get_oob_mask`, `backward_flow_warp` and the mask statements of
+    `generate_pair_data` (scripts/preprocess/davis/generate_flows.py:57-82,139-148) cut out of the reference's source
+    and executed as they are (tests/ref_exec.py) on the seeded flow pairs of tests/helpers.py.  Only the masks are
+    stored; the inputs are regenerated from the seeds."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    import ref_exec
+    out = {'cases': np.array(helpers.FLOW_MASK_CASES, dtype=np.float64)}
+    for H, W, seed, noise in helpers.FLOW_MASK_CASES:
+        f12, f21 = helpers.flow_pair(H, W, seed, noise)
+        m1, m2 = ref_exec.reference_masks(f12.numpy(), f21.numpy())
+        out['mask_1_%dx%d' % (H, W)] = np.packbits(m1)
+        out['mask_2_%dx%d' % (H, W)] = np.packbits(m2)
+        out['flow_crc_%dx%d' % (H, W)] = np.array([float(f12.double().sum()), float(f21.double().sum())])
+        print(name, (H, W), 'masked fraction', m1.mean(), m2.mean())
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'flow_masks':
+        case_flow_masks('flow_masks')
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'midas':               # both MiDaS fixtures (round 3: oracle encoder)
+        case_full_step('fullstep_midas_b1_64x96_train', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=107)
+        case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'midas_192x384':       # only the configs[0]-shape fixture (round 2)
         case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
         return
@@ -286,6 +314,7 @@ def main():
                    over=dict(use_motion_seg=True))
     # BASELINE configs[0] shape (192x384, the reference's training resolution of record), MiDaS, 2 pairs
     case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
+    case_flow_masks('flow_masks')
 
 
 if __name__ == '__main__':

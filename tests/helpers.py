@@ -89,3 +89,18 @@ FULL_STEP_OPT = dict(
     use_embedding=False, midas=False, use_disp=True, use_disp_ratio=False, time_dependent=True, flow_mul=1.0,
     disp_mul=1.0, acc_mul=1.0, sf_mag_div=100.0, interp_steps=5, warm_reg=False, weight_steps=False,
     use_motion_seg=False, n_freq_xyz=16, n_freq_t=16, warm_sf=5, n_down=3, mlp_stash_gb=48.0, depth_chunk=8)
+
+
+def flow_pair(H, W, seed, noise):
+    """A smooth forward flow, its approximate inverse, plus noise of about the consistency threshold's size (1 px)
+    and a band whose targets leave the image: inputs of the occlusion-mask tests and of the mask fixture."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing='ij')
+    f12 = torch.stack([6.0 * torch.sin(yy / 17.0) + 0.02 * xx, 4.0 * torch.cos(xx / 23.0) - 0.03 * yy], -1)
+    f21 = -f12 + noise * torch.randn(H, W, 2, generator=g)
+    f12 = f12 + 0.3 * noise * torch.randn(H, W, 2, generator=g)
+    f12[:5] += 40.0                        # a band whose targets leave the image
+    return f12.contiguous(), f21.contiguous()
+
+
+FLOW_MASK_CASES = [(48, 64, 1, 0.6), (96, 168, 2, 0.9), (192, 384, 3, 0.5), (33, 51, 4, 1.5)]

@@ -123,3 +123,17 @@ def test_full_step_oracle_reproduces_the_reference_logs(name):
     for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss'):
         np.testing.assert_allclose(log[k], float(gd['log_' + k]), rtol=1e-5, err_msg=k)
     np.testing.assert_allclose(log['acc_reg'], float(gd['log_acc_reg']), rtol=1e-4, atol=1e-10)
+
+
+def test_flow_consistency_masks_match_the_reference_code():
+    """oracle/preprocess.py against tests/golden/flow_masks.npz (the reference's own mask code, executed)."""
+    import helpers
+    from oracle import preprocess as OP
+    gd = load_golden('flow_masks')
+    for H, W, seed, noise in helpers.FLOW_MASK_CASES:
+        f12, f21 = helpers.flow_pair(H, W, seed, noise)
+        np.testing.assert_allclose(gd['flow_crc_%dx%d' % (H, W)], [float(f12.double().sum()), float(f21.double().sum())],
+                                   rtol=1e-12)
+        m1, m2 = OP.consistency_masks(f12.numpy(), f21.numpy())
+        assert np.array_equal(np.packbits(m1), gd['mask_1_%dx%d' % (H, W)])
+        assert np.array_equal(np.packbits(m2), gd['mask_2_%dx%d' % (H, W)])

@@ -1,8 +1,9 @@
 """Checkpoint interchange: the depth networks and the scene-flow MLP expose the reference's state_dict keys
 and shapes.  Needs the reference checkout (build container only; skipped on the GPU box, where
 /root/reference does not exist).  The MiDaS encoder comes from torch.hub in the reference (unreachable
-here), so its keys are compared through the same local torchvision-style ResNeXt the golden generator
-uses; decoder, hourglass and MLP are compared against the reference's own modules."""
+here): `torch.hub.load` returns oracle/resnext.py's independent restatement of torchvision's ResNeXt-101 32x8d (the one
+the golden generator uses), assembled by the reference's own `_make_resnet_backbone`; decoder, hourglass and MLP are
+compared against the reference's own modules."""
 import os
 import sys
 import unittest.mock as mock
@@ -28,8 +29,10 @@ def test_state_dict_keys_and_shapes_match_the_reference():
         from networks.sceneflow_field import SceneFlowFieldNet as RefMLP
         from dvd_hip.networks.sceneflow_field import SceneFlowFieldNet
         from dvd_hip.third_party.hourglass import HourglassModel_Embed
-        from dvd_hip.third_party.MiDaS import MidasNet, make_resnext101_32x8d_backbone
-        with mock.patch.object(RB, '_make_pretrained_resnext101_wsl', lambda use_pretrained: make_resnext101_32x8d_backbone()), \
+        from dvd_hip.third_party.MiDaS import MidasNet
+        from oracle import resnext
+        import torch
+        with mock.patch.object(torch.hub, 'load', lambda repo, entry, *a, **k: resnext.resnext101_32x8d()), \
                 mock.patch.object(RM.BaseModel, 'load', lambda self, path: None):
             ref_midas = RM.MidasNet(path=None, non_negative=True)
         _same(MidasNet().state_dict(), ref_midas.state_dict())
