@@ -4,10 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): synthetic 384x672 video, 48 frame pairs per GPU,
-MiDaS depth net (ResNeXt-101 32x8d, random init + calibrated head; dense convolutions on
-MIOpen, grouped convolutions / BatchNorm+ReLU / up-sampling on the HIP kernels of
-dvd_hip/csrc) + scene-flow MLP, non-warm phase (L1 + acceleration regulariser), gap 1, fp32.  A "step" is one
+With --gpus N > 1 and no torch.distributed environment the script re-launches itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); DVD_DIST_BACKEND=gloo lets the N ranks
+share one GPU (a smoke test of the N > 1 path on a 1-GPU box).
+
+Workload (BASELINE.json configs[1] = configs[2]): synthetic 384x672 video, 48 frame pairs per GPU,
+MiDaS depth net (ResNeXt-101 32x8d, random init + calibrated head; every convolution, BatchNorm+ReLU, pooling and
+up-sampling on the hand-written HIP kernels of dvd_hip/csrc -- split-bf16 MFMA implicit GEMMs with fp32 accumulation)
++ scene-flow MLP, non-warm phase (L1 + acceleration regulariser), gap 1, fp32 storage.  A "step" is one
 `Model._train_on_batch`: depth nets forward, geometry + MLP + fused warp/loss forward and
 backward, depth-net backward, gradient all-reduce (N>1) and both Adam updates.  Inputs are
 resident in HBM before the timed region.
@@ -15,7 +19,9 @@ resident in HBM before the timed region.
 Prints ONE JSON line: whole-job `value` in 48-pair iterations per second (weak scaling:
 every rank owns 48 pairs), plus
   roofline     -- the fused warp+loss op (HBM bound), timed live with events on its stream;
-  cpu_baseline -- the CPU oracle (a port of the reference step) on a bounded sample.
+  cpu_baseline -- the CPU oracle (a port of the reference step) on a bounded sample;
+  parity       -- the HIP Model against that oracle on the SAME frame pair and weights at the benchmark's image size
+                  (losses and gradients of one step).
 """
 import argparse
 import json
@@ -48,7 +54,7 @@ def make_opt(**over):
     return SimpleNamespace(**o)
 
 
-def build_model(opt, device, seed=0):
+def build_model(opt, device, seed=0, to_device=True):
     import warnings
     from dvd_hip.models.scene_flow_motion_field import Model
     from dvd_hip.third_party.MiDaS import calibrate_head_for_random_init
@@ -58,7 +64,8 @@ def build_model(opt, device, seed=0):
         model = Model(opt, None)
     if opt.midas:
         calibrate_head_for_random_init(model.net_depth)
-    model.to(device)
+    if to_device:
+        model.to(device)
     return model
 
 
@@ -104,12 +111,10 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(timed_steps=3, budget_s=240.0):
-    """The oracle step (a port of the reference's `_train_on_batch`, pinned to the real reference's logs by
-    tests/golden/fullstep_*.npz) on the host cores: ONE frame pair of the same workload at 384x672 -- the
-    48-pair step needs >400 GB of autograd state on the CPU path -- 1 warm-up step +
-    `timed_steps` timed steps, median (BASELINE.md section 3); value = pairs/s / 48.  Stops timing early
-    once `budget_s` of CPU time is spent (at least one timed step)."""
+def oracle_first_step(pairs=1):
+    """The oracle's first optimisation step (seeded weights) on `pairs` frame pairs of the benchmark workload at 384x672:
+    returns everything the cpu_baseline leg continues from and the parity leg compares with -- the initial weights,
+    the batch, the step's log and the gradients its Adam steps consumed."""
     from dvd_hip import synthetic
     from dvd_hip.third_party.MiDaS import MidasNet, calibrate_head_for_random_init
     from oracle import sceneflow_mlp as M
@@ -118,28 +123,90 @@ def cpu_baseline(timed_steps=3, budget_s=240.0):
     torch.manual_seed(0)
     net = calibrate_head_for_random_init(MidasNet(non_negative=True, normalize_input=True)).eval()
     sd = M.init_params(seed=0)
+    init = ({k: v.detach().clone() for k, v in net.state_dict().items()}, {k: v.clone() for k, v in sd.items()})
     opt = default_opt()
-    batch = synthetic.make_batch(1, H, W, gap=GAP, seed=1234)
+    batch = synthetic.make_batch(pairs, H, W, gap=GAP, seed=1234)
+    state = {}
+    t0 = time.time()
+    log, tm = T.train_step(opt, net, sd, batch, warm=False, lr_depth=1e-6, lr_mlp=1e-3, adam_state=state, return_grads=True)
+    return {'net': net, 'sd': sd, 'opt': opt, 'batch': batch, 'state': state, 'init': init, 'log': log,
+            'mlp_grads': tm['mlp_grads'], 'depth_grad_norms': tm['depth_grad_norms'], 'seconds': time.time() - t0}
+
+
+def hip_parity(first, device):
+    """One `_train_on_batch` of the HIP Model on the oracle's pair and initial weights; returns the `parity` object of
+    the bench line: both losses, relative differences of every logged loss, the worst relative difference of the
+    per-parameter gradient norms of the depth net and the worst element of the MLP gradients (relative to each
+    tensor's largest element)."""
+    from dvd_hip import synthetic
+    opt = make_opt(depth_chunk=1)
+    model = build_model(opt, torch.device('cpu'), seed=0, to_device=False)
+    model.net_depth.load_state_dict(first['init'][0])
+    model.net_sceneflow.load_state_dict(first['init'][1])
+    model.to(device)
+    b = {k: (v.to(device) if torch.is_tensor(v) and k != 'time_step' else v) for k, v in first['batch'].items()}
+    log = model._train_on_batch(opt.warm_sf + 1, 0, synthetic.with_loader_dim(b))
+    torch.cuda.synchronize()
+    rel = lambda a, c: abs(a - c) / max(abs(c), 1e-30)       # noqa: E731
+    out = {'sample': '%d frame pair(s) at %dx%d, gap %d, seeded weights, one step' % (first['batch']['img_1'].shape[0], H, W, GAP),
+           'loss_cpu': first['log']['loss'], 'loss_hip': log['loss'], 'rel': rel(log['loss'], first['log']['loss'])}
+    for k in ('flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
+        out[k + '_rel'] = rel(log[k], first['log'][k])
+    worst, worst_name = 0.0, None
+    for k, p in model.net_depth.named_parameters():
+        want = first['depth_grad_norms'].get(k)
+        if not want:
+            continue
+        r = rel(float(p.grad.double().norm()), want)
+        if r > worst:
+            worst, worst_name = r, k
+    out['depth_grad_norm_worst_rel'], out['depth_grad_norm_worst_param'] = worst, worst_name
+    wm = 0.0
+    for k, p in model.net_sceneflow.named_parameters():
+        g = first['mlp_grads'][k]
+        wm = max(wm, float((p.grad.cpu() - g).abs().max() / g.abs().max().clamp_min(1e-30)))
+    out['mlp_grad_worst_of_max'] = wm
+    del model
+    return out
+
+
+def cpu_baseline(first, timed_steps=3, budget_s=240.0):
+    """The oracle step (a port of the reference's `_train_on_batch`, pinned to the real reference's logs by
+    tests/golden/fullstep_*.npz) on the host cores: ONE frame pair of the same workload at 384x672 -- the
+    48-pair step needs >400 GB of autograd state on the CPU path -- 1 warm-up step (`first`) +
+    `timed_steps` timed steps, median (BASELINE.md section 3); value = pairs/s / 48.  Stops timing early
+    once `budget_s` of CPU time is spent (at least one timed step)."""
+    from oracle import train_step as T
     threads = torch.get_num_threads()
-    state, times, log = {}, [], None
+    times, log, warm_s = [], first['log'], first['seconds']
     t_all = time.time()
-    for i in range(1 + timed_steps):
+    for i in range(timed_steps):
         t0 = time.time()
-        log, _ = T.train_step(opt, net, sd, batch, warm=False, lr_depth=1e-6, lr_mlp=1e-3, adam_state=state)
-        dt = time.time() - t0
-        if i > 0:
-            times.append(dt)
-        if i > 0 and time.time() - t_all > budget_s:
+        log, _ = T.train_step(first['opt'], first['net'], first['sd'], first['batch'], warm=False, lr_depth=1e-6, lr_mlp=1e-3,
+                              adam_state=first['state'])
+        times.append(time.time() - t0)
+        if time.time() - t_all > budget_s:
             break
-        warm_s = dt if i == 0 else warm_s
     times.sort()
     med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     return {'value': (1.0 / med) / PAIRS, 'unit': 'iters/s (48-pair steps)', 'cores': threads, 'kind': 'port',
             'sample': '1 frame pair at %dx%d, gap %d: 1 warm-up step (%.1f s) + %d timed oracle steps, median %.1f s '
                       '(all: %s); value = pairs/s / 48' % (H, W, GAP, warm_s, len(times), med,
                                                            ', '.join('%.1f' % t for t in times)),
-            'pairs_per_s': 1.0 / med, 'loss': log['loss'], 'cpu_model': _cpu_model(), 'os_cpu_count': os.cpu_count(),
-            'torch_threads': threads}
+            'pairs_per_s': 1.0 / med, 'first_step_loss': first['log']['loss'], 'cpu_model': _cpu_model(),
+            'os_cpu_count': os.cpu_count(), 'torch_threads': threads}
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a torch.distributed environment: start N ranks of this script."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -160,6 +227,8 @@ def main():
                          "step's batch starts in host memory and goes through the pinned double-buffered feeder "
                          "(dvd_hip.datasets.davis_sequence.DeviceFeeder), so the PCIe copy is inside the timed region")
     a = ap.parse_args()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        relaunch_under_torchrun(a.gpus)
 
     from dvd_hip import parallel, synthetic
     # DVD_DIST_BACKEND=gloo lets two ranks share one GPU (smoke test of the N>1 path on a 1-GPU box);
@@ -168,8 +237,7 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)
     world, rank = parallel.world_size(), parallel.rank()
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (a.gpus, a.gpus))
+        raise SystemExit('--gpus %d but the torch.distributed world has %d ranks' % (a.gpus, world))
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
@@ -184,7 +252,6 @@ def main():
         from dvd_hip.datasets.davis_sequence import DeviceFeeder
         host = [synthetic.with_loader_dim({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()})
                 for _ in range(2)]
-        feeder = iter(DeviceFeeder((host[i & 1] for i in range(a.warmup + a.steps)), device))
 
     def one_step(i):
         if a.feed == 'host':
@@ -218,7 +285,9 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
     ms_per_step = dt / a.steps * 1e3
-    if parallel.is_distributed():
+    dist_on = parallel.is_distributed()
+    dist_backend = torch.distributed.get_backend() if dist_on else None
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
@@ -227,10 +296,12 @@ def main():
         'metric': 'train iters/s (depth+sceneflow step) at 384x672, 48 pairs; warp+loss HBM GB/s',
         'value': world * (a.pairs / float(PAIRS)) * a.steps / dt, 'unit': 'iters/s (48-pair steps, whole job)',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (storage and accumulation fp32; conv / MLP contractions as 3-term split-bf16 MFMA products: 24-bit '
+                 'operands, 6 of 9 partial products, <= 2.5e-6 of max|y| against float64)', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]/[2]: synthetic %dx%d, %d frame pairs per GPU, gap %d, MiDaS '
                                '(ResNeXt-101 32x8d) depth net with hand-written split-bf16 MFMA convolution kernels '
-                               '(forward, data and weight gradients; only the 7x7 stride-2 stem on MIOpen) '
+                               '(forward, data and weight gradients) '
                                'under PyTorch-ROCm autograd + HIP scene-flow MLP + HIP fused warp/reprojection/loss, '
                                'non-warm phase with acceleration regulariser' % (H, W, a.pairs, GAP),
                    'pairs_per_gpu': a.pairs, 'height': H, 'width': W, 'parallelism': 'dp%d over frame pairs' % world},
@@ -239,6 +310,7 @@ def main():
         'hbm_peak_reserved_GB': torch.cuda.max_memory_reserved(device) / 2 ** 30,
         'hbm_graph_pools_GB': getattr(model, '_pool_bytes', 0) / 2 ** 30,      # kept depth-net activations + graph temporaries
         'last_loss': log['loss'],
+        'dist_backend': dist_backend, 'ranks_seen': world,
     }
     if warp is not None:
         # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 --pmc passes of
@@ -259,7 +331,14 @@ def main():
                            'algorithmic_bytes_per_launch': warp['pixels_per_launch'] * WARP_BYTES_PER_PIXEL,
                            'avg_launch_ms': warp['avg_ms'], 'launches_timed': warp['launches']}
     if world == 1 and not a.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(timed_steps=max(1, a.cpu_steps))
+        # the 48-pair model's graph slots hold most of the HBM: release them before the 1-pair parity model is built
+        import gc
+        del model, batch
+        gc.collect()
+        torch.cuda.empty_cache()
+        first = oracle_first_step()
+        out['parity'] = hip_parity(first, device)
+        out['cpu_baseline'] = cpu_baseline(first, timed_steps=max(1, a.cpu_steps))
     print(json.dumps(out))
 
 

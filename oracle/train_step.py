@@ -22,9 +22,10 @@ def mlp_state_from_module(net_sceneflow):
     return {k: v.detach().cpu().clone() for k, v in net_sceneflow.state_dict().items()}
 
 
-def train_step(opt, depth_net, sd_mlp, batch, warm, lr_depth, lr_mlp, betas=(0.5, 0.9), adam_state=None):
+def train_step(opt, depth_net, sd_mlp, batch, warm, lr_depth, lr_mlp, betas=(0.5, 0.9), adam_state=None, return_grads=False):
     """Runs one step IN PLACE on `depth_net` (CPU module) and `sd_mlp` (dict of leaf tensors).
-    Returns (batch_log, timings)."""
+    Returns (batch_log, timings); with `return_grads` the timings dict also carries the gradients the Adam steps
+    consumed: 'mlp_grads' {key: tensor} and 'depth_grad_norms' {parameter name: float64 norm}."""
     t0 = time.time()
     depth_net.eval()
     for p in depth_net.parameters():
@@ -50,6 +51,11 @@ def train_step(opt, depth_net, sd_mlp, batch, warm, lr_depth, lr_mlp, betas=(0.5
         loss.backward()
         acc = 0.0
     t_grad = time.time()
+    grads = {}
+    if return_grads:
+        grads['mlp_grads'] = {k: v.grad.detach().clone() for k, v in leaves.items()}
+        grads['depth_grad_norms'] = {k: float(p.grad.double().norm()) for k, p in depth_net.named_parameters()
+                                     if p.grad is not None}
     state = adam_state if adam_state is not None else {}
     groups = []
     if not warm:
@@ -67,4 +73,4 @@ def train_step(opt, depth_net, sd_mlp, batch, warm, lr_depth, lr_mlp, betas=(0.5
     log = {'loss': logged_loss, 'flow_loss_1_2': float(parts['flow_loss_1_2'].detach()),
            'disp_loss_1_2': float(parts['disp_loss_1_2'].detach()), 'sf_loss': float(parts['sf_loss'].detach()),
            'acc_reg': acc}
-    return log, {'total_s': time.time() - t0, 'fwd_bwd_s': t_grad - t0}
+    return log, dict(grads, total_s=time.time() - t0, fwd_bwd_s=t_grad - t0)

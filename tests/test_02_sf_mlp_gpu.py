@@ -36,6 +36,12 @@ def _close(got, want, rel, name, max_outliers=0):
     scale = max(np.abs(want).max(), 1e-30)
     err = np.abs(got - want) / scale
     bad = int((err > rel).sum())
+    import json
+    import os
+    if os.environ.get('DVD_PARITY_LOG'):
+        with open(os.environ['DVD_PARITY_LOG'], 'a') as f:
+            f.write(json.dumps({'test': 'sf_mlp', 'name': name, 'tol': rel, 'worst': float(err.max()),
+                                'median': float(np.median(err)), 'outliers': bad}) + '\n')
     assert bad <= max_outliers, '%s: %d elements off by more than %.1e of max|ref| (worst %.3e)' % (
         name, bad, rel, err.max())
 

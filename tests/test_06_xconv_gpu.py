@@ -166,7 +166,13 @@ def test_sixteen_per_group_module_incl_stride_two(stride):
     mg = mod.cuda()
     xg = x.cuda().requires_grad_(True)
     y = mg(xg)
-    assert y.shape == want.shape and 'XConv' in type(y.grad_fn).__name__ or stride == 2
+    assert y.shape == want.shape
+
+    def on_hip_kernel(fn, depth=0):        # the convolution in y's autograd graph is the package's kernel, not ATen's
+        if fn is None or depth > 4:
+            return False
+        return 'XConv' in type(fn).__name__ or any(on_hip_kernel(n, depth + 1) for n, _ in fn.next_functions)
+    assert on_hip_kernel(y.grad_fn)
     y.backward(gy.cuda())
     assert _err(y.detach(), want.detach()) < TOL
     assert _err(xg.grad, xd.grad) < TOL

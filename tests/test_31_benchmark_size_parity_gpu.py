@@ -1,0 +1,31 @@
+"""Full-step parity at the BENCHMARK'S image size (384x672, MiDaS, non-warm, gap 1): one `_train_on_batch` of the HIP
+Model against the CPU oracle's step (oracle/train_step.py, pinned to the real reference's logged losses and gradients by
+tests/golden/fullstep_*.npz) on the same frame pair and the same seeded weights -- the comparison `bench.py` reports as
+`parity` next to `cpu_baseline`.  One pair: the reference path needs > 60 GB of autograd state per pair at this size.
+
+Tolerances (fp32; different reduction orders; split-bf16 MFMA products <= 2.5e-6 of max|y|): losses rtol 2e-4, acc_reg
+rtol 2e-3, per-parameter gradient norms of the depth net 5e-3, MLP gradient elements 2e-3 of the tensor's largest element.
+The measured values are printed and written to $DVD_PARITY_LOG (json lines) when set."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_step_matches_the_oracle_at_384x672():
+    import bench
+    first = bench.oracle_first_step()
+    par = bench.hip_parity(first, torch.device('cuda', 0))
+    print('parity at 384x672:', json.dumps(par))
+    if os.environ.get('DVD_PARITY_LOG'):
+        with open(os.environ['DVD_PARITY_LOG'], 'a') as f:
+            f.write(json.dumps({'test': 'benchmark_size', **par}) + '\n')
+    assert par['rel'] < 2e-4
+    for k in ('flow_loss_1_2', 'disp_loss_1_2', 'sf_loss'):
+        assert par[k + '_rel'] < 2e-4, k
+    assert par['acc_reg_rel'] < 2e-3
+    assert par['depth_grad_norm_worst_rel'] < 5e-3, par['depth_grad_norm_worst_param']
+    assert par['mlp_grad_worst_of_max'] < 2e-3
