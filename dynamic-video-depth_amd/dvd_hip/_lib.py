@@ -109,6 +109,7 @@ SIGNATURES = {
     'dvd_xconv_packed_bytes': (c_size_t, [c_int] * 5),
     'dvd_xconv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_xconv_fwd': (c_int, [c_void_p] * 5 + [ctypes.POINTER(BnParams), c_void_p] + [c_int] * 8 + [c_void_p]),
+    'dvd_xconv_select': (c_int, [c_int]),
     'dvd_xconv_pack_scaled': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                       c_void_p]),
     'dvd_convbn_finalize': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -58,6 +58,15 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsign
   l = __builtin_bit_cast(unsigned, lb);
 }
 
+// A pointer the compiler can see is wave-uniform (block indices divided by run-time values pass through VGPRs): buffer
+// resources must sit in SGPRs, a resource of unknown uniformity costs a waterfall loop around every load.
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ void split8(const float v[8], uint4& h, uint4& m, uint4& l) {
   split_pair(v[0], v[1], h.x, m.x, l.x);
   split_pair(v[2], v[3], h.y, m.y, l.y);
@@ -131,7 +140,12 @@ struct XArgs {
 // One block = WM x WN waves, each wave TM x TN tiles of 32 x 32; A and B double buffered in LDS, one barrier per
 // K step (16 channels x one tap); two blocks share a CU, so one block's staging / barrier / epilogue overlaps
 // the other's MFMAs.
-template <int TM, int TN, int WM, int WN, int FIT>
+// FAST (host: Cin a multiple of 16, one image's input channels span < 2^31 bytes): all main-loop global loads are raw
+// BUFFER loads whose per-thread offset is computed once before the loop -- the chunk / channel / K-step advance is a
+// wave-uniform SGPR offset, halo and padding items carry an out-of-range offset and read 0 from the hardware's bounds check.
+// The generic path (64-bit per-element addresses, per-element clamps and selects) spent ~150 VALU instructions per staged
+// item and chunk, ~35 of them the fp32 -> 3 x bf16 split itself; FAST leaves the split (+ ReLU) and three LDS stores.
+template <int TM, int TN, int WM, int WN, int FIT, bool FAST>
 __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr bool kDirect = FIT == 0;             // big halos (k >= 5): stage without the register prefetch
@@ -174,8 +188,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
     lidx[it] = live ? (cig * npos + p) : (npos - 1);
     cig8[it] = live ? cig * 8 : 0;
   }
+  // FAST: byte offset of channel (0 | 8) of the item's position from the image's base, or an offset beyond the buffer
+  const int planeB = (int)plane * 4;
+  int voff[FI];
+#pragma unroll
+  for (int it = 0; it < FI; ++it) voff[it] = gok[it] ? (goff[it] + cig8[it] * (int)plane) * 4 : (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<float*>(xn)), 0, FAST ? a.Cin * planeB : 0, 0x00020000);
   float raw[FI][8];
   auto load_raw = [&](int kc) {
+    if (FAST) {
+      const int s0 = kc * 16 * planeB;               // wave-uniform: channel kc * 16 + e of this image
+#pragma unroll
+      for (int it = 0; it < FI; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          raw[it][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdB, voff[it], s0 + e * planeB, 0));
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < FI; ++it) {
       const int ch0 = kc * 16 + cig8[it];
@@ -192,10 +222,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
     for (int it = 0; it < FI; ++it) {
       const int ch0 = kc * 16 + cig8[it];
       float v[8];
+      if (FAST) {                                    // invalid items were loaded as 0 by the bounds check
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (gok[it] && (ch0 + e) < a.Cin) ? raw[it][e] : 0.0f;
-        v[e] = a.relu_in ? fmaxf(t, 0.0f) : t;
+        for (int e = 0; e < 8; ++e) v[e] = raw[it][e];
+        if (a.relu_in) {                             // uniform branch
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = (gok[it] && (ch0 + e) < a.Cin) ? raw[it][e] : 0.0f;
+          v[e] = a.relu_in ? fmaxf(t, 0.0f) : t;
+        }
       }
       uint4 h, m, l;
       split8(v, h, m, l);
@@ -219,15 +258,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
       const int go = ok ? (row * a.W + col) : 0;
       const int ch0 = kc * 16 + (live ? cig * 8 : 0);
       float v[8];
+      if (FAST) {
+        const int vo = ok ? (go + cig * 8 * (int)plane) * 4 : (int)0x80000000;
+        const int s0 = kc * 16 * planeB;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ch = (ch0 + e) < a.Cin ? (ch0 + e) : (a.Cin - 1);
-        v[e] = xn[(size_t)ch * plane + go];
-      }
+        for (int e = 0; e < 8; ++e)
+          v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdB, vo, s0 + e * planeB, 0));
+        if (a.relu_in) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float t = (ok && (ch0 + e) < a.Cin) ? v[e] : 0.0f;
-        v[e] = a.relu_in ? fmaxf(t, 0.0f) : t;
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ch = (ch0 + e) < a.Cin ? (ch0 + e) : (a.Cin - 1);
+          v[e] = xn[(size_t)ch * plane + go];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = (ok && (ch0 + e) < a.Cin) ? v[e] : 0.0f;
+          v[e] = a.relu_in ? fmaxf(t, 0.0f) : t;
+        }
       }
       uint4 h, m, l;
       split8(v, h, m, l);
@@ -248,10 +299,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
     const int mtl = jj / 192, rem = jj - mtl * 192;
     asrc[i] = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(grp * a.mtiles + mt0 + mtl) * nkt) * 192 + rem;
   }
+  // FAST: the block's fragments start at a wave-uniform base; thread-constant byte offset + K step * 3072 bytes (SGPR)
+  const u32x4* abase = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(grp * a.mtiles + mt0) * nkt) * 192;
+  const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(
+      uniform_ptr(const_cast<u32x4*>(abase)), 0, FAST ? MT * nkt * 192 * 16 : 0, 0x00020000);
+  int aoff[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int j = i * NT + tid;
+    const int jj = j < AU ? j : 0;
+    const int mtl = jj / 192, rem = jj - mtl * 192;
+    aoff[i] = (mtl * nkt * 192 + rem) * 16;
+  }
   struct ARegs {
     u32x4 v[AI];
   };
   auto load_a = [&](ARegs& r, int kt) {
+    if (FAST) {
+#pragma unroll
+      for (int i = 0; i < AI; ++i)
+        r.v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srdA, aoff[i], kt * 3072, 0));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AI; ++i) r.v[i] = asrc[i][(size_t)kt * 192];
   };
@@ -308,12 +377,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
   };
 
   // ---- prologue: A(0), B(0) staged; A(1), A(2) and raw(1) in flight
+  // Wide wave tiles (TM >= 4: 48 MFMAs = 1 500+ matrix-pipe cycles per wave and K step) keep ONE register set for the weight
+  // fragments: A(kt + 1) is requested right after the step's barrier and written to LDS behind the step's own MFMAs, which
+  // cover the L2 round trip; the narrow tiles (24 MFMAs per step) need the request two to three steps ahead, in two sets.
+  constexpr bool kSingleA = TM >= 4;
   ARegs ra, rb;
   load_a(ra, 0);
   if (!kDirect) load_raw(0);
   write_a(ra, 0);
-  load_a(rb, nkt > 1 ? 1 : 0);                     // set of odd steps
-  load_a(ra, nkt > 2 ? 2 : 0);                     // set of even steps
+  if (!kSingleA) {
+    load_a(rb, nkt > 1 ? 1 : 0);                     // set of odd steps
+    load_a(ra, nkt > 2 ? 2 : 0);                     // set of even steps
+  }
   if (kDirect) {
     stage_direct(0, 0);
   } else {
@@ -322,13 +397,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
   }
 
   int kc = 0, ky = 0, kx = 0;
-  auto step = [&](int kt, ARegs& rn) {             // rn holds A(kt + 1)
+  auto step = [&](int kt, ARegs& rn) {             // rn holds A(kt + 1) (two-set scheme)
     __syncthreads();
     Frag f;
     read_frags(f, kt & 1, kc, ky * P + kx);
+    if (kSingleA) {
+      load_a(rn, kt + 1 < nkt ? kt + 1 : kt);
+      __builtin_amdgcn_sched_barrier(0);             // keep the request above the MFMAs (the scheduler sinks it to its use)
+    }
     mfmas(f);
     write_a(rn, (kt + 1) & 1);                      // (a spare write after the last step is harmless)
-    load_a(rn, kt + 3 < nkt ? kt + 3 : kt);
+    if (!kSingleA) load_a(rn, kt + 3 < nkt ? kt + 3 : kt);
     if (++kx == KS) {
       kx = 0;
       if (++ky == KS) {                             // last tap of the chunk (block-uniform)
@@ -343,9 +422,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
       }
     }
   };
-  for (int kt = 0; kt < nkt; kt += 2) {
-    step(kt, rb);
-    if (kt + 1 < nkt) step(kt + 1, ra);
+  if (kSingleA) {
+    for (int kt = 0; kt < nkt; ++kt) step(kt, ra);
+  } else {
+    for (int kt = 0; kt < nkt; kt += 2) {
+      step(kt, rb);
+      if (kt + 1 < nkt) step(kt + 1, ra);
+    }
   }
 
   // ---- epilogue (uniform branches only; the optional operands are loaded in batches of 16; 32-bit offsets
@@ -443,9 +526,21 @@ struct XCfg {
   int NQ() const { return TN * WN * 32; }
   int NT() const { return 64 * WM * WN; }
 };
-static XCfg pick_cfg(int M) {
+// Block shapes.  Every activation element a block stages is split into its three bf16 terms ONCE per block (VALU work) and
+// read from LDS once per 32-channel tile row, so the split / LDS cost per MFMA falls with the number of output channels a
+// block owns: with >= 256 of them a block takes 256 channels (wave tile 128 channels x 64 positions: 48 MFMAs against 18
+// fragment reads per K step, round 2: 24 against 12) -- 256 x 128 positions at two blocks per CU for 1x1 kernels, 256 x 256
+// positions in ONE 512-thread block per CU for k >= 3 (the haloed tile of 256 positions needs ~120 KB of LDS).
+static int g_xcfg = 0;    // test / A-B hook (dvd_xconv_select): 0 auto, 1 round-2 shapes only, 2 force 256x128, 3 force 256x256,
+                          // 4 round-2 shapes on the generic (pointer-addressed) main loop
+static XCfg pick_cfg(int M, int KS) {
   if (M <= 32) return {1, 2, 1, 4};     // 32 channels x 256 positions
   if (M <= 64) return {2, 2, 1, 4};     // 64 x 256
+  if (M >= 256 && g_xcfg != 1 && g_xcfg != 4) {
+    if (g_xcfg == 2) return {4, 2, 2, 2};
+    if (g_xcfg == 3) return {4, 2, 2, 4};
+    return KS == 1 ? XCfg{4, 2, 2, 2} : XCfg{4, 2, 2, 4};
+  }
   return {2, 2, 2, 2};                  // 128 x 128
 }
 constexpr int kXLdsBudget = 78 * 1024;    // two blocks per CU
@@ -495,11 +590,12 @@ static bool pick_tile_budget(int H, int W, int KS, const XCfg& c, XTile& best, i
 }
 
 static bool pick_tile(int H, int W, int KS, const XCfg& c, XTile& best) {
-  // two blocks per CU where the haloed tile allows it, one block (big kernels: k >= 7) otherwise
+  // two blocks per CU where the haloed tile allows it, one block (big kernels: k >= 7; the 512-thread shape) otherwise
+  if (c.NT() >= 512) return pick_tile_budget(H, W, KS, c, best, 156 * 1024);
   return pick_tile_budget(H, W, KS, c, best, kXLdsBudget) || pick_tile_budget(H, W, KS, c, best, 156 * 1024);
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, bool FAST>
 static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t s) {
   auto go = [&](auto kern) -> int {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -508,16 +604,18 @@ static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t 
     return DVD_OK;
   };
   switch (FI) {
-    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1>);
-    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2>);
-    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3>);
-    default: return go(xconv_kernel<TM, TN, WM, WN, 0>);
+    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1, FAST>);
+    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2, FAST>);
+    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3, FAST>);
+    default: return go(xconv_kernel<TM, TN, WM, WN, 0, FAST>);
   }
 }
 
+// 32-row tiles per group in the packed buffer: M padded to the largest block height any shape of pick_cfg may use for it
+// (the packing must not depend on the kernel size or on the A/B hook)
 static int xconv_mtiles(int M) {
-  const XCfg c = pick_cfg(M);
-  return (M + c.blockM() - 1) / c.blockM() * (c.blockM() / 32);
+  const int bm = M <= 32 ? 32 : (M <= 64 ? 64 : (M >= 256 ? 256 : 128));
+  return (M + bm - 1) / bm * (bm / 32);
 }
 
 }  // namespace dvd
@@ -559,6 +657,12 @@ int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int K
   return xconv_pack_impl(w, packed, Cout, Cin, KS, groups, transposed, bn_gamma, bn_var, bn_eps, stream);
 }
 
+int dvd_xconv_select(int cfg) {
+  DVD_REQUIRE(cfg >= 0 && cfg <= 4, "xconv_select: cfg %d", cfg);
+  dvd::g_xcfg = cfg;
+  return DVD_OK;
+}
+
 int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
                   const dvd_bn_params* bn, float* y, int N, int Cin_total, int Cout_total, int H, int W, int KS, int groups,
                   int flags, dvd_stream_t stream) {
@@ -572,7 +676,11 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   DVD_REQUIRE((long long)H * W * (long long)(Cin_total > Cout_total ? Cin_total : Cout_total) < (1ll << 31),
               "xconv: image too large for 32-bit offsets");
   const int Cin = Cin_total / groups, Cout = Cout_total / groups;
-  const dvd::XCfg c = dvd::pick_cfg(Cout);
+  // buffer-addressed main loop: whole 16-channel chunks, 31-bit byte offsets inside one image's input channels and
+  // inside the packed weights of one block row
+  const bool fast = (Cin % 16 == 0) && ((long long)Cin * H * W * 4 < (1ll << 31)) &&
+                    ((long long)8 * ((Cin + 15) / 16) * KS * KS * 3072 < (1ll << 31)) && dvd::g_xcfg != 4;
+  const dvd::XCfg c = dvd::pick_cfg(fast ? Cout : (Cout < 128 ? Cout : 128), KS);   // the wide shapes exist as FAST kernels only
   int Hh = H, Ww = W;
   if (KS == 1) {           // no spatial structure: one row of H * W positions
     Hh = 1;
@@ -605,9 +713,16 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   const dim3 grid(t.ntr * t.ntc, mblocks * groups, N);
   const size_t lds = t.lds;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2>(a, t.FI, grid, lds, s);
-  if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4>(a, t.FI, grid, lds, s);
-  return dvd::launch_fi<1, 2, 1, 4>(a, t.FI, grid, lds, s);
+  if (fast) {
+    if (c.TM == 4 && c.WN == 4) return dvd::launch_fi<4, 2, 2, 4, true>(a, t.FI, grid, lds, s);
+    if (c.TM == 4) return dvd::launch_fi<4, 2, 2, 2, true>(a, t.FI, grid, lds, s);
+    if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2, true>(a, t.FI, grid, lds, s);
+    if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4, true>(a, t.FI, grid, lds, s);
+    return dvd::launch_fi<1, 2, 1, 4, true>(a, t.FI, grid, lds, s);
+  }
+  if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2, false>(a, t.FI, grid, lds, s);
+  if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4, false>(a, t.FI, grid, lds, s);
+  return dvd::launch_fi<1, 2, 1, 4, false>(a, t.FI, grid, lds, s);
 }
 
 }  // extern "C"

@@ -316,6 +316,11 @@ typedef struct dvd_bn_params {
 int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
                   const dvd_bn_params* bn, float* y, int N, int Cin, int Cout, int H, int W, int KS, int groups, int flags,
                   dvd_stream_t stream);
+/* Test / A-B hook (process wide, like dvd_warp_loss_select): block shape of dvd_xconv_fwd for >= 256 output channels.
+ * 0 = automatic (256 channels x 128 positions for 1x1 kernels, 256 x 256 for k >= 3), 1 = round 2's 128 x 128 blocks,
+ * 2 / 3 = force 256 x 128 / 256 x 256, 4 = round 2's blocks on the generic pointer-addressed main loop (the path shapes
+ * with Cin % 16 != 0 take).  Results are identical in every setting (same products, same K order). */
+int dvd_xconv_select(int cfg);
 /* Transposed / forward packing with every weight of output channel co scaled by gamma[co] / sqrt(var[co] + eps): the
  * backward-data pass through a fused BatchNorm is dvd_xconv_fwd on the masked, UNSCALED output gradient. */
 int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed,

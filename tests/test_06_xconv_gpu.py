@@ -83,6 +83,9 @@ CASES = [
     (1, 32, 32, 21, 33, 7),
     (1, 32, 32, 24, 40, 11),
     (1, 3, 64, 16, 24, 7),           # 3 input channels
+    (1, 512, 512, 13, 22, 1),        # >= 256 output channels: the 256-channel block shapes (1x1: 256 x 128 positions)
+    (1, 256, 512, 10, 15, 3),        # (k >= 3: 256 x 256 positions, one 512-thread block per CU)
+    (2, 272, 288, 9, 14, 3),         # 256-channel blocks with a ragged last block, Cin a multiple of 16 only
 ]
 
 
@@ -115,6 +118,32 @@ def test_forward_and_input_gradient(N, Cin, Cout, H, W, KS):
     print('wgrad err %.2e' % e)
     assert e < 2e-5, 'wgrad: ' + _where(cg.weight.grad, wd.grad, 'co,ci,ky,kx')
     assert _err(cg.bias.grad, bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize('KS', [1, 3])
+def test_block_shapes_give_identical_results(KS):
+    """dvd_xconv_select: the block shape / addressing mode changes which workgroup computes a product, never the product
+    or the order of a pixel's K sum -- outputs are bitwise equal, forward and backward-data, with every epilogue option."""
+    from dvd_hip import _lib, conv as C
+    torch.manual_seed(40 + KS)
+    N, Cin, Cout, H, W = 2, 256, 256, 24, 42
+    x, res = torch.randn(N, Cin, H, W).cuda(), torch.randn(N, Cout, H, W).cuda()
+    conv = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2).cuda()
+    gy = torch.randn(N, Cout, H, W).cuda()
+    lib = _lib.load()
+    outs = []
+    try:
+        for cfg in (0, 1, 2, 3, 4):
+            _lib.check(lib.dvd_xconv_select(cfg), 'dvd_xconv_select')
+            xg = x.clone().requires_grad_(True)
+            y = C.xconv2d(conv, xg, relu_in=True, residual=res, res_relu=True)
+            y.backward(gy)
+            outs.append((y.detach().clone(), xg.grad.clone()))
+    finally:
+        _lib.check(lib.dvd_xconv_select(0), 'dvd_xconv_select')
+    for cfg, (y, gx) in enumerate(outs[1:], start=1):
+        assert torch.equal(y, outs[0][0]), 'forward differs for block shape %d' % cfg
+        assert torch.equal(gx, outs[0][1]), 'backward-data differs for block shape %d' % cfg
 
 
 GROUPED = [
