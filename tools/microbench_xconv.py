@@ -38,6 +38,10 @@ def main():
     only = sys.argv[1:]
     shapes = SHAPES[:int(os.environ.get('XCONV_NSHAPES', len(SHAPES)))]
     nmul = int(os.environ.get('XCONV_NMUL', '1'))            # 3: the 48-image chunks of the bench
+    cfg = int(os.environ.get('XCONV_CFG', '0'))              # dvd_xconv_select: 0 auto, 1 round-2 blocks, 2/3 forced, 4 generic loop
+    from dvd_hip import _lib
+    _lib.check(_lib.load().dvd_xconv_select(cfg), 'dvd_xconv_select')
+    skip_wgrad = bool(os.environ.get('XCONV_NO_WGRAD'))
     for (N, Cin, Cout, H, W, KS) in shapes:
         N *= nmul
         torch.manual_seed(0)
@@ -50,7 +54,9 @@ def main():
         it = 10
         rec['xconv_fwd_ms'] = timeit(lambda: C._xconv_run(x, pk, Cout, KS, bias=conv.bias), it)
         rec['xconv_dgrad_ms'] = timeit(lambda: C._xconv_run(gy, pkT, Cin, KS), it)
-        rec['xconv_wgrad_ms'] = timeit(lambda: C.xconv_wgrad(x, gy, conv.weight.shape, False), it)
+        if not skip_wgrad:
+            rec['xconv_wgrad_ms'] = timeit(lambda: C.xconv_wgrad(x, gy, conv.weight.shape, False), it)
+        rec['cfg'] = cfg
         rec['pack_ms'] = timeit(lambda: (conv.weight._dvd_xpack.clear(), C.xconv_packed(conv.weight, False)), it)
         if 'nomiopen' not in only:
             with torch.no_grad():
