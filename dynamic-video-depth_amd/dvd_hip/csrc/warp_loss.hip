@@ -30,6 +30,13 @@
 #ifndef DVD_WARP_PREFETCH
 #define DVD_WARP_PREFETCH 0
 #endif
+#ifndef DVD_WARP_DIRECT_INTERIOR
+#define DVD_WARP_DIRECT_INTERIOR 1
+#endif
+#ifndef DVD_WARP_PINHOLE
+#define DVD_WARP_PINHOLE 1      // 0: A/B builds without the pinhole-intrinsics instantiation (tools/build_variant.sh)
+#endif
+#include <type_traits>
 
 namespace dvd {
 
@@ -141,7 +148,12 @@ __device__ __forceinline__ float2 load_pair(const float* p) {
 // SHIPPED=true folds the flag set of experiments/davis/train_sequence.sh
 // (--midas --use_disp) at compile time; false reads the flags from the config.
 #define DVD_FMA __builtin_fmaf
-template <bool GRADS, bool SHIPPED, class IO>
+// PIN = true: the pair's intrinsics have the pinhole form without skew,
+//   K^T = [fx 0 0; 0 fy 0; cx cy 1],  (K^-1)^T = [a 0 0; 0 b 0; c d 1]   (exact zeros, exact one)
+// -- what generate_frame_midas.py:135-139 writes for every frame; the tile kernel tests the ten entries of the pair's
+// matrices (wave-uniform) and takes this instantiation.  Products with an exact 0 are +-0 and adding them is exact, so every
+// EXACT quantity below is bit-identical to the general expression; it is ~50 VALU instructions per pixel less.
+template <bool GRADS, bool SHIPPED, bool PIN, class IO>
 __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, int y, int x,
                                       float d1, float fx, float fy, float mk, float s0, float s1,
                                       float s2, float acc[4], float& g_d1_out, float g_s_out[3]) {
@@ -151,8 +163,14 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
   const float xf = (float)x, yf = (float)y;
   // --- EXACT: ray = (x,y,1) @ K_inv ; p1c = d1*ray ; P1 = p1c@R1 + t1
   float r0, r1, r2;
-  rowvec_mat3(xf, yf, 1.0f, c.Ki, r0, r1, r2);
-  const float pc0 = d1 * r0, pc1 = d1 * r1, pc2 = d1 * r2;
+  if (PIN) {
+    r0 = xf * c.Ki[0] + c.Ki[6];     // (x*a + y*0) + 1*c
+    r1 = yf * c.Ki[4] + c.Ki[7];
+    r2 = 1.0f;
+  } else {
+    rowvec_mat3(xf, yf, 1.0f, c.Ki, r0, r1, r2);
+  }
+  const float pc0 = d1 * r0, pc1 = d1 * r1, pc2 = PIN ? d1 : d1 * r2;
   float P0, P1, P2;
   rowvec_mat3(pc0, pc1, pc2, c.R1, P0, P1, P2);
   P0 = P0 + c.t1[0];
@@ -172,18 +190,29 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
   float dnw, dne, dsw, dse;  // 0 for out-of-image taps, like ATen's masked gather
   io.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
   // EXACT: z of the camera-2 points at the taps, W2.z = warped_p2_camera_2.z
-  const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
-  const float zn0 = (x0f * c.Ki[2] + y0f * c.Ki[5]) + c.Ki[8];
-  const float zn1 = (x1f * c.Ki[2] + y0f * c.Ki[5]) + c.Ki[8];
-  const float zs0 = (x0f * c.Ki[2] + y1f * c.Ki[5]) + c.Ki[8];
-  const float zs1 = (x1f * c.Ki[2] + y1f * c.Ki[5]) + c.Ki[8];
-  const float W2z = bilinear(dnw * zn0, dne * zn1, dsw * zs0, dse * zs1, w_nw, w_ne, w_sw, w_se);
+  float W2z;
+  if (PIN) {                                   // the four tap rays have z = (0 + 0) + 1
+    W2z = bilinear(dnw, dne, dsw, dse, w_nw, w_ne, w_sw, w_se);
+  } else {
+    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    const float zn0 = (x0f * c.Ki[2] + y0f * c.Ki[5]) + c.Ki[8];
+    const float zn1 = (x1f * c.Ki[2] + y0f * c.Ki[5]) + c.Ki[8];
+    const float zs0 = (x0f * c.Ki[2] + y1f * c.Ki[5]) + c.Ki[8];
+    const float zs1 = (x1f * c.Ki[2] + y1f * c.Ki[5]) + c.Ki[8];
+    W2z = bilinear(dnw * zn0, dne * zn1, dsw * zs0, dse * zs1, w_nw, w_ne, w_sw, w_se);
+  }
 
   // --- EXACT: dynamic reprojection  Q = (P1 + s - t2) @ R2T ; I = Q @ K
   const float A0 = (P0 + s0) - c.t2[0], A1 = (P1 + s1) - c.t2[1], A2 = (P2 + s2) - c.t2[2];
   float Q0, Q1, Q2, I0, I1, I2;
   rowvec_mat3(A0, A1, A2, c.R2T, Q0, Q1, Q2);
-  rowvec_mat3(Q0, Q1, Q2, c.K, I0, I1, I2);
+  if (PIN) {
+    I0 = Q0 * c.K[0] + Q2 * c.K[6];            // (Q0*fx + Q1*0) + Q2*cx
+    I1 = Q1 * c.K[4] + Q2 * c.K[7];
+    I2 = Q2;                                   // (0 + 0) + Q2*1
+  } else {
+    rowvec_mat3(Q0, Q1, Q2, c.K, I0, I1, I2);
+  }
   const float den = I2 + 1e-8f;
   const bool behind = I2 < 1e-3f;
   const float yden = rcp_refined(den);     // IEEE-exact quotients: sign(dflow - flow) must match the reference
@@ -193,14 +222,14 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
 
   // --- FAST: warped world point of frame 2, G = sum_k w_k (d2_k ray_k @ R2 + t2), via
   //     ray(x0+i, y0+j) = ray(x0,y0) + i*Ki[0,:] + j*Ki[1,:]
-  const float q0 = DVD_FMA(x0f, c.Ki[0], DVD_FMA(y0f, c.Ki[3], c.Ki[6]));
-  const float q1 = DVD_FMA(x0f, c.Ki[1], DVD_FMA(y0f, c.Ki[4], c.Ki[7]));
-  const float q2 = DVD_FMA(x0f, c.Ki[2], DVD_FMA(y0f, c.Ki[5], c.Ki[8]));
+  const float q0 = PIN ? DVD_FMA(x0f, c.Ki[0], c.Ki[6]) : DVD_FMA(x0f, c.Ki[0], DVD_FMA(y0f, c.Ki[3], c.Ki[6]));
+  const float q1 = PIN ? DVD_FMA(y0f, c.Ki[4], c.Ki[7]) : DVD_FMA(x0f, c.Ki[1], DVD_FMA(y0f, c.Ki[4], c.Ki[7]));
+  const float q2 = PIN ? 1.0f : DVD_FMA(x0f, c.Ki[2], DVD_FMA(y0f, c.Ki[5], c.Ki[8]));
   const float a_nw = w_nw * dnw, a_ne = w_ne * dne, a_sw = w_sw * dsw, a_se = w_se * dse;
   const float sE = a_ne + a_se, sS = a_sw + a_se, sA = (a_nw + a_ne) + sS;
-  const float V0 = DVD_FMA(q0, sA, DVD_FMA(c.Ki[0], sE, c.Ki[3] * sS));
-  const float V1 = DVD_FMA(q1, sA, DVD_FMA(c.Ki[1], sE, c.Ki[4] * sS));
-  const float V2 = DVD_FMA(q2, sA, DVD_FMA(c.Ki[2], sE, c.Ki[5] * sS));
+  const float V0 = PIN ? DVD_FMA(q0, sA, c.Ki[0] * sE) : DVD_FMA(q0, sA, DVD_FMA(c.Ki[0], sE, c.Ki[3] * sS));
+  const float V1 = PIN ? DVD_FMA(q1, sA, c.Ki[4] * sS) : DVD_FMA(q1, sA, DVD_FMA(c.Ki[1], sE, c.Ki[4] * sS));
+  const float V2 = PIN ? sA : DVD_FMA(q2, sA, DVD_FMA(c.Ki[2], sE, c.Ki[5] * sS));
   const float G0 = DVD_FMA(V0, c.R2[0], DVD_FMA(V1, c.R2[3], DVD_FMA(V2, c.R2[6], c.t2[0])));
   const float G1 = DVD_FMA(V0, c.R2[1], DVD_FMA(V1, c.R2[4], DVD_FMA(V2, c.R2[7], c.t2[1])));
   const float G2 = DVD_FMA(V0, c.R2[2], DVD_FMA(V1, c.R2[5], DVD_FMA(V2, c.R2[8], c.t2[2])));
@@ -241,9 +270,15 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
     const float rden = __builtin_amdgcn_rcpf(den);
     const float gI0 = gu * rden, gI1 = gv * rden;
     const float gI2 = -DVD_FMA(gu, u, gv * v) * rden;
-    gQ0 = DVD_FMA(gI0, c.K[0], DVD_FMA(gI1, c.K[1], gI2 * c.K[2]));
-    gQ1 = DVD_FMA(gI0, c.K[3], DVD_FMA(gI1, c.K[4], gI2 * c.K[5]));
-    gQ2 = DVD_FMA(gI0, c.K[6], DVD_FMA(gI1, c.K[7], gI2 * c.K[8]));
+    if (PIN) {
+      gQ0 = gI0 * c.K[0];
+      gQ1 = gI1 * c.K[4];
+      gQ2 = DVD_FMA(gI0, c.K[6], DVD_FMA(gI1, c.K[7], gI2));
+    } else {
+      gQ0 = DVD_FMA(gI0, c.K[0], DVD_FMA(gI1, c.K[1], gI2 * c.K[2]));
+      gQ1 = DVD_FMA(gI0, c.K[3], DVD_FMA(gI1, c.K[4], gI2 * c.K[5]));
+      gQ2 = DVD_FMA(gI0, c.K[6], DVD_FMA(gI1, c.K[7], gI2 * c.K[8]));
+    }
   }
   // The second loss term only reaches depth_2 through W2.z / G, both linear in disp_mul:
   // keep those two in units of disp_mul (`u*`), the IO policy multiplies it back.
@@ -272,7 +307,7 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
   const float gp0 = DVD_FMA(gA0, c.R1[0], DVD_FMA(gA1, c.R1[1], gA2 * c.R1[2]));
   const float gp1 = DVD_FMA(gA0, c.R1[3], DVD_FMA(gA1, c.R1[4], gA2 * c.R1[5]));
   const float gp2 = DVD_FMA(gA0, c.R1[6], DVD_FMA(gA1, c.R1[7], gA2 * c.R1[8]));
-  g_d1_out = DVD_FMA(gp0, r0, DVD_FMA(gp1, r1, gp2 * r2));
+  g_d1_out = PIN ? DVD_FMA(gp0, r0, DVD_FMA(gp1, r1, gp2)) : DVD_FMA(gp0, r0, DVD_FMA(gp1, r1, gp2 * r2));
   // depth_2 taps (units of disp_mul): d/d(d2_k) = w_k * (h . ray_k),  h = uG @ R2^T + (0,0,uW2z)
   float h0 = 0.0f, h1 = 0.0f, h2 = uW2z;
   if (loss_on_sf) {
@@ -281,10 +316,14 @@ __device__ __forceinline__ void pixel(const WarpArgs& a, const Cam& c, IO& io, i
     h2 += DVD_FMA(uG0, c.R2[6], DVD_FMA(uG1, c.R2[7], uG2 * c.R2[8]));
   }
   if (h0 != 0.0f || h1 != 0.0f || h2 != 0.0f) {
-    const float hb = DVD_FMA(h0, q0, DVD_FMA(h1, q1, h2 * q2));
-    const float hx = DVD_FMA(h0, c.Ki[0], DVD_FMA(h1, c.Ki[1], h2 * c.Ki[2]));
-    const float hy = DVD_FMA(h0, c.Ki[3], DVD_FMA(h1, c.Ki[4], h2 * c.Ki[5]));
-    io.scatter(o_n, x0, y0, in_e, in_s, w_nw * hb, w_ne * (hb + hx), w_sw * (hb + hy), w_se * ((hb + hx) + hy));
+    if (PIN && !loss_on_sf) {                  // h = (0, 0, uW2z): every tap ray has z = 1
+      io.scatter(o_n, x0, y0, in_e, in_s, w_nw * h2, w_ne * h2, w_sw * h2, w_se * h2);
+    } else {
+      const float hb = DVD_FMA(h0, q0, DVD_FMA(h1, q1, h2 * q2));
+      const float hx = PIN ? h0 * c.Ki[0] : DVD_FMA(h0, c.Ki[0], DVD_FMA(h1, c.Ki[1], h2 * c.Ki[2]));
+      const float hy = PIN ? h1 * c.Ki[4] : DVD_FMA(h0, c.Ki[3], DVD_FMA(h1, c.Ki[4], h2 * c.Ki[5]));
+      io.scatter(o_n, x0, y0, in_e, in_s, w_nw * hb, w_ne * (hb + hx), w_sw * (hb + hy), w_se * ((hb + hx) + hy));
+    }
   }
 }
 
@@ -364,7 +403,7 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
     for (int i = 0; i < PX; ++i) {
       gd1[i] = 0.0f;
       gs[i][0] = gs[i][1] = gs[i][2] = 0.0f;
-      pixel<GRADS, false>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
+      pixel<GRADS, false, false>(a, c, io, y, x + i, d1[i], fl[2 * i], fl[2 * i + 1], mk[i], s0[i], s1[i], s2[i], acc,
                           gd1[i], gs[i]);
     }
     if (GRADS) {
@@ -495,10 +534,21 @@ struct TileIO {
                                           float tsw, float tse) const {
     if (inside(x0, y0)) {
       unsigned long long* p = accw + (y0 - wy0) * WW + (x0 - wx0);
-      add_fixed(p, o_n, tnw);
-      if (in_e) add_fixed(p + 1, o_n + 1, tne);
-      if (in_s) add_fixed(p + WW, o_n + W, tsw);
-      if (in_e && in_s) add_fixed(p + WW + 1, o_n + W + 1, tse);
+      // A tap beyond the image's right / bottom edge has weight exactly 0 (the sampling coordinate is clamped to W-1 / H-1,
+      // so its fractional part is 0) and its window cell exists (`inside`) and is never read by the combine: all four adds
+      // are unconditional, and ONE magnitude test per pixel guards the fixed-point range (round 2: a branch per tap).
+      const float big = fmaxf(fmaxf(fabsf(tnw), fabsf(tne)), fmaxf(fabsf(tsw), fabsf(tse)));
+      if (big < kFixMax) {
+        atomicAdd(p, to_fixed(tnw));
+        atomicAdd(p + 1, to_fixed(tne));
+        atomicAdd(p + WW, to_fixed(tsw));
+        atomicAdd(p + WW + 1, to_fixed(tse));
+      } else {
+        add_fixed(p, o_n, tnw);
+        if (in_e) add_fixed(p + 1, o_n + 1, tne);
+        if (in_s) add_fixed(p + WW, o_n + W, tsw);
+        if (in_e && in_s) add_fixed(p + WW + 1, o_n + W + 1, tse);
+      }
     } else {
       spill(o_n, tnw);
       if (in_e) spill(o_n + 1, tne);
@@ -513,7 +563,17 @@ struct TileArgs {
   Overflow ovf;
   const int2* offs;   // per pair: window offset (multiple of 4 in x), written by warp_prep_kernel
   int ntx, nty;
+  int direct;         // 1: window cells no neighbouring window covers go straight to g_depth_2 (needs W % 4 == 0)
 };
+
+// The windows of adjacent tiles overlap by the halo: cell (wx, wy) of a tile's window is covered by that tile ALONE when
+// wx in [2R + 4, TW) and wy in [2R + 1, TH) (76 x 15 of the 116 x 49 cells of a 96 x 32 tile).  Those cells are final when
+// the tile is done: the tile kernel converts and stores them into g_depth_2 itself, only the ring goes through the slab and
+// the combine kernel (which skips the exclusive pixels).  Both kernels use this one predicate.
+template <int TW, int TH, int R>
+__device__ __forceinline__ bool tile_exclusive(int wx, int wy) {
+  return wx >= 2 * R + 4 && wx < TW && wy >= 2 * R + 1 && wy < TH;
+}
 
 __device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
   // dispatcher places block b on XCD b % 8 (speed only, never correctness)
@@ -553,6 +613,10 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   const int wx0 = tx0 - R + off.x, wy0 = ty0 - R + off.y;
   Cam c;
   load_cam(a, b, c);
+  // pinhole intrinsics without skew (exact zeros / one in K^T and (K^-1)^T): block-uniform, selects pixel<.., PIN = true>
+  const bool pinhole = c.Ki[1] == 0.0f && c.Ki[2] == 0.0f && c.Ki[3] == 0.0f && c.Ki[5] == 0.0f && c.Ki[8] == 1.0f &&
+                       c.K[1] == 0.0f && c.K[2] == 0.0f && c.K[3] == 0.0f && c.K[5] == 0.0f && c.K[8] == 1.0f &&
+                       DVD_WARP_PINHOLE;
   // The 51 camera scalars are wave-uniform; left alone they all land in SGPRs and push the
   // kernel past the 102-SGPR file (hundreds of v_readlane spill reloads).  Pin the three
   // matrices used mostly by the FMA-heavy parts into VGPRs instead.
@@ -651,6 +715,8 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
       }
     }
   };
+  auto tile_pixels = [&](auto pin_tag) {
+  constexpr bool PIN = decltype(pin_tag)::value;
   In cur, nxt;
   fetch(threadIdx.x, cur);
   for (int q = threadIdx.x; q < QW * TH; q += NT) {
@@ -666,7 +732,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
         float gs[3] = {0.0f, 0.0f, 0.0f};
         gd1[i] = 0.0f;
         if (i < nvalid)
-          pixel<GRADS, SHIPPED>(a, c, io, y, x + i, cur.d1[i], cur.fl[2 * i], cur.fl[2 * i + 1], cur.mk[i], cur.s0[i],
+          pixel<GRADS, SHIPPED, PIN>(a, c, io, y, x + i, cur.d1[i], cur.fl[2 * i], cur.fl[2 * i + 1], cur.mk[i], cur.s0[i],
                                 cur.s1[i], cur.s2[i], acc, gd1[i], gs);
         g0[i] = gs[0];
         g1[i] = gs[1];
@@ -694,16 +760,28 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
     else
       fetch(q + NT, cur);
   }
+  };
+  if (pinhole)
+    tile_pixels(std::true_type{});
+  else
+    tile_pixels(std::false_type{});
   // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
   __syncthreads();
   if (GRADS) {
     float* slab = ta.slabs + (size_t)logical * (WW * WH);
+    float* gb = a.g_d2 + (size_t)b * a.HW;
     const float back = kFixInv * a.disp_mul;
     for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
       const longlong2 lo = reinterpret_cast<const longlong2*>(accw)[2 * i];
       const longlong2 hi = reinterpret_cast<const longlong2*>(accw)[2 * i + 1];
-      reinterpret_cast<float4*>(slab)[i] =
-          make_float4((float)lo.x * back, (float)lo.y * back, (float)hi.x * back, (float)hi.y * back);
+      const float4 v = make_float4((float)lo.x * back, (float)lo.y * back, (float)hi.x * back, (float)hi.y * back);
+      const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
+      if (ta.direct && tile_exclusive<TW, TH, R>(wx, wy)) {
+        const int x = wx0 + wx, y = wy0 + wy;          // x is a multiple of 4 (R, the offset and the tile origin are)
+        if (x >= 0 && x < a.W && y >= 0 && y < a.H) *reinterpret_cast<float4*>(gb + (size_t)y * a.W + x) = v;
+      } else {
+        reinterpret_cast<float4*>(slab)[i] = v;
+      }
     }
   }
   float* red = win;  // window no longer needed
@@ -749,7 +827,7 @@ __global__ __launch_bounds__(64) void warp_prep_kernel(const float* __restrict__
 template <int TW, int TH, int R>
 __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ slabs, const int2* __restrict__ offs,
                                                             float* __restrict__ g_d2, int H, int W, int ntx,
-                                                            int nty, int total_quads) {
+                                                            int nty, int total_quads, int direct) {
   constexpr int WW = TW + 2 * R + 4;
   constexpr int WH = TH + 2 * R + 1;
   static_assert(2 * R + 4 <= TW && 2 * R + 1 <= TH, "only adjacent tiles may overlap a pixel");
@@ -762,6 +840,8 @@ __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restr
   const int2 off = offs[b];
   const int xs = x - off.x, ys = y - off.y;          // coordinates in the pair's shifted tile grid
   const int ti = xs >= 0 ? xs / TW : -((TW - 1 - xs) / TW), tj = ys >= 0 ? ys / TH : -((TH - 1 - ys) / TH);
+  // written by the pixel's own tile (tile_exclusive; a quad is exclusive as a whole: every bound is a multiple of 4)
+  if (direct && ti >= 0 && ti < ntx && tj >= 0 && tj < nty && tile_exclusive<TW, TH, R>(xs - ti * TW + R, ys - tj * TH + R)) return;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int dj = -1; dj <= 1; ++dj) {
@@ -956,6 +1036,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.offs = offs;
   ta.ntx = p.ntx;
   ta.nty = p.nty;
+  ta.direct = ((a.W & 3) == 0 && DVD_WARP_DIRECT_INTERIOR) ? 1 : 0;
   const int nblocks = p.ntx * p.nty * a.B;
   const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
   // launch sequence: prep (counter + window offsets) -> tile kernel -> slab combine -> finish
@@ -989,7 +1070,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
     const int qpr = (a.W + 3) / 4;
     const int total_quads = qpr * a.H * a.B;
     hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, stream,
-                       ta.slabs, (const int2*)offs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads);
+                       ta.slabs, (const int2*)offs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads, ta.direct);
     DVD_LAUNCH_OK();
   }
   // partial-sum reduction and overflow records in one launch

@@ -145,8 +145,12 @@ struct XArgs {
 // wave-uniform SGPR offset, halo and padding items carry an out-of-range offset and read 0 from the hardware's bounds check.
 // The generic path (64-bit per-element addresses, per-element clamps and selects) spent ~150 VALU instructions per staged
 // item and chunk, ~35 of them the fp32 -> 3 x bf16 split itself; FAST leaves the split (+ ReLU) and three LDS stores.
-template <int TM, int TN, int WM, int WN, int FIT, bool FAST>
-__global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
+// B1: ONE activation stage in LDS instead of two (an extra barrier at the end of each chunk separates the last fragment reads
+// from the next chunk's stores): 42 KB per 128 x 128 block, so three blocks share a CU (3 waves per SIMD).  The counters of
+// round 2 show the matrix pipe 60 % busy with two waves per SIMD -- each wave needs it 45 % of its time, the rest is barrier
+// skew, LDS latency and staging -- and independent blocks are what fills the gaps.
+template <int TM, int TN, int WM, int WN, int FIT, bool FAST, bool B1 = false>
+__global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const XArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr bool kDirect = FIT == 0;             // big halos (k >= 5): stage without the register prefetch
   constexpr int FI = kDirect ? 1 : FIT;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
   constexpr int AS = AI * NT;                    // LDS cells per A stage (>= AU)
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   u32x4* sA = smem;                              // [2][AS] : [MT][3][64] + padding
-  u32x4* sB = smem + 2 * AS;                     // [2][term 3][channel group 2][npos]
+  u32x4* sB = smem + 2 * AS;                     // [2 | 1][term 3][channel group 2][npos]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int tr = blockIdx.x / a.ntc, tc = blockIdx.x - tr * a.ntc;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
     }
   };
   auto split_write = [&](int buf, int kc) {
-    u32x4* dst = sB + buf * 6 * npos;
+    u32x4* dst = sB + (B1 ? 0 : buf * 6 * npos);
 #pragma unroll
     for (int it = 0; it < FI; ++it) {
       const int ch0 = kc * 16 + cig8[it];
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
 
   // direct staging (kDirect): load, split and store item by item, nothing kept in registers across the MFMAs
   auto stage_direct = [&](int buf, int kc) {
-    u32x4* dst = sB + buf * 6 * npos;
+    u32x4* dst = sB + (B1 ? 0 : buf * 6 * npos);
     for (int it = 0; it < a.nfi; ++it) {
       const int item = it * NT + tid;
       const int cig = item >= a.NV ? 1 : 0;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
   };
   auto read_frags = [&](Frag& f, int abuf, int kc, int off) {
     const u32x4* Ac = sA + abuf * AS + al;
-    const u32x4* Bc = sB + (kc & 1) * 6 * npos + bl + off;
+    const u32x4* Bc = sB + (B1 ? 0 : (kc & 1) * 6 * npos) + bl + off;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -412,6 +416,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
       kx = 0;
       if (++ky == KS) {                             // last tap of the chunk (block-uniform)
         ky = 0;
+        if (B1) __syncthreads();                    // every wave has read this chunk's last fragments
         if (kDirect) {
           if (kc + 1 < a.nkc) stage_direct((kc + 1) & 1, kc + 1);
         } else {
@@ -522,6 +527,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void xconv_kernel(const XArgs a) {
 // ---- host side ------------------------------------------------------------------------------------------------
 struct XCfg {
   int TM, TN, WM, WN;
+  bool b1 = false;        // single activation stage, three blocks per CU
   int blockM() const { return TM * WM * 32; }
   int NQ() const { return TN * WN * 32; }
   int NT() const { return 64 * WM * WN; }
@@ -532,10 +538,12 @@ struct XCfg {
 // fragment reads per K step, round 2: 24 against 12) -- 256 x 128 positions at two blocks per CU for 1x1 kernels, 256 x 256
 // positions in ONE 512-thread block per CU for k >= 3 (the haloed tile of 256 positions needs ~120 KB of LDS).
 static int g_xcfg = 0;    // test / A-B hook (dvd_xconv_select): 0 auto, 1 round-2 shapes only, 2 force 256x128, 3 force 256x256,
-                          // 4 round-2 shapes on the generic (pointer-addressed) main loop
+                          // 4 round-2 shapes on the generic (pointer-addressed) main loop, 5 128 x 128 blocks with one
+                          // activation stage at three blocks per CU
 static XCfg pick_cfg(int M, int KS) {
   if (M <= 32) return {1, 2, 1, 4};     // 32 channels x 256 positions
   if (M <= 64) return {2, 2, 1, 4};     // 64 x 256
+  if (M > 64 && g_xcfg == 5) return {2, 2, 2, 2, true};
   if (M >= 256 && g_xcfg != 1 && g_xcfg != 4) {
     if (g_xcfg == 2) return {4, 2, 2, 2};
     if (g_xcfg == 3) return {4, 2, 2, 4};
@@ -554,7 +562,7 @@ struct XTile {
 static size_t xconv_lds(const XCfg& c, int npos) {
   const int AU = c.WM * c.TM * 192, NT = c.NT();
   const int AS = (AU + NT - 1) / NT * NT;
-  return ((size_t)2 * AS + (size_t)12 * npos) * sizeof(uint4);
+  return ((size_t)2 * AS + (size_t)(c.b1 ? 6 : 12) * npos) * sizeof(uint4);
 }
 // Tile of the image per block: TR x TC outputs, TR * (TC + 2 pad) <= NQ positions; choose the split of the
 // width that wastes the fewest positions, subject to the LDS budget and the staging-iteration bound.
@@ -592,10 +600,11 @@ static bool pick_tile_budget(int H, int W, int KS, const XCfg& c, XTile& best, i
 static bool pick_tile(int H, int W, int KS, const XCfg& c, XTile& best) {
   // two blocks per CU where the haloed tile allows it, one block (big kernels: k >= 7; the 512-thread shape) otherwise
   if (c.NT() >= 512) return pick_tile_budget(H, W, KS, c, best, 156 * 1024);
+  if (c.b1) return pick_tile_budget(H, W, KS, c, best, 52 * 1024);        // three blocks per CU, or not this shape
   return pick_tile_budget(H, W, KS, c, best, kXLdsBudget) || pick_tile_budget(H, W, KS, c, best, 156 * 1024);
 }
 
-template <int TM, int TN, int WM, int WN, bool FAST>
+template <int TM, int TN, int WM, int WN, bool FAST, bool B1 = false>
 static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t s) {
   auto go = [&](auto kern) -> int {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -604,10 +613,10 @@ static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t 
     return DVD_OK;
   };
   switch (FI) {
-    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1, FAST>);
-    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2, FAST>);
-    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3, FAST>);
-    default: return go(xconv_kernel<TM, TN, WM, WN, 0, FAST>);
+    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1, FAST, B1>);
+    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2, FAST, B1>);
+    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3, FAST, B1>);
+    default: return go(xconv_kernel<TM, TN, WM, WN, 0, FAST, B1>);
   }
 }
 
@@ -658,7 +667,7 @@ int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int K
 }
 
 int dvd_xconv_select(int cfg) {
-  DVD_REQUIRE(cfg >= 0 && cfg <= 4, "xconv_select: cfg %d", cfg);
+  DVD_REQUIRE(cfg >= 0 && cfg <= 5, "xconv_select: cfg %d", cfg);
   dvd::g_xcfg = cfg;
   return DVD_OK;
 }
@@ -680,13 +689,15 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   // inside the packed weights of one block row
   const bool fast = (Cin % 16 == 0) && ((long long)Cin * H * W * 4 < (1ll << 31)) &&
                     ((long long)8 * ((Cin + 15) / 16) * KS * KS * 3072 < (1ll << 31)) && dvd::g_xcfg != 4;
-  const dvd::XCfg c = dvd::pick_cfg(fast ? Cout : (Cout < 128 ? Cout : 128), KS);   // the wide shapes exist as FAST kernels only
+  dvd::XCfg c = dvd::pick_cfg(fast ? Cout : (Cout < 128 ? Cout : 128), KS);
+  if (!fast) c.b1 = false;   // the wide shapes exist as FAST kernels only
   int Hh = H, Ww = W;
   if (KS == 1) {           // no spatial structure: one row of H * W positions
     Hh = 1;
     Ww = H * W;
   }
   dvd::XTile t;
+  if (c.b1 && !dvd::pick_tile(Hh, Ww, KS, c, t)) c.b1 = false;     // (large kernels: the haloed tile needs more LDS)
   DVD_REQUIRE(dvd::pick_tile(Hh, Ww, KS, c, t), "xconv: no tile of a %dx%d image with a %dx%d kernel fits the LDS", H, W, KS, KS);
   dvd::XArgs a;
   a.x = x;
@@ -716,6 +727,7 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   if (fast) {
     if (c.TM == 4 && c.WN == 4) return dvd::launch_fi<4, 2, 2, 4, true>(a, t.FI, grid, lds, s);
     if (c.TM == 4) return dvd::launch_fi<4, 2, 2, 2, true>(a, t.FI, grid, lds, s);
+    if (c.WM == 2 && c.b1) return dvd::launch_fi<2, 2, 2, 2, true, true>(a, t.FI, grid, lds, s);
     if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2, true>(a, t.FI, grid, lds, s);
     if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4, true>(a, t.FI, grid, lds, s);
     return dvd::launch_fi<1, 2, 1, 4, true>(a, t.FI, grid, lds, s);

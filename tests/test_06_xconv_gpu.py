@@ -133,7 +133,7 @@ def test_block_shapes_give_identical_results(KS):
     lib = _lib.load()
     outs = []
     try:
-        for cfg in (0, 1, 2, 3, 4):
+        for cfg in (0, 1, 2, 3, 4, 5):
             _lib.check(lib.dvd_xconv_select(cfg), 'dvd_xconv_select')
             xg = x.clone().requires_grad_(True)
             y = C.xconv2d(conv, xg, relu_in=True, residual=res, res_relu=True)

@@ -37,6 +37,8 @@ def timeit(fn, iters):
 def main():
     only = sys.argv[1:]
     shapes = SHAPES[:int(os.environ.get('XCONV_NSHAPES', len(SHAPES)))]
+    if os.environ.get('XCONV_ONLY'):                          # comma-separated indices into SHAPES
+        shapes = [SHAPES[int(i)] for i in os.environ['XCONV_ONLY'].split(',')]
     nmul = int(os.environ.get('XCONV_NMUL', '1'))            # 3: the 48-image chunks of the bench
     cfg = int(os.environ.get('XCONV_CFG', '0'))              # dvd_xconv_select: 0 auto, 1 round-2 blocks, 2/3 forced, 4 generic loop
     from dvd_hip import _lib
