@@ -1,9 +1,11 @@
 """Parity of the fused scene-flow MLP kernels (through the C ABI) with the
 golden fixture generated from the real reference network and with the oracle.
-Tolerances (fp32 MFMA = exact fp32 FMA chains vs MKL sgemm accumulation order):
-  forward           rtol 1e-4, atol 1e-6
-  d/dx              rtol 1e-3 of max|g|
-  weight/bias grads rtol 1e-3 of per-tensor max|g|
+Arithmetic: 3-term split-bf16 MFMA products with fp32 accumulation (csrc/sf_mlp.hip) against MKL sgemm on the CPU.
+Tolerances = about 4x the worst value measured on MI355X (round 3, gpurun_out/r03a/parity.jsonl: every gradient tensor
+agrees to 2.6e-6 of its largest element, median 2e-7; the values are appended to $DVD_PARITY_LOG on every run):
+  forward           rtol 1e-4, atol 2e-6
+  d/dx              1e-5 of max|g|   (at most 6 elements = 2 LeakyReLU'-sign-flip pixels beyond it, see _close)
+  weight/bias grads 1e-5 of per-tensor max|g|
 """
 import numpy as np
 import pytest
@@ -61,9 +63,9 @@ def test_module_forward_backward_vs_golden():
     y = net(x, tt)
     np.testing.assert_allclose(y.detach().cpu().numpy(), gd['out_y'], rtol=1e-4, atol=2e-6)
     (y * t(gd['up_y']).cuda()).sum().backward()
-    _close(x.grad.cpu().numpy(), gd['g_x'], 1e-3, 'g_x')
+    _close(x.grad.cpu().numpy(), gd['g_x'], 1e-5, 'g_x')
     for k, p in net.named_parameters():
-        _close(p.grad.cpu().numpy(), gd['gsd_' + k], 1e-3, k)
+        _close(p.grad.cpu().numpy(), gd['gsd_' + k], 1e-5, k)
 
 
 @pytest.mark.parametrize('B,H,W', [(1, 8, 8), (2, 24, 40), (3, 17, 23)])
@@ -86,9 +88,9 @@ def test_forward_backward_vs_oracle_ragged(B, H, W):
     yg = net(xg, tt.cuda())
     (yg * up.cuda()).sum().backward()
     np.testing.assert_allclose(yg.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=2e-6)
-    _close(xg.grad.cpu().numpy(), xr.grad.numpy(), 1e-3, 'g_x', max_outliers=6)   # <= 2 sign-flip pixels
+    _close(xg.grad.cpu().numpy(), xr.grad.numpy(), 1e-5, 'g_x', max_outliers=6)   # <= 2 sign-flip pixels
     for k, p in net.named_parameters():
-        _close(p.grad.cpu().numpy(), sdr[k].grad.numpy(), 2e-2, k)
+        _close(p.grad.cpu().numpy(), sdr[k].grad.numpy(), 1e-5, k)
 
 
 def test_euler_steps_fused_bookkeeping():

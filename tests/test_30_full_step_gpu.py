@@ -3,10 +3,21 @@ reference `Model._train_on_batch` on CPU (tests/golden/make_golden.py::case_full
 batch_log values, the norm of every parameter gradient, selected gradients element by
 element, and the parameters after the Adam step.
 
-Tolerances: losses rtol 2e-4 (fp32, different reduction order); gradient norms rtol 5e-3,
-elements 2e-3 (MLP) / 2e-2 (depth net) of max|g|
-(MIOpen vs MKL-DNN convolution accumulation order; rare LeakyReLU'/ReLU' sign flips at
-pre-activations within fp32 noise of 0); parameters after the step atol 3*lr.
+Tolerances = about 2.5x the worst value MEASURED on MI355X with this package's own (deterministic) kernels
+(round 3, gpurun_out/r03a/parity.jsonl; every run prints its measured values and appends them to $DVD_PARITY_LOG):
+
+  quantity                                   measured worst                      tolerance
+  logged losses (rel)                        1.7e-6                              1e-5
+  acc_reg (rel)                              5.1e-7                              5e-6
+  per-parameter gradient norms (rel)         5.6e-4 (3.1e-3 on midas_b1_64x96)   1.5e-3 (8e-3)
+  MLP gradient elements / max|g|             3.8e-4                              1e-3
+  depth-net gradient elements / max|g|       2.9e-3 (8.5e-3 on midas_b1_64x96)   8e-3 (2e-2)
+
+What is left is not this package's arithmetic (at the benchmark's size, against the same ATen CPU kernels, the gradient norms
+agree to 1.9e-5: tests/test_31_benchmark_size_parity_gpu.py) but ReLU' / LeakyReLU' sign flips at pre-activations within
+fp32 noise of 0, which the tiny fixtures amplify: midas_b1_64x96 has a 2x3-pixel deepest level, and two CPU runs of the
+REAL reference on it (the fixture was regenerated in round 3 on another host) differ by 3e-4 in the MLP gradients and
+8e-5 in the depth-net gradients themselves.  Parameters after the step: atol 3*lr.
 """
 import os
 from types import SimpleNamespace
@@ -54,8 +65,10 @@ def test_train_on_batch_matches_reference(name):
     torch.cuda.synchronize()
     assert log['size'] == opt.batch_size
     for k in ('loss', 'total_loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss'):
-        np.testing.assert_allclose(log[k], float(gd['log_' + k]), rtol=2e-4, err_msg=k)
-    np.testing.assert_allclose(log['acc_reg'], float(gd['log_acc_reg']), rtol=2e-3, atol=1e-9)
+        np.testing.assert_allclose(log[k], float(gd['log_' + k]), rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(log['acc_reg'], float(gd['log_acc_reg']), rtol=5e-6, atol=1e-9)
+    tiny = name == 'fullstep_midas_b1_64x96_train'          # ill-conditioned: see the module docstring
+    norm_tol, depth_tol = (8e-3, 2e-2) if tiny else (1.5e-3, 8e-3)
     names = [str(n) for n in gd['param_names']]
     want_g = dict(zip(names, gd['grad_norms']))
     want_p = dict(zip(names, gd['param_norms_after']))
@@ -72,7 +85,7 @@ def test_train_on_batch_matches_reference(name):
             got = float(p.grad.double().norm())
             rel = abs(got - want_g[key]) / want_g[key]
             worst = max(worst, rel)
-            assert rel < 5e-3, '%s grad norm %g vs %g' % (key, got, want_g[key])
+            assert rel < norm_tol, '%s grad norm %g vs %g' % (key, got, want_g[key])
             # Adam's first step moves every element by ~lr*sign(g): elements whose gradient is within
             # rounding of 0 may move the other way, so the norm is only pinned to 2*lr*sqrt(n)
             lr = opt.lr * (opt.scene_lr_mul if prefix == 'sf' else 1.0)
@@ -84,10 +97,8 @@ def test_train_on_batch_matches_reference(name):
         want = gd[k]
         scale = np.abs(want).max()
         err = np.abs(p.grad.cpu().numpy() - want) / scale
-        # scene-flow MLP: 2e-3 of max|g|.  Depth net: the stem gradient has crossed 100+ MIOpen
-        # convolutions and ReLUs evaluated in a different fp32 order than MKL-DNN (measured worst
-        # 6.6e-3 on the 7x7 stem of ResNeXt-101 with random weights) -> 2e-2.
-        tol = 2e-3 if prefix == 'g_sf' else 2e-2
+        # scene-flow MLP: 1e-3 of max|g|; depth net: the stem gradient has crossed 100+ convolutions and ReLUs
+        tol = 1e-3 if prefix == 'g_sf' else depth_tol
         measured['elem_' + k] = float(err.max())
         assert (err > tol).sum() <= max(2, want.size // 5000), '%s: %d elements off (worst %.2e)' % (
             k, (err > tol).sum(), err.max())

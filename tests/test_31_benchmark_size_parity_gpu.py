@@ -3,9 +3,10 @@ Model against the CPU oracle's step (oracle/train_step.py, pinned to the real re
 tests/golden/fullstep_*.npz) on the same frame pair and the same seeded weights -- the comparison `bench.py` reports as
 `parity` next to `cpu_baseline`.  One pair: the reference path needs > 60 GB of autograd state per pair at this size.
 
-Tolerances (fp32; different reduction orders; split-bf16 MFMA products <= 2.5e-6 of max|y|): losses rtol 2e-4, acc_reg
-rtol 2e-3, per-parameter gradient norms of the depth net 5e-3, MLP gradient elements 2e-3 of the tensor's largest element.
-The measured values are printed and written to $DVD_PARITY_LOG (json lines) when set."""
+Tolerances = about 3-5x the values measured on MI355X (round 3, gpurun_out/r03a/parity.jsonl: losses 6e-8 .. 1.9e-7,
+acc_reg 3e-9, worst per-parameter gradient norm of the depth net 1.9e-5, worst MLP gradient element 4.2e-5 of its tensor's
+largest): losses rtol 2e-6, acc_reg 1e-6, gradient norms 1e-4, MLP elements 2e-4.  The measured values are printed and
+written to $DVD_PARITY_LOG (json lines) when set."""
 import json
 import os
 
@@ -23,9 +24,9 @@ def test_hip_step_matches_the_oracle_at_384x672():
     if os.environ.get('DVD_PARITY_LOG'):
         with open(os.environ['DVD_PARITY_LOG'], 'a') as f:
             f.write(json.dumps({'test': 'benchmark_size', **par}) + '\n')
-    assert par['rel'] < 2e-4
+    assert par['rel'] < 2e-6
     for k in ('flow_loss_1_2', 'disp_loss_1_2', 'sf_loss'):
-        assert par[k + '_rel'] < 2e-4, k
-    assert par['acc_reg_rel'] < 2e-3
-    assert par['depth_grad_norm_worst_rel'] < 5e-3, par['depth_grad_norm_worst_param']
-    assert par['mlp_grad_worst_of_max'] < 2e-3
+        assert par[k + '_rel'] < 2e-6, k
+    assert par['acc_reg_rel'] < 1e-6
+    assert par['depth_grad_norm_worst_rel'] < 1e-4, par['depth_grad_norm_worst_param']
+    assert par['mlp_grad_worst_of_max'] < 2e-4
