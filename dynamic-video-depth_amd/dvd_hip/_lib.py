@@ -17,7 +17,7 @@ c_float = ctypes.c_float
 c_void_p = ctypes.c_void_p
 
 DVD_OK, DVD_EINVAL, DVD_EHIP, DVD_ENOSPC = 0, -1, -2, -3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Cameras(ctypes.Structure):
@@ -108,15 +108,16 @@ SIGNATURES = {
                                             c_int, c_int, c_void_p]),
     'dvd_xconv_packed_bytes': (c_size_t, [c_int] * 5),
     'dvd_xconv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    'dvd_xconv_fwd': (c_int, [c_void_p] * 5 + [ctypes.POINTER(BnParams), c_void_p] + [c_int] * 8 + [c_void_p]),
+    'dvd_amax': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    'dvd_xconv_fwd': (c_int, [c_void_p] * 6 + [ctypes.POINTER(BnParams), c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     'dvd_xconv_select': (c_int, [c_int]),
     'dvd_xconv_pack_scaled': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                       c_void_p]),
     'dvd_convbn_finalize': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'dvd_xwgrad3_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad1s_workspace_bytes': (c_size_t, [c_int] * 5),
-    'dvd_xwgrad1s': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 6 + [c_void_p]),
-    'dvd_xwgrad3': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 7 + [c_void_p]),
+    'dvd_xwgrad1s': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 6 + [c_void_p]),
+    'dvd_xwgrad3': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     'dvd_xwgrad_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad': (c_int, [c_void_p] * 4 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     'dvd_flow_consistency_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

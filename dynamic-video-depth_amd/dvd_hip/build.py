@@ -31,6 +31,7 @@ SOURCES = [
     ('surfaces.hip', ['-ffp-contract=off']),
     ('upsample.hip', ['-ffp-contract=off']),
     ('bnrelu.hip', []),
+    ('amax.hip', []),
     ('xconv.hip', []),
     ('xwgrad.hip', []),
     ('xwgrad3.hip', []),

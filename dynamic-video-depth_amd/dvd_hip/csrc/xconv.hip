@@ -1,5 +1,5 @@
 // Dense stride-1 "same" convolution (1x1, 3x3, ... odd k x k), NCHW fp32 in / fp32 out, as an
-// implicit GEMM on the bf16 matrix cores of gfx950 with fp32-class accuracy: forward and
+// implicit GEMM on the 16-bit matrix cores of gfx950 with fp32-class accuracy: forward and
 // backward-data (the same kernel with the weights packed transposed and the taps flipped).
 //
 // What it replaces (reference, /root/reference): every dense nn.Conv2d of the depth networks --
@@ -10,53 +10,36 @@
 // and their autograd backward w.r.t. the input (MIOpen: fp32 Winograd / Tensile GEMMs + layout
 // transposes in profiles/r01_bench_kernel_trace_summary.txt).
 //
-// Arithmetic.  gfx950 has no TF32-like fast path for fp32 operands: v_mfma_f32_32x32x2_f32 runs at the
-// fp32 VECTOR rate (157 TF), 1/16 of the bf16 matrix rate.  So every fp32 operand is split exactly into
-// three bf16 terms  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); 24 significant
-// bits, the residuals are exact in fp32) and a product  x*w  is evaluated as the six largest of the
-// nine partial products  hh' + hm' + mh' + mm' + hl' + lh',  each on v_mfma_f32_32x32x16_bf16 with
-// fp32 accumulation.  The dropped terms (ml', lm', ll') are below 2^-23 |x w|: the result carries about
-// one more ulp of error per product than an fp32 FMA chain (far below the difference between two fp32
-// summation orders over K = 2304 terms) at 16/6 = 2.7x the fp32 MFMA rate.
+// Arithmetic (csrc/dvd_split.h): every fp32 operand, scaled by a power of two taken from its tensor's max|.|, is split
+// into two fp16 terms x * 2^e = h + l (22 significant bits) and a product is the three partial products l*h' + h*l' + h*h' on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation, unscaled (exactly) in the epilogue.  Round 2 used three bf16 terms and six
+// products; the matrix pipe is power limited, so halving the MFMAs per product is what moves the rate (183 -> ~300 TF/s on
+// the decoder's 3x3 convolution in a timing-only build, profiles/r03_xconv_power_limit.txt) at the same measured error
+// against float64 (<= 4e-6 of max|y|, tests/test_06_xconv_gpu.py).
 //
 // Mapping.  GEMM M = output channel, N = pixel, K = input channel (x taps).  D tile 32x32
 // (row = channel, column = pixel; accumulator layout of the 32x32 MFMAs: row = (r&3) + 8 (r>>2) + 4 (lane>>5),
 // column = lane & 31).  One K step = 16 input channels: lane l holds A[m = l&31][k = 8 (l>>5) .. +7] and
-// B[k = 8 (l>>5) .. +7][n = l&31] as eight bf16 (16 bytes) per split term.
+// B[k = 8 (l>>5) .. +7][n = l&31] as eight fp16 (16 bytes) per split term.
 //   * weights: packed once per weight update (dvd_xconv_pack) into fragment order, already split; per K step
 //     (16 channels x one tap) the block copies its A fragments L2 -> registers -> LDS two steps ahead of use
 //     (first version: every wave streamed its own fragments from L2 -- 15 GB of L1 traffic per decoder
 //     convolution, the kernel ran at the L1 rate, not the MFMA rate).
 //   * activations: a block owns a TR x TC tile of one image and all input channels in chunks of 16.  The
 //     chunk's haloed tile is read from HBM as fp32 (coalesced along x), split, and written to LDS as
-//     [term][channel group of 8][position][8 bf16]; positions are linear in the PADDED tile,
+//     [term][channel group of 8][position][8 fp16]; positions are linear in the PADDED tile,
 //     q = r * (TC + 2 pad) + c, so the B fragment of tap (ky, kx) is the fragment of the centre tap at a
 //     constant LDS offset ky * P + kx -- 32 consecutive 16-byte cells, conflict free -- and an N tile of 32
 //     consecutive q may straddle rows (the 2 pad columns per row are computed and dropped).  The raw fp32
 //     values of the next chunk are requested before the MFMAs of the current one.
 //   * epilogue: + bias[co], + residual (optionally relu'd), * [mask_src > 0], ReLU; coalesced stores.
-#include "dvd_common.h"
+#include "dvd_split.h"
 
 namespace dvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of it stay in registers
-
-// (a, b) -> three dwords of two bf16 each: a in the low half, b in the high half
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  const f32x2 v = {a, b};
-  const bf16x2 hb = __builtin_convertvector(v, bf16x2);
-  const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
-  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
-  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
-  h = __builtin_bit_cast(unsigned, hb);
-  m = __builtin_bit_cast(unsigned, mb);
-  l = __builtin_bit_cast(unsigned, lb);
-}
 
 // A pointer the compiler can see is wave-uniform (block indices divided by run-time values pass through VGPRs): buffer
 // resources must sit in SGPRs, a resource of unknown uniformity costs a waterfall loop around every load.
@@ -67,20 +50,35 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
-__device__ __forceinline__ void split8(const float v[8], uint4& h, uint4& m, uint4& l) {
-  split_pair(v[0], v[1], h.x, m.x, l.x);
-  split_pair(v[2], v[3], h.y, m.y, l.y);
-  split_pair(v[4], v[5], h.z, m.z, l.z);
-  split_pair(v[6], v[7], h.w, m.w, l.w);
-}
-
-// packed[(((mt * nkc + kc) * T + tap) * 3 + term) * 64 + lane] : 8 bf16
+// Packed weights: a 256-byte header (float 0: max|A| over the whole tensor, written by xconv_wamax_kernel) followed by
+// frag[(((mt * nkc + kc) * T + tap) * 2 + term) * 64 + lane] : 8 fp16 of A * pow2_scale(max|A|)
 //   forward:    A[m][k] = w[co = m][ci = k][tap]
 //   transposed: A[m][k] = w[co = k][ci = m][T - 1 - tap]      (backward-data: roles swapped, taps flipped)
 // rows m >= M and columns k >= K are zero (M, K are padded to the block / K-step granularity).
 // Grouped convolutions: Cout / Cin are per group, w is [G * Cout][Cin][T]; group g's fragments follow group g - 1's.
 // sc_gamma / sc_var (optional): every weight of output channel co is multiplied by gamma[co] / sqrt(var[co] + eps) (gamma
 // null = 1) -- the backward-data pass of a convolution whose eval-mode BatchNorm is fused into its epilogue.
+constexpr int kXHeader = 16;       // uint4 cells in front of the fragments
+
+// value of A's element as the pack kernel sees it (BatchNorm scale folded in): shared by the amax and the pack kernels
+__device__ __forceinline__ float xconv_weight(const float* __restrict__ w, int co_g, int idx, const float* __restrict__ sc_gamma,
+                                              const float* __restrict__ sc_var, float sc_eps) {
+  float val = w[idx];
+  if (sc_var) val *= (sc_gamma ? sc_gamma[co_g] : 1.0f) / sqrtf(sc_var[co_g] + sc_eps);
+  return val;
+}
+
+// max |w[co][...]| * |bn scale[co]| over all weights -> header (zeroed by a memset node before)
+__global__ __launch_bounds__(256) void xconv_wamax_kernel(const float* __restrict__ w, float* __restrict__ header, int rows,
+                                                          int row_len, const float* __restrict__ sc_gamma,
+                                                          const float* __restrict__ sc_var, float sc_eps) {
+  const long long total = (long long)rows * row_len;
+  float m = 0.0f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    m = fmaxf(m, fabsf(xconv_weight(w, (int)(i / row_len), (int)i, sc_gamma, sc_var, sc_eps)));
+  wave_amax_to(m, header);
+}
+
 __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
                                                          int Cin, int T, int transposed, int mtiles, int nkc, int G,
                                                          const float* __restrict__ sc_gamma, const float* __restrict__ sc_var,
@@ -105,16 +103,15 @@ __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict
     float val = 0.0f;
     if (m < M && k < K) {
       const int co = transposed ? k : m, ci = transposed ? m : k, tp = transposed ? T - 1 - tap : tap;
-      val = w[((size_t)co * Cin + ci) * T + tp];
-      if (sc_var) val *= (sc_gamma ? sc_gamma[g * Cout + co] : 1.0f) / sqrtf(sc_var[g * Cout + co] + sc_eps);
+      val = xconv_weight(w, g * Cout + co, (int)(((size_t)co * Cin + ci) * T + tp), sc_gamma, sc_var, sc_eps);
     }
     v[e] = val;
   }
-  uint4 h, mm, l;
-  split8(v, h, mm, l);
-  packed[(f * 3 + 0) * 64 + lane] = h;
-  packed[(f * 3 + 1) * 64 + lane] = mm;
-  packed[(f * 3 + 2) * 64 + lane] = l;
+  const float sw = pow2_scale(reinterpret_cast<const float*>(packed)[0]);
+  uint4 h, l;
+  split8_f16(v, sw, h, l);
+  packed[kXHeader + (f * 2 + 0) * 64 + lane] = h;
+  packed[kXHeader + (f * 2 + 1) * 64 + lane] = l;
 }
 
 struct XArgs {
@@ -128,6 +125,8 @@ struct XArgs {
   const float* __restrict__ bn_mean;
   const float* __restrict__ bn_var;
   float bn_eps;
+  const float* __restrict__ x_amax;     // device scalar: max|x| (or an upper bound) of the whole input tensor
+  float* y_amax;                        // optional device scalar: max|y| is folded into it (atomic max)
   float* __restrict__ y;
   int N, Cin, Cout, H, W;   // Cin = real K, Cout = real M of this launch, PER GROUP
   int G, mbpg, mtiles;      // groups, channel blocks per group, packed 32-row tiles per group
@@ -144,7 +143,7 @@ struct XArgs {
 // BUFFER loads whose per-thread offset is computed once before the loop -- the chunk / channel / K-step advance is a
 // wave-uniform SGPR offset, halo and padding items carry an out-of-range offset and read 0 from the hardware's bounds check.
 // The generic path (64-bit per-element addresses, per-element clamps and selects) spent ~150 VALU instructions per staged
-// item and chunk, ~35 of them the fp32 -> 3 x bf16 split itself; FAST leaves the split (+ ReLU) and three LDS stores.
+// item and chunk, ~35 of them the operand split itself; FAST leaves the split (+ ReLU) and the LDS stores.
 // B1: ONE activation stage in LDS instead of two (an extra barrier at the end of each chunk separates the last fragment reads
 // from the next chunk's stores): 42 KB per 128 x 128 block, so three blocks share a CU (3 waves per SIMD).  The counters of
 // round 2 show the matrix pipe 60 % busy with two waves per SIMD -- each wave needs it 45 % of its time, the rest is barrier
@@ -155,12 +154,12 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   constexpr bool kDirect = FIT == 0;             // big halos (k >= 5): stage without the register prefetch
   constexpr int FI = kDirect ? 1 : FIT;
   constexpr int MT = WM * TM;                    // 32-channel tiles per block
-  constexpr int AU = MT * 3 * 64;                // uint4 per A stage (all tiles, three terms)
+  constexpr int AU = MT * 2 * 64;                // uint4 per A stage (all tiles, two terms)
   constexpr int AI = (AU + NT - 1) / NT;         // staging loads per thread
   constexpr int AS = AI * NT;                    // LDS cells per A stage (>= AU)
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-  u32x4* sA = smem;                              // [2][AS] : [MT][3][64] + padding
-  u32x4* sB = smem + 2 * AS;                     // [2 | 1][term 3][channel group 2][npos]
+  u32x4* sA = smem;                              // [2][AS] : [MT][2][64] + padding
+  u32x4* sB = smem + 2 * AS;                     // [2 | 1][term 2][channel group 2][npos]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int tr = blockIdx.x / a.ntc, tc = blockIdx.x - tr * a.ntc;
@@ -194,6 +193,8 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   }
   // FAST: byte offset of channel (0 | 8) of the item's position from the image's base, or an offset beyond the buffer
   const int planeB = (int)plane * 4;
+  const float sx = pow2_scale(a.x_amax[0]);         // power-of-two operand scales (csrc/dvd_split.h)
+  const float sw = pow2_scale(reinterpret_cast<const float*>(a.wp)[0]);
   int voff[FI];
 #pragma unroll
   for (int it = 0; it < FI; ++it) voff[it] = gok[it] ? (goff[it] + cig8[it] * (int)plane) * 4 : (int)0x80000000;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     }
   };
   auto split_write = [&](int buf, int kc) {
-    u32x4* dst = sB + (B1 ? 0 : buf * 6 * npos);
+    u32x4* dst = sB + (B1 ? 0 : buf * 4 * npos);
 #pragma unroll
     for (int it = 0; it < FI; ++it) {
       const int ch0 = kc * 16 + cig8[it];
@@ -240,17 +241,16 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
           v[e] = a.relu_in ? fmaxf(t, 0.0f) : t;
         }
       }
-      uint4 h, m, l;
-      split8(v, h, m, l);
+      uint4 h, l;
+      split8_f16(v, sx, h, l);
       dst[lidx[it]] = (u32x4){h.x, h.y, h.z, h.w};
-      dst[2 * npos + lidx[it]] = (u32x4){m.x, m.y, m.z, m.w};
-      dst[4 * npos + lidx[it]] = (u32x4){l.x, l.y, l.z, l.w};
+      dst[2 * npos + lidx[it]] = (u32x4){l.x, l.y, l.z, l.w};
     }
   };
 
   // direct staging (kDirect): load, split and store item by item, nothing kept in registers across the MFMAs
   auto stage_direct = [&](int buf, int kc) {
-    u32x4* dst = sB + (B1 ? 0 : buf * 6 * npos);
+    u32x4* dst = sB + (B1 ? 0 : buf * 4 * npos);
     for (int it = 0; it < a.nfi; ++it) {
       const int item = it * NT + tid;
       const int cig = item >= a.NV ? 1 : 0;
@@ -284,36 +284,35 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
           v[e] = a.relu_in ? fmaxf(t, 0.0f) : t;
         }
       }
-      uint4 h, m, l;
-      split8(v, h, m, l);
+      uint4 h, l;
+      split8_f16(v, sx, h, l);
       const int li = live ? (cig * npos + p) : (npos - 1);
       dst[li] = (u32x4){h.x, h.y, h.z, h.w};
-      dst[2 * npos + li] = (u32x4){m.x, m.y, m.z, m.w};
-      dst[4 * npos + li] = (u32x4){l.x, l.y, l.z, l.w};
+      dst[2 * npos + li] = (u32x4){l.x, l.y, l.z, l.w};
     }
   };
 
-  // ---- A staging: the block's AU uint4 of K step kt are MT pieces of 192 uint4 in the packed buffer; the
+  // ---- A staging: the block's AU uint4 of K step kt are MT pieces of 128 uint4 in the packed buffer; the
   //      LDS stage is padded to AI * NT cells so that every thread loads and stores unconditionally
   const u32x4* asrc[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int j = i * NT + tid;
     const int jj = j < AU ? j : 0;
-    const int mtl = jj / 192, rem = jj - mtl * 192;
-    asrc[i] = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(grp * a.mtiles + mt0 + mtl) * nkt) * 192 + rem;
+    const int mtl = jj / 128, rem = jj - mtl * 128;
+    asrc[i] = reinterpret_cast<const u32x4*>(a.wp) + kXHeader + ((size_t)(grp * a.mtiles + mt0 + mtl) * nkt) * 128 + rem;
   }
-  // FAST: the block's fragments start at a wave-uniform base; thread-constant byte offset + K step * 3072 bytes (SGPR)
-  const u32x4* abase = reinterpret_cast<const u32x4*>(a.wp) + ((size_t)(grp * a.mtiles + mt0) * nkt) * 192;
+  // FAST: the block's fragments start at a wave-uniform base; thread-constant byte offset + K step * 2048 bytes (SGPR)
+  const u32x4* abase = reinterpret_cast<const u32x4*>(a.wp) + kXHeader + ((size_t)(grp * a.mtiles + mt0) * nkt) * 128;
   const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(const_cast<u32x4*>(abase)), 0, FAST ? MT * nkt * 192 * 16 : 0, 0x00020000);
+      uniform_ptr(const_cast<u32x4*>(abase)), 0, FAST ? MT * nkt * 128 * 16 : 0, 0x00020000);
   int aoff[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int j = i * NT + tid;
     const int jj = j < AU ? j : 0;
-    const int mtl = jj / 192, rem = jj - mtl * 192;
-    aoff[i] = (mtl * nkt * 192 + rem) * 16;
+    const int mtl = jj / 128, rem = jj - mtl * 128;
+    aoff[i] = (mtl * nkt * 128 + rem) * 16;
   }
   struct ARegs {
     u32x4 v[AI];
@@ -322,11 +321,11 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     if (FAST) {
 #pragma unroll
       for (int i = 0; i < AI; ++i)
-        r.v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srdA, aoff[i], kt * 3072, 0));
+        r.v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srdA, aoff[i], kt * 2048, 0));
       return;
     }
 #pragma unroll
-    for (int i = 0; i < AI; ++i) r.v[i] = asrc[i][(size_t)kt * 192];
+    for (int i = 0; i < AI; ++i) r.v[i] = asrc[i][(size_t)kt * 128];
   };
   auto write_a = [&](const ARegs& r, int buf) {
 #pragma unroll
@@ -343,37 +342,34 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) qb[tn] = (wn * TN + tn) * 32 + (lane & 31);
   const int bl = (lane >> 5) * npos;
-  const int al = (wm * TM) * 192 + lane;
+  const int al = (wm * TM) * 128 + lane;
 
-  // Order inside a K step: barrier | fragments of step kt from LDS | 6 * TM * TN MFMAs | stage A(kt + 1)
+  // Order inside a K step: barrier | fragments of step kt from LDS | 3 * TM * TN MFMAs | stage A(kt + 1)
   // (requested two steps ago) into the other A buffer, request A(kt + 3) | on the last tap of a chunk: split
   // the raw values of the next chunk into the other B buffer, request the chunk after it.  The waits for
   // global data sit BEHIND the wave's own MFMAs, so the matrix pipe works while they resolve (first version:
   // staging at the top of the step -- every step waited an L2 round trip before its first MFMA, pipe 60 % busy).
   struct Frag {
-    bf16x8 a[TM][3], b[TN][3];
+    f16x8 a[TM][2], b[TN][2];
   };
   auto read_frags = [&](Frag& f, int abuf, int kc, int off) {
     const u32x4* Ac = sA + abuf * AS + al;
-    const u32x4* Bc = sB + (B1 ? 0 : (kc & 1) * 6 * npos) + bl + off;
+    const u32x4* Bc = sB + (B1 ? 0 : (kc & 1) * 4 * npos) + bl + off;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) f.a[tm][s] = __builtin_bit_cast(bf16x8, Ac[(tm * 3 + s) * 64]);
+      for (int s = 0; s < 2; ++s) f.a[tm][s] = __builtin_bit_cast(f16x8, Ac[(tm * 2 + s) * 64]);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) f.b[tn][s] = __builtin_bit_cast(bf16x8, Bc[s * 2 * npos + qb[tn]]);
+      for (int s = 0; s < 2; ++s) f.b[tn][s] = __builtin_bit_cast(f16x8, Bc[s * 2 * npos + qb[tn]]);
   };
   auto mfmas = [&](const Frag& f) {
-    // six partial products, small terms first; the TM * TN accumulators are interleaved so that consecutive
-    // MFMAs are independent
+    // three partial products l*h' + h*l' + h*h', small terms first; the TM * TN accumulators are interleaved so that
+    // consecutive MFMAs are independent
 #define DVD_XTERM(SA, SB)                                                                             \
   _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) \
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[tm][SA], f.b[tn][SB], acc[tm][tn], 0, 0, 0);
-    DVD_XTERM(2, 0)
-    DVD_XTERM(0, 2)
-    DVD_XTERM(1, 1)
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][SA], f.b[tn][SB], acc[tm][tn], 0, 0, 0);
     DVD_XTERM(1, 0)
     DVD_XTERM(0, 1)
     DVD_XTERM(0, 0)
@@ -448,6 +444,8 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   // per lane and tile evaluated in place cost more than the MFMAs of a 1x1 convolution); the 16 channels a lane's
   // accumulators belong to are fetched from those lanes where they are applied (keeping them in registers tripled the
   // kernel's VGPR count and cost the 1x1 kernels their third block per CU).
+  const float unscale = 1.0f / (sx * sw);
+  float ymax = 0.0f;
   float my_sc[TM], my_sh[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -474,7 +472,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       const bool full = cob + 28 <= a.Cout - 4;     // all 16 channels of this lane exist (block-uniform in practice)
       float v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r];
+      for (int r = 0; r < 16; ++r) v[r] = acc[tm][tn][r] * unscale;        // exact: 2^-(e_x + e_w)
       if (a.bias) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -518,10 +516,14 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = cob + (r & 3) + 8 * (r >> 2);
-        if (pok && (full || co < a.Cout)) yb[o0 + ((r & 3) + 8 * (r >> 2)) * iplane] = v[r];
+        if (pok && (full || co < a.Cout)) {
+          yb[o0 + ((r & 3) + 8 * (r >> 2)) * iplane] = v[r];
+          ymax = fmaxf(ymax, fabsf(v[r]));
+        }
       }
     }
   }
+  if (a.y_amax) wave_amax_to(ymax, a.y_amax);      // the consumer's operand scale comes from this (uniform branch)
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
@@ -532,7 +534,7 @@ struct XCfg {
   int NQ() const { return TN * WN * 32; }
   int NT() const { return 64 * WM * WN; }
 };
-// Block shapes.  Every activation element a block stages is split into its three bf16 terms ONCE per block (VALU work) and
+// Block shapes.  Every activation element a block stages is split into its two fp16 terms ONCE per block (VALU work) and
 // read from LDS once per 32-channel tile row, so the split / LDS cost per MFMA falls with the number of output channels a
 // block owns: with >= 256 of them a block takes 256 channels (wave tile 128 channels x 64 positions: 48 MFMAs against 18
 // fragment reads per K step, round 2: 24 against 12) -- 256 x 128 positions at two blocks per CU for 1x1 kernels, 256 x 256
@@ -560,9 +562,9 @@ struct XTile {
   size_t lds;
 };
 static size_t xconv_lds(const XCfg& c, int npos) {
-  const int AU = c.WM * c.TM * 192, NT = c.NT();
+  const int AU = c.WM * c.TM * 128, NT = c.NT();
   const int AS = (AU + NT - 1) / NT * NT;
-  return ((size_t)2 * AS + (size_t)(c.b1 ? 6 : 12) * npos) * sizeof(uint4);
+  return ((size_t)2 * AS + (size_t)(c.b1 ? 4 : 8) * npos) * sizeof(uint4);
 }
 // Tile of the image per block: TR x TC outputs, TR * (TC + 2 pad) <= NQ positions; choose the split of the
 // width that wastes the fewest positions, subject to the LDS budget and the staging-iteration bound.
@@ -637,7 +639,7 @@ size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int groups, int transpo
   if (Cout <= 0 || Cin <= 0 || KS <= 0 || !(KS & 1) || groups <= 0 || Cout % groups || Cin % groups) return 0;
   const int co = Cout / groups, ci = Cin / groups;
   const int M = transposed ? ci : co, K = transposed ? co : ci;
-  return (size_t)groups * dvd::xconv_mtiles(M) * ((K + 15) / 16) * KS * KS * 3 * 64 * sizeof(uint4);
+  return ((size_t)dvd::kXHeader + (size_t)groups * dvd::xconv_mtiles(M) * ((K + 15) / 16) * KS * KS * 2 * 64) * sizeof(uint4);
 }
 
 static int xconv_pack_impl(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed,
@@ -649,6 +651,16 @@ static int xconv_pack_impl(const float* w, void* packed, int Cout, int Cin, int 
   const int M = transposed ? ci : co, K = transposed ? co : ci;
   const int mtiles = dvd::xconv_mtiles(M), nkc = (K + 15) / 16, T = KS * KS;
   const long long total = (long long)groups * mtiles * nkc * T * 64;
+  // header: max |A| (BatchNorm scale included) -> the power-of-two operand scale of this packing
+  DVD_HIP_OK(hipMemsetAsync(packed, 0, dvd::kXHeader * sizeof(uint4), static_cast<hipStream_t>(stream)));
+  {
+    const long long nw = (long long)Cout * ci * T;
+    long long nb = (nw + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(dvd::xconv_wamax_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       static_cast<float*>(packed), Cout, ci * T, gamma, var, eps);
+    DVD_LAUNCH_OK();
+  }
   hipLaunchKernelGGL(dvd::xconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, static_cast<uint4*>(packed), co, ci, T, transposed ? 1 : 0,
                      mtiles, nkc, groups, gamma, var, eps);
@@ -672,10 +684,11 @@ int dvd_xconv_select(int cfg) {
   return DVD_OK;
 }
 
-int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
-                  const dvd_bn_params* bn, float* y, int N, int Cin_total, int Cout_total, int H, int W, int KS, int groups,
-                  int flags, dvd_stream_t stream) {
+int dvd_xconv_fwd(const float* x, const float* x_amax, const void* packed, const float* bias, const float* residual,
+                  const float* mask_src, const dvd_bn_params* bn, float* y, float* y_amax, int N, int Cin_total, int Cout_total,
+                  int H, int W, int KS, int groups, int flags, dvd_stream_t stream) {
   DVD_REQUIRE(x && packed && y, "xconv: null pointer");
+  DVD_REQUIRE(x_amax, "xconv: the input's max|x| scalar is missing (dvd_amax, or the producer's y_amax)");
   DVD_REQUIRE(N > 0 && Cin_total > 0 && Cout_total > 0 && H > 0 && W > 0, "xconv: bad shape N=%d Cin=%d Cout=%d H=%d W=%d", N,
               Cin_total, Cout_total, H, W);
   DVD_REQUIRE(groups > 0 && Cin_total % groups == 0 && Cout_total % groups == 0, "xconv: %d groups do not divide the channels",
@@ -688,7 +701,7 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   // buffer-addressed main loop: whole 16-channel chunks, 31-bit byte offsets inside one image's input channels and
   // inside the packed weights of one block row
   const bool fast = (Cin % 16 == 0) && ((long long)Cin * H * W * 4 < (1ll << 31)) &&
-                    ((long long)8 * ((Cin + 15) / 16) * KS * KS * 3072 < (1ll << 31)) && dvd::g_xcfg != 4;
+                    ((long long)8 * ((Cin + 15) / 16) * KS * KS * 2048 < (1ll << 31)) && dvd::g_xcfg != 4;
   dvd::XCfg c = dvd::pick_cfg(fast ? Cout : (Cout < 128 ? Cout : 128), KS);
   if (!fast) c.b1 = false;   // the wide shapes exist as FAST kernels only
   int Hh = H, Ww = W;
@@ -712,6 +725,8 @@ int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const f
   a.bn_eps = bn ? bn->eps : 0.0f;
   DVD_REQUIRE(!bn || (bn->mean && bn->var), "xconv: BatchNorm statistics missing");
   a.y = y;
+  a.x_amax = x_amax;
+  a.y_amax = y_amax;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = Hh; a.W = Ww;
   a.G = groups; a.mtiles = dvd::xconv_mtiles(Cout);
   a.KS = KS; a.pad = KS / 2; a.T = KS * KS;

@@ -1,6 +1,6 @@
-// Backward-weight of the dense 3x3 stride-1 "same" convolutions on the bf16 matrix cores with fp32-class
-// accuracy (the three-term bf16 split of csrc/xconv.hip: six partial products per fp32 product, fp32
-// accumulation), deterministic (no atomics):
+// Backward-weight of the dense 3x3 stride-1 "same" convolutions on the 16-bit matrix cores with fp32-class
+// accuracy (the two-term fp16 split of csrc/dvd_split.h: both operands scaled by a power of two from their tensors'
+// max|.| scalars, three partial products per fp32 product, fp32 accumulation), deterministic (no atomics):
 //   dW[co][ci][ky][kx] = sum_{n, r, c} gy[n][co][r][c] * act(x)[n][ci][r + ky - 1][c + kx - 1]
 //
 // What it replaces (reference, /root/reference): the autograd weight gradient of the 3x3 nn.Conv2d of the MiDaS
@@ -18,31 +18,18 @@
 // split into the three bf16 terms on the way in; the next step's rows are requested before the MFMAs of the
 // current one.  Wave (pm, pn, ky) of the 12 keeps the three accumulators of kernel row ky for its 32 x 32 pair.
 // Every block writes its partial sums; xwgrad3_reduce_kernel adds them in slice order.
-#include "dvd_common.h"
+#include "dvd_split.h"
 
 namespace dvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void w3_split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  const f32x2 v = {a, b};
-  const bf16x2 hb = __builtin_convertvector(v, bf16x2);
-  const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
-  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
-  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
-  h = __builtin_bit_cast(unsigned, hb);
-  m = __builtin_bit_cast(unsigned, mb);
-  l = __builtin_bit_cast(unsigned, lb);
-}
 
 struct Wg3Args {
   const float* __restrict__ x;
   const float* __restrict__ gy;
+  const float* __restrict__ x_amax;   // device scalars: max|x|, max|gy| (or upper bounds) of the whole tensors
+  const float* __restrict__ g_amax;
   float* __restrict__ partial;   // [S][9][Cout][Cin]
   int N, Cin, Cout, H, W;        // Cin / Cout per group
   int G, nco;                    // groups, output-channel blocks per group
@@ -58,9 +45,10 @@ constexpr int kW3NT = 768;                    // 12 waves: 2 x 2 tile pairs x 3 
 
 __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  // sG [term 3][co 64][kW3GPitch], sX [term 3][ci 64][slot 3][kW3XPitch]
+  // sG [term 2][co 64][kW3GPitch], sX [term 2][ci 64][slot 3][kW3XPitch]
   unsigned char* sG = smem3;
-  unsigned char* sX = smem3 + 3 * kW3CB * kW3GPitch;
+  unsigned char* sX = smem3 + 2 * kW3CB * kW3GPitch;
+  const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ky = wave % 3, pn = (wave / 3) & 1, pm = wave / 6;
   const int grp = blockIdx.z / a.nco;                      // group of a grouped convolution (0 for dense)
@@ -115,9 +103,10 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
     for (int i = 0; i < NQ; ++i) {
       const int q = i * kW3NT + tid;
       if (q >= GQ + XQ) continue;
-      unsigned h0, m0, l0, h1, m1, l1;
-      w3_split_pair(stg[i].x, stg[i].y, h0, m0, l0);
-      w3_split_pair(stg[i].z, stg[i].w, h1, m1, l1);
+      unsigned h0, l0, h1, l1;
+      const float sc = q < GQ ? sg : sx;
+      split_pair_f16(stg[i].x * sc, stg[i].y * sc, h0, l0);
+      split_pair_f16(stg[i].z * sc, stg[i].w * sc, h1, l1);
       unsigned char* dst;
       int tstride;
       if (q < GQ) {
@@ -129,8 +118,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
         tstride = kW3CB * 3 * kW3XPitch;
       }
       *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(dst + 2 * tstride) = make_uint2(l0, l1);
+      *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(l0, l1);
     }
   };
 
@@ -163,10 +151,10 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       const unsigned char* xr = xa + slot * kW3XPitch;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                // four K steps of 16 pixels
-        bf16x8 A[3], B[3][3];
+        f16x8 A[2], B[3][2];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ga + t * (kW3CB * kW3GPitch) + s * 32));
+        for (int t = 0; t < 2; ++t) {
+          A[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ga + t * (kW3CB * kW3GPitch) + s * 32));
           const unsigned char* xc = xr + t * (kW3CB * 3 * kW3XPitch) + s * 32;
           const u32x4 cur = *reinterpret_cast<const u32x4*>(xc);
           const unsigned prev3 = *reinterpret_cast<const unsigned*>(xc - 4);
@@ -174,16 +162,13 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
           const unsigned t0 = __builtin_amdgcn_alignbit(cur.x, prev3, 16), t1 = __builtin_amdgcn_alignbit(cur.y, cur.x, 16),
                          t2 = __builtin_amdgcn_alignbit(cur.z, cur.y, 16), t3 = __builtin_amdgcn_alignbit(cur.w, cur.z, 16),
                          t4 = __builtin_amdgcn_alignbit(next0, cur.w, 16);
-          B[0][t] = __builtin_bit_cast(bf16x8, (u32x4){t0, t1, t2, t3});   // kx = 0: pixels shifted by -1
-          B[1][t] = __builtin_bit_cast(bf16x8, cur);                        // kx = 1
-          B[2][t] = __builtin_bit_cast(bf16x8, (u32x4){t1, t2, t3, t4});   // kx = 2: shifted by +1
+          B[0][t] = __builtin_bit_cast(f16x8, (u32x4){t0, t1, t2, t3});   // kx = 0: pixels shifted by -1
+          B[1][t] = __builtin_bit_cast(f16x8, cur);                        // kx = 1
+          B[2][t] = __builtin_bit_cast(f16x8, (u32x4){t1, t2, t3, t4});   // kx = 2: shifted by +1
         }
 #define DVD_W3TERM(SA, SB)                                                                                  \
   _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[kx] =                                                \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], B[kx][SB], acc[kx], 0, 0, 0);
-        DVD_W3TERM(2, 0)
-        DVD_W3TERM(0, 2)
-        DVD_W3TERM(1, 1)
+      __builtin_amdgcn_mfma_f32_32x32x16_f16(A[SA], B[kx][SB], acc[kx], 0, 0, 0);
         DVD_W3TERM(1, 0)
         DVD_W3TERM(0, 1)
         DVD_W3TERM(0, 0)
@@ -193,6 +178,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   }
   // partial[s][tap][G * Cout][Cin]
   float* dst = a.partial + (size_t)blockIdx.x * 9 * a.G * a.Cout * a.Cin;
+  const float unscale = 1.0f / (sx * sg);          // exact power of two
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
     const int tap = ky * 3 + kx;
@@ -200,7 +186,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + pm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int ci = ci0 + pn * 32 + (lane & 31);
-      if (co < a.Cout && ci < a.Cin) dst[((size_t)tap * a.G * a.Cout + grp * a.Cout + co) * a.Cin + ci] = acc[kx][r];
+      if (co < a.Cout && ci < a.Cin) dst[((size_t)tap * a.G * a.Cout + grp * a.Cout + co) * a.Cin + ci] = acc[kx][r] * unscale;
     }
   }
 }
@@ -235,8 +221,9 @@ constexpr int kW1NT = 512;
 
 __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  unsigned char* sG = smem3;                               // [term 3][co 128][kW1Pitch]
-  unsigned char* sX = smem3 + 3 * kW1CB * kW1Pitch;        // [term 3][ci 128][kW1Pitch]
+  unsigned char* sG = smem3;                               // [term 2][co 128][kW1Pitch]
+  unsigned char* sX = smem3 + 2 * kW1CB * kW1Pitch;        // [term 2][ci 128][kW1Pitch]
+  const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pn = wave & 1, pm = wave >> 1;
   const int co0 = blockIdx.z * kW1CB, ci0 = blockIdx.y * kW1CB;
@@ -274,14 +261,14 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = (i & 1) * kW1NT + tid;
-      unsigned h0, m0, l0, h1, m1, l1;
-      w3_split_pair(stg[i].x, stg[i].y, h0, m0, l0);
-      w3_split_pair(stg[i].z, stg[i].w, h1, m1, l1);
+      unsigned h0, l0, h1, l1;
+      const float sc = i >= 2 ? sx : sg;
+      split_pair_f16(stg[i].x * sc, stg[i].y * sc, h0, l0);
+      split_pair_f16(stg[i].z * sc, stg[i].w * sc, h1, l1);
       unsigned char* dst = (i >= 2 ? sX : sG) + (q >> 3) * kW1Pitch + ((q & 7) << 3);
       constexpr int tstride = kW1CB * kW1Pitch;
       *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(m0, m1);
-      *reinterpret_cast<uint2*>(dst + 2 * tstride) = make_uint2(l0, l1);
+      *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(l0, l1);
     }
   };
   f32x16 acc[2];
@@ -300,19 +287,16 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
     if (item + a.S < items) stage_load(item + a.S);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 A[3], B[2][3];
+      f16x8 A[2], B[2][2];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        A[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ga + t * (kW1CB * kW1Pitch) + s * 32));
-        B[0][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xa + t * (kW1CB * kW1Pitch) + s * 32));
-        B[1][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xa + 32 * kW1Pitch + t * (kW1CB * kW1Pitch) + s * 32));
+      for (int t = 0; t < 2; ++t) {
+        A[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ga + t * (kW1CB * kW1Pitch) + s * 32));
+        B[0][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(xa + t * (kW1CB * kW1Pitch) + s * 32));
+        B[1][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(xa + 32 * kW1Pitch + t * (kW1CB * kW1Pitch) + s * 32));
       }
 #define DVD_W1TERM(SA, SB)                                                                                \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] =                                                  \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[SA], B[j][SB], acc[j], 0, 0, 0);
-      DVD_W1TERM(2, 0)
-      DVD_W1TERM(0, 2)
-      DVD_W1TERM(1, 1)
+      __builtin_amdgcn_mfma_f32_32x32x16_f16(A[SA], B[j][SB], acc[j], 0, 0, 0);
       DVD_W1TERM(1, 0)
       DVD_W1TERM(0, 1)
       DVD_W1TERM(0, 0)
@@ -320,13 +304,14 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
     }
   }
   float* dst = a.partial + (size_t)blockIdx.x * a.Cout * a.Cin;       // partial[s][co][ci]
+  const float unscale = 1.0f / (sx * sg);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + pm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int ci = ci0 + pn * 64 + j * 32 + (lane & 31);
-      if (co < a.Cout && ci < a.Cin) dst[(size_t)co * a.Cin + ci] = acc[j][r];
+      if (co < a.Cout && ci < a.Cin) dst[(size_t)co * a.Cin + ci] = acc[j][r] * unscale;
     }
 }
 
@@ -349,7 +334,7 @@ static void wg3_plan(int N, int Cin, int Cout, int H, int W, int G, Wg3Plan& p) 
   const long long items = (long long)N * p.nstrips * p.nrseg;
   if (S > items) S = (int)items;
   p.S = S;
-  p.lds = (size_t)3 * kW3CB * kW3GPitch + (size_t)3 * kW3CB * 3 * kW3XPitch;
+  p.lds = (size_t)2 * kW3CB * kW3GPitch + (size_t)2 * kW3CB * 3 * kW3XPitch;
 }
 
 }  // namespace dvd
@@ -363,9 +348,11 @@ size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W, int g
   return (size_t)p.S * 9 * Cout * (Cin / groups) * sizeof(float);
 }
 
-int dvd_xwgrad3(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin_total,
-                int Cout_total, int H, int W, int groups, int relu_in, dvd_stream_t stream) {
+int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
+                size_t workspace_bytes, int N, int Cin_total, int Cout_total, int H, int W, int groups, int relu_in,
+                dvd_stream_t stream) {
   DVD_REQUIRE(x && gy && gw && workspace, "xwgrad3: null pointer");
+  DVD_REQUIRE(x_amax && gy_amax, "xwgrad3: the operands' max|.| scalars are missing (dvd_amax)");
   DVD_REQUIRE(N > 0 && Cin_total > 0 && Cout_total > 0 && H > 0 && W > 0, "xwgrad3: bad shape");
   DVD_REQUIRE(groups > 0 && Cin_total % groups == 0 && Cout_total % groups == 0, "xwgrad3: %d groups do not divide the channels", groups);
   DVD_REQUIRE((long long)H * W * (long long)(Cin_total > Cout_total ? Cin_total : Cout_total) < (1ll << 31),
@@ -382,6 +369,8 @@ int dvd_xwgrad3(const float* x, const float* gy, float* gw, void* workspace, siz
   dvd::Wg3Args a;
   a.x = x;
   a.gy = gy;
+  a.x_amax = x_amax;
+  a.g_amax = gy_amax;
   a.partial = static_cast<float*>(workspace);
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.G = groups; a.nco = p.nco;
@@ -406,9 +395,10 @@ size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
   return (size_t)S * Cout * Cin * sizeof(float);
 }
 
-int dvd_xwgrad1s(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
-                 int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
+int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
+                 size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
   DVD_REQUIRE(x && gy && gw && workspace, "xwgrad1s: null pointer");
+  DVD_REQUIRE(x_amax && gy_amax, "xwgrad1s: the operands' max|.| scalars are missing (dvd_amax)");
   DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgrad1s: bad shape");
   DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgrad1s: image too large for 32-bit offsets");
   const int nco = (Cout + dvd::kW1CB - 1) / dvd::kW1CB, nci = (Cin + dvd::kW1CB - 1) / dvd::kW1CB;
@@ -426,13 +416,15 @@ int dvd_xwgrad1s(const float* x, const float* gy, float* gw, void* workspace, si
   dvd::Wg3Args a;
   a.x = x;
   a.gy = gy;
+  a.x_amax = x_amax;
+  a.g_amax = gy_amax;
   a.partial = static_cast<float*>(workspace);
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.G = 1; a.nco = nco;
   a.nstrips = 0; a.RS = 0; a.nrseg = 0; a.S = S;
   a.relu_in = relu_in ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)2 * 3 * dvd::kW1CB * dvd::kW1Pitch;
+  const size_t lds = (size_t)2 * 2 * dvd::kW1CB * dvd::kW1Pitch;
   DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
   hipLaunchKernelGGL(dvd::xwgrad1s_kernel, dim3(S, nci, nco), dim3(dvd::kW1NT), lds, s, a);

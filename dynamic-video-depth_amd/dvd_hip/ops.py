@@ -77,6 +77,36 @@ def unproject_backward(g_points, planar, R, K_inv, scale=None, out=None, accumul
     return out
 
 
+# -- max|x| scalars ----------------------------------------------------------------------------------------------------
+# Every tensor that feeds a matrix kernel carries max|x| (or an upper bound) in a 1-element GPU tensor: the kernels derive
+# the power-of-two scale of their fp16 operand split from it on the device (csrc/dvd_split.h); the host never reads it.
+# The scalar hangs on the tensor OBJECT together with the tensor's version counter (an in-place update invalidates it).
+def amax(t):
+    """max|t| by the reduction kernel (one read of the tensor) -> 1-element GPU tensor."""
+    t = _dev32(t, 'tensor')
+    out = torch.zeros(1, device=t.device, dtype=torch.float32)
+    if t.numel():
+        _lib.check(_lib.load().dvd_amax(_p(t), ctypes.c_longlong(t.numel()), _p(out), _stream()), 'dvd_amax')
+    return out
+
+
+def set_amax(t, am):
+    """Attach a known max|t| (or upper bound: a sub-sampled / interpolated / ReLU'd view of a bounded tensor)."""
+    if am is not None:
+        t._dvd_amax = (t._version, am)
+    return t
+
+
+def amax_of(t):
+    """The tensor's max|.| scalar: the one its producer attached, else computed now and remembered."""
+    hit = getattr(t, '_dvd_amax', None)
+    if hit is not None and hit[0] == t._version:
+        return hit[1]
+    am = amax(t)
+    t._dvd_amax = (t._version, am)
+    return am
+
+
 _ws_cache = {}
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DVD_ABI_VERSION 1
+#define DVD_ABI_VERSION 2
 
 typedef void* dvd_stream_t; /* hipStream_t */
 
@@ -283,9 +283,15 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
                               int W_out, int align_corners, dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * Dense stride-1 "same" convolution (odd k x k up to 11, any channel counts), NCHW fp32, on the bf16
- * matrix cores with every fp32 operand split into three bf16 terms (six partial products, fp32
- * accumulation: fp32-class accuracy at 2.7x the fp32 MFMA rate; csrc/xconv.hip).  Replaces the dense
+ * max|x| of a tensor into a device scalar: out[0] = max(out[0], max|x|) (atomic; zero `out` first, or pass a running
+ * bound).  The matrix kernels derive the power-of-two scale of their fp16 operand split from such scalars on the device;
+ * nothing reads them on the host.  x 16-byte aligned. */
+int dvd_amax(const float* x, long long n, float* out, dvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Dense stride-1 "same" convolution (odd k x k up to 11, any channel counts), NCHW fp32, on the 16-bit
+ * matrix cores with every fp32 operand, scaled by a power of two, split into two fp16 terms (three partial
+ * products, fp32 accumulation: fp32-class accuracy, csrc/dvd_split.h, csrc/xconv.hip).  Replaces the dense
  * nn.Conv2d forward and backward-data of the depth networks:
  *   third_party/midas_blocks.py:102-168 (ResidualConvUnit / FeatureFusionBlock 3x3),
  *   third_party/MiDaS.py:186-195 (scratch.layerK_rn, output_conv),
@@ -313,9 +319,13 @@ typedef struct dvd_bn_params {
   const float* var;
   float eps;
 } dvd_bn_params;
-int dvd_xconv_fwd(const float* x, const void* packed, const float* bias, const float* residual, const float* mask_src,
-                  const dvd_bn_params* bn, float* y, int N, int Cin, int Cout, int H, int W, int KS, int groups, int flags,
-                  dvd_stream_t stream);
+/* x_amax: device scalar holding max|x| of the WHOLE input tensor, or an upper bound of it (written by dvd_amax or by the
+ * producing kernel through its y_amax): the power-of-two operand scale of the two-term fp16 split is derived from it on the
+ * device (csrc/dvd_split.h).  y_amax (optional): device scalar into which max|y| of this launch is folded with an atomic
+ * max -- zero it (or pass a running bound) before the launch. */
+int dvd_xconv_fwd(const float* x, const float* x_amax, const void* packed, const float* bias, const float* residual,
+                  const float* mask_src, const dvd_bn_params* bn, float* y, float* y_amax, int N, int Cin, int Cout, int H,
+                  int W, int KS, int groups, int flags, dvd_stream_t stream);
 /* Test / A-B hook (process wide, like dvd_warp_loss_select): block shape of dvd_xconv_fwd for >= 256 output channels.
  * 0 = automatic (256 channels x 128 positions for 1x1 kernels, 256 x 256 for k >= 3), 1 = round 2's 128 x 128 blocks,
  * 2 / 3 = force 256 x 128 / 256 x 256, 4 = round 2's blocks on the generic pointer-addressed main loop (the path shapes
@@ -337,15 +347,16 @@ size_t dvd_xwgrad_workspace_bytes(int N, int Cin, int Cout, int H, int W, int KS
 int dvd_xwgrad(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
                int Cout, int H, int W, int KS, int relu_in, dvd_stream_t stream);
 
-/* The 3x3 case on the bf16 matrix cores with the three-term split of dvd_xconv_fwd (fp32-class accuracy,
- * deterministic; csrc/xwgrad3.hip): what the MiDaS decoder's weight gradients run on. */
+/* The 3x3 case on the 16-bit matrix cores with the two-term fp16 split of dvd_xconv_fwd (fp32-class accuracy,
+ * deterministic; csrc/xwgrad3.hip): what the MiDaS decoder's weight gradients run on.  x_amax / gy_amax: device scalars
+ * with max|x| / max|gy| (or upper bounds) of the whole tensors, see dvd_xconv_fwd. */
 size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W, int groups);
-int dvd_xwgrad3(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
-                int Cout, int H, int W, int groups, int relu_in, dvd_stream_t stream);
+int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
+                size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int groups, int relu_in, dvd_stream_t stream);
 /* ... and the 1x1 case (ResNeXt bottleneck convolutions), same arithmetic: a K-contiguous "NT" GEMM over the pixels. */
 size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W);
-int dvd_xwgrad1s(const float* x, const float* gy, float* gw, void* workspace, size_t workspace_bytes, int N, int Cin,
-                 int Cout, int H, int W, int relu_in, dvd_stream_t stream);
+int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
+                 size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Flow-consistency (occlusion) + out-of-bounds mask of one direction of a frame pair.

@@ -62,3 +62,87 @@ def test_six_term_product_is_fp32_class():
     assert err6 < 4e-6                      # the tolerance of tests/test_06_xconv_gpu.py
     assert err6 < 4 * err32                 # same class as an fp32 accumulation of the same data
     assert err_bf16 > 100 * err6            # what a plain bf16 product would cost
+
+
+# ---- round 3: two fp16 terms of the power-of-two-scaled operand, three partial products (csrc/dvd_split.h) ----------------
+def pow2_scale(amax):
+    """2^e with amax * 2^e in [2^13, 2^14): the device function of csrc/dvd_split.h."""
+    amax = np.float32(amax)
+    if not (amax > 0) or not np.isfinite(amax):
+        return np.float32(1.0)
+    e = int((amax.view(np.uint32) >> 23) & 0xff)
+    se = min(max(267 - e, 1), 254)
+    return np.uint32(se << 23).view(np.float32)
+
+
+def split2_f16(x, s):
+    xs = (np.asarray(x, dtype=np.float32) * s).astype(np.float32)          # exact: s is a power of two
+    h = xs.astype(np.float16)                                               # round to nearest even, like v_cvt_pk_f16_f32
+    l = (xs - h.astype(np.float32)).astype(np.float32).astype(np.float16)   # xs - h is exact in fp32
+    return h.astype(np.float32), l.astype(np.float32)
+
+
+def dot3(a, b):
+    """sum_k a[k] * b[k] with the kernels' arithmetic: l*h' + h*l' + h*h', fp32 accumulation per 16-product MFMA step,
+    unscaled by the exact power of two at the end."""
+    sa, sb = pow2_scale(np.abs(a).max()), pow2_scale(np.abs(b).max())
+    ah, al = split2_f16(a, sa)
+    bh, bl = split2_f16(b, sb)
+    acc = np.zeros(a.shape[:-1], dtype=np.float32)
+    for x, y in ((al, bh), (ah, bl), (ah, bh)):
+        p = (x * y).astype(np.float32)                                      # fp16 x fp16 is exact in fp32
+        for k0 in range(0, p.shape[-1], 16):
+            acc = (acc + p[..., k0:k0 + 16].sum(-1, dtype=np.float32)).astype(np.float32)
+    return acc.astype(np.float64) / (np.float64(sa) * np.float64(sb))
+
+
+def test_pow2_scale_puts_the_maximum_below_2_to_14():
+    for amax in (1e-30, 3e-7, 0.02, 1.0, 1.9999, 2.0, 77.0, 65504.0, 3e20):
+        s = pow2_scale(amax)
+        assert 2.0 ** 13 <= np.float32(amax) * s < 2.0 ** 14 or s in (np.float32(2.0 ** 127), np.float32(2.0 ** -126))
+        assert np.log2(float(s)) == np.round(np.log2(float(s)))
+    assert pow2_scale(0.0) == 1.0 and pow2_scale(np.inf) == 1.0 and pow2_scale(np.nan) == 1.0
+
+
+def test_two_fp16_terms_carry_22_bits():
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(200000) * np.exp(3 * rng.standard_normal(200000))).astype(np.float32) * np.float32(1e-5)
+    s = pow2_scale(np.abs(x).max())
+    h, l = split2_f16(x, s)
+    back = (h.astype(np.float64) + l.astype(np.float64)) / np.float64(s)
+    err = np.abs(back - x.astype(np.float64))
+    big = np.abs(x) >= np.abs(x).max() * 2.0 ** -17             # l is a normal fp16 number: full 22 bits
+    assert (err[big] <= np.abs(x[big]) * 2.0 ** -21).all()
+    assert (err <= np.abs(x).max() * 2.0 ** -38).all() or (err[~big] <= 2.0 ** -25 / np.float64(s)).all()
+
+
+def test_three_product_fp16_pair_is_fp32_class():
+    """The error of the round-3 arithmetic against float64 on the shapes of the depth net (K = 2304: a 3x3 convolution over
+    256 channels; K = 256: a 1x1; K = 16384 pixels: a weight gradient) is in the class of the round-2 six-product bf16
+    arithmetic and BELOW a sequential fp32 multiply-add chain -- with half the MFMAs."""
+    rng = np.random.default_rng(1)
+    cases = (
+        ('3x3 conv', lambda: (rng.standard_normal((1024, 2304)).astype(np.float32),
+                              (rng.standard_normal((1024, 2304)) / np.sqrt(2304)).astype(np.float32))),
+        ('relu x small weights', lambda: ((np.maximum(rng.standard_normal((1024, 2304)), 0) * 3).astype(np.float32),
+                                          (rng.standard_normal((1024, 2304)) * 0.02).astype(np.float32))),
+        ('heavy-tailed gradients', lambda: ((rng.standard_normal((2048, 256)) * np.exp(2 * rng.standard_normal((2048, 256))) * 1e-6).astype(np.float32),
+                                            (rng.standard_normal((2048, 256)) * 0.05).astype(np.float32))),
+        ('weight gradient', lambda: ((rng.standard_normal((256, 16384)) * 1e-5).astype(np.float32),
+                                     np.maximum(rng.standard_normal((256, 16384)), 0).astype(np.float32))),
+    )
+    for name, gen in cases:
+        a, b = gen()
+        exact = (a.astype(np.float64) * b.astype(np.float64)).sum(-1)
+        scale = np.abs(exact).max()
+        e3 = np.abs(dot3(a, b) - exact).max() / scale
+        e6 = np.abs(dot6(a, b).astype(np.float64) - exact).max() / scale
+        chain = np.zeros(a.shape[0], dtype=np.float32)
+        prod = (a * b).astype(np.float32)
+        for k in range(a.shape[1]):
+            chain = (chain + prod[:, k]).astype(np.float32)
+        e32 = np.abs(chain.astype(np.float64) - exact).max() / scale
+        print('%-24s fp16 pair x3 %.2e | bf16 triple x6 %.2e | fp32 chain %.2e of max|y|' % (name, e3, e6, e32))
+        assert e3 < 4e-6                 # the tolerance of tests/test_06_xconv_gpu.py
+        assert e3 < 4 * e6 + 1e-8        # same class as the six-product arithmetic
+        assert e3 < 1.5 * e32            # not worse than an fp32 multiply-add chain over the same K

@@ -27,7 +27,7 @@ def main():
             return fwd, tot - fwd, y
 
         f1, b1, y1 = run(lambda: C.gconv3x3_c32(x, w))
-        f2, b2, y2 = run(lambda: C._XConv.apply(x, w, None, None, False, False, G))
+        f2, b2, y2 = run(lambda: C._xconv(x, w, None, None, False, False, G))
         rec.update(gconv32_fwd_ms=f1, gconv32_bwd_ms=b1, xconv_fwd_ms=f2, xconv_bwd_ms=b2,
                    max_diff=float((y1 - y2).abs().max() / y1.abs().max()))
         print(json.dumps(rec), flush=True)

@@ -48,8 +48,12 @@ def main():
         N *= nmul
         torch.manual_seed(0)
         x = torch.randn(N, Cin, H, W, device='cuda')
+        if os.environ.get('XCONV_ZERO_INPUT'):                # DVFS probe: same code, no data switching
+            x.zero_()
         conv = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2).cuda()
         gy = torch.randn(N, Cout, H, W, device='cuda')
+        if os.environ.get('XCONV_ZERO_INPUT'):
+            gy.zero_()
         flop = 2.0 * N * Cin * Cout * H * W * KS * KS
         rec = {'shape': [N, Cin, Cout, H, W, KS], 'gflop': flop / 1e9}
         pk, pkT = C.xconv_packed(conv.weight, False), C.xconv_packed(conv.weight, True)
