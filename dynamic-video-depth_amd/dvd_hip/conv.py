@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from .ops import _p, _stream, _workspace, amax, amax_of, set_amax
+from .ops import _p, _stream, _workspace, amax_of, known_amax, set_amax
 
 # Same-box A/B measurement switches (previous-generation kernels / MIOpen against the kernels in use), read ONCE at
 # import from DVD_AB="gconv32,no_bnfuse,...".  Not product configuration: every default is the fastest measured path.
@@ -116,8 +116,7 @@ def upsample_bilinear2x(x, align_corners):
     """F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=...) of the MiDaS decoder."""
     if x.is_cuda and x.dtype == torch.float32:
         y = _UpsampleBilinear.apply(x, (2 * x.shape[2], 2 * x.shape[3]), bool(align_corners))
-        hit = getattr(x, '_dvd_amax', None)          # a convex combination never exceeds the largest input magnitude
-        return set_amax(y, hit[1]) if (hit is not None and hit[0] == x._version) else y
+        return set_amax(y, known_amax(x))            # a convex combination never exceeds the largest input magnitude
     return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=align_corners)
 
 

@@ -80,7 +80,22 @@ def unproject_backward(g_points, planar, R, K_inv, scale=None, out=None, accumul
 # -- max|x| scalars ----------------------------------------------------------------------------------------------------
 # Every tensor that feeds a matrix kernel carries max|x| (or an upper bound) in a 1-element GPU tensor: the kernels derive
 # the power-of-two scale of their fp16 operand split from it on the device (csrc/dvd_split.h); the host never reads it.
-# The scalar hangs on the tensor OBJECT together with the tensor's version counter (an in-place update invalidates it).
+# The scalar hangs on the tensor OBJECT together with the tensor's version counter (an in-place update invalidates it)
+# and the capture context it was computed in.
+_capture_state = [False, 0]        # [last call was inside a HIP-graph capture, capture generation]
+
+
+def _capture_gen():
+    """0 outside a capture; inside one, a number that changes whenever a new capture begins.  A scalar computed eagerly
+    must never be baked into a graph (the replay would scale new data with the warm-up pass's maximum), and a scalar that
+    lives in a graph's private pool must not be used outside it."""
+    cap = torch.cuda.is_current_stream_capturing()
+    if cap and not _capture_state[0]:
+        _capture_state[1] += 1
+    _capture_state[0] = cap
+    return _capture_state[1] if cap else 0
+
+
 def amax(t):
     """max|t| by the reduction kernel (one read of the tensor) -> 1-element GPU tensor."""
     t = _dev32(t, 'tensor')
@@ -93,17 +108,24 @@ def amax(t):
 def set_amax(t, am):
     """Attach a known max|t| (or upper bound: a sub-sampled / interpolated / ReLU'd view of a bounded tensor)."""
     if am is not None:
-        t._dvd_amax = (t._version, am)
+        t._dvd_amax = (t._version, am, _capture_gen())
     return t
+
+
+def known_amax(t):
+    """The scalar attached to the tensor if it is still valid (same contents, same capture context), else None."""
+    hit = getattr(t, '_dvd_amax', None)
+    if hit is not None and hit[0] == t._version and hit[2] == _capture_gen():
+        return hit[1]
+    return None
 
 
 def amax_of(t):
     """The tensor's max|.| scalar: the one its producer attached, else computed now and remembered."""
-    hit = getattr(t, '_dvd_amax', None)
-    if hit is not None and hit[0] == t._version:
-        return hit[1]
-    am = amax(t)
-    t._dvd_amax = (t._version, am)
+    am = known_amax(t)
+    if am is None:
+        am = amax(t)
+        t._dvd_amax = (t._version, am, _capture_gen())
     return am
 
 

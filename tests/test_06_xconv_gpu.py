@@ -38,7 +38,8 @@ def _where(got, want, names):
 
 
 def test_identity_weights_copy_the_input():
-    """W = centre-tap identity: the output IS the input -- isolates the staging layout and the output mapping."""
+    """W = centre-tap identity: the output IS the input to the 22 bits one product carries (two fp16 terms per operand,
+    csrc/dvd_split.h: |err| <= 2^-22 |x|) -- isolates the staging layout and the output mapping."""
     from dvd_hip import conv as C
     torch.manual_seed(0)
     for KS in (1, 3):
@@ -50,7 +51,7 @@ def test_identity_weights_copy_the_input():
                 conv.weight[torch.arange(Cc), torch.arange(Cc), KS // 2, KS // 2] = 1.0
             conv = conv.cuda()
             y = C.xconv2d(conv, x.cuda())
-            assert _err(y, x.double()) < 1e-7, 'KS=%d %s: %s' % (KS, (N, Cc, H, W), _where(y, x.double(), 'n,c,y,x'))
+            assert _err(y, x.double()) < 2.5e-7, 'KS=%d %s: %s' % (KS, (N, Cc, H, W), _where(y, x.double(), 'n,c,y,x'))
 
 
 @pytest.mark.parametrize('tap', [0, 2, 4, 6, 8])
@@ -66,7 +67,7 @@ def test_single_tap_shifts_the_input(tap):
         conv.weight[torch.arange(Cc), torch.arange(Cc), tap // 3, tap % 3] = 1.0
     want = _ref(x, conv.weight.detach(), None)
     y = C.xconv2d(conv.cuda(), x.cuda())
-    assert _err(y, want) < 1e-7, _where(y, want, 'n,c,y,x')
+    assert _err(y, want) < 2.5e-7, _where(y, want, 'n,c,y,x')
 
 
 CASES = [
