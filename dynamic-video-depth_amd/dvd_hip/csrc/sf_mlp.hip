@@ -1,4 +1,4 @@
-// Fused scene-flow field MLP for gfx950 (MI355X): forward, backward-dX chain, backward-dW, on the bf16
+// Fused scene-flow field MLP for gfx950 (MI355X): forward, backward-dX chain, backward-dW, on the 16-bit
 // matrix cores with fp32-class accuracy.
 //
 // What it replaces (reference, /root/reference):
@@ -9,21 +9,23 @@
 // and the autograd backward of all of it.  The unfused reference saves 11 168 B per
 // pixel-evaluation for backward and launches ~80 kernels per evaluation.
 //
-// Arithmetic (same as csrc/xconv.hip).  gfx950 runs fp32 MFMAs at the vector rate (157 TF), 1/16 of the bf16
-// matrix rate, so every fp32 operand is split exactly into three bf16 terms x = h + m + l (24 significant bits) and a
-// product is the six largest of the nine partial products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
-// about one ulp more error per product than an fp32 FMA chain, at 16/6 = 2.7x the fp32 MFMA rate.  The first
-// generation of this file (fp32 MFMAs, 121 / 94 / 91 TF/s forward / dX / dW) is in the history.
+// Arithmetic (csrc/dvd_split.h, as in csrc/xconv.hip): every fp32 operand, scaled by a power of two, is split into two
+// fp16 terms (22 significant bits) and a product is three partial products on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation, unscaled exactly afterwards.  The scales are dynamic and never leave the device: weights per layer (max|W_l|,
+// found by the pack step), activations / gradients PER TILE AND LAYER (the epilogue that produces a tile's 256 x 64 values
+// exchanges the waves' maxima through LDS across the barrier it needs anyway), the weight-gradient kernel per launch (the
+// forward / dX kernels fold their tile maxima into per-layer scalars at the end of the stash).  Earlier generations (fp32
+// MFMAs: 121 / 94 / 91 TF/s forward / dX / dW; three bf16 terms and six products: 164 / 143 / 165) are in the history.
 //
 // 593 408 FLOP per pixel forward, the same again for dX and for dW.
 //
 // Forward and dX: a 512-thread workgroup (8 waves, two per SIMD, one workgroup per CU) owns a tile of 64 pixels.
-//   * Activations live in LDS already split: X[term][k-octet][pixel] cells of 8 bf16 (96 KB).  A lane's B fragment
+//   * Activations live in LDS already split: X[term][k-octet][pixel] cells of 8 fp16 (64 KB).  A lane's B fragment
 //     of one K step (16 channels) is one ds_read_b128 per term; 32 consecutive pixels = 32 consecutive cells.
 //   * Weights never touch LDS: dvd_sf_mlp_pack writes them split and in fragment order (both orientations,
-//     3.5 MB, resident in each XCD's 4 MB L2); a lane's A fragment is one 16-byte global load per term.
+//     2.3 MB, resident in each XCD's 4 MB L2); a lane's A fragment is one 16-byte global load per term.
 //   * Wave w computes output channels [32w, 32w+32) for all 64 pixels (1x2 tiles of 32x32), layer after layer in
-//     place: 12 MFMAs per K step against 3 global + 6 LDS fragment loads.
+//     place: 6 MFMAs per K step against 2 global + 4 LDS fragment loads.
 //   * The epilogue (bias, LeakyReLU, split, LDS write) also streams the fp32 activation to the stash as
 //     [channel][64 pixels] rows -- the K-contiguous operand layout of the dW GEMM -- and one SIGN BIT per unit:
 //     the dX chain needs LeakyReLU' only, so it reads 4 bytes per lane and layer instead of the activations.
@@ -36,14 +38,20 @@
 //   Per-workgroup partial matrices go to a workspace at the end of `gstash` and are summed in fixed order by a
 //   second kernel: the weight gradients are bitwise reproducible (the first generation used float atomics).
 
-#include "dvd_common.h"
+#include "dvd_split.h"
+
+// waves per SIMD the forward / dX kernels are compiled for: 2 = one 512-thread workgroup per CU (<= 256 VGPRs: forward 193,
+// dX 256), 4 = two per CU (the 75 KB of LDS allow it, <= 128 VGPRs do not yet: 46 / 216 spilled registers)
+#ifndef DVD_MLP_FWD_OCC
+#define DVD_MLP_FWD_OCC 2
+#endif
+#ifndef DVD_MLP_DX_OCC
+#define DVD_MLP_DX_OCC 2
+#endif
 
 namespace dvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of it stay in registers
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -53,20 +61,7 @@ constexpr int kHidden = 5;     // layers with LeakyReLU: convs.0 .. convs.4
 constexpr int kNT = 512;       // threads per workgroup (forward, dX, dW)
 constexpr float kSlope = 0.2f;
 constexpr int kTermStride = 32 * kTM * 16;   // bytes between the split terms of X: [32 k-octets][64 pixels][16 B]
-constexpr int kXBytes = 3 * kTermStride;     // 98 304
-
-// (a, b) -> three dwords of two bf16 each: a in the low half, b in the high half
-__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  const f32x2 v = {a, b};
-  const bf16x2 hb = __builtin_convertvector(v, bf16x2);
-  const f32x2 r1 = v - __builtin_convertvector(hb, f32x2);
-  const bf16x2 mb = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(mb, f32x2);
-  const bf16x2 lb = __builtin_convertvector(r2, bf16x2);
-  h = __builtin_bit_cast(unsigned, hb);
-  m = __builtin_bit_cast(unsigned, mb);
-  l = __builtin_bit_cast(unsigned, lb);
-}
+constexpr int kXBytes = 2 * kTermStride;     // 65 536
 
 struct Geometry {
   int n_freq_xyz, n_freq_t, time_dependent;
@@ -91,14 +86,15 @@ static Geometry make_geometry(const dvd_mlp_desc* d) {
 }
 
 // ---- packed weight buffer ----------------------------------------------------------------
-// fragments: [(row tile * nk + K step) * 3 + term][64 lanes] x 16 bytes; lane l holds A[32 rt + (l&31)][16 kc + 8 (l>>5) .. +7]
+// fragments: [(row tile * nk + K step) * 2 + term][64 lanes] x 16 bytes; lane l holds A[32 rt + (l&31)][16 kc + 8 (l>>5) .. +7]
+// of W_l * pow2_scale(max|W_l|)
 //   forward  layer l: A[m][k] = W_l[out = m][in = k]    8 row tiles, nk = K_l / 16
 //   backward layer l: A[m][k] = W_l[out = k][in = m]    ceil(K_l / 32) row tiles, 16 K steps
-// then fp32: W_5 [3][256], biases.
+// then fp32: W_5 [3][256], biases, max|W_l| of the five hidden layers (8 floats).
 struct PackLayout {
   size_t fwd[kHidden], bwd[kHidden];   // offsets in 16-byte units
   int nk[kHidden], rtb[kHidden];
-  size_t w5, bias[6];                  // offsets in floats
+  size_t w5, bias[6], wamax;           // offsets in floats
   size_t total_bytes;
 };
 
@@ -109,9 +105,9 @@ static PackLayout make_pack_layout(const Geometry& g) {
     L.nk[l] = l == 0 ? g.ks0 : kWidth / 16;
     L.rtb[l] = l == 0 ? g.rt0 : kWidth / 32;
     L.fwd[l] = off;
-    off += (size_t)8 * L.nk[l] * 192;
+    off += (size_t)8 * L.nk[l] * 128;
     L.bwd[l] = off;
-    off += (size_t)L.rtb[l] * 16 * 192;
+    off += (size_t)L.rtb[l] * 16 * 128;
   }
   size_t f = off * 4;
   L.w5 = f;
@@ -120,6 +116,8 @@ static PackLayout make_pack_layout(const Geometry& g) {
     L.bias[l] = f;
     f += l < 5 ? kWidth : 4;
   }
+  L.wamax = f;
+  f += 8;
   L.total_bytes = f * 4;
   return L;
 }
@@ -131,6 +129,15 @@ struct PackArgs {
   PackLayout L;
   int c_in;
 };
+
+// max|W_l| of the hidden layers -> packed tail (zeroed by a memset node before)
+__global__ __launch_bounds__(256) void mlp_wamax_kernel(const PackArgs a) {
+  const int l = blockIdx.y;
+  const int n = kWidth * (l == 0 ? a.c_in : kWidth);
+  float m = 0.0f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = fmaxf(m, fabsf(a.W[l][i]));
+  wave_amax_to(m, static_cast<float*>(a.out) + a.L.wamax + l);
+}
 
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const PackArgs a) {
   const int job = blockIdx.y;   // 0..4 forward layer, 5..9 backward layer, 10 fp32 tail
@@ -163,14 +170,14 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const PackArgs a) {
     }
     v[e] = val;
   }
-  unsigned hw[4], mw[4], lw[4];
+  const float sw = pow2_scale(outf[a.L.wamax + l]);
+  unsigned hw[4], lw[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], hw[e], mw[e], lw[e]);
-  const u32x4 h = {hw[0], hw[1], hw[2], hw[3]}, mm = {mw[0], mw[1], mw[2], mw[3]}, lo = {lw[0], lw[1], lw[2], lw[3]};
-  u32x4* dst = static_cast<u32x4*>(a.out) + (bwd ? a.L.bwd[l] : a.L.fwd[l]) + (size_t)f * 192 + lane;
+  for (int e = 0; e < 4; ++e) split_pair_f16(v[2 * e] * sw, v[2 * e + 1] * sw, hw[e], lw[e]);
+  const u32x4 h = {hw[0], hw[1], hw[2], hw[3]}, lo = {lw[0], lw[1], lw[2], lw[3]};
+  u32x4* dst = static_cast<u32x4*>(a.out) + (bwd ? a.L.bwd[l] : a.L.fwd[l]) + (size_t)f * 128 + lane;
   dst[0] = h;
-  dst[64] = mm;
-  dst[128] = lo;
+  dst[64] = lo;
 }
 
 // ---- stash layouts (floats per tile) -------------------------------------------------------
@@ -185,32 +192,32 @@ __host__ __device__ inline size_t stash_sign_off(int c_in16, int l) {
   return (size_t)(c_in16 + kHidden * kWidth) * kTM + (size_t)l * kNT;
 }
 __host__ __device__ inline size_t gstash_floats_per_tile() { return (size_t)kHidden * kWidth * kTM; }
+// After the tiles of a stash: 16 floats of per-layer maxima over ALL tiles (atomic max by the forward / dX kernels, read by
+// the weight-gradient kernel for its per-launch operand scales): [0] embedding, [1 + l] h_l, [8 + l] G_l.
+constexpr int kStashTail = 16;
 constexpr int kDwSlices = 51;                                  // workgroups per layer (5 x 51 = 255 of 256 CUs)
 constexpr size_t kDwPartial = (size_t)kWidth * kWidth + kWidth;   // floats per workgroup: dW block + row sums
 
 // ---- the GEMM core of forward and dX ---------------------------------------------------------
 // acc[ct] += A (this wave's 32 rows, fragments streamed from global / L2) x B (X in LDS, column tile ct) over nk K steps.
 // Ap = fragment base of the wave's row tile + lane; Xl = LDS base of X + (lane>>5) * 1024 + (lane&31) * 16.
-__device__ __forceinline__ void load_frags(const u32x4* __restrict__ Ap, const unsigned char* Xl, int kc, u32x4 (&A)[3],
-                                           u32x4 (&B)[2][3]) {
+__device__ __forceinline__ void load_frags(const u32x4* __restrict__ Ap, const unsigned char* Xl, int kc, u32x4 (&A)[2],
+                                           u32x4 (&B)[2][2]) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    A[t] = Ap[(size_t)kc * 192 + t * 64];
+  for (int t = 0; t < 2; ++t) {
+    A[t] = Ap[(size_t)kc * 128 + t * 64];
     B[0][t] = *reinterpret_cast<const u32x4*>(Xl + t * kTermStride + kc * 2048);
     B[1][t] = *reinterpret_cast<const u32x4*>(Xl + t * kTermStride + kc * 2048 + 512);
   }
 }
 
-__device__ __forceinline__ void mfma_step(const u32x4 (&A)[3], const u32x4 (&B)[2][3], f32x16 (&acc)[2]) {
-#define DVD_MLP_TERM(SA, SB)                                                                               \
-  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[SA]),                      \
-                                                   __builtin_bit_cast(bf16x8, B[0][SB]), acc[0], 0, 0, 0); \
-  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[SA]),                      \
-                                                   __builtin_bit_cast(bf16x8, B[1][SB]), acc[1], 0, 0, 0);
-  DVD_MLP_TERM(2, 0)   // smallest partial products first
-  DVD_MLP_TERM(0, 2)
-  DVD_MLP_TERM(1, 1)
-  DVD_MLP_TERM(1, 0)
+__device__ __forceinline__ void mfma_step(const u32x4 (&A)[2], const u32x4 (&B)[2][2], f32x16 (&acc)[2]) {
+#define DVD_MLP_TERM(SA, SB)                                                                             \
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA]),                      \
+                                                  __builtin_bit_cast(f16x8, B[0][SB]), acc[0], 0, 0, 0); \
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA]),                      \
+                                                  __builtin_bit_cast(f16x8, B[1][SB]), acc[1], 0, 0, 0);
+  DVD_MLP_TERM(1, 0)   // smallest partial products first
   DVD_MLP_TERM(0, 1)
   DVD_MLP_TERM(0, 0)
 #undef DVD_MLP_TERM
@@ -220,7 +227,7 @@ __device__ __forceinline__ void gemm_rows32(const u32x4* __restrict__ Ap, int nk
   // two fragment sets, ping-pong: the loads of step kc+1 are issued before the MFMAs of step kc.  The scheduling
   // barriers keep them there (the scheduler otherwise sinks the loads to their first use and every K step waits a
   // full L2 round trip); steps past the end re-read the last one (no conditional loads).
-  u32x4 A0[3], B0[2][3], A1[3], B1[2][3];
+  u32x4 A0[2], B0[2][2], A1[2], B1[2][2];
   load_frags(Ap, Xl, 0, A0, B0);
   int kc = 0;
 #pragma unroll 1
@@ -244,15 +251,31 @@ __device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
 }
 
-// Four consecutive channels (n4 .. n4+3, the half `hh` of k-octet ko) of pixel m -> the three split terms in X.
-__device__ __forceinline__ void store_split4(unsigned char* X, int ko, int m, int hh, float v0, float v1, float v2, float v3) {
-  unsigned h0, m0, l0, h1, m1, l1;
-  split_pair(v0, v1, h0, m0, l0);
-  split_pair(v2, v3, h1, m1, l1);
+// Four consecutive channels (n4 .. n4+3, the half `hh` of k-octet ko) of pixel m, times the tile's scale -> the two split
+// terms in X.
+__device__ __forceinline__ void store_split4(unsigned char* X, int ko, int m, int hh, float s, float v0, float v1, float v2,
+                                             float v3) {
+  unsigned h0, l0, h1, l1;
+  split_pair_f16(v0 * s, v1 * s, h0, l0);
+  split_pair_f16(v2 * s, v3 * s, h1, l1);
   unsigned char* dst = X + (ko * kTM + m) * 16 + hh * 8;
   *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
-  *reinterpret_cast<u32x2*>(dst + kTermStride) = (u32x2){m0, m1};
-  *reinterpret_cast<u32x2*>(dst + 2 * kTermStride) = (u32x2){l0, l1};
+  *reinterpret_cast<u32x2*>(dst + kTermStride) = (u32x2){l0, l1};
+}
+
+// max over the wave's lanes, in every lane
+__device__ __forceinline__ float wave_max_all(float m) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+  return m;
+}
+// tile maximum from the eight waves' maxima (LDS, written before the barrier the caller has just passed)
+__device__ __forceinline__ float tile_max(const float* tmx) {
+  const float4 a = *reinterpret_cast<const float4*>(tmx), b = *reinterpret_cast<const float4*>(tmx + 4);
+  return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+}
+__device__ __forceinline__ void fold_amax(float* dst, float m) {
+  if (m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
 }
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, kSlope * v); }
@@ -276,21 +299,21 @@ struct FwdArgs {
   float t_offset, out_scale;
 };
 
-// LDS: X | psm [4][64] | w5 [3][256] + bias5 [4] | red [8][3][64]
-constexpr size_t kFwdLds = (size_t)kXBytes + 4 * kTM * 4 + (3 * kWidth + 4) * 4 + 8 * 3 * kTM * 4;
+// LDS: X | psm [4][64] | w5 [3][256] + bias5 [4] | red [8][3][64] | tmx [8]
+constexpr size_t kFwdLds = (size_t)kXBytes + 4 * kTM * 4 + (3 * kWidth + 4) * 4 + 8 * 3 * kTM * 4 + 8 * 4;
 
 // Input embedding of one tile: split into X, fp32 to the stash.  psm = [4][64] floats: x, y, z, t of the pixels.
+// `sx` = the tile's operand scale (pow2_scale of the largest |input| of the tile; sin / cos are bounded by 1).
 template <bool STASH>
 __device__ __forceinline__ void build_embedding(const Geometry& g, const float* __restrict__ fx, const float* __restrict__ ft,
-                                                const float* psm, unsigned char* X, float* st_emb) {
+                                                const float* psm, unsigned char* X, float* st_emb, float sx) {
   const int m = threadIdx.x & 63, part = threadIdx.x >> 6;   // 8 parts
   auto put = [&](int ch, float v) {
-    unsigned h, mm, l;
-    split_pair(v, 0.0f, h, mm, l);
+    unsigned h, l;
+    split_pair_f16(v * sx, 0.0f, h, l);
     unsigned char* dst = X + ((ch >> 3) * kTM + m) * 16 + (ch & 7) * 2;
     *reinterpret_cast<unsigned short*>(dst) = (unsigned short)h;
-    *reinterpret_cast<unsigned short*>(dst + kTermStride) = (unsigned short)mm;
-    *reinterpret_cast<unsigned short*>(dst + 2 * kTermStride) = (unsigned short)l;
+    *reinterpret_cast<unsigned short*>(dst + kTermStride) = (unsigned short)l;
     if (STASH) st_emb[(size_t)ch * kTM + m] = v;
   };
   const float x0 = psm[m], x1 = psm[kTM + m], x2 = psm[2 * kTM + m], tt = psm[3 * kTM + m];
@@ -324,18 +347,20 @@ __device__ __forceinline__ void build_embedding(const Geometry& g, const float* 
 }
 
 template <bool STASH>
-__global__ __launch_bounds__(kNT) void mlp_fwd_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* X = smem;
   float* psm = reinterpret_cast<float*>(smem + kXBytes);   // [4][64]
   float* w5 = psm + 4 * kTM;                               // [3][256] + bias5[4]
   float* red = w5 + 3 * kWidth + 4;                        // [8 waves][3][64]
+  float* tmx = red + 8 * 3 * kTM;                          // [8 waves]: maxima of the values a layer's epilogue produced
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const float* pf = static_cast<const float*>(a.packed);
   const u32x4* P4 = static_cast<const u32x4*>(a.packed);
   for (int i = tid; i < 3 * kWidth + 4; i += kNT) w5[i] = pf[i < 3 * kWidth ? a.L.w5 + i : a.L.bias[5] + (i - 3 * kWidth)];
   const unsigned char* Xl = X + hh * 1024 + j * 16;
+  float* tail = STASH ? a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16) : nullptr;   // per-layer maxima
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long n0 = (long long)tile * kTM;
@@ -355,7 +380,12 @@ __global__ __launch_bounds__(kNT) void mlp_fwd_kernel(const FwdArgs a) {
     }
     __syncthreads();
     float* st = STASH ? a.stash + (size_t)tile * stash_floats_per_tile(a.g.c_in16) : nullptr;
-    build_embedding<STASH>(a.g, a.freqs_xyz, a.freqs_t, psm, X, st);
+    // operand scale of the embedding: the largest input magnitude of the tile (every wave sees all 64 pixels in its lanes)
+    const float emax = wave_max_all(fmaxf(fmaxf(fabsf(psm[lane]), fabsf(psm[kTM + lane])),
+                                          fmaxf(fmaxf(fabsf(psm[2 * kTM + lane]), fabsf(psm[3 * kTM + lane])), 1.0f)));
+    float sx = pow2_scale(emax);                       // scale of what X currently holds (uniform over the workgroup)
+    if (STASH && tid == 0) fold_amax(tail + 0, emax);
+    build_embedding<STASH>(a.g, a.freqs_xyz, a.freqs_t, psm, X, st, sx);
     __syncthreads();
 
 #pragma unroll 1
@@ -367,8 +397,28 @@ __global__ __launch_bounds__(kNT) void mlp_fwd_kernel(const FwdArgs a) {
       float4 bvq[4];   // requested before the GEMM: an L2 round trip each if loaded where they are used
 #pragma unroll
       for (int q = 0; q < 4; ++q) bvq[q] = *reinterpret_cast<const float4*>(bias + 32 * w + 8 * q + 4 * hh);
-      gemm_rows32(P4 + a.L.fwd[l] + (size_t)w * nk * 192 + lane, nk, Xl, acc);
-      __syncthreads();  // every wave has finished reading this layer's input
+      gemm_rows32(P4 + a.L.fwd[l] + (size_t)w * nk * 128 + lane, nk, Xl, acc);
+      // activations in place of the accumulators (exact unscaling: a power of two), their maximum over the wave -> LDS
+      const float unscale = 1.0f / (sx * pow2_scale(pf[a.L.wamax + l]));
+      float vmax = 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bv = bvq[q];
+          acc[ct][4 * q + 0] = lrelu(__builtin_fmaf(acc[ct][4 * q + 0], unscale, bv.x));
+          acc[ct][4 * q + 1] = lrelu(__builtin_fmaf(acc[ct][4 * q + 1], unscale, bv.y));
+          acc[ct][4 * q + 2] = lrelu(__builtin_fmaf(acc[ct][4 * q + 2], unscale, bv.z));
+          acc[ct][4 * q + 3] = lrelu(__builtin_fmaf(acc[ct][4 * q + 3], unscale, bv.w));
+          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(acc[ct][4 * q + 0]), fabsf(acc[ct][4 * q + 1]))),
+                       fmaxf(fabsf(acc[ct][4 * q + 2]), fabsf(acc[ct][4 * q + 3])));
+        }
+      vmax = wave_max_all(vmax);
+      if (lane == 0) tmx[w] = vmax;
+      __syncthreads();  // every wave has finished reading this layer's input; the waves' maxima are visible
+      const float hmax = tile_max(tmx);
+      sx = pow2_scale(hmax);                           // scale of the next layer's input
+      if (STASH && tid == 0) fold_amax(tail + 1 + l, hmax);
       float* sh = STASH ? st + stash_h_off(a.g.c_in16, l) : nullptr;
       unsigned sw = 0;
       float po[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -377,11 +427,9 @@ __global__ __launch_bounds__(kNT) void mlp_fwd_kernel(const FwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n4 = 32 * w + 8 * q + 4 * hh;  // first of 4 consecutive output channels
-          const float4 bv = bvq[q];
-          const float v0 = lrelu(acc[ct][4 * q + 0] + bv.x), v1 = lrelu(acc[ct][4 * q + 1] + bv.y);
-          const float v2 = lrelu(acc[ct][4 * q + 2] + bv.z), v3 = lrelu(acc[ct][4 * q + 3] + bv.w);
+          const float v0 = acc[ct][4 * q + 0], v1 = acc[ct][4 * q + 1], v2 = acc[ct][4 * q + 2], v3 = acc[ct][4 * q + 3];
           const int m = 32 * ct + j;
-          if (l < kHidden - 1) store_split4(X, 4 * w + q, m, hh, v0, v1, v2, v3);   // the next layer's input
+          if (l < kHidden - 1) store_split4(X, 4 * w + q, m, hh, sx, v0, v1, v2, v3);   // the next layer's input
           if (STASH) {
             float* sp = sh + (size_t)n4 * kTM + m;
             sp[0] = v0;
@@ -451,22 +499,26 @@ struct BwdArgs {
   float out_scale, gscale;
 };
 
-// LDS: X (gradient tile, split; at the end fp32 g_in [<= 256][64]) | gz5 [4][64] | w5 [3][256]
-constexpr size_t kBwdLds = (size_t)kXBytes + 4 * kTM * 4 + 3 * kWidth * 4;
+// LDS: X (gradient tile, split; at the end fp32 g_in [<= 256][64]) | gz5 [4][64] | w5 [3][256] | tmx [8]
+constexpr size_t kBwdLds = (size_t)kXBytes + 4 * kTM * 4 + 3 * kWidth * 4 + 8 * 4;
 
-__global__ __launch_bounds__(kNT) void mlp_bwd_dx_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* X = smem;
   float* Xf = reinterpret_cast<float*>(smem);
   float* gz5 = reinterpret_cast<float*>(smem + kXBytes);   // [4][64]: g of the 3 outputs (already * out_scale)
   float* w5 = gz5 + 4 * kTM;                               // [3][256]
+  float* tmx = w5 + 3 * kWidth;                            // [8 waves]
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const float* pf = static_cast<const float*>(a.packed);
   const u32x4* P4 = static_cast<const u32x4*>(a.packed);
   for (int i = tid; i < 3 * kWidth; i += kNT) w5[i] = pf[a.L.w5 + i];
+  // per-layer maxima of the pre-activation gradients over all tiles (for the weight-gradient kernel): stash tail [8 + l]
+  float* gtail = const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16) + 8;
   const float s1 = a.gscale * (a.scale_ptr ? a.scale_ptr[0] : 1.0f);
   const unsigned char* Xl = X + hh * 1024 + j * 16;
+  float sx = 1.0f;                                         // operand scale of what X currently holds
   // last layer's parameter gradients, accumulated over this workgroup's tiles: dw5[c][i] belongs to channel
   // 32 w + 8 (i >> 2) + 4 hh + (i & 3) (summed over this lane's pixels; over the 32 lanes j at the end)
   float dw5[3][16];
@@ -501,6 +553,22 @@ __global__ __launch_bounds__(kNT) void mlp_bwd_dx_kernel(const BwdArgs a) {
       const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4))[tid];
       const float* h4 = st + stash_h_off(a.g.c_in16, 4);
       float* g4 = gs + (size_t)4 * kWidth * kTM;
+      // g_z4 of (pixel m, channels n4 .. n4 + 3): three FMAs and the slope per value -- evaluated twice (first for the
+      // tile maximum, the stash and dW5, then for the split store) rather than kept in 32 registers across the barrier
+      auto gz4 = [&](int ct, int q, float (&v)[4]) {
+        const int m = 32 * ct + j, n4 = 32 * w + 8 * q + 4 * hh;
+        const float ga = gz5[m], gb = gz5[kTM + m], gc = gz5[2 * kTM + m];
+        const float4 wa = *reinterpret_cast<const float4*>(w5 + n4);
+        const float4 wb = *reinterpret_cast<const float4*>(w5 + kWidth + n4);
+        const float4 wc = *reinterpret_cast<const float4*>(w5 + 2 * kWidth + n4);
+        const float war[4] = {wa.x, wa.y, wa.z, wa.w}, wbr[4] = {wb.x, wb.y, wb.z, wb.w}, wcr[4] = {wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool pos = (sw >> (16 * ct + 4 * q + e)) & 1u;
+          v[e] = (ga * war[e] + gb * wbr[e] + gc * wcr[e]) * (pos ? 1.0f : kSlope);
+        }
+      };
+      float vmax = 0.0f;
 #pragma unroll 1
       for (int ct = 0; ct < 2; ++ct) {
         const int m = 32 * ct + j;
@@ -508,24 +576,34 @@ __global__ __launch_bounds__(kNT) void mlp_bwd_dx_kernel(const BwdArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n4 = 32 * w + 8 * q + 4 * hh;
-          const float4 wa = *reinterpret_cast<const float4*>(w5 + n4);
-          const float4 wb = *reinterpret_cast<const float4*>(w5 + kWidth + n4);
-          const float4 wc = *reinterpret_cast<const float4*>(w5 + 2 * kWidth + n4);
-          const float war[4] = {wa.x, wa.y, wa.z, wa.w}, wbr[4] = {wb.x, wb.y, wb.z, wb.w}, wcr[4] = {wc.x, wc.y, wc.z, wc.w};
           float v[4];
+          gz4(ct, q, v);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float hv = h4[(size_t)(n4 + e) * kTM + m];
-            const bool pos = (sw >> (16 * ct + 4 * q + e)) & 1u;
-            v[e] = (ga * war[e] + gb * wbr[e] + gc * wcr[e]) * (pos ? 1.0f : kSlope);
+            vmax = fmaxf(vmax, fabsf(v[e]));
             g4[(size_t)(n4 + e) * kTM + m] = v[e];
             dw5[0][4 * q + e] = __builtin_fmaf(ga, hv, dw5[0][4 * q + e]);
             dw5[1][4 * q + e] = __builtin_fmaf(gb, hv, dw5[1][4 * q + e]);
             dw5[2][4 * q + e] = __builtin_fmaf(gc, hv, dw5[2][4 * q + e]);
           }
-          store_split4(X, 4 * w + q, m, hh, v[0], v[1], v[2], v[3]);
         }
       }
+      // the tile's operand scale: the waves' maxima through LDS (X is idle here: the previous tile is done with it)
+      vmax = wave_max_all(vmax);
+      if (lane == 0) tmx[w] = vmax;
+      __syncthreads();
+      const float gmax = tile_max(tmx);
+      sx = pow2_scale(gmax);
+      if (tid == 0) fold_amax(gtail + 4, gmax);
+#pragma unroll 1
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+          gz4(ct, q, v);
+          store_split4(X, 4 * w + q, 32 * ct + j, hh, sx, v[0], v[1], v[2], v[3]);
+        }
     }
     __syncthreads();
     // layers 4..1: g_z_{l-1} = (W_l^T g_z_l) * LeakyReLU'(h_{l-1})
@@ -534,22 +612,32 @@ __global__ __launch_bounds__(kNT) void mlp_bwd_dx_kernel(const BwdArgs a) {
       f32x16 acc[2];
       zero2(acc);
       const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, l - 1))[tid];
-      gemm_rows32(P4 + a.L.bwd[l] + (size_t)w * 16 * 192 + lane, 16, Xl, acc);
-      __syncthreads();
+      gemm_rows32(P4 + a.L.bwd[l] + (size_t)w * 16 * 128 + lane, 16, Xl, acc);
+      const float unscale = 1.0f / (sx * pow2_scale(pf[a.L.wamax + l]));
+      float vmax = 0.0f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool pos = (sw >> (16 * ct + r)) & 1u;
+          acc[ct][r] *= unscale * (pos ? 1.0f : kSlope);
+          vmax = fmaxf(vmax, fabsf(acc[ct][r]));
+        }
+      vmax = wave_max_all(vmax);
+      if (lane == 0) tmx[w] = vmax;
+      __syncthreads();  // every wave has finished reading g_z_l; the waves' maxima are visible
+      const float gmax = tile_max(tmx);
+      sx = pow2_scale(gmax);
+      if (tid == 0) fold_amax(gtail + (l - 1), gmax);
       float* gl = gs + (size_t)(l - 1) * kWidth * kTM;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n4 = 32 * w + 8 * q + 4 * hh, m = 32 * ct + j;
-          float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool pos = (sw >> (16 * ct + 4 * q + e)) & 1u;
-            v[e] = acc[ct][4 * q + e] * (pos ? 1.0f : kSlope);
-            gl[(size_t)(n4 + e) * kTM + m] = v[e];
-          }
-          store_split4(X, 4 * w + q, m, hh, v[0], v[1], v[2], v[3]);
+          for (int e = 0; e < 4; ++e) gl[(size_t)(n4 + e) * kTM + m] = acc[ct][4 * q + e];
+          store_split4(X, 4 * w + q, m, hh, sx, acc[ct][4 * q + 0], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]);
         }
       __syncthreads();
     }
@@ -557,13 +645,15 @@ __global__ __launch_bounds__(kNT) void mlp_bwd_dx_kernel(const BwdArgs a) {
     {
       f32x16 acc[2];
       zero2(acc);
-      if (w < a.g.rt0) gemm_rows32(P4 + a.L.bwd[0] + (size_t)w * 16 * 192 + lane, 16, Xl, acc);
+      if (w < a.g.rt0) gemm_rows32(P4 + a.L.bwd[0] + (size_t)w * 16 * 128 + lane, 16, Xl, acc);
+      const float unscale = 1.0f / (sx * pow2_scale(pf[a.L.wamax + 0]));
       __syncthreads();  // all waves finished reading g_z0
       if (w < a.g.rt0) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Xf[(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3)) * kTM + 32 * ct + j] = acc[ct][r];
+          for (int r = 0; r < 16; ++r)
+            Xf[(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3)) * kTM + 32 * ct + j] = acc[ct][r] * unscale;
       }
       __syncthreads();
     }
@@ -619,7 +709,7 @@ struct DwArgs {
 
 constexpr int kDwPitch = 48;                       // bytes per channel row of a 16-pixel chunk in LDS (32 + 16 pad)
 constexpr int kDwTerm = 256 * kDwPitch;            // 12 288: one split term of one operand
-constexpr int kDwBuf = 2 * 3 * kDwTerm;            // 73 728: G terms, then H terms
+constexpr int kDwBuf = 2 * 2 * kDwTerm;            // 49 152: G terms, then H terms
 constexpr size_t kDwLds = 2 * (size_t)kDwBuf;      // double buffered
 
 // FULL: every H row and every column tile is live (layers 1..4) -- no predicates in the chunk loop
@@ -645,6 +735,9 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.0f;
   float rs[2] = {0.f, 0.f};                        // row sums of G (bias gradient): rows (tid >> 2) and 128 + (tid >> 2)
+  // per-launch operand scales from the maxima the forward / dX kernels left behind the stash's tiles
+  const float* tail = a.stash + (size_t)a.n_tiles * spt;
+  const float scg = pow2_scale(tail[8 + layer]), sch = pow2_scale(tail[layer]);   // G_layer; H = embedding (0) or h_{layer-1}
 
   // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread; q = i * 512 + tid, row = q >> 2, quad = q & 3.
   // Two register sets: the chunk loaded during step `it` is split and stored during step it + 1 and consumed by the
@@ -670,35 +763,32 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
     for (int i = 0; i < 4; ++i) {
       const int row = i * 128 + (tid >> 2), quad = tid & 3;
       if (i < 2) rs[i] += count ? (sg[i].x + sg[i].y) + (sg[i].z + sg[i].w) : 0.0f;
-      unsigned h0, m0, l0, h1, m1, l1;
-      split_pair(sg[i].x, sg[i].y, h0, m0, l0);
-      split_pair(sg[i].z, sg[i].w, h1, m1, l1);
-      unsigned char* dst = base + (i >= 2 ? 3 * kDwTerm : 0) + (row & 255) * kDwPitch + quad * 8;
+      unsigned h0, l0, h1, l1;
+      const float sc = i >= 2 ? sch : scg;
+      split_pair_f16(sg[i].x * sc, sg[i].y * sc, h0, l0);
+      split_pair_f16(sg[i].z * sc, sg[i].w * sc, h1, l1);
+      unsigned char* dst = base + (i >= 2 ? 2 * kDwTerm : 0) + (row & 255) * kDwPitch + quad * 8;
       *reinterpret_cast<u32x2*>(dst) = (u32x2){h0, h1};
-      *reinterpret_cast<u32x2*>(dst + kDwTerm) = (u32x2){m0, m1};
-      *reinterpret_cast<u32x2*>(dst + 2 * kDwTerm) = (u32x2){l0, l1};
+      *reinterpret_cast<u32x2*>(dst + kDwTerm) = (u32x2){l0, l1};
     }
   };
   auto mfma_chunk = [&](int buf) {
     const unsigned char* gb = smem + buf * kDwBuf + (64 * wr + i32) * kDwPitch + hh * 16;
-    const unsigned char* hb = smem + buf * kDwBuf + 3 * kDwTerm + (128 * wc + i32) * kDwPitch + hh * 16;
-    u32x4 A[2][3];
+    const unsigned char* hb = smem + buf * kDwBuf + 2 * kDwTerm + (128 * wc + i32) * kDwPitch + hh * 16;
+    u32x4 A[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) A[r][t] = *reinterpret_cast<const u32x4*>(gb + t * kDwTerm + r * 32 * kDwPitch);
+      for (int t = 0; t < 2; ++t) A[r][t] = *reinterpret_cast<const u32x4*>(gb + t * kDwTerm + r * 32 * kDwPitch);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (FULL || c < nct) {
-        u32x4 B[3];
+        u32x4 B[2];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) B[t] = *reinterpret_cast<const u32x4*>(hb + t * kDwTerm + c * 32 * kDwPitch);
-#define DVD_DW_TERM(SA, SB)                                                                                       \
-  _Pragma("unroll") for (int r = 0; r < 2; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(              \
-      __builtin_bit_cast(bf16x8, A[r][SA]), __builtin_bit_cast(bf16x8, B[SB]), acc[r][c], 0, 0, 0);
-        DVD_DW_TERM(2, 0)
-        DVD_DW_TERM(0, 2)
-        DVD_DW_TERM(1, 1)
+        for (int t = 0; t < 2; ++t) B[t] = *reinterpret_cast<const u32x4*>(hb + t * kDwTerm + c * 32 * kDwPitch);
+#define DVD_DW_TERM(SA, SB)                                                                                     \
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(             \
+      __builtin_bit_cast(f16x8, A[r][SA]), __builtin_bit_cast(f16x8, B[SB]), acc[r][c], 0, 0, 0);
         DVD_DW_TERM(1, 0)
         DVD_DW_TERM(0, 1)
         DVD_DW_TERM(0, 0)
@@ -731,6 +821,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
   // this workgroup's partial matrix: element r of acc[rr][c] in lane l is row 64 wr + 32 rr + (r&3) + 8 (r>>2) + 4 (l>>5),
   // column 128 wc + 32 c + (l&31)
   float* dst = a.partial + ((size_t)layer * a.S + s) * kDwPartial;
+  const float unscale = 1.0f / (scg * sch);          // exact power of two
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
@@ -738,7 +829,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = 64 * wr + 32 * rr + (r & 3) + 8 * (r >> 2) + 4 * hh, k = 128 * wc + 32 * c + i32;
-        dst[(size_t)n * kWidth + k] = acc[rr][c][r];
+        dst[(size_t)n * kWidth + k] = acc[rr][c][r] * unscale;
       }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -798,10 +889,11 @@ static int check_desc(const dvd_mlp_desc* d) {
 
 static int dw_slices(int n_tiles) { return n_tiles < kDwSlices ? n_tiles : kDwSlices; }
 
-static int persistent_grid(int n_tiles) {
+static int persistent_grid(int n_tiles, int occ) {
   int cus = dvd_device_cu_count();
   if (cus <= 0) cus = 256;
-  return n_tiles < cus ? n_tiles : cus;   // one 512-thread workgroup (96 KB of LDS) per CU
+  const int wgs = cus * (occ / 2);               // 512-thread workgroups resident at once
+  return n_tiles < wgs ? n_tiles : wgs;
 }
 
 }  // namespace dvd
@@ -818,7 +910,7 @@ size_t dvd_sf_mlp_packed_bytes(const dvd_mlp_desc* d) {
 size_t dvd_sf_mlp_stash_bytes(const dvd_mlp_desc* d, long long n_pix) {
   if (!d || n_pix <= 0) return 0;
   const long long tiles = (n_pix + dvd::kTM - 1) / dvd::kTM;
-  return (size_t)tiles * dvd::stash_floats_per_tile(dvd::make_geometry(d).c_in16) * 4;
+  return ((size_t)tiles * dvd::stash_floats_per_tile(dvd::make_geometry(d).c_in16) + dvd::kStashTail) * 4;
 }
 
 size_t dvd_sf_mlp_gstash_bytes(long long n_pix) {
@@ -843,6 +935,10 @@ int dvd_sf_mlp_pack(const dvd_mlp_desc* d, const float* const W[6], const float*
   a.out = packed;
   a.L = make_pack_layout(g);
   a.c_in = g.c_in;
+  // per-layer max|W_l| first (the packed buffer's tail), then the scaled split
+  DVD_HIP_OK(hipMemsetAsync(static_cast<float*>(packed) + a.L.wamax, 0, 8 * sizeof(float), static_cast<hipStream_t>(stream)));
+  hipLaunchKernelGGL(mlp_wamax_kernel, dim3(16, kHidden), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  DVD_LAUNCH_OK();
   // the largest job has 8 row tiles x 16 K steps x 64 lanes = 8192 threads
   hipLaunchKernelGGL(mlp_pack_kernel, dim3(32, 11), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   DVD_LAUNCH_OK();
@@ -877,8 +973,10 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   a.n_tiles = (int)((n_pix + kTM - 1) / kTM);
   a.t_offset = t_offset;
   a.out_scale = out_scale;
-  const int grid = persistent_grid(a.n_tiles);
+  const int grid = persistent_grid(a.n_tiles, DVD_MLP_FWD_OCC);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (stash)   // per-layer maxima behind the tiles (embedding, h_0 .. h_4; the dX kernel zeroes its own half)
+    DVD_HIP_OK(hipMemsetAsync(a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16), 0, kStashTail * sizeof(float), s));
   if (stash) {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
@@ -920,7 +1018,10 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
   a.n_tiles = (int)((n_pix + kTM - 1) / kTM);
   a.out_scale = out_scale;
   a.gscale = gscale;
-  const int grid = persistent_grid(a.n_tiles);
+  const int grid = persistent_grid(a.n_tiles, DVD_MLP_DX_OCC);
+  // maxima of G_0 .. G_4 over all tiles, folded in by the kernel: floats [8, 16) behind the stash's tiles
+  DVD_HIP_OK(hipMemsetAsync(const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16) + 8, 0,
+                            8 * sizeof(float), static_cast<hipStream_t>(stream)));
   DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
   hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(kNT), kBwdLds, static_cast<hipStream_t>(stream), a);
