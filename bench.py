@@ -10,7 +10,7 @@ share one GPU (a smoke test of the N > 1 path on a 1-GPU box).
 
 Workload (BASELINE.json configs[1] = configs[2]): synthetic 384x672 video, 48 frame pairs per GPU,
 MiDaS depth net (ResNeXt-101 32x8d, random init + calibrated head; every convolution, BatchNorm+ReLU, pooling and
-up-sampling on the hand-written HIP kernels of dvd_hip/csrc -- split-bf16 MFMA implicit GEMMs with fp32 accumulation)
+up-sampling on the hand-written HIP kernels of dvd_hip/csrc -- fp16-pair-split MFMA implicit GEMMs with fp32 accumulation)
 + scene-flow MLP, non-warm phase (L1 + acceleration regulariser), gap 1, fp32 storage.  A "step" is one
 `Model._train_on_batch`: depth nets forward, geometry + MLP + fused warp/loss forward and
 backward, depth-net backward, gradient all-reduce (N>1) and both Adam updates.  Inputs are
@@ -297,10 +297,12 @@ def main():
         'value': world * (a.pairs / float(PAIRS)) * a.steps / dt, 'unit': 'iters/s (48-pair steps, whole job)',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (storage and accumulation fp32; conv / MLP contractions as 3-term split-bf16 MFMA products: 24-bit '
-                 'operands, 6 of 9 partial products, <= 2.5e-6 of max|y| against float64)', 'data': 'synthetic',
+        'dtype': 'f32 (storage and accumulation fp32; conv / MLP contractions on v_mfma_f32_32x32x16_f16: every fp32 operand, '
+                 'scaled by a power of two from its tensor\'s max, is split into two fp16 terms (22 bits) and a product is '
+                 'three partial products; <= 4e-6 of max|y| against float64, the bound the 3-term bf16 / 6-product '
+                 'arithmetic of round 2 met)', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]/[2]: synthetic %dx%d, %d frame pairs per GPU, gap %d, MiDaS '
-                               '(ResNeXt-101 32x8d) depth net with hand-written split-bf16 MFMA convolution kernels '
+                               '(ResNeXt-101 32x8d) depth net with hand-written fp16-pair-split MFMA convolution kernels '
                                '(forward, data and weight gradients) '
                                'under PyTorch-ROCm autograd + HIP scene-flow MLP + HIP fused warp/reprojection/loss, '
                                'non-warm phase with acceleration regulariser' % (H, W, a.pairs, GAP),

@@ -122,9 +122,15 @@ class DeviceFeeder(object):
         self.loader, self.device, self.keys = loader, torch.device(device), keys
         self.stream = torch.cuda.Stream(device=self.device)
         self.pinned = [dict(), dict()]
+        self.copied = [None, None]       # event behind the last H2D copies out of each slot's pinned buffers
 
     def _stage(self, batch, slot):
         out, pins = {}, self.pinned[slot]
+        if self.copied[slot] is not None:
+            # the non-blocking copies issued from this slot two batches ago read the pinned buffers asynchronously: they
+            # must have drained before the host overwrites them (a consumer without a per-step host sync would otherwise
+            # receive a torn batch)
+            self.copied[slot].synchronize()
         with torch.cuda.stream(self.stream):
             for k, v in batch.items():
                 if not torch.is_tensor(v) or (self.keys is not None and k not in self.keys) or v.dim() == 0:
@@ -138,6 +144,7 @@ class DeviceFeeder(object):
                 out[k] = buf.to(self.device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(self.stream)
+        self.copied[slot] = ev
         return out, ev
 
     def __iter__(self):

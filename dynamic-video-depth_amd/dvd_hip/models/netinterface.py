@@ -217,28 +217,40 @@ class NetInterface(object):
         logger = self._logger
 
         def n_samples(loader):
-            bs = getattr(loader, 'batch_sampler', None)
+            """_get_num_samples (netinterface.py:26-32): samples the sampler yields, whole batches only with drop_last;
+            loaders without a batch sampler (plain iterables, the device feeder over one): one sample per step."""
+            bs = getattr(loader, 'batch_sampler', None) or getattr(getattr(loader, 'loader', None), 'batch_sampler', None)
             try:
-                return len(bs.sampler) if bs is not None else len(loader)
+                if bs is None:
+                    return len(loader), 1
+                n = len(bs.sampler)
+                return (n // bs.batch_size * bs.batch_size if bs.drop_last else n), bs.batch_size
             except TypeError:
-                return None
+                return None, 1
 
         def limits():
+            """steps / samples per training epoch and per validation pass (netinterface.py:217-232), including the
+            reference's quirk of clamping the validation samples with the TRAINING loader's batch size."""
             st = len(dataloader) if hasattr(dataloader, '__len__') else None
-            sa = n_samples(dataloader) if st is not None else None
+            sa, bsz = n_samples(dataloader) if st is not None else (None, 1)
             if max_batches_per_train is not None:
                 st = max_batches_per_train if st is None else min(st, max_batches_per_train)
-            sv = 0
+                if sa is not None:
+                    sa = min(sa, st * bsz)
+            sv = sav = 0
             if dataloader_vali is not None:
                 sv = len(dataloader_vali)
+                sav, _ = n_samples(dataloader_vali)
                 if max_batches_per_vali is not None:
                     sv = min(sv, max_batches_per_vali)
-            return st, sa, sv
+                    if sav is not None:
+                        sav = min(sav, sv * bsz)
+            return st, sa, sv, sav
 
         def announce():
-            st, sa, sv = limits()
+            st, sa, sv, sav = limits()
             logger.set_params({'epochs': epochs + initial_epoch - 1, 'steps': st, 'steps_eval': sv, 'samples': sa,
-                               'samples_eval': sv, 'verbose': verbose, 'metrics': self._metrics})
+                               'samples_eval': sav, 'verbose': 1, 'metrics': self._metrics})      # 'verbose': 1 (:239)
             return st, sv
 
         steps, steps_eval = announce()

@@ -74,7 +74,9 @@ class Model(NetInterface):
         parser.add_argument('--mlp_whole_batch_gb', type=float, default=160.0,
                             help='HBM ceiling for keeping the forward stashes of the whole batch alive so that the '
                                  'warp+loss kernel runs as ONE launch (falls back to one launch per chunk)')
-        parser.add_argument('--depth_chunk', type=int, default=16, help='images per depth-net forward/backward chunk')
+        parser.add_argument('--depth_chunk', type=int, default=48,
+                            help='images per depth-net forward/backward chunk = per kept-activation graph slot (48: the '
+                                 'configuration bench.py measures; two slots per 48-pair step)')
         parser.add_argument('--depth_graphs', type=int, default=1,
                             help='1 (default): capture the depth net per chunk shape in HIP graphs (forward, forward+backward) '
                                  'and replay them: one launch per chunk instead of ~2 000, so the step does not depend on '
@@ -132,6 +134,8 @@ class Model(NetInterface):
         self._keep_bytes = 0         # HBM held by kept-activation graph slots
         self._keep_per_px = 0.0      # measured bytes per image pixel of a captured slot
         self._pool_bytes = 0         # HBM reserved by the private pools of all captured graphs
+        self._keep_denied = {}       # slot key -> step at which it was last denied / trimmed (retried 16 steps later)
+        self._step_no = 0
         self.warm = False
 
     # flat parameter buffers + fused Adam replace the two torch.optim.Adam objects (:113-115)
@@ -233,7 +237,18 @@ class Model(NetInterface):
     def _keep_slot(self, slot, chunk, fid, reserve_bytes, last_and_all_kept=False):
         key = ('keep', slot, tuple(chunk.shape), bool(self.opt.midas))
         if key in self._depth_graphs:
-            return self._depth_graphs[key]
+            entry = self._depth_graphs[key]
+            # a slot that was denied (or trimmed) for lack of room is tried again every 16 steps: one transient
+            # low-memory moment must not pin its chunk to the recompute path for the rest of the run
+            if entry is not None or self._step_no - self._keep_denied.get(key, self._step_no) < 16:
+                return entry
+            del self._depth_graphs[key]
+        # slots captured for another chunk shape at this position (the last, smaller batch of an epoch) hold HBM this
+        # shape needs: release them
+        for k in [k for k, v in self._depth_graphs.items() if k[0] == 'keep' and k[1] == slot and k != key and v is not None]:
+            self._keep_bytes -= self._depth_graphs[k][5]
+            self._pool_bytes -= self._depth_graphs[k][5]
+            del self._depth_graphs[k]
         entry = None
         # bytes a slot will hold: measured on the slots captured so far (per image and pixel), a-priori figure (MiDaS with
         # fused epilogues: ~4.1 KB per pixel) for the first one, + packed weights
@@ -250,6 +265,7 @@ class Model(NetInterface):
                 self._keep_bytes / 2 ** 30, self._pool_bytes / 2 ** 30), file=sys.stderr, flush=True)
         if not keep_slot_fits(est, free, total, reserve_bytes, spare, self._keep_bytes, budget):
             self._depth_graphs[key] = None
+            self._keep_denied[key] = self._step_no
             return None
         try:
             import gc
@@ -322,6 +338,7 @@ class Model(NetInterface):
             self._keep_bytes -= self._depth_graphs[key][5]
             self._pool_bytes -= self._depth_graphs[key][5]
             self._depth_graphs[key] = None
+            self._keep_denied[key] = self._step_no
             import gc
             gc.collect()
             free, total = self._free_hbm(device)
@@ -408,6 +425,7 @@ class Model(NetInterface):
     # ------------------------------------------------------------------------------------
     def _train_on_batch(self, epoch, batch_ind, batch):
         opt = self.opt
+        self._step_no += 1
         self.warm = warm = epoch <= opt.warm_sf
         self.net_depth.eval()                        # BN statistics are never updated (:157,168 / hourglass.py:200-208)
         for p in self.net_depth.parameters():
@@ -476,11 +494,16 @@ class Model(NetInterface):
         # (also agreed across ranks: does ANY rank still have to capture a depth-net graph in phase 3 -- a chunk that is not
         #  kept and has no recompute graph yet?  Then every rank keeps the MLP-gradient all-reduce out of flight until after
         #  phase 3, so the order of collectives is the same everywhere)
-        c0 = inp.img_1[:max(1, int(opt.depth_chunk))]
-        recompute = any(self._depth_graphs.get(('keep', sl, tuple(c0.shape), bool(opt.midas))) is None
-                        for sl in range(2 * n_slots))
-        may_capture = bool(not warm and getattr(opt, 'depth_graphs', 1) and recompute
-                           and self._graph_key('fb', c0) not in self._depth_graphs)
+        # over the REAL chunk list of both image sets (a ragged last chunk has its own slot / graph keys)
+        may_capture = False
+        if not warm and getattr(opt, 'depth_graphs', 1):
+            cw = max(1, int(opt.depth_chunk))
+            for s0, img in ((0, inp.img_1), (n_slots, inp.img_2)):
+                for ci, b0 in enumerate(range(0, B, cw)):
+                    chunk = img[b0:b0 + cw]
+                    kept = self._depth_graphs.get(('keep', s0 + ci, tuple(chunk.shape), bool(opt.midas)))
+                    if kept is None and self._graph_key('fb', chunk) not in self._depth_graphs:
+                        may_capture = True
         late, n_global, capturing = parallel.agree_on_step_plan(dev, not (whole or Bc >= B), B, may_capture)
         early_norm = not late
         reg_coef = opt.acc_mul / (3.0 * n_global * HW + 1e-6)
