@@ -86,6 +86,8 @@ SIGNATURES = {
                               c_float, c_float, c_float, c_int, c_void_p]),
     'dvd_warp_surfaces': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Cameras),
                                   ctypes.POINTER(Surfaces), c_int, c_int, c_int, c_void_p]),
+    'dvd_warp_surfaces_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(Cameras),
+                                      ctypes.POINTER(Surfaces), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'dvd_flow_warp_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_flow_warp_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_bnrelu_fwd': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

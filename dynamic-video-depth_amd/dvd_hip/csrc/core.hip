@@ -12,6 +12,20 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+__global__ void zero_words_kernel(unsigned* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+// Small device-side clears (operand-scale scalars, headers) are KERNELS, not hipMemsetAsync: inside a captured HIP graph a
+// memset node was seen to run out of order with the kernels around it once the graph's pool re-used the block (round 3:
+// a convolution read a weight-scale header that the memset of a LATER packing zeroed; eager execution was unaffected).
+int zero_words(void* p, int n_words, hipStream_t stream) {
+  hipLaunchKernelGGL(zero_words_kernel, dim3((n_words + 63) / 64), dim3(64), 0, stream, static_cast<unsigned*>(p), n_words);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
 }  // namespace dvd
 
 extern "C" {

@@ -10,6 +10,7 @@
 namespace dvd {
 
 void set_error(const char* fmt, ...);
+int zero_words(void* p, int n_words, hipStream_t stream);   // device-side clear by a kernel (core.hip)
 
 #define DVD_REQUIRE(cond, ...)             \
   do {                                     \

@@ -936,7 +936,7 @@ int dvd_sf_mlp_pack(const dvd_mlp_desc* d, const float* const W[6], const float*
   a.L = make_pack_layout(g);
   a.c_in = g.c_in;
   // per-layer max|W_l| first (the packed buffer's tail), then the scaled split
-  DVD_HIP_OK(hipMemsetAsync(static_cast<float*>(packed) + a.L.wamax, 0, 8 * sizeof(float), static_cast<hipStream_t>(stream)));
+  if (int e = zero_words(static_cast<float*>(packed) + a.L.wamax, 8, static_cast<hipStream_t>(stream))) return e;
   hipLaunchKernelGGL(mlp_wamax_kernel, dim3(16, kHidden), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   DVD_LAUNCH_OK();
   // the largest job has 8 row tiles x 16 K steps x 64 lanes = 8192 threads
@@ -976,7 +976,7 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   const int grid = persistent_grid(a.n_tiles, DVD_MLP_FWD_OCC);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (stash)   // per-layer maxima behind the tiles (embedding, h_0 .. h_4; the dX kernel zeroes its own half)
-    DVD_HIP_OK(hipMemsetAsync(a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16), 0, kStashTail * sizeof(float), s));
+    if (int e = zero_words(a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16), kStashTail, s)) return e;
   if (stash) {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
@@ -1020,8 +1020,9 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
   a.gscale = gscale;
   const int grid = persistent_grid(a.n_tiles, DVD_MLP_DX_OCC);
   // maxima of G_0 .. G_4 over all tiles, folded in by the kernel: floats [8, 16) behind the stash's tiles
-  DVD_HIP_OK(hipMemsetAsync(const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16) + 8, 0,
-                            8 * sizeof(float), static_cast<hipStream_t>(stream)));
+  if (int e = zero_words(const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16) + 8, 8,
+                         static_cast<hipStream_t>(stream)))
+    return e;
   DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
   hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(kNT), kBwdLds, static_cast<hipStream_t>(stream), a);

@@ -200,6 +200,126 @@ __global__ __launch_bounds__(256) void warp_surfaces_kernel(const SurfArgs a) {
   }
 }
 
+// Vector-Jacobian product of warp_surfaces_kernel: upstream gradients of any subset of the surfaces (null = none) ->
+// gradients w.r.t. depth_1, depth_2 (scatter over the four bilinear taps; the flow is data) and the scene flow.  This is
+// what makes the MODULE forms of flow_by_depth / scene_flow_projection_slack differentiable like the reference's
+// (losses/scene_flow_projection.py:114-153,222-278 under autograd); the training step uses the fused kernel instead.
+// The index_put of the behind-camera fallback cuts the gradient of the projected coordinates (losses:253-263).
+struct SurfBwdArgs {
+  const float *d1, *d2, *flow, *sflow;
+  const float *R1, *R2, *R2T, *t1, *t2, *K, *Ki;
+  dvd_surfaces g;                        // upstream gradients, same layouts as the surfaces
+  float *g_d1, *g_d2, *g_sflow;          // g_d2 zeroed by the caller (atomic scatter); g_sflow may be null
+  int H, W, HW;
+};
+
+__global__ __launch_bounds__(256) void warp_surfaces_bwd_kernel(const SurfBwdArgs a) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.HW) return;
+  float Ki[9], R1[9], R2[9], R2T[9], K[9], t1[3], t2[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    Ki[i] = a.Ki[b * 9 + i];
+    R1[i] = a.R1[b * 9 + i];
+    R2[i] = a.R2[b * 9 + i];
+    R2T[i] = a.R2T[b * 9 + i];
+    K[i] = a.K[b * 9 + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    t1[i] = a.t1[b * 3 + i];
+    t2[i] = a.t2[b * 3 + i];
+  }
+  const int y = p / a.W, x = p - y * a.W;
+  const float xf = (float)x, yf = (float)y;
+  const size_t lin = (size_t)b * a.HW + p;
+  const float d1 = a.d1[lin];
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+  if (a.sflow) {
+    s0 = a.sflow[3 * lin];
+    s1 = a.sflow[3 * lin + 1];
+    s2 = a.sflow[3 * lin + 2];
+  }
+  auto g3 = [&](const float* q, float (&v)[3]) {
+    v[0] = q ? q[3 * lin] : 0.0f;
+    v[1] = q ? q[3 * lin + 1] : 0.0f;
+    v[2] = q ? q[3 * lin + 2] : 0.0f;
+  };
+  float gP[3], gG[3], gS[3], gQd[3], gW2[3];
+  g3(a.g.global_p1, gP);
+  g3(a.g.warped_global_p2, gG);
+  g3(a.g.sf_by_depth, gS);
+  g3(a.g.p1_camera_2, gQd);
+  g3(a.g.warped_p2_camera_2, gW2);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {          // sf_by_depth = warped_global_p2 - global_p1
+    gG[c] += gS[c];
+    gP[c] -= gS[c];
+  }
+  // forward values needed by the projections
+  float r0, r1, r2, P0, P1, P2;
+  rowvec_mat3(xf, yf, 1.0f, Ki, r0, r1, r2);
+  rowvec_mat3(d1 * r0, d1 * r1, d1 * r2, R1, P0, P1, P2);
+  P0 += t1[0];
+  P1 += t1[1];
+  P2 += t1[2];
+  // dynamic / static reprojection: gradient of (u - x, v - y) and of I.z w.r.t. A = P (+ s) - t2
+  auto reproject_bwd = [&](float A0, float A1, float A2, const float* gflow, float gz, float gQ_in0, float gQ_in1,
+                           float gQ_in2, float (&gA)[3]) {
+    float Q0, Q1, Q2, I0, I1, I2;
+    rowvec_mat3(A0, A1, A2, R2T, Q0, Q1, Q2);
+    rowvec_mat3(Q0, Q1, Q2, K, I0, I1, I2);
+    float gI0 = 0.0f, gI1 = 0.0f, gI2 = gz;
+    if (gflow && !(I2 < 1e-3f)) {
+      const float den = I2 + 1e-8f, rden = 1.0f / den;
+      const float gu = gflow[2 * lin], gv = gflow[2 * lin + 1];
+      gI0 = gu * rden;
+      gI1 = gv * rden;
+      gI2 -= (gu * I0 + gv * I1) * rden * rden;
+    }
+    float q0, q1, q2;
+    rowvec_mat3_T(gI0, gI1, gI2, K, q0, q1, q2);
+    rowvec_mat3_T(q0 + gQ_in0, q1 + gQ_in1, q2 + gQ_in2, R2T, gA[0], gA[1], gA[2]);
+  };
+  float gAd[3], gAs[3];
+  reproject_bwd((P0 + s0) - t2[0], (P1 + s1) - t2[1], (P2 + s2) - t2[2], a.g.dflow_1_2,
+                a.g.depth_image_1_2 ? a.g.depth_image_1_2[lin] : 0.0f, gQd[0], gQd[1], gQd[2], gAd);
+  reproject_bwd(P0 - t2[0], P1 - t2[1], P2 - t2[2], a.g.staticflow_1_2, 0.0f, 0.0f, 0.0f, 0.0f, gAs);
+  if (a.g_sflow) {
+    a.g_sflow[3 * lin] = gAd[0];
+    a.g_sflow[3 * lin + 1] = gAd[1];
+    a.g_sflow[3 * lin + 2] = gAd[2];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) gP[c] += gAd[c] + gAs[c];
+  {  // P = (d1 ray) @ R1 + t1
+    float c0, c1, c2;
+    rowvec_mat3_T(gP[0], gP[1], gP[2], R1, c0, c1, c2);
+    a.g_d1[lin] = c0 * r0 + c1 * r1 + c2 * r2;
+  }
+  // taps of frame 2: d/d(d2_k) = w_k (g_depth_warp + ray_k . (g_W2c + g_G @ R2^T))
+  float h0, h1, h2;
+  rowvec_mat3_T(gG[0], gG[1], gG[2], R2, h0, h1, h2);
+  h0 += gW2[0];
+  h1 += gW2[1];
+  h2 += gW2[2];
+  const float gdw = a.g.depth_warp_1_2 ? a.g.depth_warp_1_2[lin] : 0.0f;
+  const Taps t = make_taps(xf, yf, a.flow[2 * lin], a.flow[2 * lin + 1], a.H, a.W);
+  float* g2 = a.g_d2 + (size_t)b * a.HW;
+  const float wk[4] = {t.w_nw, t.w_ne, t.w_sw, t.w_se};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int dx = k & 1, dy = k >> 1;
+    if ((dx == 1 && !t.in_e) || (dy == 1 && !t.in_s)) continue;
+    const int tx = t.x0 + dx, ty = t.y0 + dy;
+    float q0, q1, q2;
+    rowvec_mat3((float)tx, (float)ty, 1.0f, Ki, q0, q1, q2);
+    const float v = wk[k] * (gdw + (q0 * h0 + q1 * h1 + q2 * h2));
+    if (v != 0.0f) unsafeAtomicAdd(g2 + ty * a.W + tx, v);
+  }
+}
+
 // out[b,c,y,x] = bilinear(src[b,c], (x,y) + flow[b,y,x])       (forward)
 // g_src[b,c,tap] += w_tap * g_out[b,c,y,x]                      (backward w.r.t. the buffer)
 template <bool BACKWARD>
@@ -259,6 +379,40 @@ int dvd_warp_surfaces(const float* depth_1, const float* depth_2, const float* f
   a.HW = H * W;
   hipLaunchKernelGGL(dvd::warp_surfaces_kernel, dim3((a.HW + 255) / 256, B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), a);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_warp_surfaces_bwd(const float* depth_1, const float* depth_2, const float* flow_1_2, const float* sflow_1_2,
+                          const dvd_cameras* cams, const dvd_surfaces* g_surfaces, float* g_depth_1, float* g_depth_2,
+                          float* g_sflow_1_2, int B, int H, int W, dvd_stream_t stream) {
+  DVD_REQUIRE(depth_1 && depth_2 && flow_1_2 && cams && g_surfaces && g_depth_1 && g_depth_2, "warp_surfaces_bwd: null pointer");
+  DVD_REQUIRE(B > 0 && H > 1 && W > 1 && B <= 65535, "warp_surfaces_bwd: bad shape B=%d H=%d W=%d", B, H, W);
+  DVD_REQUIRE((long long)B * H * W * 3 < (1LL << 31), "warp_surfaces_bwd: tensor too large for 32-bit indexing");
+  DVD_REQUIRE(cams->R_1 && cams->R_2 && cams->R_2_T && cams->t_1 && cams->t_2 && cams->K && cams->K_inv,
+              "warp_surfaces_bwd: null camera pointer");
+  dvd::SurfBwdArgs a;
+  a.d1 = depth_1;
+  a.d2 = depth_2;
+  a.flow = flow_1_2;
+  a.sflow = sflow_1_2;
+  a.R1 = cams->R_1;
+  a.R2 = cams->R_2;
+  a.R2T = cams->R_2_T;
+  a.t1 = cams->t_1;
+  a.t2 = cams->t_2;
+  a.K = cams->K;
+  a.Ki = cams->K_inv;
+  a.g = *g_surfaces;
+  a.g_d1 = g_depth_1;
+  a.g_d2 = g_depth_2;
+  a.g_sflow = g_sflow_1_2;
+  a.H = H;
+  a.W = W;
+  a.HW = H * W;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DVD_HIP_OK(hipMemsetAsync(g_depth_2, 0, (size_t)B * H * W * sizeof(float), s));
+  hipLaunchKernelGGL(dvd::warp_surfaces_bwd_kernel, dim3((a.HW + 255) / 256, B), dim3(256), 0, s, a);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -652,7 +652,7 @@ static int xconv_pack_impl(const float* w, void* packed, int Cout, int Cin, int 
   const int mtiles = dvd::xconv_mtiles(M), nkc = (K + 15) / 16, T = KS * KS;
   const long long total = (long long)groups * mtiles * nkc * T * 64;
   // header: max |A| (BatchNorm scale included) -> the power-of-two operand scale of this packing
-  DVD_HIP_OK(hipMemsetAsync(packed, 0, dvd::kXHeader * sizeof(uint4), static_cast<hipStream_t>(stream)));
+  if (int e = dvd::zero_words(packed, dvd::kXHeader * 4, static_cast<hipStream_t>(stream))) return e;
   {
     const long long nw = (long long)Cout * ci * T;
     long long nb = (nw + 255) / 256;

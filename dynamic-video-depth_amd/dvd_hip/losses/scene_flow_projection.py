@@ -9,10 +9,13 @@ Counterparts of /root/reference/losses/scene_flow_projection.py:
 The training step does not go through these modules: Model._train_on_batch calls the
 fused kernel (dvd_warp_loss_fused), which never materialises the ten per-pixel
 surfaces.  The module forms exist for the drop-in surface (the reference Model
-discovers their argument names with inspect, scene_flow_motion_field.py:128-138) and
-for visualisation / export / inference code that wants the surfaces: they return the
-reference's dict keys, shapes and values (dvd_warp_surfaces, same fp32 operation order),
-forward only.  BackwardWarp is differentiable w.r.t. its buffer like the reference's.
+discovers their argument names with inspect, scene_flow_motion_field.py:128-138), for
+visualisation / export / inference code that wants the surfaces, and for swapping a
+single operator into the reference's own Model: they return the reference's dict keys,
+shapes and values (dvd_warp_surfaces, same fp32 operation order) and are differentiable
+w.r.t. depth_1, depth_2 and the scene flow exactly like the reference's autograd graph
+(dvd_warp_surfaces_bwd, including the gradient cut at behind-camera pixels); the flow and
+the cameras are data.  BackwardWarp is differentiable w.r.t. its buffer.
 """
 import torch
 from torch import nn
@@ -40,11 +43,30 @@ class unproject_ptcld(nn.Module):
         return _Unproject.apply(depth_1, R_1, t_1, K_inv)
 
 
-def _no_autograd(name, *tensors):
-    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
-        raise RuntimeError('%s: the module form produces forward values only (visualisation / export / inference); '
-                           'the differentiable training path is Model._train_on_batch -> dvd_warp_loss_fused. '
-                           'Call it under torch.no_grad() or on detached tensors.' % name)
+class _WarpSurfaces(torch.autograd.Function):
+    """The surfaces in `want` as a tuple (forward: dvd_warp_surfaces; backward: dvd_warp_surfaces_bwd)."""
+
+    @staticmethod
+    def forward(ctx, depth_1, depth_2, sflow_1_2, flow_1_2, want, *cam_tensors):
+        cams = dict(zip(ops.CAM_KEYS, cam_tensors))
+        s = ops.warp_surfaces(depth_1, depth_2, flow_1_2, cams, sflow_1_2=sflow_1_2, want=want)
+        ctx.save_for_backward(depth_1, depth_2, flow_1_2, sflow_1_2, *cam_tensors)
+        ctx.want = want
+        return tuple(s[k] for k in want)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        depth_1, depth_2, flow_1_2, sflow_1_2 = ctx.saved_tensors[:4]
+        cams = dict(zip(ops.CAM_KEYS, ctx.saved_tensors[4:]))
+        g = {k: (gk.contiguous() if gk is not None else None) for k, gk in zip(ctx.want, grads)}
+        g1, g2, gs = ops.warp_surfaces_backward(depth_1, depth_2, flow_1_2, cams, g, sflow_1_2=sflow_1_2,
+                                                want_sflow_grad=sflow_1_2 is not None and ctx.needs_input_grad[2])
+        return (g1, g2, gs, None, None) + (None,) * len(ops.CAM_KEYS)
+
+
+def _surfaces(depth_1, depth_2, flow_1_2, cams, want, sflow_1_2=None):
+    out = _WarpSurfaces.apply(depth_1, depth_2, sflow_1_2, flow_1_2, tuple(want), *[cams[k] for k in ops.CAM_KEYS])
+    return dict(zip(want, out))
 
 
 class flow_by_depth(nn.Module):
@@ -55,10 +77,8 @@ class flow_by_depth(nn.Module):
         self.one_way = is_one_way
 
     def forward(self, depth_1, depth_2, flow_1_2, R_1, R_2, R_1_T, R_2_T, t_1, t_2, K, K_inv):
-        _no_autograd('flow_by_depth', depth_1, depth_2)
         cams = dict(R_1=R_1, R_2=R_2, R_1_T=R_1_T, R_2_T=R_2_T, t_1=t_1, t_2=t_2, K=K, K_inv=K_inv)
-        s = ops.warp_surfaces(depth_1.detach(), depth_2.detach(), flow_1_2, cams,
-                              want=('staticflow_1_2', 'sf_by_depth', 'warped_global_p2', 'global_p1'))
+        s = _surfaces(depth_1, depth_2, flow_1_2, cams, ('staticflow_1_2', 'sf_by_depth', 'warped_global_p2', 'global_p1'))
         return {'dflow_1_2': s['staticflow_1_2'], 'sf_by_depth': s['sf_by_depth'],
                 'warped_global_p2': s['warped_global_p2'], 'global_p1': s['global_p1']}
 
@@ -72,12 +92,11 @@ class scene_flow_projection_slack(nn.Module):
 
     def forward(self, depth_1, depth_2, flow_1_2, flow_2_1, R_1, R_2, R_1_T, R_2_T, t_1, t_2, K, K_inv, sflow_1_2,
                 sflow_2_1):
-        _no_autograd('scene_flow_projection_slack', depth_1, depth_2, sflow_1_2)
         cams = dict(R_1=R_1, R_2=R_2, R_1_T=R_1_T, R_2_T=R_2_T, t_1=t_1, t_2=t_2, K=K, K_inv=K_inv)
         B, _, H, W = depth_1.shape
-        s = ops.warp_surfaces(depth_1.detach(), depth_2.detach(), flow_1_2, cams, sflow_1_2=sflow_1_2.detach(),
-                              want=('dflow_1_2', 'depth_image_1_2', 'depth_warp_1_2', 'global_p1', 'staticflow_1_2',
-                                    'p1_camera_2', 'warped_p2_camera_2'))
+        s = _surfaces(depth_1, depth_2, flow_1_2, cams, ('dflow_1_2', 'depth_image_1_2', 'depth_warp_1_2', 'global_p1',
+                                                         'staticflow_1_2', 'p1_camera_2', 'warped_p2_camera_2'),
+                      sflow_1_2=sflow_1_2)
         s.update(depth_1=depth_1.view(B, 1, H, W), depth_2=depth_2.view(B, 1, H, W), scenef_1_2=sflow_1_2)
         return s
 

@@ -230,6 +230,32 @@ def warp_surfaces(depth_1, depth_2, flow_1_2, cams, sflow_1_2=None, want=_lib.SU
     return out
 
 
+def warp_surfaces_backward(depth_1, depth_2, flow_1_2, cams, grads, sflow_1_2=None, want_sflow_grad=False):
+    """VJP of warp_surfaces: `grads` maps surface name -> upstream gradient (same layout as the surface; missing / None =
+    no gradient).  Returns (g_depth_1, g_depth_2, g_sflow_1_2 | None)."""
+    depth_1, depth_2, flow_1_2 = _dev32(depth_1, 'depth_1'), _dev32(depth_2, 'depth_2'), _dev32(flow_1_2, 'flow_1_2')
+    B, _, H, W = depth_1.shape
+    if sflow_1_2 is not None:
+        sflow_1_2 = _dev32(sflow_1_2, 'sflow_1_2')
+    cst, keep = pack_cameras(cams)
+    st = _lib.Surfaces()
+    for k in _lib.SURFACE_KEYS:
+        g = grads.get(k)
+        if g is not None:
+            g = _dev32(g, 'grad of ' + k)
+            if g.numel() != _SURFACE_SHAPES[k] * B * H * W:
+                raise RuntimeError('gradient of %s has the wrong size' % k)
+            keep.append(g)
+            setattr(st, k, g.data_ptr())
+    g1, g2 = torch.empty_like(depth_1), torch.empty_like(depth_2)
+    gs = torch.empty(B, H, W, 1, 3, device=depth_1.device, dtype=torch.float32) if want_sflow_grad else None
+    _lib.check(_lib.load().dvd_warp_surfaces_bwd(_p(depth_1), _p(depth_2), _p(flow_1_2), _p(sflow_1_2), ctypes.byref(cst),
+                                                 ctypes.byref(st), _p(g1), _p(g2), _p(gs), B, H, W, _stream()),
+               'dvd_warp_surfaces_bwd')
+    del keep
+    return g1, g2, gs
+
+
 def flow_warp(buffer, flow_1_2):
     buffer, flow_1_2 = _dev32(buffer, 'buffer'), _dev32(flow_1_2, 'flow_1_2')
     B, C, H, W = buffer.shape

@@ -219,6 +219,14 @@ typedef struct dvd_surfaces {
 } dvd_surfaces;
 int dvd_warp_surfaces(const float* depth_1, const float* depth_2, const float* flow_1_2, const float* sflow_1_2,
                       const dvd_cameras* cams, const dvd_surfaces* out, int B, int H, int W, dvd_stream_t stream);
+/* Vector-Jacobian product of dvd_warp_surfaces: g_surfaces holds the upstream gradient of every surface that has one
+ * (NULL = none), in the surface's layout; writes d/d depth_1, d/d depth_2 (zeroed inside; the flow is data, so the taps
+ * are a scatter-add) and, if not NULL, d/d sflow_1_2.  This is the autograd backward of the reference's module forms
+ * flow_by_depth / scene_flow_projection_slack (losses/scene_flow_projection.py:114-153,222-278), including the gradient
+ * cut at behind-camera pixels (:253-263). */
+int dvd_warp_surfaces_bwd(const float* depth_1, const float* depth_2, const float* flow_1_2, const float* sflow_1_2,
+                          const dvd_cameras* cams, const dvd_surfaces* g_surfaces, float* g_depth_1, float* g_depth_2,
+                          float* g_sflow_1_2, int B, int H, int W, dvd_stream_t stream);
 
 /* Stand-alone flow warp: BackwardWarp.forward (losses/scene_flow_projection.py:281-307) =
  * F.grid_sample(buffer, (x,y)+flow, bilinear, padding_mode='border', align_corners=True) on

@@ -47,6 +47,22 @@ def test_module_forms_match_the_reference_fixtures(name):
     assert np.array_equal(dy['dflow_1_2'].cpu().numpy()[behind], np.zeros_like(gd['slack_dflow_1_2'][behind]))
     if 'behind' in name:
         assert behind.any() and not behind.all()
+    # backward of the module forms against the REAL reference's autograd: the fixture holds fixed upstream gradients of
+    # every output of both modules and the resulting gradients of depth_1, depth_2 and the scene flow
+    d1g, d2g = d1.clone().requires_grad_(True), d2.clone().requires_grad_(True)
+    sfg = t(gd['in_sf_1_2']).cuda().requires_grad_(True)                     # planar leaf, as in make_golden.py
+    sfl = sfg.permute(0, 2, 3, 1)[..., None, :]
+    st = flow_by_depth()(d1g, d2g, flow, **cams)
+    dy = scene_flow_projection_slack()(d1g, d2g, flow, -flow, sflow_1_2=sfl, sflow_2_1=sfl, **cams)
+    total = 0.0
+    for key, out in list(st.items()) + [('s_' + k, v) for k, v in dy.items()]:
+        if 'up_' + key in gd:
+            total = total + (out * t(gd['up_' + key]).cuda()).sum()
+    total.backward()
+    for got, key in ((d1g.grad, 'g_depth_1'), (d2g.grad, 'g_depth_2'), (sfg.grad, 'g_sf_1_2')):
+        want = gd[key]
+        err = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+        assert err < 2e-5, '%s: %.2e of max|g|' % (key, err)
 
 
 def test_surfaces_against_oracle_at_larger_size_and_autograd_contract():
@@ -67,10 +83,27 @@ def test_surfaces_against_oracle_at_larger_size_and_autograd_contract():
               'warped_p2_camera_2'):
         np.testing.assert_allclose(got[k].cpu().numpy(), ref[k].numpy(), rtol=3e-6, atol=3e-5, err_msg=k)
     assert np.array_equal((got['depth_image_1_2'][:, 0] < 1e-3).cpu().numpy(), ref['_behind'][..., 0, 0].numpy())
-    # forward values only: asking autograd through the module form is an error, not a silent zero gradient
-    with pytest.raises(RuntimeError, match='forward values only'):
-        scene_flow_projection_slack()(d1.cuda().requires_grad_(True), d2.cuda(), batch['flow_1_2'].cuda(), None,
-                                      sflow_1_2=sf.cuda(), sflow_2_1=None, **cg)
+    # the module forms are differentiable like the reference's: the oracle's autograd gradient of a random projection
+    gref = {}
+    for name, t0 in (('d1', d1), ('d2', d2), ('sf', sf)):
+        gref[name] = t0.clone().requires_grad_(True)
+    ref2 = G.dynamic_reprojection(gref['d1'], gref['d2'], batch['flow_1_2'], -batch['flow_1_2'], sflow_1_2=gref['sf'],
+                                  sflow_2_1=gref['sf'], **cams)
+    ggpu = {k: v.detach().clone().cuda().requires_grad_(True) for k, v in gref.items()}
+    got2 = scene_flow_projection_slack()(ggpu['d1'], ggpu['d2'], batch['flow_1_2'].cuda(), None, sflow_1_2=ggpu['sf'],
+                                         sflow_2_1=None, **cg)
+    gen = torch.Generator().manual_seed(5)
+    tot_ref = tot_gpu = 0.0
+    for k in ('dflow_1_2', 'depth_image_1_2', 'depth_warp_1_2', 'global_p1', 'staticflow_1_2', 'p1_camera_2',
+              'warped_p2_camera_2'):
+        u = torch.randn(ref2[k].shape, generator=gen)
+        tot_ref = tot_ref + (ref2[k] * u).sum()
+        tot_gpu = tot_gpu + (got2[k] * u.cuda()).sum()
+    tot_ref.backward()
+    tot_gpu.backward()
+    for name in ('d1', 'd2', 'sf'):
+        want, got_g = gref[name].grad.numpy(), ggpu[name].grad.cpu().numpy()
+        assert np.abs(got_g - want).max() <= 2e-5 * np.abs(want).max() + 1e-6, name
     # BackwardWarp is differentiable w.r.t. its buffer, like F.grid_sample
     buf = torch.randn(B, 3, H, W)
     up = torch.randn(B, 3, H, W)
