@@ -216,6 +216,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (48 = the BASELINE configuration)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--gap', type=int, default=GAP,
+                    help='frame gap of the synthetic pairs = Euler steps of the scene-flow integration (1 = the BASELINE '
+                         'configuration; the shipped DAVIS schedule mixes 1..4: extra bench lines, not the headline)')
+    ap.add_argument('--depth', choices=('midas', 'hourglass'), default='midas',
+                    help="depth network: midas (BASELINE configs[1]/[2]) or the reference's default hourglass (extra bench line)")
     ap.add_argument('--cpu_steps', type=int, default=3, help='timed oracle steps of the cpu_baseline leg (after 1 warm-up)')
     ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '1')),
                     help='1 (default): replay the depth net from HIP graphs; 0: eager launches')
@@ -243,9 +248,9 @@ def main():
 
     if os.environ.get('DVD_CUDNN_BENCHMARK'):
         torch.backends.cudnn.benchmark = True     # MIOpen find mode (experiments; the default run uses FAST immediate mode)
-    opt = make_opt(global_rank=rank, depth_chunk=a.depth_chunk, depth_graphs=bool(a.depth_graphs))
+    opt = make_opt(global_rank=rank, depth_chunk=a.depth_chunk, depth_graphs=bool(a.depth_graphs), midas=a.depth == 'midas')
     model = build_model(opt, device, seed=0)
-    batch = synthetic.make_batch(a.pairs, H, W, gap=GAP, seed=1234, rank=rank, device=device)
+    batch = synthetic.make_batch(a.pairs, H, W, gap=a.gap, seed=1234, rank=rank, device=device)
     epoch = opt.warm_sf + 1            # non-warm phase
 
     if a.feed == 'host':
@@ -305,8 +310,9 @@ def main():
                                '(ResNeXt-101 32x8d) depth net with hand-written fp16-pair-split MFMA convolution kernels '
                                '(forward, data and weight gradients) '
                                'under PyTorch-ROCm autograd + HIP scene-flow MLP + HIP fused warp/reprojection/loss, '
-                               'non-warm phase with acceleration regulariser' % (H, W, a.pairs, GAP),
-                   'pairs_per_gpu': a.pairs, 'height': H, 'width': W, 'parallelism': 'dp%d over frame pairs' % world},
+                               'non-warm phase with acceleration regulariser' % (H, W, a.pairs, a.gap),
+                   'pairs_per_gpu': a.pairs, 'height': H, 'width': W, 'gap': a.gap, 'depth_net': a.depth,
+                   'parallelism': 'dp%d over frame pairs' % world},
         'pairs_per_s': world * a.pairs * a.steps / dt, 'feed': a.feed, 'graph_setup_steps': setup_steps,
         'hbm_peak_allocated_GB': torch.cuda.max_memory_allocated(device) / 2 ** 30,
         'hbm_peak_reserved_GB': torch.cuda.max_memory_reserved(device) / 2 ** 30,
@@ -332,7 +338,7 @@ def main():
                            'frac': warp['GBps'] / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
                            'algorithmic_bytes_per_launch': warp['pixels_per_launch'] * WARP_BYTES_PER_PIXEL,
                            'avg_launch_ms': warp['avg_ms'], 'launches_timed': warp['launches']}
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and a.depth == 'midas' and a.gap == GAP:
         # the 48-pair model's graph slots hold most of the HBM: release them before the 1-pair parity model is built
         import gc
         del model, batch
