@@ -93,7 +93,7 @@ SIGNATURES = {
     'dvd_bnrelu_fwd': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_bnrelu_bwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'dvd_bnrelu_bwd': (c_int, [c_void_p] * 6 + [c_float] + [c_void_p] * 5 + [c_size_t, c_int, c_int, c_int, c_int,
-                                                                           c_void_p]),
+                                                                           c_void_p, c_void_p]),
     'dvd_upsample_bilinear_fwd': (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_upsample_bilinear_bwd': (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -118,6 +118,7 @@ SIGNATURES = {
     'dvd_convbn_finalize': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'dvd_xwgrad3_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad1s_workspace_bytes': (c_size_t, [c_int] * 5),
+    'dvd_xwgrad_select': (c_int, [c_int]),
     'dvd_xwgrad1s': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 6 + [c_void_p]),
     'dvd_xwgrad3': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     'dvd_xwgrad_workspace_bytes': (c_size_t, [c_int] * 6),

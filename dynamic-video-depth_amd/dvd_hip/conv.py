@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from .ops import _p, _stream, _workspace, amax_of, known_amax, set_amax
+from .ops import _p, _stream, _workspace, amax_of, known_amax, new_scalar, set_amax
 
 # Same-box A/B measurement switches (previous-generation kernels / MIOpen against the kernels in use), read ONCE at
 # import from DVD_AB="gconv32,no_bnfuse,...".  Not product configuration: every default is the fastest measured path.
@@ -67,7 +67,7 @@ class _BnRelu(torch.autograd.Function):
         lib = _lib.load()
         ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, C, HW), x.device)
         _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(mean), _p(var), eps, _p(gx), _p(gr), _p(gg),
-                                      _p(gb), _p(ws), ctypes.c_size_t(ws.numel()), N, C, HW, relu, _stream()),
+                                      _p(gb), _p(ws), ctypes.c_size_t(ws.numel()), N, C, HW, relu, None, _stream()),
                    'dvd_bnrelu_bwd')
         return gx, gr, gg, gb, None, None, None, None
 
@@ -206,6 +206,14 @@ class GroupedConv3x3C32(nn.Conv2d):
             # 16-image call at [1024, 24, 42] against 0.156 / 0.42 ms of the fp32-MFMA kernels (tools/microbench_gx.py)
             return _xconv(x, self.weight, None, None, False, False, self.groups)
         return gconv3x3_c32(x, self.weight)
+
+
+def add_bounded(a, b):
+    """a + b; when both operands carry a max|.| scalar the sum's bound is their sum (one tiny kernel instead of a reduction
+    pass over the sum when it feeds a convolution)."""
+    y = a + b
+    ka, kb = known_amax(a), known_amax(b)
+    return set_amax(y, ka + kb) if (ka is not None and kb is not None) else y
 
 
 def _subsample(t, st):
@@ -366,7 +374,7 @@ class _XConv(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         Cout, _, KS, _ = weight.shape
-        y_amax = torch.zeros(1, device=x.device, dtype=torch.float32)
+        y_amax = new_scalar(x.device)
         y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=bias, residual=residual, relu_in=relu_in,
                        res_relu=res_relu, groups=groups, x_amax=x_amax, y_amax=y_amax)
         ctx.save_for_backward(x, residual if res_relu else None, x_amax)
@@ -386,8 +394,10 @@ class _XConv(torch.autograd.Function):
         gx = gw = gb = gr = None
         g_amax = amax_of(gy) if (need[0] or need[2]) else None        # one reduction, shared by both gradient kernels
         if need[0]:
+            gx_amax = new_scalar(gy.device)
             gx = _xconv_run(gy, xconv_packed(weight, True, groups), Cin * groups, KS, mask_src=x if relu_in else None,
-                            groups=groups, x_amax=g_amax)
+                            groups=groups, x_amax=g_amax, y_amax=gx_amax)
+            set_amax(gx, gx_amax)         # (used by the next backward if autograd hands this very tensor on)
         if need[2]:
             gw = xconv_wgrad(x, gy, weight.shape, relu_in, groups, x_amax=x_amax, g_amax=g_amax)
         if has_bias and need[3]:
@@ -461,7 +471,7 @@ class _XConvBn(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         Cout, _, KS, _ = weight.shape
-        y_amax = torch.zeros(1, device=x.device, dtype=torch.float32)
+        y_amax = new_scalar(x.device)
         y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=cbias, residual=residual, relu_out=relu,
                        groups=groups, bn=(gamma, beta, mean, var, eps), x_amax=x_amax, y_amax=y_amax)
         ctx.save_for_backward(x, y if relu else None, gamma, mean, var, cbias, x_amax)
@@ -484,14 +494,16 @@ class _XConvBn(torch.autograd.Function):
         dbeta = torch.empty(Cout, device=gy.device, dtype=torch.float32)
         g = torch.empty_like(gy) if relu else gy
         ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, Cout, H * W), gy.device)
+        g_amax = new_scalar(gy.device)  # max|masked gradient|, folded in by the mask pass (it reads every element anyway)
         _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y), None, _p(var), _p(mean), _p(var), eps, None, _p(g) if relu else None,
                                       None, _p(dbeta), _p(ws), ctypes.c_size_t(ws.numel()), N, Cout, H * W, int(relu),
-                                      _stream()), 'dvd_bnrelu_bwd')
+                                      _p(g_amax), _stream()), 'dvd_bnrelu_bwd')
         gx = gw = gcb = gg = None
-        g_amax = amax_of(gy)            # |masked gradient| <= |gy|: a bound is all the operand scale needs
         if need[0]:
+            gx_amax = new_scalar(gy.device)
             gx = _xconv_run(g, xconv_packed_scaled(weight, groups, gamma, var, eps), Cing * groups, KS, groups=groups,
-                            x_amax=g_amax)
+                            x_amax=g_amax, y_amax=gx_amax)
+            set_amax(gx, gx_amax)
         if need[2] or (gamma is not None and need[4]) or (cbias is not None and need[3]):
             gw = xconv_wgrad(x, g, weight.shape, False, groups, x_amax=x_amax, g_amax=g_amax)
             gg = torch.empty_like(gamma) if gamma is not None else None

@@ -16,7 +16,7 @@
 // sums of the backward are reduced per block, written as partials and summed in a fixed order by
 // a second kernel (deterministic).
 
-#include "dvd_common.h"
+#include "dvd_split.h"
 
 namespace dvd {
 
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float eps, float* __restrict__ gx, float* __restrict__ gres,
                                                          float2* __restrict__ partial, int N, int C, int HW,
-                                                         int chunks, int relu) {
+                                                         int chunks, int relu, float* g_amax) {
   const int chunk = blockIdx.x % chunks;
   const long long pl = blockIdx.x / chunks;
   const int c = (int)(pl % C), n = (int)(pl / C);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
   const float mu = mean[c];
   const long long base = pl * HW;
   const int lo = chunk * kBnChunk, hi = min(HW, lo + kBnChunk);
-  float sg = 0.0f, sgx = 0.0f;
+  float sg = 0.0f, sgx = 0.0f, gmax = 0.0f;
   if ((HW & 3) == 0) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
       float4 g = *reinterpret_cast<const float4*>(gy + base + i);
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
         g.w = o.w > 0.0f ? g.w : 0.0f;
       }
       sg += (g.x + g.y) + (g.z + g.w);
+      gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
       if (x) {
         const float4 v = *reinterpret_cast<const float4*>(x + base + i);
         sgx = __builtin_fmaf(g.x, v.x - mu,
@@ -104,11 +105,13 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
       float g = gy[base + i];
       if (relu) g = y[base + i] > 0.0f ? g : 0.0f;
       sg += g;
+      gmax = fmaxf(gmax, fabsf(g));
       if (x) sgx = __builtin_fmaf(g, x[base + i] - mu, sgx);
       if (gres) gres[base + i] = g;
       if (gx) gx[base + i] = g * s;
     }
   }
+  if (g_amax) wave_amax_to(gmax, g_amax);          // the operand scale of the gradient kernels that consume g (uniform branch)
   __shared__ float red[2][4];
   sg = wave_sum(sg);
   sgx = wave_sum(sgx);
@@ -195,7 +198,7 @@ size_t dvd_bnrelu_bwd_workspace_bytes(int N, int C, int HW) {
 
 int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* mean,
                    const float* var, float eps, float* gx, float* g_residual, float* g_gamma, float* g_beta,
-                   void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu, dvd_stream_t stream) {
+                   void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu, float* g_amax, dvd_stream_t stream) {
   DVD_REQUIRE(gy && gamma && mean && var && workspace, "bnrelu bwd: null pointer");
   DVD_REQUIRE(x || !g_gamma, "bnrelu bwd: the gamma gradient needs the BatchNorm input");
   DVD_REQUIRE(!relu || y, "bnrelu bwd: the ReLU mask needs the forward output");
@@ -209,7 +212,7 @@ int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float*
   DVD_REQUIRE(blocks < (1LL << 31), "bnrelu bwd: grid too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(dvd::bnrelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, y, x, gamma, mean, var, eps, gx,
-                     g_residual, static_cast<float2*>(workspace), N, C, HW, chunks, relu);
+                     g_residual, static_cast<float2*>(workspace), N, C, HW, chunks, relu, g_amax);
   DVD_LAUNCH_OK();
   if (g_gamma || g_beta) {
     hipLaunchKernelGGL(dvd::bnrelu_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, s,

@@ -25,6 +25,8 @@ namespace dvd {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+static int g_w1_variant = 0;      // test / A-B hook (dvd_xwgrad_select): 0 auto, 1 always the 128 x 128 blocks
+
 struct Wg3Args {
   const float* __restrict__ x;
   const float* __restrict__ gy;
@@ -315,6 +317,137 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
     }
 }
 
+// ---- 1x1, wide layers: one 512-thread workgroup owns 256 x 256 channels (the whole weight matrix of a ResNeXt stage-1 /
+// decoder 1x1; a 256 x 256 block of the wider ones) for a run of 16-pixel chunks.  With 128 x 128 blocks each operand row
+// is read by two workgroups and the kernel sits on the HBM roofline of that blocking (32 FLOP/B -> ~160 TF/s, measured
+// 156-179); 256 x 256 halves the traffic.  The structure is the scene-flow MLP's weight-gradient kernel (csrc/sf_mlp.hip
+// dw_body): 512 channel rows x 16 pixels are loaded as fp32, split and written to a double-buffered LDS stage while the
+// MFMAs of the previous chunk run, one barrier per chunk, wave (wr, wc) keeps rows [64 wr, +64) x columns [128 wc, +128) in
+// 128 accumulators.  Each slice writes its partial matrix; xwgrad3_reduce_kernel sums them in slice order (deterministic).
+constexpr int kWbPitch = 48;                       // bytes per channel row of a 16-pixel chunk in LDS (32 + 16 pad)
+constexpr int kWbTerm = 256 * kWbPitch;            // one split term of one operand
+constexpr int kWbBuf = 2 * 2 * kWbTerm;            // gy terms, then x terms
+constexpr size_t kWbLds = 2 * (size_t)kWbBuf;      // double buffered: 98 304
+
+__global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int i32 = lane & 31, hh = lane >> 5;
+  const int co0 = blockIdx.z * 256, ci0 = blockIdx.y * 256, s = blockIdx.x;
+  const int HW = a.H * a.W;
+  const size_t plane = (size_t)HW;
+  const int cpi = (HW + 15) / 16;                              // 16-pixel chunks per image
+  const long long items = (long long)a.N * cpi;
+  const long long t0 = items * s / a.S, t1 = items * (s + 1) / a.S;
+  const int n_it = (int)(t1 - t0);
+  const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread; q = i * 512 + tid, row = q >> 2 (0..255 gy, 256..511 x)
+  float4 sg0[4], sg1[4];
+  auto stage_load = [&](int it, float4 (&st)[4]) {
+    const long long item = t0 + it;
+    const int n = (int)(item / cpi), p0 = (int)(item - (long long)n * cpi) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 128 + (tid >> 2), quad = tid & 3;
+      const bool isx = i >= 2;
+      const int r = row & 255;
+      const int C = isx ? a.Cin : a.Cout, c = (isx ? ci0 : co0) + r;
+      const int px = p0 + quad * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C && px < HW)                                      // HW % 4 == 0 (host): a quad is inside or outside as a whole
+        v = *reinterpret_cast<const float4*>((isx ? a.x : a.gy) + ((size_t)n * C + c) * plane + px);
+      if (isx && a.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      st[i] = v;
+    }
+  };
+  auto stage_store = [&](int buf, const float4 (&st)[4]) {
+    unsigned char* base = smem3 + buf * kWbBuf;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 128 + (tid >> 2), quad = tid & 3;
+      unsigned h0, l0, h1, l1;
+      const float sc = i >= 2 ? sx : sg;
+      split_pair_f16(st[i].x * sc, st[i].y * sc, h0, l0);
+      split_pair_f16(st[i].z * sc, st[i].w * sc, h1, l1);
+      unsigned char* dst = base + (i >= 2 ? 2 * kWbTerm : 0) + (row & 255) * kWbPitch + quad * 8;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + kWbTerm) = make_uint2(l0, l1);
+    }
+  };
+  auto mfma_chunk = [&](int buf) {
+    const unsigned char* gb = smem3 + buf * kWbBuf + (64 * wr + i32) * kWbPitch + hh * 16;
+    const unsigned char* hb = smem3 + buf * kWbBuf + 2 * kWbTerm + (128 * wc + i32) * kWbPitch + hh * 16;
+    u32x4 A[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) A[r][t] = *reinterpret_cast<const u32x4*>(gb + t * kWbTerm + r * 32 * kWbPitch);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      u32x4 B[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) B[t] = *reinterpret_cast<const u32x4*>(hb + t * kWbTerm + c * 32 * kWbPitch);
+#define DVD_WB_TERM(SA, SB)                                                                                   \
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(           \
+      __builtin_bit_cast(f16x8, A[r][SA]), __builtin_bit_cast(f16x8, B[SB]), acc[r][c], 0, 0, 0);
+      DVD_WB_TERM(1, 0)
+      DVD_WB_TERM(0, 1)
+      DVD_WB_TERM(0, 0)
+#undef DVD_WB_TERM
+    }
+  };
+
+  // chunk it is loaded during step it - 2, split and stored during step it - 1, consumed by the MFMAs of step it: no wave
+  // ever waits for HBM.  One barrier per chunk: buffer b is complete and every wave is done reading buffer b ^ 1.
+  if (n_it > 0) {
+    const int last = n_it - 1;
+    stage_load(0, sg0);
+    stage_store(0, sg0);
+    stage_load(1 < last ? 1 : last, sg0);
+    for (int it = 0; it < n_it; it += 2) {
+      __syncthreads();
+      stage_load(it + 2 < last ? it + 2 : last, sg1);
+      __builtin_amdgcn_sched_barrier(0);   // the loads stay above the MFMAs
+      mfma_chunk(0);
+      stage_store(1, sg0);                 // chunk it + 1 (past the end: a copy of the last chunk into the idle buffer)
+      __syncthreads();
+      stage_load(it + 3 < last ? it + 3 : last, sg0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < n_it) mfma_chunk(1);
+      stage_store(0, sg1);
+    }
+  }
+  float* dst = a.partial + (size_t)s * a.Cout * a.Cin;       // partial[s][co][ci]
+  const float unscale = 1.0f / (sx * sg);
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 64 * wr + 32 * rr + (r & 3) + 8 * (r >> 2) + 4 * hh, ci = ci0 + 128 * wc + 32 * c + i32;
+        if (co < a.Cout && ci < a.Cin) dst[(size_t)co * a.Cin + ci] = acc[rr][c][r] * unscale;
+      }
+}
+
+// which 1x1 kernel: the 256 x 256 blocks when both channel counts fill them reasonably and rows are float4 aligned
+static bool wg1_wide(int Cin, int Cout, int HW) { return Cin >= 192 && Cout >= 192 && (HW & 3) == 0 && g_w1_variant != 1; }
+static int wg1_wide_slices(int N, int Cin, int Cout, int HW) {
+  const int pairs = ((Cout + 255) / 256) * ((Cin + 255) / 256);
+  int S = pairs >= 256 ? 1 : (256 + pairs - 1) / pairs;       // one workgroup per CU: a whole round over the 256 CUs
+  const long long items = (long long)N * ((HW + 15) / 16);
+  if (S > items) S = (int)items;
+  return S;
+}
+
 struct Wg3Plan {
   int nstrips, RS, nrseg, S, nco, nci;
   size_t lds;
@@ -391,8 +524,16 @@ int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const floa
 size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
   if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   const int pairs = ((Cout + dvd::kW1CB - 1) / dvd::kW1CB) * ((Cin + dvd::kW1CB - 1) / dvd::kW1CB);
-  const int S = pairs >= 512 ? 1 : (1024 + pairs - 1) / pairs;
+  int S = pairs >= 512 ? 1 : (1024 + pairs - 1) / pairs;
+  const int Sw = dvd::wg1_wide_slices(N, Cin, Cout, H * W);      // (either kernel may serve the call)
+  if (Sw > S) S = Sw;
   return (size_t)S * Cout * Cin * sizeof(float);
+}
+
+int dvd_xwgrad_select(int variant) {
+  DVD_REQUIRE(variant == 0 || variant == 1, "xwgrad_select: variant %d", variant);
+  dvd::g_w1_variant = variant;
+  return DVD_OK;
 }
 
 int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
@@ -401,6 +542,34 @@ int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const flo
   DVD_REQUIRE(x_amax && gy_amax, "xwgrad1s: the operands' max|.| scalars are missing (dvd_amax)");
   DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgrad1s: bad shape");
   DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgrad1s: image too large for 32-bit offsets");
+  if (dvd::wg1_wide(Cin, Cout, H * W)) {
+    const int S = dvd::wg1_wide_slices(N, Cin, Cout, H * W);
+    const size_t need = (size_t)S * Cout * Cin * sizeof(float);
+    if (workspace_bytes < need) {
+      dvd::set_error("xwgrad1s: workspace %zu < %zu bytes", workspace_bytes, need);
+      return DVD_ENOSPC;
+    }
+    dvd::Wg3Args a;
+    a.x = x;
+    a.gy = gy;
+    a.x_amax = x_amax;
+    a.g_amax = gy_amax;
+    a.partial = static_cast<float*>(workspace);
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.G = 1; a.nco = (Cout + 255) / 256;
+    a.nstrips = 0; a.RS = 0; a.nrseg = 0; a.S = S;
+    a.relu_in = relu_in ? 1 : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)dvd::kWbLds));
+    hipLaunchKernelGGL(dvd::xwgrad1b_kernel, dim3(S, (Cin + 255) / 256, (Cout + 255) / 256), dim3(512), dvd::kWbLds, s, a);
+    DVD_LAUNCH_OK();
+    const long long per = (long long)Cout * Cin;
+    hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), gw, S, 1, Cout, Cin);
+    DVD_LAUNCH_OK();
+    return DVD_OK;
+  }
   const int nco = (Cout + dvd::kW1CB - 1) / dvd::kW1CB, nci = (Cin + dvd::kW1CB - 1) / dvd::kW1CB;
   const int pairs = nco * nci;
   // two blocks per CU are resident: whole rounds over 512 slots

@@ -96,10 +96,30 @@ def _capture_gen():
     return _capture_state[1] if cap else 0
 
 
+_scalar_pool = {}        # (device index, capture generation) -> [zeroed chunk, next free element]
+
+
+def new_scalar(device):
+    """A zeroed 1-element GPU tensor for a max|.| scalar.  Scalars are handed out from zero-filled chunks of 512 (one fill
+    launch per 512 instead of one per scalar: a MiDaS step needs ~800 of them); a chunk belongs to the capture context it
+    was allocated in (inside a HIP graph the fill is part of the graph, so every replay starts from zeros again)."""
+    gen = _capture_gen()
+    key = (torch.device(device).index or 0, gen)
+    for k in [k for k in _scalar_pool if k[1] not in (0, gen)]:       # chunks of finished captures: their graphs own them
+        del _scalar_pool[k]
+    ent = _scalar_pool.get(key)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = [torch.zeros(512, device=device, dtype=torch.float32), 0]
+        _scalar_pool[key] = ent
+    out = ent[0][ent[1]:ent[1] + 1]
+    ent[1] += 1
+    return out
+
+
 def amax(t):
     """max|t| by the reduction kernel (one read of the tensor) -> 1-element GPU tensor."""
     t = _dev32(t, 'tensor')
-    out = torch.zeros(1, device=t.device, dtype=torch.float32)
+    out = new_scalar(t.device)
     if t.numel():
         _lib.check(_lib.load().dvd_amax(_p(t), ctypes.c_longlong(t.numel()), _p(out), _stream()), 'dvd_amax')
     return out

@@ -272,13 +272,15 @@ int dvd_gconv3x3_c32_bwd_weight(const float* x, const float* gy, float* gw, int 
  * training (models/scene_flow_motion_field.py:157,168), so running statistics are used and gamma/beta
  * still get gradients.  y = max(0, x*s[c] + b[c] (+ residual)), s = gamma/sqrt(var+eps), b = beta - mean*s.
  * bwd: gx = g*s, g_residual = g, g_beta = sum g, g_gamma = sum g*(x-mean)/sqrt(var+eps), g = gy*[y>0];
- * any of gx, g_residual, g_gamma, g_beta may be NULL; channel sums are deterministic (two stages). */
+ * any of gx, g_residual, g_gamma, g_beta may be NULL; channel sums are deterministic (two stages).  g_amax (optional):
+ * device scalar into which max|g| is folded (atomic max; zero it first) -- the operand scale of the gradient kernels
+ * that consume g (dvd_xconv_fwd / dvd_xwgrad*). */
 int dvd_bnrelu_fwd(const float* x, const float* residual, const float* gamma, const float* beta, const float* mean,
                    const float* var, float eps, float* y, int N, int C, int HW, int relu, dvd_stream_t stream);
 size_t dvd_bnrelu_bwd_workspace_bytes(int N, int C, int HW);
 int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* mean,
                    const float* var, float eps, float* gx, float* g_residual, float* g_gamma, float* g_beta,
-                   void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu, dvd_stream_t stream);
+                   void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu, float* g_amax, dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Bilinear up-sampling of [planes, H_in, W_in] -> [planes, H_out, W_out] (planes = N*C) and its backward.
@@ -365,6 +367,10 @@ int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const floa
 size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W);
 int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
                  size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream);
+/* Test / A-B hook (process wide): 0 = automatic (256 x 256-channel workgroups for wide 1x1 layers, 128 x 128 otherwise),
+ * 1 = always 128 x 128.  Same products and the same per-element summation order within a slice; the number of slices
+ * (partial sums added at the end) differs, so results agree to fp32 rounding, not bitwise. */
+int dvd_xwgrad_select(int variant);
 
 /* ------------------------------------------------------------------------
  * Flow-consistency (occlusion) + out-of-bounds mask of one direction of a frame pair.

@@ -87,6 +87,8 @@ CASES = [
     (1, 512, 512, 13, 22, 1),        # >= 256 output channels: the 256-channel block shapes (1x1: 256 x 128 positions)
     (1, 256, 512, 10, 15, 3),        # (k >= 3: 256 x 256 positions, one 512-thread block per CU)
     (2, 272, 288, 9, 14, 3),         # 256-channel blocks with a ragged last block, Cin a multiple of 16 only
+    (2, 256, 320, 12, 20, 1),        # 1x1 weight gradient on 256 x 256-channel workgroups (H * W a multiple of 4), ragged
+    (3, 512, 256, 8, 18, 1),         # ... two input-channel blocks, 9 chunks per image
 ]
 
 
