@@ -274,8 +274,9 @@ __device__ __forceinline__ float tile_max(const float* tmx) {
   const float4 a = *reinterpret_cast<const float4*>(tmx), b = *reinterpret_cast<const float4*>(tmx + 4);
   return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
 }
-__device__ __forceinline__ void fold_amax(float* dst, float m) {
-  if (m > 0.0f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+__device__ __forceinline__ void fold_amax(float* dst, float m) {      // (read first: see wave_amax_to)
+  unsigned* p = reinterpret_cast<unsigned*>(dst);
+  if (m > 0.0f && __float_as_uint(m) > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, __float_as_uint(m));
 }
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, kSlope * v); }

@@ -16,9 +16,9 @@
 // Layout / mapping: one thread owns PX horizontally adjacent pixels so every
 // streaming access is a 16-byte vector (PX=4); a 256-thread block owns 1024
 // consecutive pixels of one pair, so the camera block of the pair is
-// wave-uniform and lives in SGPRs.  The bilinear taps of depth_2 are gathered
-// as two 8-byte loads (west/east taps are adjacent); the depth_2 gradient is
-// scattered with hardware fp32 atomics (global_atomic_add_f32).
+// wave-uniform and lives in SGPRs.  That is the DIRECT reference variant (global gathers, depth_2 gradient scattered
+// with global_atomic_add_f32; kept for A/B runs and as a second implementation); the production path is the TILED
+// kernel further down: depth_2 window and a Q31.32 fixed-point gradient accumulator (ds_add_u64) in LDS per tile.
 //
 // Numerics: the forward follows the reference's fp32 operation order exactly
 // (see dvd_common.h rowvec_mat3 and sample_coord/bilinear below), so the
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
 // one pair and keeps two LDS windows that extend the tile by R pixels:
 //   win  : depth_2 values, filled with coalesced 16-byte loads; the bilinear
 //          taps are read from it (ds_read2_b32);
-//   accw : depth_2-gradient accumulator (ds_add_f32).
+//   accw : depth_2-gradient accumulator, Q31.32 fixed point (ds_add_u64; see kFixScale below).
 // At the end the accumulator window is stored, coalesced, to the tile's slab
 // in the workspace; `combine_slabs_kernel` then sums, in a fixed order, the
 // <= 4 slabs that cover each pixel and writes g_depth_2 once with plain

@@ -9,21 +9,24 @@ with the keys of :226,321-323,195.
 What is different is HOW a step runs.  The reference builds one autograd graph out of
 ~250 ATen launches per pair; here the step is three phases over device-resident data:
 
-  1. depth nets forward WITHOUT a graph (chunks of images) -> depth_1, depth_2;
+  1. depth nets forward, chunk by chunk (--depth_chunk images), every chunk WITH its autograd state kept in a slot of
+     its own (a forward HIP graph and a backward HIP graph on one private memory pool) -> depth_1, depth_2; chunks that
+     do not fit --depth_keep_gb take a no-graph forward and are recomputed in phase 3;
   2. everything downstream of the depths in hand-written HIP kernels, per chunk of
      pairs: unproject -> fused MLP (Euler steps, activations stashed) -> ONE fused
      warp+reprojection+loss forward/backward launch -> MLP backward (dX chain, dW) ->
-     unproject backward; then the acceleration regulariser the same way.  Gradients
+     unproject backward; the acceleration regulariser shares the first MLP evaluation.  Gradients
      are produced UN-normalised; the batch-global 1/(sum(mask)+1e-8) is a device
      scalar applied at the very end, after the (data-parallel) all-reduce of the five
      loss sums, so there is no host synchronisation inside the step and N ranks
      reproduce the single-device result on the concatenated batch;
-  3. (not in the warm-up phase) depth nets forward WITH a graph, chunk by chunk, and
-     backward from the depth gradients of phase 2 - the autograd graph of 96 MiDaS
-     forwards at 384x672 (293 GB) never exists at once; then one RCCL all-reduce per
-     net over its flat gradient buffer and one fused Adam launch per net.
+  3. (not in the warm-up phase) depth nets backward from the depth gradients of phase 2: a replay of each kept slot's
+     backward graph (or a forward+backward recompute graph); then one RCCL all-reduce per net over its flat gradient
+     buffer and one fused Adam launch per net.
 
-Depth-net convolutions run on PyTorch-ROCm/MIOpen in this round (BASELINE config 2).
+Every convolution, BatchNorm+ReLU, up-sampling and the MLP run on this package's HIP kernels (csrc/); the matrix kernels
+evaluate fp32 products from two fp16 terms per operand (csrc/dvd_split.h).  Only the 7x7 stride-2 stem, its BatchNorm and
+the max-pool of the ResNeXt encoder are ATen / MIOpen calls (< 1 % of a step).
 """
 import os
 import sys

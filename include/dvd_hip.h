@@ -90,8 +90,11 @@ int dvd_unproject_bwd(const float* g_points, int planar, const float* R, const f
  *   flow_mul*S1 + disp_mul*(use_disp ? S2 : S3);
  * the global 1/(S0+1e-8) (after the data-parallel all-reduce of the sums,
  * SURVEY.md section 8e) is applied by the consumers through a device scalar
- * (dvd_loss_finalize writes it).  g_depth_2 is zeroed inside the call and
- * accumulated with hardware fp32 atomics (bilinear scatter). */
+ * (dvd_loss_finalize writes it).  g_depth_2 (bilinear scatter) is accumulated in Q31.32 fixed point in the LDS
+ * windows of the tiles (ds_add_u64: integer adds commute, so the result is bitwise reproducible), cells only one
+ * window covers are stored directly, the halo ring is summed over the <= 4 overlapping windows in a fixed order; only
+ * taps that leave a window (|flow - pair mean| > 8 px) go through a record list and global fp32 atomics.  No memset of
+ * g_depth_2 is needed. */
 typedef struct dvd_warp_cfg {
   int B, H, W;
   int midas_mask;  /* 1: m *= [depth_1<100]*[W2.z<100]   (model:286-289)        */
