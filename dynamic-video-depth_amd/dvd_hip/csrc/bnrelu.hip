@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float eps, float* __restrict__ gx, float* __restrict__ gres,
                                                          float2* __restrict__ partial, int N, int C, int HW,
-                                                         int chunks, int relu, float* g_amax) {
+                                                         int chunks, int relu, float* __restrict__ pmax) {
   const int chunk = blockIdx.x % chunks;
   const long long pl = blockIdx.x / chunks;
   const int c = (int)(pl % C), n = (int)(pl / C);
@@ -111,36 +111,47 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
       if (gx) gx[base + i] = g * s;
     }
   }
-  if (g_amax) wave_amax_to(gmax, g_amax);          // the operand scale of the gradient kernels that consume g (uniform branch)
-  __shared__ float red[2][4];
+  __shared__ float red[3][4];
   sg = wave_sum(sg);
   sgx = wave_sum(sgx);
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_down(gmax, off, kWave));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     red[0][wave] = sg;
     red[1][wave] = sgx;
+    red[2][wave] = gmax;
   }
   __syncthreads();
-  if (threadIdx.x == 0)
-    partial[((size_t)c * N + n) * chunks + chunk] =
-        make_float2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  if (threadIdx.x == 0) {
+    const size_t rec = ((size_t)c * N + n) * chunks + chunk;
+    partial[rec] = make_float2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    // max|g| of the block: reduced to the scalar by the second kernel (tens of thousands of blocks folding it in with
+    // atomics on one address cost more than the whole pass)
+    if (pmax) pmax[rec] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+  }
 }
 
 // ggamma[c] = sum g (x - mean) / sqrt(var + eps), gbeta[c] = sum g   (fixed order over the records)
 __global__ __launch_bounds__(64) void bnrelu_param_grad_kernel(const float2* __restrict__ partial,
                                                                const float* __restrict__ var, float eps,
                                                                float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                                               int C, int records) {
+                                                               int C, int records, const float* __restrict__ pmax,
+                                                               float* g_amax) {
   const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
   double sg = 0.0, sgx = 0.0;
-  for (int r = 0; r < records; ++r) {
-    const float2 v = partial[(size_t)c * records + r];
-    sg += v.x;
-    sgx += v.y;
+  float m = 0.0f;
+  if (c < C) {
+    for (int r = 0; r < records; ++r) {
+      const float2 v = partial[(size_t)c * records + r];
+      sg += v.x;
+      sgx += v.y;
+      if (pmax) m = fmaxf(m, pmax[(size_t)c * records + r]);
+    }
+    if (gbeta) gbeta[c] = (float)sg;
+    if (ggamma) ggamma[c] = (float)(sgx / sqrt((double)var[c] + (double)eps));
   }
-  if (gbeta) gbeta[c] = (float)sg;
-  if (ggamma) ggamma[c] = (float)(sgx / sqrt((double)var[c] + (double)eps));
+  if (g_amax) wave_amax_to(m, g_amax);      // C / 64 waves: a handful of atomics
 }
 
 // Convolution + fused eval-mode BatchNorm, backward bookkeeping of one site.  The weight-gradient kernels ran on the
@@ -193,7 +204,7 @@ int dvd_bnrelu_fwd(const float* x, const float* residual, const float* gamma, co
 size_t dvd_bnrelu_bwd_workspace_bytes(int N, int C, int HW) {
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
   const size_t chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
-  return (size_t)N * C * chunks * sizeof(float2);
+  return (size_t)N * C * chunks * (sizeof(float2) + sizeof(float));      // channel-sum records + block maxima
 }
 
 int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* mean,
@@ -211,12 +222,13 @@ int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float*
   const long long blocks = (long long)N * C * chunks;
   DVD_REQUIRE(blocks < (1LL << 31), "bnrelu bwd: grid too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  float* pmax = g_amax ? reinterpret_cast<float*>(static_cast<float2*>(workspace) + (size_t)N * C * chunks) : nullptr;
   hipLaunchKernelGGL(dvd::bnrelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, y, x, gamma, mean, var, eps, gx,
-                     g_residual, static_cast<float2*>(workspace), N, C, HW, chunks, relu, g_amax);
+                     g_residual, static_cast<float2*>(workspace), N, C, HW, chunks, relu, pmax);
   DVD_LAUNCH_OK();
-  if (g_gamma || g_beta) {
+  if (g_gamma || g_beta || g_amax) {
     hipLaunchKernelGGL(dvd::bnrelu_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, s,
-                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, N * chunks);
+                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, N * chunks, pmax, g_amax);
     DVD_LAUNCH_OK();
   }
   return DVD_OK;

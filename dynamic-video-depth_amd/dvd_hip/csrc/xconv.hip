@@ -660,7 +660,7 @@ static int xconv_pack_impl(const float* w, void* packed, int Cout, int Cin, int 
   // header: max |A| (BatchNorm scale included) -> the power-of-two operand scale of this packing
   if (int e = dvd::zero_words(packed, dvd::kXHeader * 4, static_cast<hipStream_t>(stream))) return e;
   {
-    const int nb = Cout < 1024 ? Cout : 1024;
+    const int nb = Cout < 128 ? Cout : 128;      // few blocks: every wave ends with an atomic on the one header word
     hipLaunchKernelGGL(dvd::xconv_wamax_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), w,
                        static_cast<float*>(packed), Cout, ci * T, gamma, var, eps);
     DVD_LAUNCH_OK();

@@ -14,7 +14,7 @@
 // one dword of its neighbour with v_alignbit_b32 (five of them give both shifted fragments of a term).
 // A block owns 64 output x 64 input channels and walks DOWN a 64-pixel-wide column strip of an image, one row
 // per step: the gy row (64 channels x 64 pixels) and ONE new x row (64 channels x 80 pixels: the strip, one
-// 8-pixel cell left and right) are staged per step -- the three x rows a step needs live in a rolling buffer --
+// 8-pixel cell left and right) are staged per step -- the x rows a step needs live in a rolling buffer of four --
 // split into the three bf16 terms on the way in; the next step's rows are requested before the MFMAs of the
 // current one.  Wave (pm, pn, ky) of the 12 keeps the three accumulators of kernel row ky for its 32 x 32 pair.
 // Every block writes its partial sums; xwgrad3_reduce_kernel adds them in slice order.
@@ -47,9 +47,9 @@ constexpr int kW3NT = 768;                    // 12 waves: 2 x 2 tile pairs x 3 
 
 __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  // sG [term 2][co 64][kW3GPitch], sX [term 2][ci 64][slot 3][kW3XPitch]
+  // sG [buffer 2][term 2][co 64][kW3GPitch], sX [term 2][ci 64][slot 4][kW3XPitch]
   unsigned char* sG = smem3;
-  unsigned char* sX = smem3 + 2 * kW3CB * kW3GPitch;
+  unsigned char* sX = smem3 + 2 * 2 * kW3CB * kW3GPitch;
   const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ky = wave % 3, pn = (wave / 3) & 1, pm = wave / 6;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       stg[i] = v;
     }
   };
-  auto stage_store = [&](int xslot) {      // split and write: 4 pixels = 8 bytes per term
+  auto stage_store = [&](int xslot, int gbuf) {      // split and write: 4 pixels = 8 bytes per term
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int q = i * kW3NT + tid;
@@ -112,12 +112,12 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       unsigned char* dst;
       int tstride;
       if (q < GQ) {
-        dst = sG + (q >> 4) * kW3GPitch + ((q & 15) << 3);
+        dst = sG + gbuf * (2 * kW3CB * kW3GPitch) + (q >> 4) * kW3GPitch + ((q & 15) << 3);
         tstride = kW3CB * kW3GPitch;
       } else {
         const int qq = q - GQ, ch = qq / 20;
-        dst = sX + (ch * 3 + xslot) * kW3XPitch + ((qq - ch * 20) << 3);
-        tstride = kW3CB * 3 * kW3XPitch;
+        dst = sX + (ch * 4 + xslot) * kW3XPitch + ((qq - ch * 20) << 3);
+        tstride = kW3CB * 4 * kW3XPitch;
       }
       *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(l0, l1);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   for (int k = 0; k < 3; ++k) acc[k] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int half = lane >> 5;
   const unsigned char* ga = sG + (pm * 32 + (lane & 31)) * kW3GPitch + half * 16;
-  const unsigned char* xa = sX + ((pn * 32 + (lane & 31)) * 3) * kW3XPitch + 16 + half * 16;   // cell 1 + half of slot 0
+  const unsigned char* xa = sX + ((pn * 32 + (lane & 31)) * 4) * kW3XPitch + 16 + half * 16;   // cell 1 + half of slot 0
 
   for (int item = blockIdx.x; item < items; item += a.S) {
     const int n = item / (a.nstrips * a.nrseg);
@@ -137,27 +137,32 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
     const int strip = rem / a.nrseg, seg = rem - strip * a.nrseg;
     const int c0 = strip * kW3Strip, r0 = seg * a.RS;
     const int r1 = (r0 + a.RS) < a.H ? (r0 + a.RS) : a.H;
-    // x rows r0 - 1 and r0 into their slots ((row + 3) % 3), then the loop stages row r + 1 with gy row r
+    // Four x-row slots (row & 3) and two gy buffers (row & 1): step r reads x rows r - 1 .. r + 1 and gy row r while the
+    // rows of step r + 1 (x row r + 2, gy row r + 1: loaded during step r - 1) are split and stored and the rows of step
+    // r + 2 are requested -- ONE barrier per step, and no phase in which every wave of the block does staging work while
+    // the matrix pipe idles (round 2 stored between two barriers).
     __syncthreads();                               // the previous item's MFMAs have read their operands
     stage_load(n, c0, r0 - 2, false);
-    stage_store((r0 - 1 + 3) % 3);
+    stage_store((r0 - 1) & 3, (r0 + 1) & 1);       // x row r0 - 1 (the gy half of these two stores is zeros into the idle buffer)
     stage_load(n, c0, r0 - 1, false);
-    stage_store(r0 % 3);
+    stage_store(r0 & 3, (r0 + 1) & 1);             // x row r0
     stage_load(n, c0, r0, true);
+    stage_store((r0 + 1) & 3, r0 & 1);             // gy row r0, x row r0 + 1
+    stage_load(n, c0, r0 + 1, true);               // gy row r0 + 1, x row r0 + 2 in registers
     for (int r = r0; r < r1; ++r) {
-      __syncthreads();                             // step r - 1 is done with the gy row and with slot (r + 1) % 3
-      stage_store((r + 1) % 3);
-      __syncthreads();
-      if (r + 1 < r1) stage_load(n, c0, r + 1, true);
-      const int slot = (r - 1 + ky + 3) % 3;       // x row r - 1 + ky
+      __syncthreads();                             // the rows of step r are complete; step r - 1 has been read by every wave
+      stage_store((r + 2) & 3, (r + 1) & 1);       // for step r + 1 (x row r - 2 / gy row r - 1 are no longer needed)
+      stage_load(n, c0, r + 2, true);              // for step r + 2: in flight under this step's MFMAs
+      const int slot = (r - 1 + ky) & 3;           // x row r - 1 + ky
       const unsigned char* xr = xa + slot * kW3XPitch;
+      const unsigned char* gr = ga + (r & 1) * (2 * kW3CB * kW3GPitch);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                // four K steps of 16 pixels
         f16x8 A[2], B[3][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          A[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ga + t * (kW3CB * kW3GPitch) + s * 32));
-          const unsigned char* xc = xr + t * (kW3CB * 3 * kW3XPitch) + s * 32;
+          A[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(gr + t * (kW3CB * kW3GPitch) + s * 32));
+          const unsigned char* xc = xr + t * (kW3CB * 4 * kW3XPitch) + s * 32;
           const u32x4 cur = *reinterpret_cast<const u32x4*>(xc);
           const unsigned prev3 = *reinterpret_cast<const unsigned*>(xc - 4);
           const unsigned next0 = *reinterpret_cast<const unsigned*>(xc + 16);
@@ -467,7 +472,7 @@ static void wg3_plan(int N, int Cin, int Cout, int H, int W, int G, Wg3Plan& p) 
   const long long items = (long long)N * p.nstrips * p.nrseg;
   if (S > items) S = (int)items;
   p.S = S;
-  p.lds = (size_t)2 * kW3CB * kW3GPitch + (size_t)2 * kW3CB * 3 * kW3XPitch;
+  p.lds = (size_t)2 * 2 * kW3CB * kW3GPitch + (size_t)2 * kW3CB * 4 * kW3XPitch;
 }
 
 }  // namespace dvd
