@@ -133,7 +133,7 @@ _lib = None
 
 
 def library_path():
-    return os.environ.get('DVD_HIP_LIB', _build.lib_path())
+    return os.environ.get('DVD_HIP_LIB') or _build.lib_path()        # an empty DVD_HIP_LIB counts as unset
 
 
 def load():
@@ -149,7 +149,7 @@ def load():
         if _lib is not None:
             return _lib
         path = library_path()
-        if not os.path.exists(path) and 'DVD_HIP_LIB' not in os.environ:
+        if not os.path.exists(path) and not os.environ.get('DVD_HIP_LIB'):
             try:                                  # fresh checkout: compile in-tree (hipcc cross-compiles gfx950)
                 _build.build_library()
             except Exception as e:                # noqa: BLE001 -- reported below as the missing-library error

@@ -40,11 +40,14 @@ __device__ __forceinline__ void src_index(const Axis& a, int dst, int& i0, int& 
   w0 = 1.0f - w1;
 }
 
-// Linear index over (row group, quad); a thread produces 4 adjacent output pixels of kRows consecutive rows, so the
-// column indices / weights are computed once per kRows rows (the kernel is VALU-bound otherwise: ~150 instructions per
-// 16-byte store); row index = plane * n_out_y + oy, 32-bit arithmetic only (the first version decomposed a 64-bit linear
-// index with three 64-bit divisions per thread and ran at 0.9 TB/s).
-constexpr int kRows = 4;
+// Linear index over (row group, quad): a thread produces 4 adjacent output pixels of kRows consecutive rows.  The column
+// indices / weights are computed once per thread, and so is the HORIZONTAL blend of a source row: consecutive output rows
+// share their source rows (x2 up-sampling: 8 output rows read 5 source rows), so a thread keeps the blended quads of the
+// two source rows it last used and only loads a row it has not seen -- 5 x 8 instead of 8 x 16 tap loads per thread, and
+// bit-identical results (ATen's association w_y0 * (w_x0 * a + w_x1 * b) + w_y1 * (w_x0 * c + w_x1 * d) IS "horizontal
+// first").  Round 2's kernel re-loaded and re-blended both source rows for every output row and ran at 1.7 TB/s.
+// Row index = plane * n_out_y + oy, 32-bit arithmetic only.
+constexpr int kRows = 8;
 __global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                     Axis ay, Axis ax, unsigned rows) {
   const unsigned quads = (unsigned)(ax.n_out + 3) >> 2;
@@ -61,21 +64,44 @@ __global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float*
     src_index(ax, ox < ax.n_out ? ox : ax.n_out - 1, x0[j], x1[j], wx0[j], wx1[j]);
   }
   const bool vec = (ax.n_out & 3) == 0;
+  unsigned p = rb / (unsigned)ay.n_out;
+  int oy = (int)(rb - p * (unsigned)ay.n_out);
+  unsigned c0 = 0xffffffffu, c1 = 0xffffffffu;   // source rows (plane * n_in_y + y) whose blends h0 / h1 hold
+  float h0[4], h1[4];
+  auto blend = [&](unsigned g, float (&h)[4]) {
+    const float* rp = x + (size_t)g * ax.n_in;
 #pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = wx0[j] * rp[x0[j]] + wx1[j] * rp[x1[j]];
+  };
+#pragma unroll 2
   for (int k = 0; k < kRows; ++k) {
     const unsigned r = rb + k;
     if (r >= rows) break;
-    const unsigned p = r / (unsigned)ay.n_out;
-    const int oy = (int)(r - p * (unsigned)ay.n_out);
     int y0, y1;
     float wy0, wy1;
     src_index(ay, oy, y0, y1, wy0, wy1);
-    const float* r0 = x + ((size_t)p * ay.n_in + y0) * ax.n_in;
-    const float* r1 = x + ((size_t)p * ay.n_in + y1) * ax.n_in;
+    const unsigned g0 = p * (unsigned)ay.n_in + (unsigned)y0, g1 = p * (unsigned)ay.n_in + (unsigned)y1;
+    if (g0 != c0) {
+      if (g0 == c1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h0[j] = h1[j];
+      } else {
+        blend(g0, h0);
+      }
+      c0 = g0;
+    }
+    if (g1 != c1) {
+      if (g1 == c0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h1[j] = h0[j];
+      } else {
+        blend(g1, h1);
+      }
+      c1 = g1;
+    }
     float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)   // ATen: w_y0 * (w_x0 * a + w_x1 * b) + w_y1 * (w_x0 * c + w_x1 * d)
-      o[j] = wy0 * (wx0[j] * r0[x0[j]] + wx1[j] * r0[x1[j]]) + wy1 * (wx0[j] * r1[x0[j]] + wx1[j] * r1[x1[j]]);
+    for (int j = 0; j < 4; ++j) o[j] = wy0 * h0[j] + wy1 * h1[j];
     float* dst = y + (size_t)r * ax.n_out + q * 4;
     if (vec) {
       *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
@@ -83,6 +109,10 @@ __global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float*
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if ((int)q * 4 + j < ax.n_out) dst[j] = o[j];
+    }
+    if (++oy == ay.n_out) {
+      oy = 0;
+      ++p;
     }
   }
 }
@@ -113,22 +143,24 @@ __device__ __forceinline__ void axis_weights(const Axis& a, int i, int lo, float
   }
 }
 
-// Linear index over (row group of kRows input rows, input column): the column bracket and its weights are computed once
-// per thread; row index = plane * n_in_y + iy.
+// Linear index over (row group of kBRows input rows, input column): the column bracket and its weights are computed once
+// per thread; row index = plane * n_in_y + iy.  (General gather: any factor up to 3, any width.  The decoder's x2 maps
+// take upsample_bilinear_bwd_sep_kernel below.)
+constexpr int kBRows = 4;
 template <int kCand>
 __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                     Axis ay, Axis ax, unsigned rows) {
   const unsigned idx = blockIdx.x * 256 + threadIdx.x;          // (row group, input column), columns fastest
   const unsigned rg = idx / (unsigned)ax.n_in;
   const unsigned ixu = idx - rg * (unsigned)ax.n_in;
-  const unsigned rb = rg * kRows;
+  const unsigned rb = rg * kBRows;
   if (rb >= rows) return;
   const int ix = (int)ixu;
   const int xlo = dst_lo(ax, ix);
   float wx[kCand];
   axis_weights<kCand>(ax, ix, xlo, wx);
 #pragma unroll 1
-  for (int k = 0; k < kRows; ++k) {
+  for (int k = 0; k < kBRows; ++k) {
     const unsigned r = rb + k;
     if (r >= rows) break;
     const unsigned p = r / (unsigned)ay.n_in;
@@ -150,6 +182,97 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float*
     }
     gx[(size_t)r * ax.n_in + ix] = acc;
   }
+}
+
+
+// Separable backward for the decoder's maps (n_out <= 2.5 n_in on both axes, W_out a multiple of 4): gx = Wy^T gy Wx.
+// A thread owns TWO adjacent input columns and a segment of kSegRows input rows of one plane and walks DOWN the output
+// rows that touch the segment: per output row three aligned 16-byte loads cover every output column that can read either
+// input column (their exact weights -- zero for the ones that do not -- are computed once per thread), the two horizontal
+// sums go into two running accumulators (the input rows y0 and y0 + 1 of that output row), and an input row is stored when
+// the walk has passed its last reader.  Per input element ~3.3 16-byte loads instead of the gather's 16 scalar loads;
+// the summation order (output rows ascending, columns ascending inside) is fixed: deterministic, no atomics, no memset.
+constexpr int kSegRows = 16, kSepCand = 12;
+__global__ __launch_bounds__(256) void upsample_bilinear_bwd_sep_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                        Axis ay, Axis ax, unsigned segs, unsigned nseg) {
+  const unsigned pairs = (unsigned)(ax.n_in + 1) >> 1;
+  const unsigned idx = blockIdx.x * 256 + threadIdx.x;          // (plane, segment, column pair), pairs fastest
+  const unsigned sg = idx / pairs;
+  if (sg >= segs) return;
+  const int ix = (int)(idx - sg * pairs) * 2;
+  const unsigned p = sg / nseg;
+  const int m0 = (int)(sg - p * nseg) * kSegRows;
+  const int m1 = m0 + kSegRows < ay.n_in ? m0 + kSegRows : ay.n_in;
+  const bool two = ix + 1 < ax.n_in;
+  // column bracket: kSepCand outputs from the 4-aligned column at or below the first reader of column ix
+  const int a0 = dst_lo(ax, ix) & ~3;
+  float wa[kSepCand], wb[kSepCand];
+#pragma unroll
+  for (int k = 0; k < kSepCand; ++k) {
+    const int o = a0 + k;
+    int i0, i1;
+    float w0, w1;
+    src_index(ax, o < ax.n_out ? o : ax.n_out - 1, i0, i1, w0, w1);
+    const bool in = o < ax.n_out;
+    wa[k] = in ? (i0 == ix ? w0 : 0.0f) + (i1 == ix ? w1 : 0.0f) : 0.0f;
+    wb[k] = in && two ? (i0 == ix + 1 ? w0 : 0.0f) + (i1 == ix + 1 ? w1 : 0.0f) : 0.0f;
+  }
+  const float* g = gy + (size_t)p * ay.n_out * ax.n_out + a0;
+  float* out = gx + (size_t)p * ay.n_in * ax.n_in + ix;
+  const bool ld0 = a0 < ax.n_out, ld1 = a0 + 4 < ax.n_out, ld2 = a0 + 8 < ax.n_out;   // W_out % 4 == 0: all or nothing
+  int oy = dst_lo(ay, m0);
+  int A;                                   // the input row acc_a belongs to (acc_b: A + 1)
+  {
+    int y1;
+    float w0, w1;
+    src_index(ay, oy, A, y1, w0, w1);
+  }
+  float a_a = 0.0f, a_b = 0.0f, b_a = 0.0f, b_b = 0.0f;      // [column a / b]_[row A / A + 1]
+  auto flush = [&]() {
+    if (A >= m0 && A < m1) {
+      out[(size_t)A * ax.n_in] = a_a;
+      if (two) out[(size_t)A * ax.n_in + 1] = b_a;
+    }
+    a_a = a_b;
+    b_a = b_b;
+    a_b = b_b = 0.0f;
+    ++A;
+  };
+  const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 n0 = z, n1 = z, n2 = z;           // the NEXT output row's three quads: requested one row ahead of their use
+  auto request = [&](int r) {
+    const float4* row = reinterpret_cast<const float4*>(g + (size_t)r * ax.n_out);
+    n0 = ld0 ? row[0] : z;
+    n1 = ld1 ? row[1] : z;
+    n2 = ld2 ? row[2] : z;
+  };
+  if (oy < ay.n_out) request(oy);
+  for (; oy < ay.n_out; ++oy) {
+    int y0, y1;
+    float wy0, wy1;
+    src_index(ay, oy, y0, y1, wy0, wy1);
+    if (y0 >= m1) break;
+    const float4 v0 = n0, v1 = n1, v2 = n2;
+    if (oy + 1 < ay.n_out) request(oy + 1);
+    while (y0 > A) flush();
+    const float v[kSepCand] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+    float ta = 0.0f, tb = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kSepCand; ++k) {
+      ta = __builtin_fmaf(wa[k], v[k], ta);
+      tb = __builtin_fmaf(wb[k], v[k], tb);
+    }
+    a_a = __builtin_fmaf(wy0, ta, a_a);
+    b_a = __builtin_fmaf(wy0, tb, b_a);
+    if (y1 != y0) {
+      a_b = __builtin_fmaf(wy1, ta, a_b);
+      b_b = __builtin_fmaf(wy1, tb, b_b);
+    } else {                               // far edge: both taps are row y0
+      a_a = __builtin_fmaf(wy1, ta, a_a);
+      b_a = __builtin_fmaf(wy1, tb, b_a);
+    }
+  }
+  while (A < m1) flush();
 }
 
 static Axis make_axis(int n_in, int n_out, int align) {
@@ -191,13 +314,23 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
   const dvd::Axis ay = dvd::make_axis(H_in, H_out, align_corners), ax = dvd::make_axis(W_in, W_out, align_corners);
   const long long rows = planes * H_in;
   DVD_REQUIRE(rows < (1LL << 32) - 4, "upsample bwd: too many rows");
-  const long long total = (rows + dvd::kRows - 1) / dvd::kRows * W_in;
+  const long long total = (rows + dvd::kBRows - 1) / dvd::kBRows * W_in;
   DVD_REQUIRE(total < (1LL << 32) - 256, "upsample bwd: too large");
   // the candidate bracket must cover every output that reads an input pixel (or simply all outputs of a short axis)
   const auto covered = [](const dvd::Axis& a, int k, float smin) { return a.scale >= smin || a.n_out <= k; };
   DVD_REQUIRE(covered(ay, 8, 1.0f / 3.0f) && covered(ax, 8, 1.0f / 3.0f), "upsample bwd: up-sampling factors above 3 are not covered");
-  const dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (covered(ay, 6, 0.4f) && covered(ax, 6, 0.4f) && ax.scale >= 0.4f && (W_out & 3) == 0 && H_out > H_in) {
+    // the decoder's x2 maps: separable walk (a segment's first reader row comes from dst_lo, which needs scale > 0)
+    const long long nseg = (H_in + dvd::kSegRows - 1) / dvd::kSegRows, segs = planes * nseg;
+    const long long threads = segs * ((W_in + 1) / 2);
+    DVD_REQUIRE(threads < (1LL << 32) - 256, "upsample bwd: too large");
+    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_sep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, gy, gx,
+                       ay, ax, (unsigned)segs, (unsigned)nseg);
+    DVD_LAUNCH_OK();
+    return DVD_OK;
+  }
+  const dim3 grid((unsigned)((total + 255) / 256));
   if (covered(ay, 6, 0.4f) && covered(ax, 6, 0.4f))
     hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<6>, grid, dim3(256), 0, s, gy, gx, ay, ax, (unsigned)rows);
   else

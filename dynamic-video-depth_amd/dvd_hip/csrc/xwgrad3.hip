@@ -47,7 +47,8 @@ constexpr int kW3NT = 768;                    // 12 waves: 2 x 2 tile pairs x 3 
 
 __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  // sG [buffer 2][term 2][co 64][kW3GPitch], sX [term 2][ci 64][slot 4][kW3XPitch]
+  // sG [buffer 2][term 2][co 64][kW3GPitch], sX [term 2][slot 4][ci 64][kW3XPitch] (slot-major: a channel stride of
+  // 44 dwords keeps the 16-byte fragment reads of 32 channels conflict free; 4 x 44 did not)
   unsigned char* sG = smem3;
   unsigned char* sX = smem3 + 2 * 2 * kW3CB * kW3GPitch;
   const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
         tstride = kW3CB * kW3GPitch;
       } else {
         const int qq = q - GQ, ch = qq / 20;
-        dst = sX + (ch * 4 + xslot) * kW3XPitch + ((qq - ch * 20) << 3);
+        dst = sX + (xslot * kW3CB + ch) * kW3XPitch + ((qq - ch * 20) << 3);
         tstride = kW3CB * 4 * kW3XPitch;
       }
       *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   for (int k = 0; k < 3; ++k) acc[k] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int half = lane >> 5;
   const unsigned char* ga = sG + (pm * 32 + (lane & 31)) * kW3GPitch + half * 16;
-  const unsigned char* xa = sX + ((pn * 32 + (lane & 31)) * 4) * kW3XPitch + 16 + half * 16;   // cell 1 + half of slot 0
+  const unsigned char* xa = sX + (pn * 32 + (lane & 31)) * kW3XPitch + 16 + half * 16;   // cell 1 + half of slot 0
 
   for (int item = blockIdx.x; item < items; item += a.S) {
     const int n = item / (a.nstrips * a.nrseg);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       stage_store((r + 2) & 3, (r + 1) & 1);       // for step r + 1 (x row r - 2 / gy row r - 1 are no longer needed)
       stage_load(n, c0, r + 2, true);              // for step r + 2: in flight under this step's MFMAs
       const int slot = (r - 1 + ky) & 3;           // x row r - 1 + ky
-      const unsigned char* xr = xa + slot * kW3XPitch;
+      const unsigned char* xr = xa + slot * (kW3CB * kW3XPitch);
       const unsigned char* gr = ga + (r & 1) * (2 * kW3CB * kW3GPitch);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                // four K steps of 16 pixels

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize('align', [True, False])
 @pytest.mark.parametrize('N,C,H,W', [(2, 3, 12, 21), (1, 8, 24, 42), (2, 4, 5, 7), (1, 2, 1, 9), (1, 16, 48, 84),
-                                     (1, 2, 70, 150), (3, 1, 6, 131)])
+                                     (1, 2, 70, 150), (3, 1, 6, 131),
+                                     # separable backward: row segments of 16 that do not divide H, narrow maps
+                                     (1, 2, 35, 42), (2, 3, 17, 6), (1, 1, 33, 84), (2, 2, 16, 4)])
 def test_matches_torch_cpu(N, C, H, W, align):
     from dvd_hip.conv import upsample_bilinear2x
     g = torch.Generator().manual_seed(H * 100 + W)
@@ -28,7 +30,7 @@ def test_matches_torch_cpu(N, C, H, W, align):
     for name, got, want in (('y', y.detach(), yr.detach()), ('gx', xg.grad, xr.grad)):
         got, want = got.cpu().numpy(), want.numpy()
         assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max() + 1e-7, name
-    # deterministic backward (a gather, no atomics)
+    # deterministic backward (fixed summation order, no atomics)
     xg2 = x.cuda().requires_grad_(True)
     upsample_bilinear2x(xg2, align).backward(up.cuda())
     assert torch.equal(xg.grad, xg2.grad)

@@ -14,7 +14,8 @@ mkdir -p $OUT/obj_$NAME
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/include -I$PKG/csrc"
 EXTRA=""
 case $UNIT in warp_loss|unproject|elementwise|surfaces|upsample|consistency) EXTRA="-ffp-contract=off";; esac
-hipcc $COMMON $EXTRA "$@" -c $PKG/csrc/$UNIT.hip -o $OUT/obj_$NAME/$UNIT.o
+SRC=${SRC:-$PKG/csrc/$UNIT.hip}          # SRC=<file>: another revision of the unit (git show <rev>:<path> > file)
+hipcc $COMMON $EXTRA "$@" -c $SRC -o $OUT/obj_$NAME/$UNIT.o
 OBJS=""
 for o in $PKG/lib/*.o; do
   [ "$(basename $o)" = "$UNIT.o" ] && continue

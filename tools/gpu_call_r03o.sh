@@ -1,0 +1,20 @@
+#!/bin/bash
+# new up-sampling kernels (row-cached forward, separable backward); xwgrad3 four-slot kernel with the slot-major x layout
+# vs the three-slot kernel (variant library)
+set -u
+OUT=gpurun_out/r03o; mkdir -p $OUT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST MIOPEN_LOG_LEVEL=1
+V=$(pwd)/dynamic-video-depth_amd/dvd_hip/lib/variants/libdvd_hip_w3slot3.so
+timeout 600 python -m pytest tests/test_05_upsample_gpu.py tests/test_06_xconv_gpu.py -m gpu -q > $OUT/pytest.log 2>&1
+grep -E "passed|failed|error" $OUT/pytest.log | tail -3; grep -E "^FAILED|^ERROR" $OUT/pytest.log | head
+timeout 200 python tools/microbench_upsample.py > $OUT/upsample.jsonl 2> $OUT/upsample.err; cut -c1-200 $OUT/upsample.jsonl
+XCONV_NMUL=3 XCONV_ONLY=0,1,2,3,4,6 timeout 300 python tools/microbench_xconv.py nomiopen > $OUT/xconv_slot4.jsonl 2> $OUT/xconv_slot4.err
+python - $OUT/xconv_slot4.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    r=json.loads(l); print('  ',r['shape'],'wgrad %.3f ms %.0f TF'%(r.get('xconv_wgrad_ms',0),r.get('xconv_wgrad_tfs',0)))
+PY
+timeout 600 python bench.py --steps 3 --warmup 1 --no_cpu_baseline > $OUT/bench_slot4.log 2> $OUT/bench_slot4.err
+echo slot4; tail -1 $OUT/bench_slot4.log | cut -c1-220
+DVD_HIP_LIB=$V timeout 600 python bench.py --steps 3 --warmup 1 --no_cpu_baseline > $OUT/bench_slot3.log 2> $OUT/bench_slot3.err
+echo slot3; tail -1 $OUT/bench_slot3.log | cut -c1-220
