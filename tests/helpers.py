@@ -42,6 +42,16 @@ def golden_mlp_sd(gd, device='cpu', prefix='sd_'):
     return {k[len(prefix):]: t(v, device) for k, v in gd.items() if k.startswith(prefix)}
 
 
+def log_measured(name, value, bound):
+    """Append one measured-vs-bound record to $DVD_PARITY_LOG (json lines) when it is set: the evidence visit keeps the
+    file under profiles/, so every tolerance in the tests sits next to the value it was derived from."""
+    import json
+    import os
+    if os.environ.get('DVD_PARITY_LOG'):
+        with open(os.environ['DVD_PARITY_LOG'], 'a') as f:
+            f.write(json.dumps({'test': name, 'measured': float(value), 'bound': float(bound)}) + '\n')
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

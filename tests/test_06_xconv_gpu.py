@@ -1,11 +1,15 @@
-"""Dense convolutions on the split-bf16 MFMA kernels (csrc/xconv.hip, csrc/xwgrad.hip) against F.conv2d on the
+"""Dense convolutions on the split-operand MFMA kernels (csrc/xconv.hip, csrc/xwgrad3.hip) against F.conv2d on the
 CPU in float64 (the reference's nn.Conv2d arithmetic, third_party/midas_blocks.py:102-168, MiDaS.py:186-195,
 hourglass.py:21-57).
 
-Tolerance: fp32 class.  Every product is evaluated from three bf16 terms per operand (six partial products,
-fp32 accumulation), so the error against the float64 result must be of the size of an fp32 convolution's own
-rounding error: max |err| <= 4e-6 * max |y| (an fp32 CPU convolution of the same data measures 1-2e-6 on these
-shapes; a plain bf16 product would be 4e-3)."""
+Tolerance: fp32 class.  Every operand is scaled by a power of two and split into two fp16 terms (22 bits), a product is
+three partial products with fp32 accumulation (csrc/dvd_split.h; round 2: three bf16 terms / six products), so the error
+against the float64 result must be of the size of an fp32 convolution's own rounding error:
+  * max |err| <= 4e-6 * max |y| on zero-mean data (an fp32 CPU convolution of the same data measures 1-2e-6 on these
+    shapes; a plain fp16 / bf16 product would be 5e-4 / 4e-3), weight gradients 2e-5 (K = N*H*W up to 4e4 terms);
+  * ELEMENT-WISE relative error on a well-conditioned case (all operands positive: no cancellation, every output is
+    as large as the sum of its terms' magnitudes) <= 2e-6, next to the fp32 CPU convolution's own figure
+    (test_elementwise_relative_error_without_cancellation)."""
 import numpy as np
 import pytest
 import torch
@@ -121,6 +125,44 @@ def test_forward_and_input_gradient(N, Cin, Cout, H, W, KS):
     print('wgrad err %.2e' % e)
     assert e < 2e-5, 'wgrad: ' + _where(cg.weight.grad, wd.grad, 'co,ci,ky,kx')
     assert _err(cg.bias.grad, bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W,KS', [(2, 256, 256, 24, 40, 3), (2, 512, 256, 16, 24, 1), (1, 64, 32, 20, 36, 3)])
+def test_elementwise_relative_error_without_cancellation(N, Cin, Cout, H, W, KS):
+    """All inputs, weights and output gradients in [0.5, 1.5]: nothing cancels, so max |err| / |y| PER ELEMENT measures the
+    arithmetic itself (22-bit operands, dropped low x low partial product, fp32 accumulation) and not the conditioning of
+    the data.  Bound 2e-6 = 34 fp32 ulps of the result for sums of 64 .. 2 304 products (forward / input gradient) and of
+    1 000 .. 2 000 products (weight gradient); the fp32 CPU convolution's own element-wise error is printed beside it."""
+    from dvd_hip import conv as C
+    from helpers import log_measured
+    g = torch.Generator().manual_seed(7 * Cin + KS)
+    x = torch.rand(N, Cin, H, W, generator=g) + 0.5
+    conv = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.rand(conv.weight.shape, generator=g) + 0.5)
+    gy = torch.rand(N, Cout, H, W, generator=g) + 0.5
+    xd = x.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, padding=KS // 2)
+    yd.backward(gy.double())
+    x32 = x.clone().requires_grad_(True)
+    y32 = conv(x32)
+    y32.backward(gy)
+    xg = x.cuda().requires_grad_(True)
+    cg = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2, bias=False).cuda()
+    cg.load_state_dict(conv.state_dict())
+    y = C.xconv2d(cg, xg)
+    y.backward(gy.cuda())
+
+    def rel(got, want):
+        return float(((got.double().cpu() - want).abs() / want.abs()).max())
+    rows = {'fwd': (rel(y.detach(), yd.detach()), rel(y32.detach(), yd.detach())),
+            'dgrad': (rel(xg.grad, xd.grad), rel(x32.grad, xd.grad)),
+            'wgrad': (rel(cg.weight.grad, wd.grad), rel(conv.weight.grad, wd.grad))}
+    for k, (e, e32) in rows.items():
+        print('%s element-wise rel err %.2e (fp32 CPU convolution: %.2e)' % (k, e, e32))
+        log_measured('xconv_elementwise_%s_%dx%dx%d' % (k, Cin, Cout, KS), e, 2e-6)
+        assert e < 2e-6, k
 
 
 @pytest.mark.parametrize('KS', [1, 3])
