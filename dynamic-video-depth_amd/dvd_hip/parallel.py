@@ -44,6 +44,13 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     dist.init_process_group(backend=backend)
+    if backend == 'nccl':
+        # RCCL creates its communicator (channels, staging buffers: a few GB of HBM) at the FIRST collective.  Run one now,
+        # so that the step's memory planner (Model._keep_slot reads the free HBM) sees what the collectives will occupy
+        # instead of finding out after the kept-activation slots have been sized.
+        warm = torch.zeros(1, device=torch.device('cuda', torch.cuda.current_device()))
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
     return local
 
 
