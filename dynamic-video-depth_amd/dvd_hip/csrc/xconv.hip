@@ -58,6 +58,9 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // Grouped convolutions: Cout / Cin are per group, w is [G * Cout][Cin][T]; group g's fragments follow group g - 1's.
 // sc_gamma / sc_var (optional): every weight of output channel co is multiplied by gamma[co] / sqrt(var[co] + eps) (gamma
 // null = 1) -- the backward-data pass of a convolution whose eval-mode BatchNorm is fused into its epilogue.
+#ifndef DVD_XCONV_ROLL
+#define DVD_XCONV_ROLL 1
+#endif
 constexpr int kXHeader = 16;       // uint4 cells in front of the fragments
 
 // value of A's element as the pack kernel sees it (BatchNorm scale folded in): shared by the amax and the pack kernels
@@ -387,7 +390,103 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   // fragments: A(kt + 1) is requested right after the step's barrier and written to LDS behind the step's own MFMAs, which
   // cover the L2 round trip; the narrow tiles (24 MFMAs per step) need the request two to three steps ahead, in two sets.
   constexpr bool kSingleA = TM >= 4;
+  // Rolling fragment prefetch (wide wave tiles, DVD_XCONV_ROLL): the fragments of step kt + 1 are read from LDS DURING the
+  // MFMAs of step kt -- the activation fragments into a second register set, the weight fragments of tile row tm into the
+  // registers that tile row's MFMAs have just released -- so that after a barrier every wave starts on the matrix pipe at
+  // once instead of all eight waves first queueing on LDS (one 512-thread block per CU runs in lock step: counters showed
+  // the pipe 45 % busy).  For that the stages run one step further ahead: A(kt + 2) is requested at the top of step kt and
+  // stored at its end into the buffer of A(kt), whose fragments were read during step kt - 1; the activation chunk of step
+  // kt + 2 is stored at the end of step kt whenever step kt + 1 is the last tap of its chunk.
+  constexpr bool kRoll = kSingleA && !B1 && (DVD_XCONV_ROLL != 0);
   ARegs ra, rb;
+  if (kRoll) {
+    load_a(ra, 0);
+    if (!kDirect) load_raw(0);
+    write_a(ra, 0);
+    load_a(ra, nkt > 1 ? 1 : 0);
+    if (kDirect) {
+      stage_direct(0, 0);
+      if (T == 1 && a.nkc > 1) stage_direct(1, 1);
+    } else {
+      split_write(0, 0);
+      load_raw(a.nkc > 1 ? 1 : 0);
+      if (T == 1) {
+        if (a.nkc > 1) split_write(1, 1);
+        load_raw(a.nkc > 2 ? 2 : 0);
+      }
+    }
+    write_a(ra, 1);
+    __syncthreads();
+    f16x8 fa[TM][2], fb[2][TN][2];
+    {
+      const u32x4* Ac = sA + al;
+      const u32x4* Bc = sB + bl;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[tm][t] = __builtin_bit_cast(f16x8, Ac[(tm * 2 + t) * 64]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fb[0][tn][t] = __builtin_bit_cast(f16x8, Bc[t * 2 * npos + qb[tn]]);
+    }
+    // tap counters of the step whose fragments are being fetched (kt + 1)
+    int nc = 0, ny = 0, nx = 0;
+    auto advance = [&]() {
+      if (++nx == KS) {
+        nx = 0;
+        if (++ny == KS) {
+          ny = 0;
+          ++nc;
+        }
+      }
+    };
+    advance();
+    auto step_roll = [&](int kt, f16x8 (&bc)[TN][2], f16x8 (&bn)[TN][2]) {
+      __syncthreads();
+      load_a(ra, kt + 2 < nkt ? kt + 2 : kt);
+      const u32x4* Ac = sA + ((kt + 1) & 1) * AS + al;
+      const u32x4* Bc = sB + (nc & 1) * 4 * npos + bl + ny * P + nx;      // (past the last step: in range, never used)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bn[tn][t] = __builtin_bit_cast(f16x8, Bc[t * 2 * npos + qb[tn]]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        // l*h' + h*l' + h*h' per accumulator, small terms first (the order of the other block shapes: identical results)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][1], bc[tn][0], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][0], bc[tn][1], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][0], bc[tn][0], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);           // the reload below stays behind this tile row's MFMAs
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[tm][t] = __builtin_bit_cast(f16x8, Ac[(tm * 2 + t) * 64]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      write_a(ra, kt & 1);                           // A(kt + 2) over A(kt)
+      // activations: is step kt + 1 the last tap of its chunk?  then step kt + 2 opens chunk nc + 1
+      if (nx == KS - 1 && ny == KS - 1) {            // block-uniform
+        const int c2 = nc + 1;
+        if (kDirect) {
+          if (c2 < a.nkc) stage_direct(c2 & 1, c2);
+        } else {
+          split_write(c2 & 1, c2);                   // (beyond the last chunk: zeros into the idle buffer)
+          load_raw(c2 + 1 < a.nkc ? c2 + 1 : c2);
+        }
+      }
+      advance();
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+      step_roll(kt, fb[0], fb[1]);
+      if (kt + 1 < nkt) step_roll(kt + 1, fb[1], fb[0]);
+    }
+  } else {
   load_a(ra, 0);
   if (!kDirect) load_raw(0);
   write_a(ra, 0);
@@ -436,6 +535,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       step(kt, rb);
       if (kt + 1 < nkt) step(kt + 1, ra);
     }
+  }
   }
 
   // ---- epilogue (uniform branches only; the optional operands are loaded in batches of 16; 32-bit offsets
