@@ -388,47 +388,66 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
       *reinterpret_cast<uint2*>(dst + kWbTerm) = make_uint2(l0, l1);
     }
   };
-  auto mfma_chunk = [&](int buf) {
-    const unsigned char* gb = smem3 + buf * kWbBuf + (64 * wr + i32) * kWbPitch + hh * 16;
-    const unsigned char* hb = smem3 + buf * kWbBuf + 2 * kWbTerm + (128 * wc + i32) * kWbPitch + hh * 16;
-    u32x4 A[2][2];
+  // Fragments of chunk it + 1 are read from LDS DURING the MFMAs of chunk it (the rolling prefetch of csrc/xconv.hip: one
+  // 512-thread block per CU runs in lock step, so fragment reads placed right after the barrier leave the matrix pipe idle
+  // while all eight waves queue on LDS): the gy fragments into a second register set, the x fragments of column tile c into
+  // the registers that tile's MFMAs have just released.  Chunk it is therefore loaded during step it - 3, split and stored
+  // during step it - 2 (into the buffer whose fragments were read during step it - 3), read during step it - 1.
+  const unsigned char* gb0 = smem3 + (64 * wr + i32) * kWbPitch + hh * 16;
+  const unsigned char* hb0 = smem3 + 2 * kWbTerm + (128 * wc + i32) * kWbPitch + hh * 16;
+  u32x4 Bf[4][2];
+  auto read_a = [&](int buf, u32x4 (&A)[2][2]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) A[r][t] = *reinterpret_cast<const u32x4*>(gb + t * kWbTerm + r * 32 * kWbPitch);
+      for (int t = 0; t < 2; ++t) A[r][t] = *reinterpret_cast<const u32x4*>(gb0 + buf * kWbBuf + t * kWbTerm + r * 32 * kWbPitch);
+  };
+  auto read_b = [&](int buf, int c) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) Bf[c][t] = *reinterpret_cast<const u32x4*>(hb0 + buf * kWbBuf + t * kWbTerm + c * 32 * kWbPitch);
+  };
+  auto mfma_roll = [&](int nbuf, const u32x4 (&A)[2][2], u32x4 (&An)[2][2]) {    // MFMAs on (A, Bf); next fragments from nbuf
+    read_a(nbuf, An);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      u32x4 B[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) B[t] = *reinterpret_cast<const u32x4*>(hb + t * kWbTerm + c * 32 * kWbPitch);
 #define DVD_WB_TERM(SA, SB)                                                                                   \
   _Pragma("unroll") for (int r = 0; r < 2; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(           \
-      __builtin_bit_cast(f16x8, A[r][SA]), __builtin_bit_cast(f16x8, B[SB]), acc[r][c], 0, 0, 0);
+      __builtin_bit_cast(f16x8, A[r][SA]), __builtin_bit_cast(f16x8, Bf[c][SB]), acc[r][c], 0, 0, 0);
       DVD_WB_TERM(1, 0)
       DVD_WB_TERM(0, 1)
       DVD_WB_TERM(0, 0)
 #undef DVD_WB_TERM
+      __builtin_amdgcn_sched_barrier(0);           // the reload stays behind this column tile's MFMAs
+      read_b(nbuf, c);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // chunk it is loaded during step it - 2, split and stored during step it - 1, consumed by the MFMAs of step it: no wave
-  // ever waits for HBM.  One barrier per chunk: buffer b is complete and every wave is done reading buffer b ^ 1.
   if (n_it > 0) {
     const int last = n_it - 1;
+    auto clamp = [&](int i) { return i < last ? i : last; };
     stage_load(0, sg0);
     stage_store(0, sg0);
-    stage_load(1 < last ? 1 : last, sg0);
+    stage_load(clamp(1), sg0);
+    stage_store(1, sg0);
+    stage_load(clamp(2), sg0);
+    __syncthreads();
+    u32x4 A0[2][2], A1[2][2];
+    read_a(0, A0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) read_b(0, c);
     for (int it = 0; it < n_it; it += 2) {
-      __syncthreads();
-      stage_load(it + 2 < last ? it + 2 : last, sg1);
+      __syncthreads();                     // chunk it + 1 is complete in buffer 1; buffer 0 has been read by every wave
+      stage_load(clamp(it + 3), sg1);
       __builtin_amdgcn_sched_barrier(0);   // the loads stay above the MFMAs
-      mfma_chunk(0);
-      stage_store(1, sg0);                 // chunk it + 1 (past the end: a copy of the last chunk into the idle buffer)
+      mfma_roll(1, A0, A1);                // chunk it
+      stage_store(0, sg0);                 // chunk it + 2 (past the end: a copy of the last chunk into an idle buffer)
       __syncthreads();
-      stage_load(it + 3 < last ? it + 3 : last, sg0);
+      stage_load(clamp(it + 4), sg0);
       __builtin_amdgcn_sched_barrier(0);
-      if (it + 1 < n_it) mfma_chunk(1);
-      stage_store(0, sg1);
+      if (it + 1 < n_it) mfma_roll(0, A1, A0);   // chunk it + 1
+      stage_store(1, sg1);                 // chunk it + 3
     }
   }
   float* dst = a.partial + (size_t)s * a.Cout * a.Cin;       // partial[s][co][ci]
