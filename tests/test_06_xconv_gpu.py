@@ -95,6 +95,12 @@ CASES = [
     (2, 272, 288, 9, 14, 3),         # 256-channel blocks with a ragged last block, Cin a multiple of 16 only
     (2, 256, 320, 12, 20, 1),        # 1x1 weight gradient on 256 x 256-channel workgroups (H * W a multiple of 4), ragged
     (3, 512, 256, 8, 18, 1),         # ... two input-channel blocks, 9 chunks per image
+    (1, 64, 256, 11, 17, 5),         # 256-row block shape with the direct activation staging of the large kernels (k >= 5)
+    (1, 256, 64, 10, 13, 7),         # ... reached by the backward-data pass (M = Cin = 256): hourglass 7x7 / 11x11 branches
+    (1, 256, 32, 9, 12, 11),
+    (1, 16, 256, 7, 9, 3),           # a single 16-channel chunk: the pipeline's prologue covers the whole K loop of a tap row
+    (1, 32, 256, 6, 10, 1),          # 1x1 with two K steps only
+    (2, 256, 256, 96, 128, 1),       # wide 1x1 weight gradient with six 16-pixel chunks per workgroup (its chunk pipeline in steady state)
 ]
 
 
