@@ -202,7 +202,7 @@ class GroupedConv3x3C32(nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32 and not AB['gconv32']:
-            # the grouped split-bf16 kernels (csrc/xconv.hip, csrc/xwgrad3.hip): 0.097 ms forward / 0.37 ms backward per
+            # the grouped split-operand MFMA kernels (csrc/xconv.hip, csrc/xwgrad3.hip): 0.097 ms forward / 0.37 ms backward per
             # 16-image call at [1024, 24, 42] against 0.156 / 0.42 ms of the fp32-MFMA kernels (tools/microbench_gx.py)
             return _xconv(x, self.weight, None, None, False, False, self.groups)
         return gconv3x3_c32(x, self.weight)
@@ -274,7 +274,7 @@ class GroupedConv3x3C8(nn.Conv2d):
 
 
 # ---------------------------------------------------------------------------------------
-# Dense stride-1 convolutions on the split-bf16 MFMA kernels (csrc/xconv.hip)
+# Dense stride-1 convolutions on the split-operand MFMA kernels (csrc/xconv.hip; two fp16 terms per operand, csrc/dvd_split.h)
 
 def xconv_packed_scaled(weight, groups, gamma, var, eps):
     """Transposed packing with row co scaled by gamma[co] / sqrt(var[co] + eps): backward-data through a fused BatchNorm.
@@ -429,7 +429,7 @@ def xconv_wgrad(x, gy, wshape, relu_in, groups=1, x_amax=None, g_amax=None):
         _lib.check(lib.dvd_xwgrad3(_p(x), _p(x_amax), _p(gy), _p(g_amax), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin,
                                    wshape[0], H, W, groups, int(bool(relu_in)), _stream()), 'dvd_xwgrad3')
         return gw
-    if wshape[2] in (1, 3) and not AB['no_xwgrad3']:      # split-bf16 MFMA (csrc/xwgrad3.hip)
+    if wshape[2] in (1, 3) and not AB['no_xwgrad3']:      # split-operand MFMA (csrc/xwgrad3.hip)
         N, Cin, H, W = x.shape
         Cout = wshape[0]
         gw = torch.empty(wshape, device=x.device, dtype=torch.float32)

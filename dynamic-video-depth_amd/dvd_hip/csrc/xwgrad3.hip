@@ -7,7 +7,7 @@
 // decoder (third_party/midas_blocks.py:102-168, MiDaS.py:186-195); MIOpen's igemm_wrw (atomics, 113 TF/s) and the
 // exact-fp32 kernel of csrc/xwgrad.hip (86 TF/s: the fp32 MFMA rate is the ceiling there).
 //
-// Mapping.  GEMM M = output channel, N = input channel, K = pixels.  v_mfma_f32_32x32x16_bf16: lane l holds
+// Mapping.  GEMM M = output channel, N = input channel, K = pixels.  v_mfma_f32_32x32x16_f16: lane l holds
 // A[co = l&31][8 consecutive pixels, run (l>>5)] = gy and B[the same 8 pixels shifted by the tap][ci = l&31] = x.
 // Pixels are contiguous in NCHW, so both operands are read as 16-byte runs along x; the run of tap kx = 1 is a
 // cell of the LDS row, the runs of kx = 0 / 2 start one pixel earlier / later and are assembled from the cell and
@@ -15,7 +15,7 @@
 // A block owns 64 output x 64 input channels and walks DOWN a 64-pixel-wide column strip of an image, one row
 // per step: the gy row (64 channels x 64 pixels) and ONE new x row (64 channels x 80 pixels: the strip, one
 // 8-pixel cell left and right) are staged per step -- the x rows a step needs live in a rolling buffer of four --
-// split into the three bf16 terms on the way in; the next step's rows are requested before the MFMAs of the
+// scaled and split into the two fp16 terms on the way in; the next step's rows are requested before the MFMAs of the
 // current one.  Wave (pm, pn, ky) of the 12 keeps the three accumulators of kernel row ky for its 32 x 32 pair.
 // Every block writes its partial sums; xwgrad3_reduce_kernel adds them in slice order.
 #include "dvd_split.h"
@@ -40,8 +40,8 @@ struct Wg3Args {
 };
 
 constexpr int kW3Strip = 64;                  // pixels per row step
-constexpr int kW3GPitch = 128 + 16;           // bytes per gy row in LDS (64 bf16 + pad: conflict-free 16-byte reads across rows)
-constexpr int kW3XPitch = 160 + 16;           // bytes per x row in LDS (80 bf16 + pad)
+constexpr int kW3GPitch = 128 + 16;           // bytes per gy row in LDS (64 fp16 + pad: conflict-free 16-byte reads across rows)
+constexpr int kW3XPitch = 160 + 16;           // bytes per x row in LDS (80 fp16 + pad)
 constexpr int kW3CB = 64;                     // channels per block, both operands
 constexpr int kW3NT = 768;                    // 12 waves: 2 x 2 tile pairs x 3 kernel rows
 
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void xwgrad3_reduce_kernel(const float* __rest
 // each) and walks over chunks of 32 consecutive pixels of the flattened images; two blocks share a CU so that one
 // block's staging (load, split, LDS write, barrier) overlaps the other's MFMAs.
 constexpr int kW1Chunk = 32;
-constexpr int kW1Pitch = 64 + 16;             // bytes per channel row in LDS (32 bf16 + pad)
+constexpr int kW1Pitch = 64 + 16;             // bytes per channel row in LDS (32 fp16 + pad)
 constexpr int kW1CB = 128;
 constexpr int kW1NT = 512;
 

@@ -126,7 +126,7 @@ int dvd_loss_finalize(const dvd_warp_cfg* cfg, const float* sums, float* scalars
                       dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * Scene-flow field MLP (fused; bf16 matrix cores on three-term split operands = fp32-class accuracy).
+ * Scene-flow field MLP (fused; fp16 matrix cores on two-term split, power-of-two scaled operands = fp32-class accuracy).
  * Replaces SceneFlowFieldNet.forward (networks/sceneflow_field.py:43-53):
  *   PeriodicEmbed of t and xyz (networks/blocks.py:19-34), 1x1 conv C_in->256,
  *   4 x (256->256), each + LeakyReLU(0.2), then 256->3 (blocks.py:50-102),

@@ -1,6 +1,6 @@
 """Parity of the fused scene-flow MLP kernels (through the C ABI) with the
 golden fixture generated from the real reference network and with the oracle.
-Arithmetic: 3-term split-bf16 MFMA products with fp32 accumulation (csrc/sf_mlp.hip) against MKL sgemm on the CPU.
+Arithmetic: two-term fp16-split MFMA products (three partial products, fp32 accumulation; csrc/sf_mlp.hip, csrc/dvd_split.h) against MKL sgemm on the CPU.
 Tolerances = about 4x the worst value measured on MI355X (round 3, gpurun_out/r03a/parity.jsonl: every gradient tensor
 agrees to 2.6e-6 of its largest element, median 2e-7; the values are appended to $DVD_PARITY_LOG on every run):
   forward           rtol 1e-4, atol 2e-6

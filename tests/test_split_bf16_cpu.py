@@ -1,8 +1,10 @@
-"""The arithmetic every matrix kernel of this package uses (csrc/xconv.hip, xwgrad3.hip, sf_mlp.hip), emulated in numpy:
-an fp32 operand is split exactly into three bf16 terms x = h + m + l (round to nearest even, like v_cvt_pk_bf16_f32) and
-a product is the six largest of the nine partial products, accumulated in fp32, small terms first.  Pins the claims made
-in DESIGN.md section 5.2: the split is exact, and a K = 2304 dot product (a 3x3 convolution over 256 channels) lands in
-the error class of an fp32 FMA chain -- orders of magnitude below a plain bf16 product."""
+"""The arithmetic of the matrix kernels of this package (csrc/xconv.hip, xwgrad3.hip, sf_mlp.hip; csrc/dvd_split.h), emulated
+in numpy.  Round 3 (what the kernels run): every operand tensor is scaled by a power of two taken from its max|x| and split
+into TWO fp16 terms (22 bits), a product is THREE partial products l*h' + h*l' + h*h' accumulated in fp32, small terms first
+(pow2_scale / split2_f16 / dot3 below).  Round 2 (kept as the yardstick): an exact split into three bf16 terms and the six
+largest of nine partial products (split3 / dot6).  Pins the claims of DESIGN.md section 5.0: the bf16 split is exact, and a
+K = 2304 dot product (a 3x3 convolution over 256 channels), a heavy-tailed gradient and a K = 16384 weight gradient land,
+in BOTH arithmetics, in the error class of an fp32 multiply-add chain -- orders of magnitude below a plain 16-bit product."""
 import numpy as np
 
 

@@ -1,4 +1,4 @@
-"""Grouped 3x3 convolution, 32 channels per group: fp32-MFMA kernels (csrc/gconv32.hip) vs the grouped split-bf16 path
+"""Grouped 3x3 convolution, 32 channels per group: fp32-MFMA kernels (csrc/gconv32.hip) vs the grouped split-operand MFMA path
 (csrc/xconv.hip, csrc/xwgrad3.hip) at the ResNeXt stage-3 / stage-2 shapes of a 16-image chunk."""
 import json
 import sys
