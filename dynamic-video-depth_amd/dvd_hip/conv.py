@@ -29,7 +29,8 @@ from .ops import _p, _stream, _workspace, amax_of, known_amax, new_scalar, set_a
 #   no_xwgrad3  weight gradients on the exact-fp32 MFMA kernel (csrc/xwgrad.hip);  no_xwgrad: on MIOpen
 #   no_bnfuse   BatchNorm (+ residual, ReLU) as a separate pass after the convolution
 #   no_xconv    dense convolutions on MIOpen
-AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv')}
+#   no_alias    gradient joins of residual blocks by autograd's accumulation (ATen add) instead of the backward-data epilogue
+AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias')}
 for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
     if _k not in AB:
         raise RuntimeError('DVD_AB: unknown switch %r (known: %s)' % (_k, ', '.join(sorted(AB))))
@@ -366,10 +367,19 @@ def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, rel
 class _XConv(torch.autograd.Function):
     """y = conv2d(act(x), w, stride 1, padding k//2) + bias + res'   with act = ReLU or identity and
     res' = residual or relu(residual).  Forward and backward-data on csrc/xconv.hip; backward-weight on
-    csrc/xwgrad.hip (deterministic)."""
+    csrc/xwgrad.hip (deterministic).
+
+    Fused gradient joins (round 3).  `alias`: the Function also returns its input as a second differentiable output; the
+    OTHER consumers of x (a residual connection, a shortcut convolution) take that alias instead of x, so their gradient
+    arrives HERE, as an argument of backward, and is added in the backward-data kernel's epilogue (`residual` operand) --
+    autograd's own accumulation (an ATen add over the whole tensor: read 8, write 4 bytes per element) never runs.  With
+    relu_in the epilogue masks AFTER the add, (dgrad + g_alias) * [x > 0], so the alias's consumer must hand over its
+    gradient UNMASKED: that is `res_unmasked` on the consuming convolution, whose residual is relu(alias) (the
+    ResidualConvUnit of the MiDaS decoder: both terms carry the same mask [x > 0])."""
 
     @staticmethod
-    def forward(ctx, x, x_amax, weight, bias, residual, relu_in, res_relu, groups=1):
+    def forward(ctx, x, x_amax, weight, bias, residual, relu_in, res_relu, groups=1, alias=False, res_unmasked=False):
+        ctx.set_materialize_grads(False)
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -377,17 +387,21 @@ class _XConv(torch.autograd.Function):
         y_amax = new_scalar(x.device)
         y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=bias, residual=residual, relu_in=relu_in,
                        res_relu=res_relu, groups=groups, x_amax=x_amax, y_amax=y_amax)
-        ctx.save_for_backward(x, residual if res_relu else None, x_amax)
+        ctx.save_for_backward(x, residual if (res_relu and not res_unmasked) else None, x_amax)
         ctx.wparam = weight          # the tensor object that carries the packed copies
-        ctx.cfg = (bool(relu_in), bool(res_relu), bias is not None, residual is not None, groups)
+        ctx.cfg = (bool(relu_in), bool(res_relu), bias is not None, residual is not None, groups, bool(res_unmasked))
         ctx.mark_non_differentiable(y_amax)
+        if alias:
+            return y, y_amax, x
         return y, y_amax
 
     @staticmethod
-    def backward(ctx, gy, _g_amax):
+    def backward(ctx, gy, _g_amax, g_alias=None):
         x, residual, x_amax = ctx.saved_tensors
         weight = ctx.wparam
-        relu_in, res_relu, has_bias, has_res, groups = ctx.cfg
+        relu_in, res_relu, has_bias, has_res, groups, res_unmasked = ctx.cfg
+        if gy is None:                      # only the alias was used downstream
+            return g_alias, None, None, None, None, None, None, None, None, None
         gy = gy.contiguous()
         Cout, Cin, KS, _ = weight.shape
         need = ctx.needs_input_grad
@@ -396,20 +410,26 @@ class _XConv(torch.autograd.Function):
         if need[0]:
             gx_amax = new_scalar(gy.device)
             gx = _xconv_run(gy, xconv_packed(weight, True, groups), Cin * groups, KS, mask_src=x if relu_in else None,
-                            groups=groups, x_amax=g_amax, y_amax=gx_amax)
+                            groups=groups, x_amax=g_amax, y_amax=gx_amax,
+                            residual=g_alias.contiguous() if g_alias is not None else None)
             set_amax(gx, gx_amax)         # (used by the next backward if autograd hands this very tensor on)
         if need[2]:
             gw = xconv_wgrad(x, gy, weight.shape, relu_in, groups, x_amax=x_amax, g_amax=g_amax)
         if has_bias and need[3]:
             gb = gy.sum((0, 2, 3))
         if has_res and need[4]:
-            gr = gy * (residual > 0).to(gy.dtype) if res_relu else gy
-        return gx, None, gw, gb, gr, None, None, None
+            gr = gy * (residual > 0).to(gy.dtype) if (res_relu and not res_unmasked) else gy
+        return gx, None, gw, gb, gr, None, None, None, None, None
 
 
-def _xconv(x, weight, bias, residual, relu_in, res_relu, groups=1):
-    """_XConv with the max|.| scalars threaded through: the input's is looked up (or computed), the output's attached."""
-    y, y_amax = _XConv.apply(x, amax_of(x), weight, bias, residual, relu_in, res_relu, groups)
+def _xconv(x, weight, bias, residual, relu_in, res_relu, groups=1, alias=False, res_unmasked=False):
+    """_XConv with the max|.| scalars threaded through: the input's is looked up (or computed), the output's attached.
+    alias=True returns (y, alias of x), see _XConv."""
+    x_amax = amax_of(x)
+    if alias:
+        y, y_amax, xa = _XConv.apply(x, x_amax, weight, bias, residual, relu_in, res_relu, groups, True, res_unmasked)
+        return set_amax(y, y_amax), set_amax(xa, x_amax)
+    y, y_amax = _XConv.apply(x, x_amax, weight, bias, residual, relu_in, res_relu, groups, False, res_unmasked)
     return set_amax(y, y_amax)
 
 
@@ -466,7 +486,8 @@ class _XConvBn(torch.autograd.Function):
     runs on g unscaled, and a tiny kernel derives dW, dgamma and the conv-bias gradient from it (csrc/bnrelu.hip)."""
 
     @staticmethod
-    def forward(ctx, x, x_amax, weight, cbias, gamma, beta, mean, var, eps, residual, relu, groups):
+    def forward(ctx, x, x_amax, weight, cbias, gamma, beta, mean, var, eps, residual, relu, groups, alias=False):
+        ctx.set_materialize_grads(False)    # (alias: see _XConv -- the gradient of the input's other consumers arrives in backward)
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -478,13 +499,17 @@ class _XConvBn(torch.autograd.Function):
         ctx.wparam = weight
         ctx.cfg = (float(eps), bool(relu), residual is not None, groups)
         ctx.mark_non_differentiable(y_amax)
+        if alias:
+            return y, y_amax, x
         return y, y_amax
 
     @staticmethod
-    def backward(ctx, gy, _g_amax):
+    def backward(ctx, gy, _g_amax, g_alias=None):
         x, y, gamma, mean, var, cbias, x_amax = ctx.saved_tensors
         weight = ctx.wparam
         eps, relu, has_res, groups = ctx.cfg
+        if gy is None:                      # only the alias was used downstream
+            return (g_alias,) + (None,) * 12
         gy = gy.contiguous()
         Cout, Cing, KS, _ = weight.shape
         N, _, H, W = gy.shape
@@ -502,8 +527,11 @@ class _XConvBn(torch.autograd.Function):
         if need[0]:
             gx_amax = new_scalar(gy.device)
             gx = _xconv_run(g, xconv_packed_scaled(weight, groups, gamma, var, eps), Cing * groups, KS, groups=groups,
-                            x_amax=g_amax, y_amax=gx_amax)
+                            x_amax=g_amax, y_amax=gx_amax,
+                            residual=g_alias.contiguous() if g_alias is not None else None)   # + the other consumers' gradient
             set_amax(gx, gx_amax)
+        elif g_alias is not None:
+            gx = g_alias
         if need[2] or (gamma is not None and need[4]) or (cbias is not None and need[3]):
             gw = xconv_wgrad(x, g, weight.shape, False, groups, x_amax=x_amax, g_amax=g_amax)
             gg = torch.empty_like(gamma) if gamma is not None else None
@@ -511,14 +539,17 @@ class _XConvBn(torch.autograd.Function):
             _lib.check(lib.dvd_convbn_finalize(_p(weight.detach()), _p(gw), _p(dbeta), _p(gamma), _p(mean), _p(var), eps,
                                                _p(cbias), Cout, Cing * KS * KS, _p(gg), _p(gcb), _stream()),
                        'dvd_convbn_finalize')
-        return gx, None, gw, gcb, gg, (dbeta if need[5] else None), None, None, None, (g if has_res else None), None, None
+        return gx, None, gw, gcb, gg, (dbeta if need[5] else None), None, None, None, (g if has_res else None), None, None, None
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=True):
+def conv_bn_act(conv, bn, x, residual=None, relu=True, alias=False):
     """relu(bn(conv(x)) (+ residual)) for an nn.Conv2d followed by an eval-mode nn.BatchNorm2d.  Convolutions the xconv
     kernels cover run as ONE launch (BatchNorm, residual and ReLU in the epilogue); everything else (CPU tensors,
     training-mode statistics, the 8/16-per-group and strided 3x3 convolutions) is conv(x) followed by the fused
-    BatchNorm+ReLU kernel / the ATen ops."""
+    BatchNorm+ReLU kernel / the ATen ops.
+    alias=True returns (y, x'): x' carries x's values and must be used by every OTHER consumer of x (the block's shortcut);
+    on the fused path their gradient is then added inside this convolution's backward-data kernel instead of by autograd's
+    accumulation pass (see _XConv); on the other paths x' is x itself."""
     if (x.is_cuda and x.dtype == torch.float32 and not bn.training and bn.track_running_stats and
             isinstance(conv, nn.Conv2d) and not AB['no_bnfuse']):
         xin = None
@@ -530,10 +561,16 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True):
             xin = _subsample(x, conv.stride[0])
         if xin is not None:
             gamma, beta = (bn.weight, bn.bias) if bn.affine else (None, None)
-            y, y_amax = _XConvBn.apply(xin, amax_of(xin), conv.weight, conv.bias, gamma, beta, bn.running_mean,
+            x_amax = amax_of(xin)
+            if alias and xin is x and not AB['no_alias']:
+                y, y_amax, xa = _XConvBn.apply(xin, x_amax, conv.weight, conv.bias, gamma, beta, bn.running_mean,
+                                               bn.running_var, bn.eps, residual, relu, conv.groups, True)
+                return set_amax(y, y_amax), set_amax(xa, x_amax)
+            y, y_amax = _XConvBn.apply(xin, x_amax, conv.weight, conv.bias, gamma, beta, bn.running_mean,
                                        bn.running_var, bn.eps, residual, relu, conv.groups)
-            return set_amax(y, y_amax)
-    return bn_eval_relu(bn, conv(x), residual=residual, relu=relu)
+            return (set_amax(y, y_amax), x) if alias else set_amax(y, y_amax)
+    y = bn_eval_relu(bn, conv(x), residual=residual, relu=relu)
+    return (y, x) if alias else y
 
 
 def xconv_supported(conv, x):
@@ -545,19 +582,22 @@ def xconv_supported(conv, x):
             conv.padding_mode == 'zeros' and not AB['no_xconv'])
 
 
-def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False):
+def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False, alias=False, res_unmasked=False):
     """`conv(relu(x) if relu_in else x) + (relu(residual) if res_relu else residual)` for an nn.Conv2d `conv`.
     GPU fp32 tensors of a dense stride-1 'same' convolution run on the HIP kernels; CPU tensors (the oracle /
     golden-fixture generator instantiates these modules on the CPU) take the ATen ops the reference uses."""
     if xconv_supported(conv, x):
-        return _xconv(x, conv.weight, conv.bias, residual, relu_in, res_relu, conv.groups)
+        if AB['no_alias']:
+            y = _xconv(x, conv.weight, conv.bias, residual, relu_in, res_relu, conv.groups)
+            return (y, x) if alias else y
+        return _xconv(x, conv.weight, conv.bias, residual, relu_in, res_relu, conv.groups, alias, res_unmasked)
     if x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and tuple(conv.stride) == (1, 1) and \
             not AB['no_xconv']:
         raise RuntimeError('xconv2d: convolution %r is not covered by the HIP kernels' % (conv,))
     y = conv(F.relu(x) if relu_in else x)
     if residual is not None:
         y = y + (F.relu(residual) if res_relu else residual)
-    return y
+    return (y, x) if alias else y
 
 
 class XConv2d(nn.Conv2d):
