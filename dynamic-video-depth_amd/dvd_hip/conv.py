@@ -30,7 +30,8 @@ from .ops import _p, _stream, _workspace, amax_of, known_amax, new_scalar, set_a
 #   no_bnfuse   BatchNorm (+ residual, ReLU) as a separate pass after the convolution
 #   no_xconv    dense convolutions on MIOpen
 #   no_alias    gradient joins of residual blocks by autograd's accumulation (ATen add) instead of the backward-data epilogue
-AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias')}
+#   no_maskfuse the ReLU mask of a BatchNorm+ReLU site always in the site's own mask pass (never in its consumer's epilogue)
+AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse')}
 for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
     if _k not in AB:
         raise RuntimeError('DVD_AB: unknown switch %r (known: %s)' % (_k, ', '.join(sorted(AB))))
@@ -364,6 +365,29 @@ def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, rel
     return y
 
 
+STATS = {'sites_premasked': 0, 'sites_masked': 0}      # how many BatchNorm+ReLU sites took which backward (tests read it)
+
+
+class _Site(object):
+    """Hand-over between a BatchNorm+ReLU site and the convolution that consumes its output (round 3).  The site's backward
+    needs g = gy * [y > 0]; the consumer's backward-data kernel PRODUCES gy and has y in hand (its own saved input), so it
+    applies the mask in its epilogue (`mask_src`) and records which tensor it wrote.  If the gradient the site receives is
+    exactly that tensor, unmodified (same storage address, same version counter: autograd neither replaced it by a sum nor
+    accumulated into it), the site's mask pass shrinks to the per-channel sums (4 instead of 12 bytes per element).  Masking
+    is idempotent, so a consumer that masks although the site will mask again (several consumers) costs time, never
+    correctness; the proof obligation sits with the site alone."""
+    __slots__ = ('ptr', 'version')
+
+    def __init__(self):
+        self.ptr, self.version = 0, -1
+
+    def wrote(self, g):
+        self.ptr, self.version = g.data_ptr(), g._version
+
+    def is_exactly(self, g):
+        return self.ptr != 0 and self.ptr == g.data_ptr() and self.version == g._version
+
+
 class _XConv(torch.autograd.Function):
     """y = conv2d(act(x), w, stride 1, padding k//2) + bias + res'   with act = ReLU or identity and
     res' = residual or relu(residual).  Forward and backward-data on csrc/xconv.hip; backward-weight on
@@ -378,8 +402,10 @@ class _XConv(torch.autograd.Function):
     ResidualConvUnit of the MiDaS decoder: both terms carry the same mask [x > 0])."""
 
     @staticmethod
-    def forward(ctx, x, x_amax, weight, bias, residual, relu_in, res_relu, groups=1, alias=False, res_unmasked=False):
+    def forward(ctx, x, x_amax, weight, bias, residual, relu_in, res_relu, groups=1, alias=False, res_unmasked=False,
+                in_site=None):
         ctx.set_materialize_grads(False)
+        ctx.in_site = in_site if (in_site is not None and not relu_in and not AB['no_maskfuse']) else None
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -401,7 +427,7 @@ class _XConv(torch.autograd.Function):
         weight = ctx.wparam
         relu_in, res_relu, has_bias, has_res, groups, res_unmasked = ctx.cfg
         if gy is None:                      # only the alias was used downstream
-            return g_alias, None, None, None, None, None, None, None, None, None
+            return g_alias, None, None, None, None, None, None, None, None, None, None
         gy = gy.contiguous()
         Cout, Cin, KS, _ = weight.shape
         need = ctx.needs_input_grad
@@ -409,27 +435,31 @@ class _XConv(torch.autograd.Function):
         g_amax = amax_of(gy) if (need[0] or need[2]) else None        # one reduction, shared by both gradient kernels
         if need[0]:
             gx_amax = new_scalar(gy.device)
-            gx = _xconv_run(gy, xconv_packed(weight, True, groups), Cin * groups, KS, mask_src=x if relu_in else None,
+            gx = _xconv_run(gy, xconv_packed(weight, True, groups), Cin * groups, KS,
+                            mask_src=x if (relu_in or ctx.in_site is not None) else None,
                             groups=groups, x_amax=g_amax, y_amax=gx_amax,
                             residual=g_alias.contiguous() if g_alias is not None else None)
             set_amax(gx, gx_amax)         # (used by the next backward if autograd hands this very tensor on)
+            if ctx.in_site is not None:
+                ctx.in_site.wrote(gx)     # x is a BatchNorm+ReLU site's output: its mask [x > 0] is already applied
         if need[2]:
             gw = xconv_wgrad(x, gy, weight.shape, relu_in, groups, x_amax=x_amax, g_amax=g_amax)
         if has_bias and need[3]:
             gb = gy.sum((0, 2, 3))
         if has_res and need[4]:
             gr = gy * (residual > 0).to(gy.dtype) if (res_relu and not res_unmasked) else gy
-        return gx, None, gw, gb, gr, None, None, None, None, None
+        return gx, None, gw, gb, gr, None, None, None, None, None, None
 
 
 def _xconv(x, weight, bias, residual, relu_in, res_relu, groups=1, alias=False, res_unmasked=False):
     """_XConv with the max|.| scalars threaded through: the input's is looked up (or computed), the output's attached.
     alias=True returns (y, alias of x), see _XConv."""
     x_amax = amax_of(x)
+    in_site = getattr(x, '_dvd_site', None)
     if alias:
-        y, y_amax, xa = _XConv.apply(x, x_amax, weight, bias, residual, relu_in, res_relu, groups, True, res_unmasked)
+        y, y_amax, xa = _XConv.apply(x, x_amax, weight, bias, residual, relu_in, res_relu, groups, True, res_unmasked, in_site)
         return set_amax(y, y_amax), set_amax(xa, x_amax)
-    y, y_amax = _XConv.apply(x, x_amax, weight, bias, residual, relu_in, res_relu, groups, False, res_unmasked)
+    y, y_amax = _XConv.apply(x, x_amax, weight, bias, residual, relu_in, res_relu, groups, False, res_unmasked, in_site)
     return set_amax(y, y_amax)
 
 
@@ -486,8 +516,11 @@ class _XConvBn(torch.autograd.Function):
     runs on g unscaled, and a tiny kernel derives dW, dgamma and the conv-bias gradient from it (csrc/bnrelu.hip)."""
 
     @staticmethod
-    def forward(ctx, x, x_amax, weight, cbias, gamma, beta, mean, var, eps, residual, relu, groups, alias=False):
+    def forward(ctx, x, x_amax, weight, cbias, gamma, beta, mean, var, eps, residual, relu, groups, alias=False, in_site=None,
+                out_site=None):
         ctx.set_materialize_grads(False)    # (alias: see _XConv -- the gradient of the input's other consumers arrives in backward)
+        ctx.in_site = in_site if (in_site is not None and not AB['no_maskfuse']) else None      # see _Site
+        ctx.out_site = out_site if relu else None
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
@@ -509,7 +542,7 @@ class _XConvBn(torch.autograd.Function):
         weight = ctx.wparam
         eps, relu, has_res, groups = ctx.cfg
         if gy is None:                      # only the alias was used downstream
-            return (g_alias,) + (None,) * 12
+            return (g_alias,) + (None,) * 14
         gy = gy.contiguous()
         Cout, Cing, KS, _ = weight.shape
         N, _, H, W = gy.shape
@@ -517,19 +550,27 @@ class _XConvBn(torch.autograd.Function):
         lib = _lib.load()
         # masked gradient + per-channel sums
         dbeta = torch.empty(Cout, device=gy.device, dtype=torch.float32)
-        g = torch.empty_like(gy) if relu else gy
+        # the consumer's backward-data epilogue has applied [y > 0] already and nothing touched the tensor since: sums only
+        premasked = relu and ctx.out_site is not None and ctx.out_site.is_exactly(gy) and not AB['no_maskfuse']
+        mask = relu and not premasked
+        if relu:
+            STATS['sites_premasked' if premasked else 'sites_masked'] += 1
+        g = torch.empty_like(gy) if mask else gy
         ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, Cout, H * W), gy.device)
         g_amax = new_scalar(gy.device)  # max|masked gradient|, folded in by the mask pass (it reads every element anyway)
-        _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y), None, _p(var), _p(mean), _p(var), eps, None, _p(g) if relu else None,
-                                      None, _p(dbeta), _p(ws), ctypes.c_size_t(ws.numel()), N, Cout, H * W, int(relu),
-                                      _p(g_amax), _stream()), 'dvd_bnrelu_bwd')
+        _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y) if mask else None, None, _p(var), _p(mean), _p(var), eps, None,
+                                      _p(g) if mask else None, None, _p(dbeta), _p(ws), ctypes.c_size_t(ws.numel()), N, Cout,
+                                      H * W, int(mask), _p(g_amax), _stream()), 'dvd_bnrelu_bwd')
         gx = gw = gcb = gg = None
         if need[0]:
             gx_amax = new_scalar(gy.device)
             gx = _xconv_run(g, xconv_packed_scaled(weight, groups, gamma, var, eps), Cing * groups, KS, groups=groups,
                             x_amax=g_amax, y_amax=gx_amax,
-                            residual=g_alias.contiguous() if g_alias is not None else None)   # + the other consumers' gradient
+                            residual=g_alias.contiguous() if g_alias is not None else None,   # + the other consumers' gradient
+                            mask_src=x if ctx.in_site is not None else None)                  # ... * [x > 0] for the site x came from
             set_amax(gx, gx_amax)
+            if ctx.in_site is not None:
+                ctx.in_site.wrote(gx)
         elif g_alias is not None:
             gx = g_alias
         if need[2] or (gamma is not None and need[4]) or (cbias is not None and need[3]):
@@ -539,7 +580,8 @@ class _XConvBn(torch.autograd.Function):
             _lib.check(lib.dvd_convbn_finalize(_p(weight.detach()), _p(gw), _p(dbeta), _p(gamma), _p(mean), _p(var), eps,
                                                _p(cbias), Cout, Cing * KS * KS, _p(gg), _p(gcb), _stream()),
                        'dvd_convbn_finalize')
-        return gx, None, gw, gcb, gg, (dbeta if need[5] else None), None, None, None, (g if has_res else None), None, None, None
+        return (gx, None, gw, gcb, gg, (dbeta if need[5] else None), None, None, None, (g if has_res else None), None, None, None,
+                None, None)
 
 
 def conv_bn_act(conv, bn, x, residual=None, relu=True, alias=False):
@@ -562,12 +604,16 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, alias=False):
         if xin is not None:
             gamma, beta = (bn.weight, bn.bias) if bn.affine else (None, None)
             x_amax = amax_of(xin)
+            in_site = getattr(xin, '_dvd_site', None)           # xin is a BatchNorm+ReLU site's output (see _Site)
+            out_site = _Site() if relu else None
             if alias and xin is x and not AB['no_alias']:
                 y, y_amax, xa = _XConvBn.apply(xin, x_amax, conv.weight, conv.bias, gamma, beta, bn.running_mean,
-                                               bn.running_var, bn.eps, residual, relu, conv.groups, True)
+                                               bn.running_var, bn.eps, residual, relu, conv.groups, True, in_site, out_site)
+                y._dvd_site = out_site
                 return set_amax(y, y_amax), set_amax(xa, x_amax)
             y, y_amax = _XConvBn.apply(xin, x_amax, conv.weight, conv.bias, gamma, beta, bn.running_mean,
-                                       bn.running_var, bn.eps, residual, relu, conv.groups)
+                                       bn.running_var, bn.eps, residual, relu, conv.groups, False, in_site, out_site)
+            y._dvd_site = out_site
             return (set_amax(y, y_amax), x) if alias else set_amax(y, y_amax)
     y = bn_eval_relu(bn, conv(x), residual=residual, relu=relu)
     return (y, x) if alias else y

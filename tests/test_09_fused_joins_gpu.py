@@ -1,7 +1,8 @@
-"""Gradient joins of residual blocks fused into the backward-data epilogue (dvd_hip/conv.py `_XConv` / `_XConvBn`, `alias`):
+"""Gradient joins of residual blocks and the ReLU masks of BatchNorm+ReLU sites fused into the backward-data epilogue of
+the consuming convolution (dvd_hip/conv.py `_XConv` / `_XConvBn`: `alias`, `_Site`):
 the blocks of the MiDaS depth net (third_party/MiDaS.py:164-246 + torchvision's Bottleneck behind midas_blocks.py:35-50,
-ResidualConvUnit midas_blocks.py:102-135) on the GPU with the fused joins, with autograd's own accumulation (`no_alias`),
-and on the CPU in float64 through the ATen ops the reference uses.
+ResidualConvUnit midas_blocks.py:102-135) on the GPU with both fusions, with autograd's own accumulation and the sites'
+own mask passes (`no_alias`, `no_maskfuse`), and on the CPU in float64 through the ATen ops the reference uses.
 
 Tolerances: fused vs unfused are the same arithmetic (the epilogue adds the other consumers' gradient to the exactly
 unscaled accumulator: one rounding, like the ATen add) -> 1e-6 of max|.|; against float64 the convolution bounds of
@@ -38,21 +39,26 @@ def _rel(a, b):
 def _compare(module, x, gy):
     from dvd_hip import conv as C
     want = _grads(module, x, gy, 'cpu', torch.float64)
+    C.STATS['sites_premasked'] = C.STATS['sites_masked'] = 0
     fused = _grads(module, x, gy, 'cuda', torch.float32)
-    C.AB['no_alias'] = True
+    taken = dict(C.STATS)
+    C.AB['no_alias'] = C.AB['no_maskfuse'] = True
     try:
         plain = _grads(module, x, gy, 'cuda', torch.float32)
+        C.AB['no_alias'] = False                          # joins fused, ReLU masks in the sites' own passes
+        nomask = _grads(module, x, gy, 'cuda', torch.float32)
     finally:
-        C.AB['no_alias'] = False
+        C.AB['no_alias'] = C.AB['no_maskfuse'] = False
     worst = {}
     for k in want:
-        e64, eab = _rel(fused[k], want[k]), _rel(fused[k], plain[k])
+        e64, eab = _rel(fused[k], want[k]), max(_rel(fused[k], plain[k]), _rel(fused[k], nomask[k]))
         worst[k] = (e64, eab)
         tol = 1e-4 if (k.startswith('g_') and k.endswith('weight') and want[k].dim() == 4) else 2e-5
         assert e64 < tol, '%s: %.2e of max against float64' % (k, e64)
         assert eab < 1e-6, '%s: fused and unfused joins differ by %.2e of max' % (k, eab)
-    print('worst vs float64 %.2e, fused vs autograd accumulation %.2e' % (max(v[0] for v in worst.values()),
-                                                                         max(v[1] for v in worst.values())))
+    print('worst vs float64 %.2e, fused vs unfused %.2e, sites %s' % (max(v[0] for v in worst.values()),
+                                                                    max(v[1] for v in worst.values()), taken))
+    return taken
 
 
 @pytest.mark.parametrize('c_in,planes,stride,down', [(256, 64, 1, False),     # stage 1, identity shortcut (8 per group)
@@ -65,7 +71,9 @@ def test_resnext_bottleneck(c_in, planes, stride, down):
     g = torch.Generator().manual_seed(c_in + planes)
     x = torch.randn(2, c_in, 12, 20, generator=g).relu()          # a block's input is a ReLU output
     gy = torch.randn(2, planes * 4, 12 // stride, 20 // stride, generator=g)
-    _compare(blk, x, gy)
+    taken = _compare(blk, x, gy)
+    if planes == 256:      # stage 3: both inner sites feed convolutions of the xconv family -> their masks come pre-applied
+        assert taken['sites_premasked'] == 2 and taken['sites_masked'] == 1, taken
 
 
 def test_residual_conv_unit_and_fusion_block():
