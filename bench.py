@@ -318,6 +318,9 @@ def main():
         'hbm_peak_reserved_GB': torch.cuda.max_memory_reserved(device) / 2 ** 30,
         'hbm_graph_pools_GB': getattr(model, '_pool_bytes', 0) / 2 ** 30,      # kept depth-net activations + graph temporaries
         'last_loss': log['loss'],
+        # BatchNorm+ReLU sites of the depth net's captured backward passes: how many found their ReLU mask already applied by
+        # the consuming convolution's epilogue (conv._Site) and how many ran their own mask pass
+        'bn_relu_sites': dict(__import__('dvd_hip.conv', fromlist=['STATS']).STATS),
         'dist_backend': dist_backend, 'ranks_seen': world,
     }
     if warp is not None:
