@@ -71,15 +71,29 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float eps, float* __restrict__ gx, float* __restrict__ gres,
                                                          float2* __restrict__ partial, int N, int C, int HW,
-                                                         int chunks, int relu, float* __restrict__ pmax) {
-  const int chunk = blockIdx.x % chunks;
-  const long long pl = blockIdx.x / chunks;
-  const int c = (int)(pl % C), n = (int)(pl / C);
+                                                         int chunks, int relu, float* __restrict__ pmax, int npb) {
+  // npb > 1 (small planes, chunks == 1): a block owns the planes of npb consecutive images of one channel -- the deep
+  // levels of the encoder have 1 008 / 252 elements per plane, and a block per plane spent its time on the reductions
+  int chunk, c, n, n_end;
+  if (npb > 1) {
+    chunk = 0;
+    c = blockIdx.x % C;
+    n = (blockIdx.x / C) * npb;
+    n_end = min(N, n + npb);
+  } else {
+    chunk = blockIdx.x % chunks;
+    const long long pl = blockIdx.x / chunks;
+    c = (int)(pl % C);
+    n = (int)(pl / C);
+    n_end = n + 1;
+  }
+  const int n_first = n;
   const float s = gamma[c] / sqrtf(var[c] + eps);
   const float mu = mean[c];
-  const long long base = pl * HW;
   const int lo = chunk * kBnChunk, hi = min(HW, lo + kBnChunk);
   float sg = 0.0f, sgx = 0.0f, gmax = 0.0f;
+  for (; n < n_end; ++n) {
+  const long long base = ((long long)n * C + c) * HW;
   if ((HW & 3) == 0) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
       float4 g = *reinterpret_cast<const float4*>(gy + base + i);
@@ -111,6 +125,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
       if (gx) gx[base + i] = g * s;
     }
   }
+  }
   __shared__ float red[3][4];
   sg = wave_sum(sg);
   sgx = wave_sum(sgx);
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const size_t rec = ((size_t)c * N + n) * chunks + chunk;
+    const size_t rec = npb > 1 ? (size_t)c * ((N + npb - 1) / npb) + n_first / npb : ((size_t)c * N + n_first) * chunks + chunk;
     partial[rec] = make_float2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
     // max|g| of the block: reduced to the scalar by the second kernel (tens of thousands of blocks folding it in with
     // atomics on one address cost more than the whole pass)
@@ -219,16 +234,25 @@ int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float*
     return DVD_ENOSPC;
   }
   const int chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
-  const long long blocks = (long long)N * C * chunks;
+  // small planes: several images of a channel per block (as many as make ~4 096 elements, while >= 1 024 blocks remain)
+  int npb = 1;
+  if (chunks == 1 && HW <= dvd::kBnChunk / 2) {
+    npb = dvd::kBnChunk / HW;
+    while (npb > 1 && (long long)C * ((N + npb - 1) / npb) < 1024) npb >>= 1;
+    if (npb > N) npb = N;
+    if (npb < 1) npb = 1;
+  }
+  const int records = npb > 1 ? (N + npb - 1) / npb : N * chunks;          // per channel (<= the workspace's N * chunks)
+  const long long blocks = (long long)C * records;
   DVD_REQUIRE(blocks < (1LL << 31), "bnrelu bwd: grid too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* pmax = g_amax ? reinterpret_cast<float*>(static_cast<float2*>(workspace) + (size_t)N * C * chunks) : nullptr;
   hipLaunchKernelGGL(dvd::bnrelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, y, x, gamma, mean, var, eps, gx,
-                     g_residual, static_cast<float2*>(workspace), N, C, HW, chunks, relu, pmax);
+                     g_residual, static_cast<float2*>(workspace), N, C, HW, chunks, relu, pmax, npb);
   DVD_LAUNCH_OK();
   if (g_gamma || g_beta || g_amax) {
     hipLaunchKernelGGL(dvd::bnrelu_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, s,
-                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, N * chunks, pmax, g_amax);
+                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, records, pmax, g_amax);
     DVD_LAUNCH_OK();
   }
   return DVD_OK;

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize('N,C,H,W,res,relu', [(2, 8, 12, 20, False, True), (3, 5, 7, 9, True, True),
                                               (2, 16, 24, 42, True, True), (1, 4, 96, 168, False, True),
-                                              (2, 6, 5, 5, False, False)])
+                                              (2, 6, 5, 5, False, False),
+                                              # small planes: several images of a channel per block in the backward pass
+                                              (8, 512, 12, 21, True, True), (6, 700, 7, 9, False, True)])
 def test_matches_aten(N, C, H, W, res, relu):
     from dvd_hip.conv import bn_eval_relu
     g = torch.Generator().manual_seed(C * 100 + H)
