@@ -340,7 +340,14 @@ def main():
                            'achieved': warp['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                            'frac': warp['GBps'] / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
                            'algorithmic_bytes_per_launch': warp['pixels_per_launch'] * WARP_BYTES_PER_PIXEL,
-                           'avg_launch_ms': warp['avg_ms'], 'launches_timed': warp['launches']}
+                           'avg_launch_ms': warp['avg_ms'], 'launches_timed': warp['launches'],
+                           # the kernel's OTHER roofline: it is VALU-issue bound (the reference's exact fp32 rounding sequence
+                           # for everything that decides a mask or a tap index).  Static, from the committed SQ counters of
+                           # this kernel: wave instructions x 64 lanes / pixels, and the time they take at 100 % issue
+                           # (256 CUs x 64 lanes per clock at the measured 2.16 GHz)
+                           'valu_issue': {'instr_per_pixel': 371, 'issue_bound_ms': round(
+                               371.0 * warp['pixels_per_launch'] / (256 * 64 * 2.16e9) * 1e3, 4),
+                               'source': 'static: profiles/r03_warp_loss_sq_counters.txt (SQ_INSTS_VALU 7.18e7 for 48x384x672)'}}
     if world == 1 and not a.no_cpu_baseline and a.depth == 'midas' and a.gap == GAP:
         # the 48-pair model's graph slots hold most of the HBM: release them before the 1-pair parity model is built
         import gc

@@ -31,7 +31,9 @@ from .ops import _p, _stream, _workspace, amax_of, known_amax, new_scalar, set_a
 #   no_xconv    dense convolutions on MIOpen
 #   no_alias    gradient joins of residual blocks by autograd's accumulation (ATen add) instead of the backward-data epilogue
 #   no_maskfuse the ReLU mask of a BatchNorm+ReLU site always in the site's own mask pass (never in its consumer's epilogue)
-AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse')}
+#   no_rowsum   a pre-masked site still sums its gradient per channel in a pass of its own (not inside the 1x1 weight-gradient kernel)
+AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse',
+                         'no_rowsum')}
 for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
     if _k not in AB:
         raise RuntimeError('DVD_AB: unknown switch %r (known: %s)' % (_k, ', '.join(sorted(AB))))
@@ -365,7 +367,7 @@ def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, rel
     return y
 
 
-STATS = {'sites_premasked': 0, 'sites_masked': 0}      # how many BatchNorm+ReLU sites took which backward (tests read it)
+STATS = {'sites_premasked': 0, 'sites_masked': 0, 'sites_no_pass': 0}      # how many BatchNorm+ReLU sites took which backward (tests read it)
 
 
 class _Site(object):
@@ -376,13 +378,14 @@ class _Site(object):
     accumulated into it), the site's mask pass shrinks to the per-channel sums (4 instead of 12 bytes per element).  Masking
     is idempotent, so a consumer that masks although the site will mask again (several consumers) costs time, never
     correctness; the proof obligation sits with the site alone."""
-    __slots__ = ('ptr', 'version')
+    __slots__ = ('ptr', 'version', 'amax')
 
     def __init__(self):
-        self.ptr, self.version = 0, -1
+        self.ptr, self.version, self.amax = 0, -1, None
 
-    def wrote(self, g):
-        self.ptr, self.version = g.data_ptr(), g._version
+    def wrote(self, g, amax=None):
+        """amax: the device scalar max|g| the writing kernel's epilogue produced (the site's operand scale)."""
+        self.ptr, self.version, self.amax = g.data_ptr(), g._version, amax
 
     def is_exactly(self, g):
         return self.ptr != 0 and self.ptr == g.data_ptr() and self.version == g._version
@@ -441,7 +444,7 @@ class _XConv(torch.autograd.Function):
                             residual=g_alias.contiguous() if g_alias is not None else None)
             set_amax(gx, gx_amax)         # (used by the next backward if autograd hands this very tensor on)
             if ctx.in_site is not None:
-                ctx.in_site.wrote(gx)     # x is a BatchNorm+ReLU site's output: its mask [x > 0] is already applied
+                ctx.in_site.wrote(gx, gx_amax)     # x is a BatchNorm+ReLU site's output: its mask [x > 0] is already applied
         if need[2]:
             gw = xconv_wgrad(x, gy, weight.shape, relu_in, groups, x_amax=x_amax, g_amax=g_amax)
         if has_bias and need[3]:
@@ -463,7 +466,12 @@ def _xconv(x, weight, bias, residual, relu_in, res_relu, groups=1, alias=False, 
     return set_amax(y, y_amax)
 
 
-def xconv_wgrad(x, gy, wshape, relu_in, groups=1, x_amax=None, g_amax=None):
+def wgrad_reports_rowsum(wshape, groups):
+    """Does xconv_wgrad(..., rowsum=t) fill t?  (dense 1x1: csrc/xwgrad3.hip dvd_xwgrad1s_rowsum)"""
+    return wshape[2] == 1 and groups == 1 and not AB['no_xwgrad3']
+
+
+def xconv_wgrad(x, gy, wshape, relu_in, groups=1, x_amax=None, g_amax=None, rowsum=None):
     """dW[co][ci][tap] = sum_{n,p} gy[n][co][p] * act(x)[n][ci][p + tap]."""
     lib = _lib.load()
     if x_amax is None:
@@ -490,8 +498,10 @@ def xconv_wgrad(x, gy, wshape, relu_in, groups=1, x_amax=None, g_amax=None):
             _lib.check(lib.dvd_xwgrad3(_p(x), _p(x_amax), _p(gy), _p(g_amax), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N,
                                        Cin, Cout, H, W, 1, int(bool(relu_in)), _stream()), 'dvd_xwgrad3')
         else:
-            _lib.check(lib.dvd_xwgrad1s(_p(x), _p(x_amax), _p(gy), _p(g_amax), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N,
-                                        Cin, Cout, H, W, int(bool(relu_in)), _stream()), 'dvd_xwgrad1s')
+            # rowsum: [Cout] tensor that receives sum_{n,p} gy[n][co][p] (the wide kernel sums the rows it stages anyway)
+            _lib.check(lib.dvd_xwgrad1s_rowsum(_p(x), _p(x_amax), _p(gy), _p(g_amax), _p(gw), _p(rowsum), _p(ws),
+                                               ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W, int(bool(relu_in)), _stream()),
+                       'dvd_xwgrad1s_rowsum')
         return gw
     if wshape[2] in (1, 3) and not AB['no_xwgrad']:
         N, Cin, H, W = x.shape
@@ -553,14 +563,22 @@ class _XConvBn(torch.autograd.Function):
         # the consumer's backward-data epilogue has applied [y > 0] already and nothing touched the tensor since: sums only
         premasked = relu and ctx.out_site is not None and ctx.out_site.is_exactly(gy) and not AB['no_maskfuse']
         mask = relu and not premasked
+        need_w = need[2] or (gamma is not None and need[4]) or (cbias is not None and need[3])
+        # ... and if the weight gradient runs on the 1x1 kernel, that kernel reports the per-channel sums of the rows it stages
+        # and the consumer's epilogue has left max|g|: no pass of this site's own at all
+        no_pass = (premasked and need_w and ctx.out_site.amax is not None and wgrad_reports_rowsum(weight.shape, groups) and
+                   not AB['no_rowsum'])
         if relu:
-            STATS['sites_premasked' if premasked else 'sites_masked'] += 1
+            STATS['sites_no_pass' if no_pass else ('sites_premasked' if premasked else 'sites_masked')] += 1
         g = torch.empty_like(gy) if mask else gy
-        ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, Cout, H * W), gy.device)
-        g_amax = new_scalar(gy.device)  # max|masked gradient|, folded in by the mask pass (it reads every element anyway)
-        _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y) if mask else None, None, _p(var), _p(mean), _p(var), eps, None,
-                                      _p(g) if mask else None, None, _p(dbeta), _p(ws), ctypes.c_size_t(ws.numel()), N, Cout,
-                                      H * W, int(mask), _p(g_amax), _stream()), 'dvd_bnrelu_bwd')
+        if no_pass:
+            g_amax = ctx.out_site.amax
+        else:
+            ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, Cout, H * W), gy.device)
+            g_amax = new_scalar(gy.device)  # max|masked gradient|, folded in by the mask pass (it reads every element anyway)
+            _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y) if mask else None, None, _p(var), _p(mean), _p(var), eps, None,
+                                          _p(g) if mask else None, None, _p(dbeta), _p(ws), ctypes.c_size_t(ws.numel()), N,
+                                          Cout, H * W, int(mask), _p(g_amax), _stream()), 'dvd_bnrelu_bwd')
         gx = gw = gcb = gg = None
         if need[0]:
             gx_amax = new_scalar(gy.device)
@@ -570,11 +588,11 @@ class _XConvBn(torch.autograd.Function):
                             mask_src=x if ctx.in_site is not None else None)                  # ... * [x > 0] for the site x came from
             set_amax(gx, gx_amax)
             if ctx.in_site is not None:
-                ctx.in_site.wrote(gx)
+                ctx.in_site.wrote(gx, gx_amax)
         elif g_alias is not None:
             gx = g_alias
-        if need[2] or (gamma is not None and need[4]) or (cbias is not None and need[3]):
-            gw = xconv_wgrad(x, g, weight.shape, False, groups, x_amax=x_amax, g_amax=g_amax)
+        if need_w:
+            gw = xconv_wgrad(x, g, weight.shape, False, groups, x_amax=x_amax, g_amax=g_amax, rowsum=dbeta if no_pass else None)
             gg = torch.empty_like(gamma) if gamma is not None else None
             gcb = torch.empty_like(cbias) if cbias is not None else None
             _lib.check(lib.dvd_convbn_finalize(_p(weight.detach()), _p(gw), _p(dbeta), _p(gamma), _p(mean), _p(var), eps,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DVD_ABI_VERSION 2
+#define DVD_ABI_VERSION 3
 
 typedef void* dvd_stream_t; /* hipStream_t */
 
@@ -370,6 +370,13 @@ int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const floa
 size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W);
 int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
                  size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream);
+/* The same, and additionally (gy_rowsum != NULL) gy_rowsum[co] = sum over images and pixels of gy[n][co][:] -- the bias
+ * gradient of the convolution / the shift gradient of a BatchNorm fused behind it (nn.Conv2d bias, BatchNorm2d.bias of the
+ * ResNeXt bottlenecks behind third_party/midas_blocks.py:35-50).  The wide kernel sums the rows it stages anyway (fixed
+ * order: deterministic); other shapes take one extra pass over gy.  Workspace: dvd_xwgrad1s_workspace_bytes. */
+int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, float* gy_rowsum,
+                        void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in,
+                        dvd_stream_t stream);
 /* Test / A-B hook (process wide): 0 = automatic (256 x 256-channel workgroups for wide 1x1 layers, 128 x 128 otherwise),
  * 1 = always 128 x 128.  Same products and the same per-element summation order within a slice; the number of slices
  * (partial sums added at the end) differs, so results agree to fp32 rounding, not bitwise. */

@@ -39,7 +39,8 @@ def _rel(a, b):
 def _compare(module, x, gy):
     from dvd_hip import conv as C
     want = _grads(module, x, gy, 'cpu', torch.float64)
-    C.STATS['sites_premasked'] = C.STATS['sites_masked'] = 0
+    for k in C.STATS:
+        C.STATS[k] = 0
     fused = _grads(module, x, gy, 'cuda', torch.float32)
     taken = dict(C.STATS)
     C.AB['no_alias'] = C.AB['no_maskfuse'] = True
@@ -49,6 +50,8 @@ def _compare(module, x, gy):
         nomask = _grads(module, x, gy, 'cuda', torch.float32)
     finally:
         C.AB['no_alias'] = C.AB['no_maskfuse'] = False
+    # (the channel sums a 1x1 weight-gradient kernel reports are added in another order than the site's own pass: the two
+    # differ in the last bits of the BatchNorm shift / scale gradients)
     worst = {}
     for k in want:
         e64, eab = _rel(fused[k], want[k]), max(_rel(fused[k], plain[k]), _rel(fused[k], nomask[k]))
@@ -72,8 +75,9 @@ def test_resnext_bottleneck(c_in, planes, stride, down):
     x = torch.randn(2, c_in, 12, 20, generator=g).relu()          # a block's input is a ReLU output
     gy = torch.randn(2, planes * 4, 12 // stride, 20 // stride, generator=g)
     taken = _compare(blk, x, gy)
-    if planes == 256:      # stage 3: both inner sites feed convolutions of the xconv family -> their masks come pre-applied
-        assert taken['sites_premasked'] == 2 and taken['sites_masked'] == 1, taken
+    if planes == 256:      # stage 3: both inner sites feed convolutions of the xconv family -> their masks come pre-applied;
+        # the first one's own weight gradient is a 1x1: it also gets its channel sums from that kernel (no pass of its own)
+        assert taken == {'sites_no_pass': 1, 'sites_premasked': 1, 'sites_masked': 1}, taken
 
 
 def test_residual_conv_unit_and_fusion_block():
