@@ -31,9 +31,10 @@ from .ops import _p, _stream, _workspace, amax_of, known_amax, new_scalar, set_a
 #   no_xconv    dense convolutions on MIOpen
 #   no_alias    gradient joins of residual blocks by autograd's accumulation (ATen add) instead of the backward-data epilogue
 #   no_maskfuse the ReLU mask of a BatchNorm+ReLU site always in the site's own mask pass (never in its consumer's epilogue)
-#   no_rowsum   a pre-masked site still sums its gradient per channel in a pass of its own (not inside the 1x1 weight-gradient kernel)
+#   rowsum      (opt-in experiment) a pre-masked site takes its per-channel sums from dvd_xwgrad1s_rowsum and max|g| from the
+#               consumer's epilogue instead of running its sum pass
 AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse',
-                         'no_rowsum')}
+                         'rowsum')}
 for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
     if _k not in AB:
         raise RuntimeError('DVD_AB: unknown switch %r (known: %s)' % (_k, ', '.join(sorted(AB))))
@@ -567,7 +568,7 @@ class _XConvBn(torch.autograd.Function):
         # ... and if the weight gradient runs on the 1x1 kernel, that kernel reports the per-channel sums of the rows it stages
         # and the consumer's epilogue has left max|g|: no pass of this site's own at all
         no_pass = (premasked and need_w and ctx.out_site.amax is not None and wgrad_reports_rowsum(weight.shape, groups) and
-                   not AB['no_rowsum'])
+                   AB['rowsum'])
         if relu:
             STATS['sites_no_pass' if no_pass else ('sites_premasked' if premasked else 'sites_masked')] += 1
         g = torch.empty_like(gy) if mask else gy

@@ -33,7 +33,6 @@ struct Wg3Args {
   const float* __restrict__ x_amax;   // device scalars: max|x|, max|gy| (or upper bounds) of the whole tensors
   const float* __restrict__ g_amax;
   float* __restrict__ partial;   // [S][9][Cout][Cin]
-  float* __restrict__ rowsum;    // optional (1x1, wide kernel): [S][Cout] partial sums of gy over the slice's pixels
   int N, Cin, Cout, H, W;        // Cin / Cout per group
   int G, nco;                    // groups, output-channel blocks per group
   int nstrips, RS, nrseg, S;     // column strips per image, rows per work item, row segments per image, slices
@@ -375,13 +374,11 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
       st[i] = v;
     }
   };
-  float rs[2] = {0.0f, 0.0f};     // sums of this thread's two gy rows over the chunks it stores (a.rowsum: the bias / BatchNorm shift gradient)
-  auto stage_store = [&](int buf, const float4 (&st)[4], bool count = true) {
+  auto stage_store = [&](int buf, const float4 (&st)[4]) {
     unsigned char* base = smem3 + buf * kWbBuf;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = i * 128 + (tid >> 2), quad = tid & 3;
-      if (i < 2) rs[i] += count ? (st[i].x + st[i].y) + (st[i].z + st[i].w) : 0.0f;
       unsigned h0, l0, h1, l1;
       const float sc = i >= 2 ? sx : sg;
       split_pair_f16(st[i].x * sc, st[i].y * sc, h0, l0);
@@ -433,7 +430,7 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
     stage_load(0, sg0);
     stage_store(0, sg0);
     stage_load(clamp(1), sg0);
-    stage_store(1, sg0, 1 < n_it);       // (copies of the last chunk past the end are not counted in the row sums)
+    stage_store(1, sg0);
     stage_load(clamp(2), sg0);
     __syncthreads();
     u32x4 A0[2][2], A1[2][2];
@@ -445,22 +442,12 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
       stage_load(clamp(it + 3), sg1);
       __builtin_amdgcn_sched_barrier(0);   // the loads stay above the MFMAs
       mfma_roll(1, A0, A1);                // chunk it
-      stage_store(0, sg0, it + 2 < n_it);  // chunk it + 2 (past the end: a copy of the last chunk into an idle buffer)
+      stage_store(0, sg0);                 // chunk it + 2 (past the end: a copy of the last chunk into an idle buffer)
       __syncthreads();
       stage_load(clamp(it + 4), sg0);
       __builtin_amdgcn_sched_barrier(0);
       if (it + 1 < n_it) mfma_roll(0, A1, A0);   // chunk it + 1
-      stage_store(1, sg1, it + 3 < n_it);  // chunk it + 3
-    }
-  }
-  if (a.rowsum && blockIdx.y == 0) {       // every input-channel block stages the same gy rows: the first one reports them
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float v = rs[i];
-      v += __shfl_xor(v, 1, 64);           // the four quads of a row sit in four adjacent lanes
-      v += __shfl_xor(v, 2, 64);
-      const int co = co0 + i * 128 + (tid >> 2);
-      if ((tid & 3) == 0 && co < a.Cout) a.rowsum[(size_t)s * a.Cout + co] = v;
+      stage_store(1, sg1);                 // chunk it + 3
     }
   }
   float* dst = a.partial + (size_t)s * a.Cout * a.Cin;       // partial[s][co][ci]
@@ -476,16 +463,9 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
       }
 }
 
-// out[co] = sum_s partial[s][co], ascending s
-__global__ __launch_bounds__(256) void rowsum_reduce_kernel(const float* __restrict__ partial, int S, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float v = 0.0f;
-  for (int s = 0; s < S; ++s) v += partial[(size_t)s * C + c];
-  out[c] = v;
-}
-// out[c] = sum over images and pixels of g[n][c][:] -- the narrow 1x1 kernel does not report row sums; one block per channel,
-// fixed order (per-thread strided partial sums, then a fixed tree)
+// out[c] = sum over images and pixels of g[n][c][:]: one block per channel, fixed order (per-thread strided partial sums, then
+// a fixed tree).  (Summing the gy rows inside xwgrad1b_kernel, which stages them anyway, was tried in round 3: the eight extra
+// adds per chunk cost the kernel 10 % -- more than this pass)
 __global__ __launch_bounds__(256) void chansum_kernel(const float* __restrict__ g, int N, int C, int HW, float* __restrict__ out) {
   const int c = blockIdx.x;
   float v = 0.0f;
@@ -567,7 +547,6 @@ int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const floa
   a.x_amax = x_amax;
   a.g_amax = gy_amax;
   a.partial = static_cast<float*>(workspace);
-  a.rowsum = nullptr;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.G = groups; a.nco = p.nco;
   a.nstrips = p.nstrips; a.RS = p.RS; a.nrseg = p.nrseg; a.S = p.S;
@@ -590,7 +569,7 @@ size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
   int S = pairs >= 512 ? 1 : (1024 + pairs - 1) / pairs;
   const int Sw = dvd::wg1_wide_slices(N, Cin, Cout, H * W);      // (either kernel may serve the call)
   if (Sw > S) S = Sw;
-  return (size_t)S * Cout * Cin * sizeof(float) + (size_t)Sw * Cout * sizeof(float);      // + the wide kernel's row-sum partials
+  return (size_t)S * Cout * Cin * sizeof(float);
 }
 
 int dvd_xwgrad_select(int variant) {
@@ -599,21 +578,26 @@ int dvd_xwgrad_select(int variant) {
   return DVD_OK;
 }
 
-int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
-                 size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
-  return dvd_xwgrad1s_rowsum(x, x_amax, gy, gy_amax, gw, nullptr, workspace, workspace_bytes, N, Cin, Cout, H, W, relu_in, stream);
-}
-
 int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, float* gy_rowsum,
                         void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in,
                         dvd_stream_t stream) {
+  if (int e = dvd_xwgrad1s(x, x_amax, gy, gy_amax, gw, workspace, workspace_bytes, N, Cin, Cout, H, W, relu_in, stream)) return e;
+  if (gy_rowsum) {
+    hipLaunchKernelGGL(dvd::chansum_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream), gy, N, Cout, H * W, gy_rowsum);
+    DVD_LAUNCH_OK();
+  }
+  return DVD_OK;
+}
+
+int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
+                 size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
   DVD_REQUIRE(x && gy && gw && workspace, "xwgrad1s: null pointer");
   DVD_REQUIRE(x_amax && gy_amax, "xwgrad1s: the operands' max|.| scalars are missing (dvd_amax)");
   DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgrad1s: bad shape");
   DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgrad1s: image too large for 32-bit offsets");
   if (dvd::wg1_wide(Cin, Cout, H * W)) {
     const int S = dvd::wg1_wide_slices(N, Cin, Cout, H * W);
-    const size_t need = (size_t)S * Cout * Cin * sizeof(float) + (gy_rowsum ? (size_t)S * Cout * sizeof(float) : 0);
+    const size_t need = (size_t)S * Cout * Cin * sizeof(float);
     if (workspace_bytes < need) {
       dvd::set_error("xwgrad1s: workspace %zu < %zu bytes", workspace_bytes, need);
       return DVD_ENOSPC;
@@ -624,7 +608,6 @@ int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, co
     a.x_amax = x_amax;
     a.g_amax = gy_amax;
     a.partial = static_cast<float*>(workspace);
-    a.rowsum = gy_rowsum ? static_cast<float*>(workspace) + (size_t)S * Cout * Cin : nullptr;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.G = 1; a.nco = (Cout + 255) / 256;
     a.nstrips = 0; a.RS = 0; a.nrseg = 0; a.S = S;
@@ -638,15 +621,7 @@ int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, co
     hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
                        static_cast<const float*>(workspace), gw, S, 1, Cout, Cin);
     DVD_LAUNCH_OK();
-    if (gy_rowsum) {
-      hipLaunchKernelGGL(dvd::rowsum_reduce_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, a.rowsum, S, Cout, gy_rowsum);
-      DVD_LAUNCH_OK();
-    }
     return DVD_OK;
-  }
-  if (gy_rowsum) {                      // the narrow kernel does not report them: a pass of its own
-    hipLaunchKernelGGL(dvd::chansum_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream), gy, N, Cout, H * W, gy_rowsum);
-    DVD_LAUNCH_OK();
   }
   const int nco = (Cout + dvd::kW1CB - 1) / dvd::kW1CB, nci = (Cin + dvd::kW1CB - 1) / dvd::kW1CB;
   const int pairs = nco * nci;
@@ -666,7 +641,6 @@ int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, co
   a.x_amax = x_amax;
   a.g_amax = gy_amax;
   a.partial = static_cast<float*>(workspace);
-  a.rowsum = nullptr;
   a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   a.G = 1; a.nco = nco;
   a.nstrips = 0; a.RS = 0; a.nrseg = 0; a.S = S;

@@ -372,8 +372,8 @@ int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const flo
                  size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream);
 /* The same, and additionally (gy_rowsum != NULL) gy_rowsum[co] = sum over images and pixels of gy[n][co][:] -- the bias
  * gradient of the convolution / the shift gradient of a BatchNorm fused behind it (nn.Conv2d bias, BatchNorm2d.bias of the
- * ResNeXt bottlenecks behind third_party/midas_blocks.py:35-50).  The wide kernel sums the rows it stages anyway (fixed
- * order: deterministic); other shapes take one extra pass over gy.  Workspace: dvd_xwgrad1s_workspace_bytes. */
+ * ResNeXt bottlenecks behind third_party/midas_blocks.py:35-50), by one extra pass over gy in fixed order (deterministic).
+ * Workspace: dvd_xwgrad1s_workspace_bytes. */
 int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, float* gy_rowsum,
                         void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in,
                         dvd_stream_t stream);
