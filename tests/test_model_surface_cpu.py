@@ -97,4 +97,6 @@ def test_grouped_conv_modules_on_cpu_are_plain_convolutions():
         ref.load_state_dict(m.state_dict())
         x = torch.randn(2, 64, 9, 14)
         assert torch.equal(m(x), ref(x))
-    assert set(C.AB) == {'gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv'} and not any(C.AB.values())
+    # the A/B switches are exactly these, and none is on by default (DVD_AB is an experimenter's tool, not a configuration)
+    assert set(C.AB) == {'gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse',
+                         'rowsum'} and not any(C.AB.values())
