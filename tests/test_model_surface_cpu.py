@@ -100,3 +100,19 @@ def test_grouped_conv_modules_on_cpu_are_plain_convolutions():
     # the A/B switches are exactly these, and none is on by default (DVD_AB is an experimenter's tool, not a configuration)
     assert set(C.AB) == {'gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse',
                          'rowsum'} and not any(C.AB.values())
+
+
+def test_site_handover_detects_a_modified_or_replaced_gradient():
+    """conv._Site: a BatchNorm+ReLU site may skip its mask pass only if the gradient it receives is EXACTLY the tensor its
+    consumer's epilogue wrote -- same storage, same version counter.  An in-place accumulation (what autograd does when a
+    second consumer's gradient arrives) or a different tensor (a sum) must both be noticed."""
+    import torch
+    from dvd_hip.conv import _Site
+    site = _Site()
+    g = torch.zeros(8)
+    assert not site.is_exactly(g)                 # nothing recorded yet
+    site.wrote(g, amax=torch.ones(1))
+    assert site.is_exactly(g) and site.is_exactly(g.view(8)) and site.amax is not None
+    assert not site.is_exactly(g + 0.0)           # another tensor (autograd replaced it by a sum)
+    g.add_(1.0)                                   # accumulated into in place: same storage, version counter moved on
+    assert not site.is_exactly(g)
