@@ -148,3 +148,41 @@ def test_three_product_fp16_pair_is_fp32_class():
         assert e3 < 4e-6                 # the tolerance of tests/test_06_xconv_gpu.py
         assert e3 < 4 * e6 + 1e-8        # same class as the six-product arithmetic
         assert e3 < 1.5 * e32            # not worse than an fp32 multiply-add chain over the same K
+
+
+# ---- groundwork for BASELINE configs[4] (fp16 activations, fp32 accumulation; NOT built) -------------
+def dot2_fp16_activations(a16, b):
+    """sum_k a[k] * b[k] for an activation tensor a that is STORED in fp16 (one term, scaled by a power of two from its
+    maximum like every operand) against a two-term weight: two partial products a*l' + a*h' -- two MFMAs per product
+    instead of three, and half the activation bytes."""
+    sa, sb = pow2_scale(np.abs(a16).max()), pow2_scale(np.abs(b).max())
+    a1 = (a16.astype(np.float32) * sa).astype(np.float16).astype(np.float32)
+    bh, bl = split2_f16(b, sb)
+    acc = np.zeros(a16.shape[:-1], dtype=np.float32)
+    for x, y in ((a1, bl), (a1, bh)):
+        p = (x * y).astype(np.float32)
+        for k0 in range(0, p.shape[-1], 16):
+            acc = (acc + p[..., k0:k0 + 16].sum(-1, dtype=np.float32)).astype(np.float32)
+    return acc.astype(np.float64) / (np.float64(sa) * np.float64(sb))
+
+
+def test_fp16_activation_arithmetic_error_budget():
+    """What configs[4] would cost in accuracy, so that its parity tolerance can be stated before it is built: with
+    activations rounded ONCE to fp16 (11 bits) and weights kept at 22 bits, (1) the matrix arithmetic itself adds nothing
+    measurable to that rounding (against the float64 product of the ROUNDED activations it stays in the fp32 class), and
+    (2) against fp32 activations a K = 2304 convolution output moves by ~1e-4 of max|y| (the 2^-12 relative rounding of every
+    activation, averaged over K terms) -- three orders above this package's fp32-class bound, the price of the format."""
+    rng = np.random.default_rng(11)
+    a = (np.maximum(rng.standard_normal((512, 2304)), 0) * 3).astype(np.float32)          # post-ReLU activations
+    b = (rng.standard_normal((512, 2304)) * 0.02).astype(np.float32)
+    sa = pow2_scale(np.abs(a).max())
+    a16 = ((a * sa).astype(np.float16).astype(np.float32) / sa).astype(np.float32)        # what HBM would hold (scaled fp16)
+    exact_rounded = (a16.astype(np.float64) * b.astype(np.float64)).sum(-1)
+    exact_fp32 = (a.astype(np.float64) * b.astype(np.float64)).sum(-1)
+    got = dot2_fp16_activations(a16, b)
+    scale = np.abs(exact_fp32).max()
+    e_arith = np.abs(got - exact_rounded).max() / scale
+    e_format = np.abs(exact_rounded - exact_fp32).max() / scale
+    print('fp16 activations: arithmetic %.2e, storage format %.2e of max|y|' % (e_arith, e_format))
+    assert e_arith < 4e-6                       # two products against two-term weights: still fp32 class
+    assert 1e-5 < e_format < 1e-3               # the activation rounding dominates: ~1e-4
