@@ -191,3 +191,32 @@ def test_residual_conv_unit_shares_the_mask(fake_kernels):
     for a, b in zip([t.grad for t in (x, a1, c1, a2, c2)], want):
         assert torch.allclose(a, b, rtol=1e-9, atol=1e-11)
     assert calls['residual'] == 2 and lib.__dict__.get('mask_passes', 0) == 0       # forward skip + the join; no ATen-style mask pass
+
+
+def test_encoder_level_feeds_projection_and_next_level(fake_kernels):
+    """MidasNet.forward: a level's output (a BatchNorm+ReLU site) feeds its decoder projection (plain convolution) and, through
+    the projection's alias, the next level: the projection's backward-data launch adds the next level's gradient and applies
+    the site's mask to the sum."""
+    C, lib, calls = fake_kernels
+    g = torch.Generator().manual_seed(8)
+    w0 = torch.randn(5, 3, 1, 1, generator=g, dtype=torch.float64) * 0.5
+    wp = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64) * 0.2
+    w1 = torch.randn(6, 5, 1, 1, generator=g, dtype=torch.float64) * 0.4
+    bn0, bn1 = _bn_params(5, g), _bn_params(6, g)
+    x0 = torch.randn(2, 3, 6, 4, generator=g, dtype=torch.float64)
+    gp, gn = torch.randn(2, 4, 6, 4, generator=g, dtype=torch.float64), torch.randn(2, 6, 6, 4, generator=g, dtype=torch.float64)
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in (x0, w0, wp, w1)]
+    x, a0, ap, a1 = leaves()
+    lvl = _ref_site(x, a0, bn0)
+    (F.conv2d(lvl, ap, padding=1) * gp).sum().add((_ref_site(lvl, a1, bn1) * gn).sum()).backward()
+    want = [t.grad for t in (x, a0, ap, a1)]
+    x, a0, ap, a1 = leaves()
+    lvl = _site(C, x, a0, bn0)
+    r, lvl_a = C._xconv(lvl, ap, None, None, False, False, 1, alias=True)
+    ((r * gp).sum() + (_site(C, lvl_a, a1, bn1) * gn).sum()).backward()
+    for i, (a, b) in enumerate(zip([t.grad for t in (x, a0, ap, a1)], want)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (i, float((a - b).abs().max()))
+    # the level's site found its mask applied (by the projection's epilogue, on the SUM of the two gradients)
+    assert C.STATS['sites_premasked'] == 1 and C.STATS['sites_masked'] == 1 and calls['mask_src'] == 1
