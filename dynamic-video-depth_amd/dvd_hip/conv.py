@@ -223,7 +223,9 @@ def add_bounded(a, b):
 
 def _subsample(t, st):
     """t[:, :, ::st, ::st] as a contiguous tensor; max|t| stays an upper bound of the result's."""
-    return set_amax(t[:, :, ::st, ::st].contiguous(), amax_of(t))
+    y = t[:, :, ::st, ::st].contiguous()
+    k = known_amax(t)                     # the producer's bound if there is one; else reduce the (st^2 x smaller) result
+    return set_amax(y, k) if k is not None else y
 
 
 def _pair_groups_of_16(weight):
@@ -379,17 +381,20 @@ class _Site(object):
     accumulated into it), the site's mask pass shrinks to the per-channel sums (4 instead of 12 bytes per element).  Masking
     is idempotent, so a consumer that masks although the site will mask again (several consumers) costs time, never
     correctness; the proof obligation sits with the site alone."""
-    __slots__ = ('ptr', 'version', 'amax')
+    __slots__ = ('ref', 'version', 'amax')
 
     def __init__(self):
-        self.ptr, self.version, self.amax = 0, -1, None
+        self.ref, self.version, self.amax = None, -1, None
 
     def wrote(self, g, amax=None):
-        """amax: the device scalar max|g| the writing kernel's epilogue produced (the site's operand scale)."""
-        self.ptr, self.version, self.amax = g.data_ptr(), g._version, amax
+        """amax: the device scalar max|g| the writing kernel's epilogue produced (the site's operand scale).
+        The hand-over is by tensor OBJECT (a weak reference), not by address: a sum (gA + gB) + gC that the allocator
+        happens to place at a freed gA's address has version 0 like every kernel-written tensor, but it is another object."""
+        import weakref
+        self.ref, self.version, self.amax = weakref.ref(g), g._version, amax
 
     def is_exactly(self, g):
-        return self.ptr != 0 and self.ptr == g.data_ptr() and self.version == g._version
+        return self.ref is not None and self.ref() is g and self.version == g._version
 
 
 class _XConv(torch.autograd.Function):

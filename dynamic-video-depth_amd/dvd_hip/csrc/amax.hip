@@ -5,9 +5,13 @@
 
 namespace dvd {
 
-__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
-  const long long nv = n >> 2;
+// `head` leading elements bring x to a 16-byte boundary (a contiguous batch slice of odd-sized planes is only 4-byte aligned)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int head, long long n, float* __restrict__ out) {
   float m = 0.0f;
+  if (blockIdx.x == 0 && threadIdx.x < head) m = fabsf(x[threadIdx.x]);
+  x += head;
+  n -= head;
+  const long long nv = n >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -20,14 +24,18 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 
 extern "C" {
 
-// out[0] = max(out[0], max|x|): the caller zeroes `out` (or passes a running bound).  x must be 16-byte aligned.
+// out[0] = max(out[0], max|x|): the caller zeroes `out` (or passes a running bound).  x: any 4-byte aligned pointer.
 int dvd_amax(const float* x, long long n, float* out, dvd_stream_t stream) {
   DVD_REQUIRE(x && out && n > 0, "amax: bad arguments");
-  DVD_REQUIRE(((uintptr_t)x & 15) == 0, "amax: tensor must be 16-byte aligned");
-  const long long nv = (n + 3) / 4;
+  DVD_REQUIRE(((uintptr_t)x & 3) == 0, "amax: tensor must be 4-byte aligned");
+  long long head = (long long)(((16 - ((uintptr_t)x & 15)) & 15) >> 2);
+  if (head > n) head = n;
+  const long long nv = (n - head + 3) / 4;
   long long blocks = (nv + 255) / 256;
   if (blocks > 2048) blocks = 2048;            // 8 blocks per CU, grid-stride
-  hipLaunchKernelGGL(dvd::amax_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, out);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(dvd::amax_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, (int)head, n,
+                     out);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

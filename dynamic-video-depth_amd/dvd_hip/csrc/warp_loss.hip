@@ -537,7 +537,9 @@ struct TileIO {
       // A tap beyond the image's right / bottom edge has weight exactly 0 (the sampling coordinate is clamped to W-1 / H-1,
       // so its fractional part is 0) and its window cell exists (`inside`) and is never read by the combine: all four adds
       // are unconditional, and ONE magnitude test per pixel guards the fixed-point range (round 2: a branch per tap).
-      const float big = fmaxf(fmaxf(fabsf(tnw), fabsf(tne)), fmaxf(fabsf(tsw), fabsf(tse)));
+      // (a SUM of magnitudes, not a max: fmaxf drops NaNs, and a NaN tap must reach the spill list -- and g_depth_2 -- instead
+      //  of being converted to 0; the sum is >= the largest magnitude, so the test is only stricter; same instruction count)
+      const float big = (fabsf(tnw) + fabsf(tne)) + (fabsf(tsw) + fabsf(tse));
       if (big < kFixMax) {
         atomicAdd(p, to_fixed(tnw));
         atomicAdd(p + 1, to_fixed(tne));

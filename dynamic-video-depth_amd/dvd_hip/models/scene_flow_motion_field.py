@@ -206,6 +206,7 @@ class Model(NetInterface):
             # thread_local: calls made by other threads (the RCCL watchdog polling its events) do not invalidate
             # the capture; the step also keeps collectives out of flight while a graph is being captured
             mode = dict(capture_error_mode='thread_local')
+            ops.begin_capture()
             if kind == 'f':
                 with torch.no_grad(), torch.cuda.graph(graph, **mode):
                     static_out = self._depth_forward(static_in, fid)
@@ -290,11 +291,13 @@ class Model(NetInterface):
             mode = dict(capture_error_mode='thread_local')
             pool = torch.cuda.graph_pool_handle()
             g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            ops.begin_capture()
             with torch.cuda.graph(g_f, pool=pool, **mode):
                 with torch.enable_grad():
                     static_out = self._depth_forward(static_in, fid)
             static_g = torch.zeros(chunk.shape[0], 1, chunk.shape[2], chunk.shape[3], device=chunk.device)
             self._flat_depth.detach_grads()
+            ops.begin_capture()         # its own generation: g_b's scalars are zero-filled by g_b's replay
             with torch.cuda.graph(g_b, pool=pool, **mode):
                 static_out.backward(static_g)
                 self._flat_depth.absorb_grads()

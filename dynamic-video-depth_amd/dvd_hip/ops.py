@@ -82,18 +82,28 @@ def unproject_backward(g_points, planar, R, K_inv, scale=None, out=None, accumul
 # the power-of-two scale of their fp16 operand split from it on the device (csrc/dvd_split.h); the host never reads it.
 # The scalar hangs on the tensor OBJECT together with the tensor's version counter (an in-place update invalidates it)
 # and the capture context it was computed in.
-_capture_state = [False, 0]        # [last call was inside a HIP-graph capture, capture generation]
+_capture_state = [0]        # capture generation: bumped by begin_capture(), i.e. once per HIP-graph capture
+
+
+def begin_capture():
+    """Call right before every `torch.cuda.graph(...)`: opens a new capture generation.  Scalars (and scalar-pool chunks)
+    of one capture are never continued by another -- a chunk lives in the private pool of the graph that allocated it and
+    its zero-fill node replays with THAT graph only (round 3 inferred the boundary from an eager call happening between two
+    captures; back-to-back captures of two kept slots then shared a chunk: slot N+1's scalars were zeroed by slot N's
+    replay, or never)."""
+    _capture_state[0] += 1
+    return _capture_state[0]
 
 
 def _capture_gen():
-    """0 outside a capture; inside one, a number that changes whenever a new capture begins.  A scalar computed eagerly
-    must never be baked into a graph (the replay would scale new data with the warm-up pass's maximum), and a scalar that
-    lives in a graph's private pool must not be used outside it."""
-    cap = torch.cuda.is_current_stream_capturing()
-    if cap and not _capture_state[0]:
-        _capture_state[1] += 1
-    _capture_state[0] = cap
-    return _capture_state[1] if cap else 0
+    """0 outside a capture; inside one, the generation begin_capture() opened.  A scalar computed eagerly must never be
+    baked into a graph (the replay would scale new data with the warm-up pass's maximum), and a scalar that lives in a
+    graph's private pool must not be used outside it."""
+    if not torch.cuda.is_current_stream_capturing():
+        return 0
+    if _capture_state[0] == 0:          # a capture nobody announced (user code): still never generation 0
+        _capture_state[0] = 1
+    return _capture_state[0]
 
 
 _scalar_pool = {}        # (device index, capture generation) -> [zeroed chunk, next free element]

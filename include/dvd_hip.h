@@ -298,7 +298,7 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
 /* ------------------------------------------------------------------------
  * max|x| of a tensor into a device scalar: out[0] = max(out[0], max|x|) (atomic; zero `out` first, or pass a running
  * bound).  The matrix kernels derive the power-of-two scale of their fp16 operand split from such scalars on the device;
- * nothing reads them on the host.  x 16-byte aligned. */
+ * nothing reads them on the host.  x: any 4-byte aligned address (a misaligned head is read by scalar loads). */
 int dvd_amax(const float* x, long long n, float* out, dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 evidence visit: full GPU test suite (with the measured-parity log), the full bench line (parity + CPU leg),
+# One GPU-box visit (parameterised by TAG and STAGES; replaces the per-call scripts of earlier rounds): full GPU test suite (with the measured-parity log), the full bench line (parity + CPU leg),
 # a kernel trace of the same command, PMC traffic + SQ counters of the warp+loss launch sequence, SQ counters of the
 # convolution kernel, the MLP / convolution micro-benchmarks.  STAGES selects a subset.
 set -u
-OUT=gpurun_out/${TAG:-r03final}; mkdir -p $OUT
+OUT=gpurun_out/${TAG:-visit}; mkdir -p $OUT
 STAGES=${STAGES:-"tests bench trace pmc sq xsq micro"}
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 MIOPEN_FIND_MODE=FAST MIOPEN_LOG_LEVEL=1
 ROOT=$(pwd)
@@ -34,12 +34,12 @@ if has pmc; then
         python $ROOT/tools/microbench_warp.py --iters 5 > $ROOT/$OUT/pmc_$name.log 2>&1 )
   done
   python tools/pmc_summary.py "$OUT/pmc_*/" > $OUT/pmc_summary.txt 2>&1
-  python tools/pmc_to_json.py $OUT/pmc_summary.txt $OUT/warp_loss_pmc.json 'rocprofv3 --pmc passes, round 3 final binary'
+  python tools/pmc_to_json.py $OUT/pmc_summary.txt $OUT/warp_loss_pmc.json 'rocprofv3 --pmc passes'
   rm -rf $OUT/pmc_*/
   head -30 $OUT/pmc_summary.txt | cut -c1-160; cat $OUT/warp_loss_pmc.json | cut -c1-300
 fi
 if has sq; then
-  bash tools/warp_pmc_sq.sh ${TAG:-r03final}/warp_sq > /dev/null 2>&1
+  bash tools/warp_pmc_sq.sh ${TAG:-visit}/warp_sq > /dev/null 2>&1
   cat $OUT/warp_sq/sq_summary.txt | cut -c1-200 | head -12
 fi
 if has xsq; then
