@@ -33,6 +33,8 @@
 //     consecutive q may straddle rows (the 2 pad columns per row are computed and dropped).  The raw fp32
 //     values of the next chunk are requested before the MFMAs of the current one.
 //   * epilogue: + bias[co], + residual (optionally relu'd), * [mask_src > 0], ReLU; coalesced stores.
+#include <type_traits>
+
 #include "dvd_split.h"
 
 namespace dvd {
@@ -124,11 +126,11 @@ __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict
 }
 
 struct XArgs {
-  const float* __restrict__ x;
+  const void* __restrict__ x;           // float, or _Float16 in the IN16 kernels (fp16 activation storage, BASELINE configs[4])
   const uint4* __restrict__ wp;
   const float* __restrict__ bias;
-  const float* __restrict__ res;
-  const float* __restrict__ mask_src;
+  const void* __restrict__ res;         // residual / mask source / y: float, or _Float16 in the OUT16 kernels
+  const void* __restrict__ mask_src;
   const float* __restrict__ bn_gamma;   // fused eval-mode BatchNorm of the output (bn_var != null): gamma / beta may be null
   const float* __restrict__ bn_beta;
   const float* __restrict__ bn_mean;
@@ -136,7 +138,7 @@ struct XArgs {
   float bn_eps;
   const float* __restrict__ x_amax;     // device scalar: max|x| (or an upper bound) of the whole input tensor
   float* y_amax;                        // optional device scalar: max|y| is folded into it (atomic max)
-  float* __restrict__ y;
+  void* __restrict__ y;
   int N, Cin, Cout, H, W;   // Cin = real K, Cout = real M of this launch, PER GROUP
   int G, mbpg, mtiles;      // groups, channel blocks per group, packed 32-row tiles per group
   int KS, pad, T;
@@ -157,8 +159,18 @@ struct XArgs {
 // from the next chunk's stores): 42 KB per 128 x 128 block, so three blocks share a CU (3 waves per SIMD).  The counters of
 // round 2 show the matrix pipe 60 % busy with two waves per SIMD -- each wave needs it 45 % of its time, the rest is barrier
 // skew, LDS latency and staging -- and independent blocks are what fills the gaps.
-template <int TM, int TN, int WM, int WN, int FIT, bool FAST, bool B1 = false>
+// IN16 / OUT16 (round 4, fp16 activation storage): the input is read as _Float16 and IS the matrix operand -- one term, no
+// scale, no split (the staging is a transposing copy), so a product costs TWO MFMAs (two-term weight x one-term activation)
+// instead of three and the activation planes in LDS halve; the output (and the residual / mask operands of its epilogue) is
+// _Float16.  The weights stay fp32 in HBM and two-term in the packed buffer, accumulation stays fp32.
+template <int TM, int TN, int WM, int WN, int FIT, bool FAST, bool B1 = false, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const XArgs a) {
+  static_assert(!IN16 || FAST, "fp16 activations exist on the buffer-addressed main loop only");
+  using TX = std::conditional_t<IN16, _Float16, float>;
+  using TY = std::conditional_t<OUT16, _Float16, float>;
+  using RawT = std::conditional_t<IN16, unsigned short, float>;
+  constexpr int BT = IN16 ? 1 : 2;               // split terms of an activation in LDS
+  constexpr int XB = IN16 ? 2 : 4;               // bytes per activation element in HBM
   constexpr int NT = 64 * WM * WN;
   constexpr bool kDirect = FIT == 0;             // big halos (k >= 5): stage without the register prefetch
   constexpr int FI = kDirect ? 1 : FIT;
@@ -177,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   const int mt0 = (blockIdx.y - grp * a.mbpg) * MT;
   const int n = blockIdx.z;
   const size_t plane = (size_t)a.H * a.W;
-  const float* xn = a.x + ((size_t)n * a.G + grp) * a.Cin * plane;
+  const TX* xn = static_cast<const TX*>(a.x) + ((size_t)n * a.G + grp) * a.Cin * plane;
   const int npos = a.npos, P = a.P, T = a.T, KS = a.KS;
   const int nkt = a.nkc * T;
 
@@ -201,16 +213,35 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     cig8[it] = live ? cig * 8 : 0;
   }
   // FAST: byte offset of channel (0 | 8) of the item's position from the image's base, or an offset beyond the buffer
-  const int planeB = (int)plane * 4;
-  const float sx = pow2_scale(a.x_amax[0]);         // power-of-two operand scales (csrc/dvd_split.h)
+  const int planeB = (int)plane * XB;
+  const float sx = IN16 ? 1.0f : pow2_scale(a.x_amax[0]);         // power-of-two operand scales (csrc/dvd_split.h)
   const float sw = pow2_scale(reinterpret_cast<const float*>(a.wp)[0]);
   int voff[FI];
 #pragma unroll
-  for (int it = 0; it < FI; ++it) voff[it] = gok[it] ? (goff[it] + cig8[it] * (int)plane) * 4 : (int)0x80000000;
+  for (int it = 0; it < FI; ++it) voff[it] = gok[it] ? (goff[it] + cig8[it] * (int)plane) * XB : (int)0x80000000;
   const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(
-      uniform_ptr(const_cast<float*>(xn)), 0, FAST ? a.Cin * planeB : 0, 0x00020000);
-  float raw[FI][8];
+      uniform_ptr(const_cast<TX*>(xn)), 0, FAST ? a.Cin * planeB : 0, 0x00020000);
+  RawT raw[FI][8];
+  // 8 fp16 channel values of one position -> one LDS cell (+ ReLU on packed halves): the whole "split" of the IN16 kernels
+  auto cell16 = [&](const unsigned short (&r)[8]) {
+    u32x4 c = {(unsigned)r[0] | ((unsigned)r[1] << 16), (unsigned)r[2] | ((unsigned)r[3] << 16),
+               (unsigned)r[4] | ((unsigned)r[5] << 16), (unsigned)r[6] | ((unsigned)r[7] << 16)};
+    if (a.relu_in) {                                 // uniform branch
+      const f16x2 z = {(_Float16)0.0f, (_Float16)0.0f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        c[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, (unsigned)c[j]), z));
+    }
+    return c;
+  };
   auto load_raw = [&](int kc) {
+    if constexpr (IN16) {
+      const int s0 = kc * 16 * planeB;
+#pragma unroll
+      for (int it = 0; it < FI; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[it][e] = __builtin_amdgcn_raw_buffer_load_b16(srdB, voff[it], s0 + e * planeB, 0);
+    } else {
     if (FAST) {
       const int s0 = kc * 16 * planeB;               // wave-uniform: channel kc * 16 + e of this image
 #pragma unroll
@@ -229,9 +260,14 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
         raw[it][e] = xn[(size_t)ch * plane + goff[it]];
       }
     }
+    }
   };
   auto split_write = [&](int buf, int kc) {
-    u32x4* dst = sB + (B1 ? 0 : buf * 4 * npos);
+    u32x4* dst = sB + (B1 ? 0 : buf * 2 * BT * npos);
+    if constexpr (IN16) {
+#pragma unroll
+      for (int it = 0; it < FI; ++it) dst[lidx[it]] = cell16(raw[it]);
+    } else {
 #pragma unroll
     for (int it = 0; it < FI; ++it) {
       const int ch0 = kc * 16 + cig8[it];
@@ -255,11 +291,12 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       dst[lidx[it]] = (u32x4){h.x, h.y, h.z, h.w};
       dst[2 * npos + lidx[it]] = (u32x4){l.x, l.y, l.z, l.w};
     }
+    }
   };
 
   // direct staging (kDirect): load, split and store item by item, nothing kept in registers across the MFMAs
   auto stage_direct = [&](int buf, int kc) {
-    u32x4* dst = sB + (B1 ? 0 : buf * 4 * npos);
+    u32x4* dst = sB + (B1 ? 0 : buf * 2 * BT * npos);
     for (int it = 0; it < a.nfi; ++it) {
       const int item = it * NT + tid;
       const int cig = item >= a.NV ? 1 : 0;
@@ -270,6 +307,16 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       const bool ok = live && row >= 0 && row < a.H && col >= 0 && col < a.W;
       const int go = ok ? (row * a.W + col) : 0;
       const int ch0 = kc * 16 + (live ? cig * 8 : 0);
+      const int li = live ? (cig * npos + p) : (npos - 1);
+      if constexpr (IN16) {
+        const int vo = ok ? (go + cig * 8 * (int)plane) * XB : (int)0x80000000;
+        const int s0 = kc * 16 * planeB;
+        unsigned short r16[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r16[e] = __builtin_amdgcn_raw_buffer_load_b16(srdB, vo, s0 + e * planeB, 0);
+        dst[li] = cell16(r16);
+        continue;
+      }
       float v[8];
       if (FAST) {
         const int vo = ok ? (go + cig * 8 * (int)plane) * 4 : (int)0x80000000;
@@ -285,7 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int ch = (ch0 + e) < a.Cin ? (ch0 + e) : (a.Cin - 1);
-          v[e] = xn[(size_t)ch * plane + go];
+          v[e] = (float)xn[(size_t)ch * plane + go];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -295,7 +342,6 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       }
       uint4 h, l;
       split8_f16(v, sx, h, l);
-      const int li = live ? (cig * npos + p) : (npos - 1);
       dst[li] = (u32x4){h.x, h.y, h.z, h.w};
       dst[2 * npos + li] = (u32x4){l.x, l.y, l.z, l.w};
     }
@@ -359,11 +405,11 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   // global data sit BEHIND the wave's own MFMAs, so the matrix pipe works while they resolve (first version:
   // staging at the top of the step -- every step waited an L2 round trip before its first MFMA, pipe 60 % busy).
   struct Frag {
-    f16x8 a[TM][2], b[TN][2];
+    f16x8 a[TM][2], b[TN][BT];
   };
   auto read_frags = [&](Frag& f, int abuf, int kc, int off) {
     const u32x4* Ac = sA + abuf * AS + al;
-    const u32x4* Bc = sB + (B1 ? 0 : (kc & 1) * 4 * npos) + bl + off;
+    const u32x4* Bc = sB + (B1 ? 0 : (kc & 1) * 2 * BT * npos) + bl + off;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -371,7 +417,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) f.b[tn][s] = __builtin_bit_cast(f16x8, Bc[s * 2 * npos + qb[tn]]);
+      for (int s = 0; s < BT; ++s) f.b[tn][s] = __builtin_bit_cast(f16x8, Bc[s * 2 * npos + qb[tn]]);
   };
   auto mfmas = [&](const Frag& f) {
     // three partial products l*h' + h*l' + h*h', small terms first; the TM * TN accumulators are interleaved so that
@@ -380,7 +426,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) \
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[tm][SA], f.b[tn][SB], acc[tm][tn], 0, 0, 0);
     DVD_XTERM(1, 0)
-    DVD_XTERM(0, 1)
+    if constexpr (!IN16) { DVD_XTERM(0, 1) }
     DVD_XTERM(0, 0)
 #undef DVD_XTERM
   };
@@ -417,7 +463,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     }
     write_a(ra, 1);
     __syncthreads();
-    f16x8 fa[TM][2], fb[2][TN][2];
+    f16x8 fa[TM][2], fb[2][TN][BT];
     {
       const u32x4* Ac = sA + al;
       const u32x4* Bc = sB + bl;
@@ -428,7 +474,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) fb[0][tn][t] = __builtin_bit_cast(f16x8, Bc[t * 2 * npos + qb[tn]]);
+        for (int t = 0; t < BT; ++t) fb[0][tn][t] = __builtin_bit_cast(f16x8, Bc[t * 2 * npos + qb[tn]]);
     }
     // tap counters of the step whose fragments are being fetched (kt + 1)
     int nc = 0, ny = 0, nx = 0;
@@ -442,15 +488,15 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       }
     };
     advance();
-    auto step_roll = [&](int kt, f16x8 (&bc)[TN][2], f16x8 (&bn)[TN][2]) {
+    auto step_roll = [&](int kt, f16x8 (&bc)[TN][BT], f16x8 (&bn)[TN][BT]) {
       __syncthreads();
       load_a(ra, kt + 2 < nkt ? kt + 2 : kt);
       const u32x4* Ac = sA + ((kt + 1) & 1) * AS + al;
-      const u32x4* Bc = sB + (nc & 1) * 4 * npos + bl + ny * P + nx;      // (past the last step: in range, never used)
+      const u32x4* Bc = sB + (nc & 1) * 2 * BT * npos + bl + ny * P + nx;      // (past the last step: in range, never used)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) bn[tn][t] = __builtin_bit_cast(f16x8, Bc[t * 2 * npos + qb[tn]]);
+        for (int t = 0; t < BT; ++t) bn[tn][t] = __builtin_bit_cast(f16x8, Bc[t * 2 * npos + qb[tn]]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
@@ -458,9 +504,11 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][1], bc[tn][0], acc[tm][tn], 0, 0, 0);
+        if constexpr (!IN16) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][0], bc[tn][1], acc[tm][tn], 0, 0, 0);
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][0], bc[tn][1], acc[tm][tn], 0, 0, 0);
+        }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][0], bc[tn][0], acc[tm][tn], 0, 0, 0);
@@ -543,7 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   const int TRv = (a.H - r0) < a.TR ? (a.H - r0) : a.TR;
   const int TCv = (a.W - c0) < a.TC ? (a.W - c0) : a.TC;
   const size_t ibase = ((size_t)n * a.G + grp) * a.Cout * plane;     // this group's channels of image n
-  float* __restrict__ yb = a.y + ibase;
+  TY* __restrict__ yb = static_cast<TY*>(a.y) + ibase;
   const int iplane = (int)plane;
   // fused eval-mode BatchNorm: y = (z - mean) / sqrt(var + eps) * gamma + beta as z * s + (beta - mean * s), the formula of
   // csrc/bnrelu.hip.  Lane j computes s and the shift of channel 32 * tile + j ONCE (IEEE sqrt and division: 16 channels
@@ -594,23 +642,23 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
         }
       }
       if (a.res) {
-        const float* __restrict__ rb = a.res + ibase;
+        const TY* __restrict__ rb = static_cast<const TY*>(a.res) + ibase;
         float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = cob + (r & 3) + 8 * (r >> 2);
-          rv[r] = rb[(full || co < a.Cout) ? o0 + ((r & 3) + 8 * (r >> 2)) * iplane : pix];
+          rv[r] = (float)rb[(full || co < a.Cout) ? o0 + ((r & 3) + 8 * (r >> 2)) * iplane : pix];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] += a.res_relu ? fmaxf(rv[r], 0.0f) : rv[r];
       }
       if (a.mask_src) {
-        const float* __restrict__ mb = a.mask_src + ibase;
+        const TY* __restrict__ mb = static_cast<const TY*>(a.mask_src) + ibase;
         float mv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = cob + (r & 3) + 8 * (r >> 2);
-          mv[r] = mb[(full || co < a.Cout) ? o0 + ((r & 3) + 8 * (r >> 2)) * iplane : pix];
+          mv[r] = (float)mb[(full || co < a.Cout) ? o0 + ((r & 3) + 8 * (r >> 2)) * iplane : pix];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = mv[r] > 0.0f ? v[r] : 0.0f;
@@ -623,7 +671,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       for (int r = 0; r < 16; ++r) {
         const int co = cob + (r & 3) + 8 * (r >> 2);
         if (pok && (full || co < a.Cout)) {
-          yb[o0 + ((r & 3) + 8 * (r >> 2)) * iplane] = v[r];
+          yb[o0 + ((r & 3) + 8 * (r >> 2)) * iplane] = (TY)v[r];
           ymax = fmaxf(ymax, fabsf(v[r]));
         }
       }
@@ -636,6 +684,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 struct XCfg {
   int TM, TN, WM, WN;
   bool b1 = false;        // single activation stage, three blocks per CU
+  bool in16 = false;      // fp16 activations: one split term in LDS
   int blockM() const { return TM * WM * 32; }
   int NQ() const { return TN * WN * 32; }
   int NT() const { return 64 * WM * WN; }
@@ -670,7 +719,7 @@ struct XTile {
 static size_t xconv_lds(const XCfg& c, int npos) {
   const int AU = c.WM * c.TM * 128, NT = c.NT();
   const int AS = (AU + NT - 1) / NT * NT;
-  return ((size_t)2 * AS + (size_t)(c.b1 ? 4 : 8) * npos) * sizeof(uint4);
+  return ((size_t)2 * AS + (size_t)(c.b1 ? 4 : 8) * npos / (c.in16 ? 2 : 1)) * sizeof(uint4);
 }
 // Tile of the image per block: TR x TC outputs, TR * (TC + 2 pad) <= NQ positions; choose the split of the
 // width that wastes the fewest positions, subject to the LDS budget and the staging-iteration bound.
@@ -712,7 +761,7 @@ static bool pick_tile(int H, int W, int KS, const XCfg& c, XTile& best) {
   return pick_tile_budget(H, W, KS, c, best, kXLdsBudget) || pick_tile_budget(H, W, KS, c, best, 156 * 1024);
 }
 
-template <int TM, int TN, int WM, int WN, bool FAST, bool B1 = false>
+template <int TM, int TN, int WM, int WN, bool FAST, bool B1 = false, bool IN16 = false, bool OUT16 = false>
 static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t s) {
   auto go = [&](auto kern) -> int {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -721,10 +770,10 @@ static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t 
     return DVD_OK;
   };
   switch (FI) {
-    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1, FAST, B1>);
-    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2, FAST, B1>);
-    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3, FAST, B1>);
-    default: return go(xconv_kernel<TM, TN, WM, WN, 0, FAST, B1>);
+    case 1: return go(xconv_kernel<TM, TN, WM, WN, 1, FAST, B1, IN16, OUT16>);
+    case 2: return go(xconv_kernel<TM, TN, WM, WN, 2, FAST, B1, IN16, OUT16>);
+    case 3: return go(xconv_kernel<TM, TN, WM, WN, 3, FAST, B1, IN16, OUT16>);
+    default: return go(xconv_kernel<TM, TN, WM, WN, 0, FAST, B1, IN16, OUT16>);
   }
 }
 
@@ -788,11 +837,11 @@ int dvd_xconv_select(int cfg) {
   return DVD_OK;
 }
 
-int dvd_xconv_fwd(const float* x, const float* x_amax, const void* packed, const float* bias, const float* residual,
-                  const float* mask_src, const dvd_bn_params* bn, float* y, float* y_amax, int N, int Cin_total, int Cout_total,
-                  int H, int W, int KS, int groups, int flags, dvd_stream_t stream) {
+static int xconv_fwd_impl(const void* x, const float* x_amax, const void* packed, const float* bias, const void* residual,
+                          const void* mask_src, const dvd_bn_params* bn, void* y, float* y_amax, int N, int Cin_total,
+                          int Cout_total, int H, int W, int KS, int groups, int flags, int in16, int out16, dvd_stream_t stream) {
   DVD_REQUIRE(x && packed && y, "xconv: null pointer");
-  DVD_REQUIRE(x_amax, "xconv: the input's max|x| scalar is missing (dvd_amax, or the producer's y_amax)");
+  DVD_REQUIRE(in16 || x_amax, "xconv: the input's max|x| scalar is missing (dvd_amax, or the producer's y_amax)");
   DVD_REQUIRE(N > 0 && Cin_total > 0 && Cout_total > 0 && H > 0 && W > 0, "xconv: bad shape N=%d Cin=%d Cout=%d H=%d W=%d", N,
               Cin_total, Cout_total, H, W);
   DVD_REQUIRE(groups > 0 && Cin_total % groups == 0 && Cout_total % groups == 0, "xconv: %d groups do not divide the channels",
@@ -801,13 +850,17 @@ int dvd_xconv_fwd(const float* x, const float* x_amax, const void* packed, const
   DVD_REQUIRE(N <= 65535, "xconv: too many images for the grid");
   DVD_REQUIRE((long long)H * W * (long long)(Cin_total > Cout_total ? Cin_total : Cout_total) < (1ll << 31),
               "xconv: image too large for 32-bit offsets");
+  DVD_REQUIRE(in16 || !out16, "xconv: fp32 input with fp16 output is not a configuration of this kernel");
   const int Cin = Cin_total / groups, Cout = Cout_total / groups;
   // buffer-addressed main loop: whole 16-channel chunks, 31-bit byte offsets inside one image's input channels and
   // inside the packed weights of one block row
   const bool fast = (Cin % 16 == 0) && ((long long)Cin * H * W * 4 < (1ll << 31)) &&
                     ((long long)8 * ((Cin + 15) / 16) * KS * KS * 2048 < (1ll << 31)) && dvd::g_xcfg != 4;
+  DVD_REQUIRE(fast || !in16, "xconv: fp16 activations need input channels in multiples of 16 (got %d per group)", Cin);
   dvd::XCfg c = dvd::pick_cfg(fast ? Cout : (Cout < 128 ? Cout : 128), KS);
   if (!fast) c.b1 = false;   // the wide shapes exist as FAST kernels only
+  if (in16) c.b1 = false;
+  c.in16 = in16 != 0;
   int Hh = H, Ww = W;
   if (KS == 1) {           // no spatial structure: one row of H * W positions
     Hh = 1;
@@ -843,17 +896,38 @@ int dvd_xconv_fwd(const float* x, const float* x_amax, const void* packed, const
   const dim3 grid(t.ntr * t.ntc, mblocks * groups, N);
   const size_t lds = t.lds;
   hipStream_t s = static_cast<hipStream_t>(stream);
+#define DVD_XGO(TM_, TN_, WM_, WN_)                                                                                      \
+  do {                                                                                                                   \
+    if (in16 && out16) return dvd::launch_fi<TM_, TN_, WM_, WN_, true, false, true, true>(a, t.FI, grid, lds, s);         \
+    if (in16) return dvd::launch_fi<TM_, TN_, WM_, WN_, true, false, true, false>(a, t.FI, grid, lds, s);                 \
+    return dvd::launch_fi<TM_, TN_, WM_, WN_, true>(a, t.FI, grid, lds, s);                                               \
+  } while (0)
   if (fast) {
-    if (c.TM == 4 && c.WN == 4) return dvd::launch_fi<4, 2, 2, 4, true>(a, t.FI, grid, lds, s);
-    if (c.TM == 4) return dvd::launch_fi<4, 2, 2, 2, true>(a, t.FI, grid, lds, s);
+    if (c.TM == 4 && c.WN == 4) DVD_XGO(4, 2, 2, 4);
+    if (c.TM == 4) DVD_XGO(4, 2, 2, 2);
     if (c.WM == 2 && c.b1) return dvd::launch_fi<2, 2, 2, 2, true, true>(a, t.FI, grid, lds, s);
-    if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2, true>(a, t.FI, grid, lds, s);
-    if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4, true>(a, t.FI, grid, lds, s);
-    return dvd::launch_fi<1, 2, 1, 4, true>(a, t.FI, grid, lds, s);
+    if (c.WM == 2) DVD_XGO(2, 2, 2, 2);
+    if (c.TM == 2) DVD_XGO(2, 2, 1, 4);
+    DVD_XGO(1, 2, 1, 4);
   }
+#undef DVD_XGO
   if (c.WM == 2) return dvd::launch_fi<2, 2, 2, 2, false>(a, t.FI, grid, lds, s);
   if (c.TM == 2) return dvd::launch_fi<2, 2, 1, 4, false>(a, t.FI, grid, lds, s);
   return dvd::launch_fi<1, 2, 1, 4, false>(a, t.FI, grid, lds, s);
+}
+
+int dvd_xconv_fwd(const float* x, const float* x_amax, const void* packed, const float* bias, const float* residual,
+                  const float* mask_src, const dvd_bn_params* bn, float* y, float* y_amax, int N, int Cin_total, int Cout_total,
+                  int H, int W, int KS, int groups, int flags, dvd_stream_t stream) {
+  return xconv_fwd_impl(x, x_amax, packed, bias, residual, mask_src, bn, y, y_amax, N, Cin_total, Cout_total, H, W, KS, groups,
+                        flags, 0, 0, stream);
+}
+
+int dvd_xconv_fwd_h(const void* x, const void* packed, const float* bias, const void* residual, const void* mask_src,
+                    const dvd_bn_params* bn, void* y, float* y_amax, int N, int Cin_total, int Cout_total, int H, int W, int KS,
+                    int groups, int flags, int out_f16, dvd_stream_t stream) {
+  return xconv_fwd_impl(x, nullptr, packed, bias, residual, mask_src, bn, y, y_amax, N, Cin_total, Cout_total, H, W, KS, groups,
+                        flags, 1, out_f16 ? 1 : 0, stream);
 }
 
 }  // extern "C"

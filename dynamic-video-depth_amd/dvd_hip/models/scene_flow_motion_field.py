@@ -425,7 +425,9 @@ class Model(NetInterface):
     def _whole_batch_fits(self, B, Bc, HW, steps, with_reg):
         """Forward stashes of all B pairs + the backward / regulariser scratch of one chunk."""
         stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
-        need = B * steps * stash + Bc * (gstash + (2 * stash if with_reg else 0))
+        # (merged backward: the regulariser's second evaluation needs a stash of its own only at gap 1; from gap 2 on it is
+        #  Euler evaluation 1)
+        need = B * steps * stash + Bc * (gstash + (stash if (with_reg and steps == 1) else 0))
         return need <= float(getattr(self.opt, 'mlp_whole_batch_gb', 160.0)) * 2 ** 30
 
     # ------------------------------------------------------------------------------------
@@ -462,7 +464,7 @@ class Model(NetInterface):
         else:
             Bc0 = self._pairs_per_chunk(B, HW, steps, do_reg)
             stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
-            mlp_need = min(B * steps * stash + Bc0 * (gstash + (2 * stash if do_reg else 0)),
+            mlp_need = min(B * steps * stash + Bc0 * (gstash + (stash if (do_reg and steps == 1) else 0)),
                            float(getattr(opt, 'mlp_whole_batch_gb', 160.0)) * 2 ** 30) + 24 * B * HW * 4
             depth_1 = self._depths_keep(inp.img_1, fid1, 0, mlp_need, 2 * n_slots)
             depth_2 = self._depths_keep(inp.img_2, fid2, n_slots, mlp_need, 2 * n_slots)
@@ -531,11 +533,15 @@ class Model(NetInterface):
                 st = mlp.new_stash(n_pix)
                 want_next = i + 1 < steps or (keep_first and i == 0)
                 p_next = torch.empty_like(p_cur) if want_next else None
-                sf_i = torch.empty_like(p_cur) if (keep_first and i == 0 and steps > 1) else None
+                # the regulariser's two evaluations ARE Euler evaluations 0 and 1 (see merged_backward_chunk): keep their
+                # outputs (evaluation 0's only when it is not the accumulated flow itself)
+                sf_i = torch.empty_like(p_cur) if (keep_first and i < 2 and steps > 1) else None
                 mlp.forward(p_cur, ts, t_offset=i * time_step, out_scale=inv_div, sf_out=sf_i, p_next=p_next,
                             acc=sf_all[b0:b1], stash=st)
                 if keep_first and i == 0:
-                    first = (sf_i, p_next)          # sf_i is None when steps == 1: sf_0 is the accumulated flow itself
+                    first = [sf_i, p_next, None]    # sf_i is None when steps == 1: sf_0 is the accumulated flow itself
+                if keep_first and i == 1:
+                    first[2] = sf_i                 # sf_1 = MLP(P1 + sf_0, t_1 + dt)
                 stashes.append(st)
                 p_cur = p_next
             return (stashes, first) if keep_first is not None else stashes
@@ -596,36 +602,45 @@ class Model(NetInterface):
             path (:360-367: same points, same time, same weights), so its forward, stash, dX and dW
             passes are shared: with G = inv * g_sf (main, late normaliser already known) the first
             evaluation receives  G + g_p1 - g1 + g_q  where g1 = dR/dsf_1, g_q = J_b^T g1, and
-            g_P1 = g_p1 + g_q + J_0^T(...).  One MLP evaluation per step less than the reference."""
+            g_P1 = g_p1 + g_q + J_0^T(...).  One MLP evaluation per step less than the reference.
+            From gap 2 on the regulariser's sf_1 = MLP(P1 + sf_0, t_1 + dt) (:335-338) is Euler evaluation 1 as well
+            (:360-367), so that one is shared too (round 4): evaluation 1 receives G + g_p2 + g1, and a gap-k step costs k
+            evaluations instead of the reference's k + 2."""
             nb, n_pix = b1 - b0, (b1 - b0) * HW
             cams = cams_of(b0, b1)
             ts = inp.time_stamp_1[b0:b1] if opt.time_dependent else None
             P1, g_sf = P1_all[b0:b1], g_sf_all[b0:b1]
             g_q = g1 = None
+            shared1 = do_reg and steps > 1      # the regulariser's second evaluation is Euler evaluation 1 as well (:335-338 = :360-367)
             if do_reg:
                 sf0 = first[0] if first[0] is not None else sf_all[b0:b1]
-                sb, sf1 = mlp.new_stash(n_pix), torch.empty_like(P1)
-                mlp.forward(first[1], ts, time_step, inv_div, sf_out=sf1, stash=sb)
                 g1 = torch.empty_like(P1)
-                ops.acc_reg(sf0, sf1, reg_coef, g1, sums[4:5], accumulate=True)
-                g_q = torch.empty_like(P1)
-                mlp.backward_dx(sb, inv_div, g1, g_q, gst, gW_reg[5], gb_reg[5], (nb, H, W))
-                mlp.backward_dw(sb, gst, n_pix, gW_reg[:5], gb_reg[:5])
-                del sb, sf1
+                if shared1:
+                    ops.acc_reg(sf0, first[2], reg_coef, g1, sums[4:5], accumulate=True)
+                else:
+                    sb, sf1 = mlp.new_stash(n_pix), torch.empty_like(P1)
+                    mlp.forward(first[1], ts, time_step, inv_div, sf_out=sf1, stash=sb)
+                    ops.acc_reg(sf0, sf1, reg_coef, g1, sums[4:5], accumulate=True)
+                    g_q = torch.empty_like(P1)
+                    mlp.backward_dx(sb, inv_div, g1, g_q, gst, gW_reg[5], gb_reg[5], (nb, H, W))
+                    mlp.backward_dw(sb, gst, n_pix, gW_reg[:5], gb_reg[:5])
+                    del sb, sf1
             g_p = None
             for i in reversed(range(1, steps)):
                 g_new = torch.empty_like(P1)
+                g_o2 = g_p
+                if shared1 and i == 1:          # evaluation 1's output also feeds the regulariser: + dR/dsf_1 (not normalised)
+                    g_o2 = g1 if g_p is None else ops.scale_add(torch.empty_like(P1), g1, b=g_p)
                 mlp.backward_dx(stashes[i], inv_div, g_sf, g_new, gst, gW_reg[5], gb_reg[5], (nb, H, W), scale_ptr=inv,
-                                g_out2=g_p, g_p_add=g_p)
+                                g_out2=g_o2, g_p_add=g_p)
                 mlp.backward_dw(stashes[i], gst, n_pix, gW_reg[:5], gb_reg[:5])
                 g_p = g_new
             extra, add = g_p, g_p                    # gradient reaching sf_0 besides G, and reaching P1 directly
-            if do_reg:
+            if shared1:                              # g_p already holds everything that reaches q = P1 + sf_0
+                extra = ops.scale_add(torch.empty_like(P1), g1, scale=-1.0, b=g_p)          # g_p - g1
+            elif do_reg:
                 extra = ops.scale_add(torch.empty_like(P1), g1, scale=-1.0, b=g_q)          # -g1 + g_q
                 add = g_q
-                if g_p is not None:
-                    extra = ops.scale_add(extra, g_p, b=extra)
-                    add = ops.scale_add(torch.empty_like(P1), g_p, b=g_q)
             g_P = torch.empty_like(P1)
             mlp.backward_dx(stashes[0], inv_div, g_sf, g_P, gst, gW_reg[5], gb_reg[5], (nb, H, W), scale_ptr=inv,
                             g_out2=extra, g_p_add=add)
