@@ -39,6 +39,7 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch  # noqa: E402
 
 H, W, PAIRS, GAP = 384, 672, 48, 1
+PAIRS_CFG4 = 16                  # BASELINE configs[4] (768x1344, fp16 activations): frame pairs per GPU that fit one MI355X
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 WARP_BYTES_PER_PIXEL = 52        # fused fwd+bwd, unique bytes
 
@@ -49,7 +50,7 @@ def make_opt(**over):
              batch_size=1, global_rank=0, use_cnn=False, use_embedding=False, midas=True, use_disp=True,
              use_disp_ratio=False, time_dependent=True, flow_mul=1.0, disp_mul=1.0, acc_mul=1.0, sf_mag_div=100.0,
              interp_steps=5, warm_reg=False, weight_steps=False, use_motion_seg=False, n_freq_xyz=16, n_freq_t=16,
-             warm_sf=5, mlp_stash_gb=64.0, depth_chunk=16, full_logdir='/tmp')
+             warm_sf=5, mlp_stash_gb=64.0, depth_chunk=16, full_logdir='/tmp', act_fp16=False)
     o.update(over)
     return SimpleNamespace(**o)
 
@@ -227,11 +228,24 @@ def main():
     ap.add_argument('--depth_chunk', type=int, default=48,
                     help='images per depth-net forward/backward chunk = per kept-activation graph slot (48: two slots per step; '
                          '16 / 24 / 48 measured 0.840 / 0.843 / 0.851 iters/s on one box)')
+    ap.add_argument('--act_fp16', action='store_true',
+                    help='fp16 ACTIVATION storage in the depth net (fp32 parameters / accumulation / loss sums): the arithmetic of '
+                         'BASELINE configs[4] at the headline image size -- an extra bench line, not the headline')
+    ap.add_argument('--config', type=int, default=2, choices=(2, 4),
+                    help='2 (default): BASELINE configs[1]/[2], the headline.  4: BASELINE configs[4] on ONE GPU -- synthetic '
+                         '768x1344, fp16 activations with fp32 loss accumulation, as many frame pairs as fit one MI355X '
+                         '(--pairs, default %d)' % PAIRS_CFG4)
     ap.add_argument('--feed', choices=('hbm', 'host'), default='hbm',
                     help="hbm (default, the contract's `value`): inputs resident in HBM before the timed region; host: every "
                          "step's batch starts in host memory and goes through the pinned double-buffered feeder "
                          "(dvd_hip.datasets.davis_sequence.DeviceFeeder), so the PCIe copy is inside the timed region")
     a = ap.parse_args()
+    global H, W
+    if a.config == 4:
+        H, W = 768, 1344
+        a.act_fp16 = True
+        if a.pairs == PAIRS:
+            a.pairs = PAIRS_CFG4
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(a.gpus)
 
@@ -248,7 +262,8 @@ def main():
 
     if os.environ.get('DVD_CUDNN_BENCHMARK'):
         torch.backends.cudnn.benchmark = True     # MIOpen find mode (experiments; the default run uses FAST immediate mode)
-    opt = make_opt(global_rank=rank, depth_chunk=a.depth_chunk, depth_graphs=bool(a.depth_graphs), midas=a.depth == 'midas')
+    opt = make_opt(global_rank=rank, depth_chunk=min(a.depth_chunk, a.pairs), depth_graphs=bool(a.depth_graphs),
+                   midas=a.depth == 'midas', act_fp16=bool(a.act_fp16))
     model = build_model(opt, device, seed=0)
     batch = synthetic.make_batch(a.pairs, H, W, gap=a.gap, seed=1234, rank=rank, device=device)
     epoch = opt.warm_sf + 1            # non-warm phase
@@ -298,20 +313,27 @@ def main():
     if rank != 0:
         return
     out = {
-        'metric': 'train iters/s (depth+sceneflow step) at 384x672, 48 pairs; warp+loss HBM GB/s',
-        'value': world * (a.pairs / float(PAIRS)) * a.steps / dt, 'unit': 'iters/s (48-pair steps, whole job)',
+        'metric': 'train iters/s (depth+sceneflow step) at %dx%d, %d pairs; warp+loss HBM GB/s' % (H, W, a.pairs if a.config == 4 else PAIRS),
+        'value': world * (1.0 if a.config == 4 else a.pairs / float(PAIRS)) * a.steps / dt,
+        'unit': ('iters/s (%d-pair steps at %dx%d, whole job)' % (a.pairs, H, W)) if a.config == 4 else 'iters/s (48-pair steps, whole job)',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (storage and accumulation fp32; conv / MLP contractions on v_mfma_f32_32x32x16_f16: every fp32 operand, '
+        'dtype': ('f16 activations / f32 accumulate (depth-net activations and their gradients stored as fp16, one-term MFMA operands: '
+                  '2 MFMAs per activation x weight product, 1 per weight-gradient product; fp32 parameters, parameter gradients, '
+                  'loss sums and optimiser state; power-of-two loss scale kept on the device, csrc/a16.hip)') if a.act_fp16 else
+                 'f32 (storage and accumulation fp32; conv / MLP contractions on v_mfma_f32_32x32x16_f16: every fp32 operand, '
                  'scaled by a power of two from its tensor\'s max, is split into two fp16 terms (22 bits) and a product is '
                  'three partial products; <= 4e-6 of max|y| against float64, the bound the 3-term bf16 / 6-product '
                  'arithmetic of round 2 met)', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[1]/[2]: synthetic %dx%d, %d frame pairs per GPU, gap %d, MiDaS '
+        'config': {'workload': ('BASELINE configs[4] on one GPU' if a.config == 4 else
+                                ('BASELINE configs[1]/[2] with fp16 activation storage' if a.act_fp16 else 'BASELINE configs[1]/[2]')) +
+                               ': synthetic %dx%d, %d frame pairs per GPU, gap %d, MiDaS '
                                '(ResNeXt-101 32x8d) depth net with hand-written fp16-pair-split MFMA convolution kernels '
                                '(forward, data and weight gradients) '
                                'under PyTorch-ROCm autograd + HIP scene-flow MLP + HIP fused warp/reprojection/loss, '
                                'non-warm phase with acceleration regulariser' % (H, W, a.pairs, a.gap),
                    'pairs_per_gpu': a.pairs, 'height': H, 'width': W, 'gap': a.gap, 'depth_net': a.depth,
+                   'activations': 'fp16' if a.act_fp16 else 'fp32',
                    'parallelism': 'dp%d over frame pairs' % world},
         'pairs_per_s': world * a.pairs * a.steps / dt, 'feed': a.feed, 'graph_setup_steps': setup_steps,
         'hbm_peak_allocated_GB': torch.cuda.max_memory_allocated(device) / 2 ** 30,
@@ -348,7 +370,11 @@ def main():
                            'valu_issue': {'instr_per_pixel': 371, 'issue_bound_ms': round(
                                371.0 * warp['pixels_per_launch'] / (256 * 64 * 2.16e9) * 1e3, 4),
                                'source': 'static: profiles/r03_warp_loss_sq_counters.txt (SQ_INSTS_VALU 7.18e7 for 48x384x672)'}}
-    if world == 1 and not a.no_cpu_baseline and a.depth == 'midas' and a.gap == GAP:
+    if a.act_fp16:
+        st = model._gscale.tolist()
+        out['loss_scale'] = {'log2_S': __import__('math').log2(st[0]) if st[0] > 0 else None, 'target_exponent': st[2],
+                             'steps_skipped': st[5]}
+    if world == 1 and not a.no_cpu_baseline and a.depth == 'midas' and a.gap == GAP and a.config == 2 and not a.act_fp16:
         # the 48-pair model's graph slots hold most of the HBM: release them before the 1-pair parity model is built
         import gc
         del model, batch

@@ -17,7 +17,7 @@ c_float = ctypes.c_float
 c_void_p = ctypes.c_void_p
 
 DVD_OK, DVD_EINVAL, DVD_EHIP, DVD_ENOSPC = 0, -1, -2, -3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Cameras(ctypes.Structure):
@@ -127,6 +127,28 @@ SIGNATURES = {
     'dvd_flow_consistency_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'dvd_sf_mlp_bwd_dw': (c_int, [ctypes.POINTER(MlpDesc), c_void_p, c_void_p, c_longlong, ctypes.POINTER(PtrArr5),
                                   ctypes.POINTER(PtrArr5), c_void_p]),
+    # fp16 activation storage (configs[4])
+    'dvd_xconv_fwd_h': (c_int, [c_void_p] * 5 + [ctypes.POINTER(BnParams), c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'dvd_xwgrad3_h': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 7 + [c_void_p]),
+    'dvd_xwgrad1s_h': (c_int, [c_void_p] * 5 + [c_size_t] + [c_int] * 6 + [c_void_p]),
+    'dvd_bnrelu_fwd_t': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_bnrelu_bwd_t': (c_int, [c_void_p] * 6 + [c_float] + [c_void_p] * 5 + [c_size_t, c_int, c_void_p, c_int, c_int, c_int,
+                                                                             c_int, c_void_p, c_void_p]),
+    'dvd_upsample_bilinear_fwd_t': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_upsample_bilinear_bwd_t': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_gconv3x3_c8_fwd_t': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_gconv3x3_c8_bwd_data_t': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_gconv3x3_c8_bwd_weight_t': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p, c_int,
+                                             c_int, c_int, c_int, c_void_p]),
+    'dvd_head1x1_fwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_head1x1_bwd_workspace_bytes': (c_size_t, [c_int]),
+    'dvd_head1x1_bwd': (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_gscale_init': (c_int, [c_void_p, c_float, c_void_p]),
+    'dvd_gscale_begin': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'dvd_gscale_end': (c_int, [c_void_p, c_void_p]),
+    'dvd_cast_scale_f32': (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_void_p, c_void_p]),
+    'dvd_adam_step_guarded': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,
+                                      c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
 }
 
 _lock = threading.Lock()

@@ -36,6 +36,7 @@ SOURCES = [
     ('xwgrad.hip', []),
     ('xwgrad3.hip', []),
     ('consistency.hip', ['-ffp-contract=off']),
+    ('a16.hip', []),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

@@ -41,6 +41,34 @@ for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
     AB[_k] = True
 
 
+# ---- fp16 activation storage (BASELINE configs[4]) ------------------------------------------------------------------
+# Activations between the encoder stem and the depth head may be torch.float16 tensors: the same autograd Functions then call the
+# "_h" / "_t" entry points (csrc/xconv.hip IN16 / OUT16, csrc/xwgrad3.hip H16, the templated helper kernels).  fp16 gradients
+# carry the step's loss scale S (csrc/a16.hip); every PARAMETER gradient is multiplied by 1 / S where it is produced, so the
+# flat gradient buffers hold true fp32 gradients.  The loss-scale state (8 floats on the device) belongs to the model that is
+# stepping; it is registered here because the backward Functions need its address.
+ACT_DTYPES = (torch.float32, torch.float16)
+GRAD_SCALE = {'state': None}
+
+
+def set_grad_scale_state(state):
+    """state: the 8-float device tensor of dvd_gscale_* (or None).  Its address is baked into captured HIP graphs, so a model
+    allocates it once and keeps it for its lifetime."""
+    GRAD_SCALE['state'] = state
+
+
+def _is16(t):
+    return t.dtype == torch.float16
+
+
+def _gs(i):
+    """1-element view of the loss-scale state: 1 = 1 / S (out_scale of parameter gradients), 3 = observed max |S g|."""
+    st = GRAD_SCALE['state']
+    if st is None:
+        raise RuntimeError('fp16 gradients need a loss-scale state (conv.set_grad_scale_state; Model does it with --act_fp16)')
+    return st[i:i + 1]
+
+
 class _BnRelu(torch.autograd.Function):
     """y = relu(bn_eval(x) (+ residual)); see csrc/bnrelu.hip."""
 
@@ -53,8 +81,8 @@ class _BnRelu(torch.autograd.Function):
             residual = residual.contiguous()
         y = torch.empty_like(x)
         lib = _lib.load()
-        _lib.check(lib.dvd_bnrelu_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(y), N, C,
-                                      HW, int(relu), _stream()), 'dvd_bnrelu_fwd')
+        _lib.check(lib.dvd_bnrelu_fwd_t(_p(x), _p(residual), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(y),
+                                        int(_is16(x)), N, C, HW, int(relu), _stream()), 'dvd_bnrelu_fwd')
         ctx.save_for_backward(x, y if relu else None, gamma, mean, var)
         ctx.cfg = (N, C, HW, float(eps), int(relu), residual is not None)
         return y
@@ -71,9 +99,10 @@ class _BnRelu(torch.autograd.Function):
         gb = torch.empty_like(gamma) if need[3] else None
         lib = _lib.load()
         ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, C, HW), x.device)
-        _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y), _p(x), _p(gamma), _p(mean), _p(var), eps, _p(gx), _p(gr), _p(gg),
-                                      _p(gb), _p(ws), ctypes.c_size_t(ws.numel()), N, C, HW, relu, None, _stream()),
-                   'dvd_bnrelu_bwd')
+        h16 = _is16(gy)
+        _lib.check(lib.dvd_bnrelu_bwd_t(_p(gy), _p(y), _p(x), _p(gamma), _p(mean), _p(var), eps, _p(gx), _p(gr), _p(gg),
+                                        _p(gb), _p(ws), ctypes.c_size_t(ws.numel()), int(h16), _p(_gs(1)) if h16 else None, N, C,
+                                        HW, relu, _p(_gs(3)) if h16 else None, _stream()), 'dvd_bnrelu_bwd')
         return gx, gr, gg, gb, None, None, None, None
 
 
@@ -81,7 +110,7 @@ def bn_eval_relu(bn, x, residual=None, relu=True):
     """relu(bn(x) (+ residual)) for an nn.BatchNorm2d in eval mode (running statistics; gamma / beta keep
     their gradients) on the fused HIP kernel; anything else (training-mode BN, CPU, other dtypes) takes the
     ATen ops the reference uses."""
-    if (not bn.training and bn.track_running_stats and x.is_cuda and x.dtype == torch.float32):
+    if (not bn.training and bn.track_running_stats and x.is_cuda and x.dtype in ACT_DTYPES):
         if bn.affine:
             gamma, beta = bn.weight, bn.bias
         else:                                   # hourglass inception blocks: BatchNorm2d(affine=False)
@@ -93,6 +122,75 @@ def bn_eval_relu(bn, x, residual=None, relu=True):
     return F.relu(y) if relu else y
 
 
+class _ToHalf(torch.autograd.Function):
+    """The fp32 -> fp16 boundary behind the encoder stem: forward casts; backward hands the fp32 stem the TRUE gradient, i.e.
+    the fp16 gradient times 1 / (loss scale) (dvd_cast_scale_f32), so the stem's parameter gradients need no special case."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.float16)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty(g.shape, device=g.device, dtype=torch.float32)
+        if g.numel() % 4:
+            return g.float() * _gs(1)
+        _lib.check(_lib.load().dvd_cast_scale_f32(_p(g), 1, _p(out), ctypes.c_longlong(g.numel()), _p(_gs(1)), _stream()),
+                   'dvd_cast_scale_f32')
+        return out
+
+
+def to_half(x):
+    return _ToHalf.apply(x)
+
+
+class _Head1x1(torch.autograd.Function):
+    """`Conv2d(C, 1, 1)(relu(x))` of the depth head (third_party/MiDaS.py:192-194) with fp16 (or fp32) features and fp32
+    output: the fp16 / fp32 boundary at the network's end.  Backward starts the pass's loss scale (dvd_gscale_begin from
+    max|g_out| and max|w|), then writes the feature gradient times S in x's storage and the fp32 weight / bias gradients
+    (csrc/a16.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu_in):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty(N, 1, H, W, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.load().dvd_head1x1_fwd(_p(x), int(_is16(x)), _p(weight), _p(bias), _p(y), N, C, H * W, int(bool(relu_in)),
+                                               _stream()), 'dvd_head1x1_fwd')
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (bool(relu_in), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .ops import amax
+        x, weight = ctx.saved_tensors
+        relu_in, has_bias = ctx.cfg
+        gy = gy.contiguous().float()
+        N, C, H, W = x.shape
+        lib = _lib.load()
+        h16 = _is16(x)
+        state = None
+        if h16:
+            state = GRAD_SCALE['state']
+            if state is None:
+                raise RuntimeError('fp16 gradients need a loss-scale state (conv.set_grad_scale_state)')
+            _lib.check(lib.dvd_gscale_begin(_p(state), _p(amax(gy)), _p(weight), C, _stream()), 'dvd_gscale_begin')
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(weight)
+        gb = torch.empty(1, device=x.device, dtype=torch.float32) if has_bias else None
+        ws = _workspace(lib.dvd_head1x1_bwd_workspace_bytes(C), x.device)
+        _lib.check(lib.dvd_head1x1_bwd(_p(x), int(h16), _p(weight), _p(gy), _p(state), _p(gx), _p(gw), _p(gb), _p(ws),
+                                       ctypes.c_size_t(ws.numel()), N, C, H * W, int(relu_in), _stream()), 'dvd_head1x1_bwd')
+        return gx, gw, gb, None
+
+
+def head1x1(conv, x, relu_in=True):
+    """conv(relu(x)) for an nn.Conv2d(C, 1, 1) on the boundary kernel (GPU tensors, C <= 64, H * W % 4 == 0)."""
+    return _Head1x1.apply(x, conv.weight, conv.bias, relu_in)
+
+
 class _UpsampleBilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, out_hw, align_corners):
@@ -101,8 +199,8 @@ class _UpsampleBilinear(torch.autograd.Function):
         Ho, Wo = out_hw
         y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=x.dtype)
         lib = _lib.load()
-        _lib.check(lib.dvd_upsample_bilinear_fwd(_p(x), _p(y), N * C, H, W, Ho, Wo, int(align_corners), _stream()),
-                   'dvd_upsample_bilinear_fwd')
+        _lib.check(lib.dvd_upsample_bilinear_fwd_t(_p(x), _p(y), int(_is16(x)), N * C, H, W, Ho, Wo, int(align_corners),
+                                                   _stream()), 'dvd_upsample_bilinear_fwd')
         ctx.shape, ctx.align = (N, C, H, W, Ho, Wo), int(align_corners)
         return y
 
@@ -112,14 +210,14 @@ class _UpsampleBilinear(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty(N, C, H, W, device=gy.device, dtype=gy.dtype)
         lib = _lib.load()
-        _lib.check(lib.dvd_upsample_bilinear_bwd(_p(gy), _p(gx), N * C, H, W, Ho, Wo, ctx.align, _stream()),
+        _lib.check(lib.dvd_upsample_bilinear_bwd_t(_p(gy), _p(gx), int(_is16(gy)), N * C, H, W, Ho, Wo, ctx.align, _stream()),
                    'dvd_upsample_bilinear_bwd')
         return gx, None, None
 
 
 def upsample_bilinear2x(x, align_corners):
     """F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=...) of the MiDaS decoder."""
-    if x.is_cuda and x.dtype == torch.float32:
+    if x.is_cuda and x.dtype in ACT_DTYPES:
         y = _UpsampleBilinear.apply(x, (2 * x.shape[2], 2 * x.shape[3]), bool(align_corners))
         return set_amax(y, known_amax(x))            # a convex combination never exceeds the largest input magnitude
     return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=align_corners)
@@ -133,7 +231,7 @@ class _GConv3x3C8(torch.autograd.Function):
         N, C, H, W = x.shape
         y = torch.empty_like(x)
         lib = _lib.load()
-        _lib.check(lib.dvd_gconv3x3_c8_fwd(_p(x), _p(w), _p(y), N, C, H, W, _stream()), 'dvd_gconv3x3_c8_fwd')
+        _lib.check(lib.dvd_gconv3x3_c8_fwd_t(_p(x), _p(w), _p(y), int(_is16(x)), N, C, H, W, _stream()), 'dvd_gconv3x3_c8_fwd')
         ctx.save_for_backward(x, w)
         return y
 
@@ -146,14 +244,16 @@ class _GConv3x3C8(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            _lib.check(lib.dvd_gconv3x3_c8_bwd_data(_p(gy), _p(w), _p(gx), N, C, H, W, _stream()),
+            _lib.check(lib.dvd_gconv3x3_c8_bwd_data_t(_p(gy), _p(w), _p(gx), int(_is16(gy)), N, C, H, W, _stream()),
                        'dvd_gconv3x3_c8_bwd_data')
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             nws = lib.dvd_gconv3x3_c8_wgrad_workspace_bytes(N, C, H, W)
             ws = _workspace(nws, x.device)
-            _lib.check(lib.dvd_gconv3x3_c8_bwd_weight(_p(x), _p(gy), _p(gw), 0, _p(ws), ctypes.c_size_t(ws.numel()),
-                                                      N, C, H, W, _stream()), 'dvd_gconv3x3_c8_bwd_weight')
+            h16 = _is16(gy)
+            _lib.check(lib.dvd_gconv3x3_c8_bwd_weight_t(_p(x), _p(gy), _p(gw), 0, _p(ws), ctypes.c_size_t(ws.numel()), int(h16),
+                                                        _p(_gs(1)) if h16 else None, N, C, H, W, _stream()),
+                       'dvd_gconv3x3_c8_bwd_weight')
         return gx, gw
 
 
@@ -206,7 +306,7 @@ class GroupedConv3x3C32(nn.Conv2d):
         super().__init__(channels, channels, 3, stride=1, padding=1, groups=channels // 32, bias=False)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and not AB['gconv32']:
+        if x.is_cuda and x.dtype in ACT_DTYPES and not AB['gconv32']:
             # the grouped split-operand MFMA kernels (csrc/xconv.hip, csrc/xwgrad3.hip): 0.097 ms forward / 0.37 ms backward per
             # 16-image call at [1024, 24, 42] against 0.156 / 0.42 ms of the fp32-MFMA kernels (tools/microbench_gx.py)
             return _xconv(x, self.weight, None, None, False, False, self.groups)
@@ -251,7 +351,7 @@ class GroupedConv3x3C16(nn.Conv2d):
 
     def forward(self, x):
         st = self.stride[0]
-        if x.is_cuda and x.dtype == torch.float32 and not AB['no_c16'] and (st == 1 or not AB['gconv32']):
+        if x.is_cuda and x.dtype in ACT_DTYPES and not AB['no_c16'] and (st == 1 or not AB['gconv32']):
             if not AB['gconv32']:
                 y = _xconv(x, _pair_groups_of_16(self.weight), None, None, False, False, self.groups // 2)
                 # the stride-2 entry of stage 2: out[i][j] of a strided 'same' 3x3 is the stride-1 result at [s*i][s*j]
@@ -263,7 +363,7 @@ class GroupedConv3x3C16(nn.Conv2d):
 
 def gconv3x3_c8(x, weight):
     """y = conv2d(x, weight, padding=1, groups=C // 8) for weight [C, 8, 3, 3]."""
-    if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32:
+    if x.is_cuda and x.dtype in ACT_DTYPES and weight.dtype == torch.float32:
         return _GConv3x3C8.apply(x, weight)
     return F.conv2d(x, weight, None, 1, 1, 1, x.shape[1] // 8)
 
@@ -355,9 +455,10 @@ def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, rel
     x_amax: the input's max|x| scalar (computed here if not given); y_amax: optional zeroed 1-element tensor that
     receives max|y|."""
     N, Cin, H, W = x.shape
-    if x_amax is None:
+    h16 = _is16(x)
+    if x_amax is None and not h16:
         x_amax = amax_of(x)
-    y = torch.empty(N, Cout, H, W, device=x.device, dtype=torch.float32)
+    y = torch.empty(N, Cout, H, W, device=x.device, dtype=x.dtype)
     flags = int(bool(relu_in)) | (int(bool(relu_out)) << 1) | (int(bool(res_relu)) << 2)
     lib = _lib.load()
     bnp = None
@@ -365,6 +466,13 @@ def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, rel
         g, b, m, v, eps = bn
         bnp = ctypes.byref(_lib.BnParams(g.data_ptr() if g is not None else None, b.data_ptr() if b is not None else None,
                                          m.data_ptr(), v.data_ptr(), float(eps)))
+    if h16:        # fp16 activations: no operand scale, two MFMAs per product (csrc/xconv.hip IN16 / OUT16)
+        for t, name in ((residual, 'residual'), (mask_src, 'mask source')):
+            if t is not None and not _is16(t):
+                raise RuntimeError('xconv: fp16 convolution with an fp32 %s' % name)
+        _lib.check(lib.dvd_xconv_fwd_h(_p(x), _p(packed), _p(bias), _p(residual), _p(mask_src), bnp, _p(y), _p(y_amax), N, Cin,
+                                       Cout, H, W, KS, groups, flags, 1, _stream()), 'dvd_xconv_fwd_h')
+        return y
     _lib.check(lib.dvd_xconv_fwd(_p(x), _p(x_amax), _p(packed), _p(bias), _p(residual), _p(mask_src), bnp, _p(y), _p(y_amax),
                                  N, Cin, Cout, H, W, KS, groups, flags, _stream()), 'dvd_xconv_fwd')
     return y
@@ -419,13 +527,14 @@ class _XConv(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         Cout, _, KS, _ = weight.shape
-        y_amax = new_scalar(x.device)
+        y_amax = None if _is16(x) else new_scalar(x.device)       # fp16 activations carry no operand scale
         y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=bias, residual=residual, relu_in=relu_in,
                        res_relu=res_relu, groups=groups, x_amax=x_amax, y_amax=y_amax)
         ctx.save_for_backward(x, residual if (res_relu and not res_unmasked) else None, x_amax)
         ctx.wparam = weight          # the tensor object that carries the packed copies
         ctx.cfg = (bool(relu_in), bool(res_relu), bias is not None, residual is not None, groups, bool(res_unmasked))
-        ctx.mark_non_differentiable(y_amax)
+        if y_amax is not None:
+            ctx.mark_non_differentiable(y_amax)
         if alias:
             return y, y_amax, x
         return y, y_amax
@@ -441,20 +550,22 @@ class _XConv(torch.autograd.Function):
         Cout, Cin, KS, _ = weight.shape
         need = ctx.needs_input_grad
         gx = gw = gb = gr = None
-        g_amax = amax_of(gy) if (need[0] or need[2]) else None        # one reduction, shared by both gradient kernels
+        h16 = _is16(gy)
+        g_amax = amax_of(gy) if ((need[0] or need[2]) and not h16) else None   # one reduction, shared by both gradient kernels
         if need[0]:
-            gx_amax = new_scalar(gy.device)
+            gx_amax = _gs(3) if h16 else new_scalar(gy.device)      # fp16: the loss-scale policy's observed maximum
             gx = _xconv_run(gy, xconv_packed(weight, True, groups), Cin * groups, KS,
                             mask_src=x if (relu_in or ctx.in_site is not None) else None,
                             groups=groups, x_amax=g_amax, y_amax=gx_amax,
                             residual=g_alias.contiguous() if g_alias is not None else None)
-            set_amax(gx, gx_amax)         # (used by the next backward if autograd hands this very tensor on)
+            if not h16:
+                set_amax(gx, gx_amax)     # (used by the next backward if autograd hands this very tensor on)
             if ctx.in_site is not None:
-                ctx.in_site.wrote(gx, gx_amax)     # x is a BatchNorm+ReLU site's output: its mask [x > 0] is already applied
+                ctx.in_site.wrote(gx, None if h16 else gx_amax)     # x is a BatchNorm+ReLU site's output: [x > 0] is already applied
         if need[2]:
             gw = xconv_wgrad(x, gy, weight.shape, relu_in, groups, x_amax=x_amax, g_amax=g_amax)
         if has_bias and need[3]:
-            gb = gy.sum((0, 2, 3))
+            gb = gy.sum((0, 2, 3), dtype=torch.float32) * _gs(1) if h16 else gy.sum((0, 2, 3))
         if has_res and need[4]:
             gr = gy * (residual > 0).to(gy.dtype) if (res_relu and not res_unmasked) else gy
         return gx, None, gw, gb, gr, None, None, None, None, None, None
@@ -463,7 +574,7 @@ class _XConv(torch.autograd.Function):
 def _xconv(x, weight, bias, residual, relu_in, res_relu, groups=1, alias=False, res_unmasked=False):
     """_XConv with the max|.| scalars threaded through: the input's is looked up (or computed), the output's attached.
     alias=True returns (y, alias of x), see _XConv."""
-    x_amax = amax_of(x)
+    x_amax = None if _is16(x) else amax_of(x)
     in_site = getattr(x, '_dvd_site', None)
     if alias:
         y, y_amax, xa = _XConv.apply(x, x_amax, weight, bias, residual, relu_in, res_relu, groups, True, res_unmasked, in_site)
@@ -480,6 +591,22 @@ def wgrad_reports_rowsum(wshape, groups):
 def xconv_wgrad(x, gy, wshape, relu_in, groups=1, x_amax=None, g_amax=None, rowsum=None):
     """dW[co][ci][tap] = sum_{n,p} gy[n][co][p] * act(x)[n][ci][p + tap]."""
     lib = _lib.load()
+    if _is16(gy):        # fp16 operands: one MFMA per product, result times 1 / (loss scale) (csrc/xwgrad3.hip H16)
+        if not _is16(x):
+            raise RuntimeError('xconv_wgrad: fp16 gradient with an fp32 activation')
+        if wshape[2] not in (1, 3) or (groups > 1 and wshape[2] != 3):
+            raise RuntimeError('xconv: the fp16 weight gradient exists for 1x1 and 3x3 kernels only (got %s)' % (tuple(wshape),))
+        N, Cin, H, W = x.shape
+        gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+        if wshape[2] == 3:
+            ws = _workspace(lib.dvd_xwgrad3_workspace_bytes(N, Cin, wshape[0], H, W, groups), x.device)
+            _lib.check(lib.dvd_xwgrad3_h(_p(x), _p(gy), _p(_gs(1)), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, wshape[0],
+                                         H, W, groups, int(bool(relu_in)), _stream()), 'dvd_xwgrad3_h')
+        else:
+            ws = _workspace(lib.dvd_xwgrad1s_workspace_bytes(N, Cin, wshape[0], H, W), x.device)
+            _lib.check(lib.dvd_xwgrad1s_h(_p(x), _p(gy), _p(_gs(1)), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, wshape[0],
+                                          H, W, int(bool(relu_in)), _stream()), 'dvd_xwgrad1s_h')
+        return gw
     if x_amax is None:
         x_amax = amax_of(x)
     if g_amax is None:
@@ -541,13 +668,14 @@ class _XConvBn(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         Cout, _, KS, _ = weight.shape
-        y_amax = new_scalar(x.device)
+        y_amax = None if _is16(x) else new_scalar(x.device)
         y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=cbias, residual=residual, relu_out=relu,
                        groups=groups, bn=(gamma, beta, mean, var, eps), x_amax=x_amax, y_amax=y_amax)
         ctx.save_for_backward(x, y if relu else None, gamma, mean, var, cbias, x_amax)
         ctx.wparam = weight
         ctx.cfg = (float(eps), bool(relu), residual is not None, groups)
-        ctx.mark_non_differentiable(y_amax)
+        if y_amax is not None:
+            ctx.mark_non_differentiable(y_amax)
         if alias:
             return y, y_amax, x
         return y, y_amax
@@ -577,24 +705,28 @@ class _XConvBn(torch.autograd.Function):
         if relu:
             STATS['sites_no_pass' if no_pass else ('sites_premasked' if premasked else 'sites_masked')] += 1
         g = torch.empty_like(gy) if mask else gy
+        h16 = _is16(gy)
         if no_pass:
             g_amax = ctx.out_site.amax
         else:
             ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, Cout, H * W), gy.device)
-            g_amax = new_scalar(gy.device)  # max|masked gradient|, folded in by the mask pass (it reads every element anyway)
-            _lib.check(lib.dvd_bnrelu_bwd(_p(gy), _p(y) if mask else None, None, _p(var), _p(mean), _p(var), eps, None,
-                                          _p(g) if mask else None, None, _p(dbeta), _p(ws), ctypes.c_size_t(ws.numel()), N,
-                                          Cout, H * W, int(mask), _p(g_amax), _stream()), 'dvd_bnrelu_bwd')
+            # max|masked gradient|, folded in by the mask pass (it reads every element anyway); fp16: the policy's observed maximum
+            g_amax = _gs(3) if h16 else new_scalar(gy.device)
+            _lib.check(lib.dvd_bnrelu_bwd_t(_p(gy), _p(y) if mask else None, None, _p(var), _p(mean), _p(var), eps, None,
+                                            _p(g) if mask else None, None, _p(dbeta), _p(ws), ctypes.c_size_t(ws.numel()),
+                                            int(h16), _p(_gs(1)) if h16 else None, N, Cout, H * W, int(mask), _p(g_amax),
+                                            _stream()), 'dvd_bnrelu_bwd')
         gx = gw = gcb = gg = None
         if need[0]:
-            gx_amax = new_scalar(gy.device)
+            gx_amax = _gs(3) if h16 else new_scalar(gy.device)
             gx = _xconv_run(g, xconv_packed_scaled(weight, groups, gamma, var, eps), Cing * groups, KS, groups=groups,
                             x_amax=g_amax, y_amax=gx_amax,
                             residual=g_alias.contiguous() if g_alias is not None else None,   # + the other consumers' gradient
                             mask_src=x if ctx.in_site is not None else None)                  # ... * [x > 0] for the site x came from
-            set_amax(gx, gx_amax)
+            if not h16:
+                set_amax(gx, gx_amax)
             if ctx.in_site is not None:
-                ctx.in_site.wrote(gx, gx_amax)
+                ctx.in_site.wrote(gx, None if h16 else gx_amax)
         elif g_alias is not None:
             gx = g_alias
         if need_w:
@@ -616,7 +748,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, alias=False):
     alias=True returns (y, x'): x' carries x's values and must be used by every OTHER consumer of x (the block's shortcut);
     on the fused path their gradient is then added inside this convolution's backward-data kernel instead of by autograd's
     accumulation pass (see _XConv); on the other paths x' is x itself."""
-    if (x.is_cuda and x.dtype == torch.float32 and not bn.training and bn.track_running_stats and
+    if (x.is_cuda and x.dtype in ACT_DTYPES and not bn.training and bn.track_running_stats and
             isinstance(conv, nn.Conv2d) and not AB['no_bnfuse']):
         xin = None
         if xconv_supported(conv, x):
@@ -627,7 +759,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, alias=False):
             xin = _subsample(x, conv.stride[0])
         if xin is not None:
             gamma, beta = (bn.weight, bn.bias) if bn.affine else (None, None)
-            x_amax = amax_of(xin)
+            x_amax = None if _is16(xin) else amax_of(xin)
             in_site = getattr(xin, '_dvd_site', None)           # xin is a BatchNorm+ReLU site's output (see _Site)
             out_site = _Site() if relu else None
             if alias and xin is x and not AB['no_alias']:
@@ -645,7 +777,7 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, alias=False):
 
 def xconv_supported(conv, x):
     k = conv.kernel_size
-    return (x.is_cuda and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and
+    return (x.is_cuda and x.dtype in ACT_DTYPES and conv.weight.dtype == torch.float32 and
             (conv.groups == 1 or (k[0] == 3 and conv.in_channels // conv.groups >= 32)) and
             k[0] == k[1] and k[0] % 2 == 1 and k[0] <= 11 and tuple(conv.stride) == (1, 1) and
             tuple(conv.dilation) == (1, 1) and tuple(conv.padding) == (k[0] // 2, k[0] // 2) and
@@ -661,7 +793,7 @@ def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False, alias=False, 
             y = _xconv(x, conv.weight, conv.bias, residual, relu_in, res_relu, conv.groups)
             return (y, x) if alias else y
         return _xconv(x, conv.weight, conv.bias, residual, relu_in, res_relu, conv.groups, alias, res_unmasked)
-    if x.is_cuda and x.dtype == torch.float32 and conv.groups == 1 and tuple(conv.stride) == (1, 1) and \
+    if x.is_cuda and x.dtype in ACT_DTYPES and conv.groups == 1 and tuple(conv.stride) == (1, 1) and \
             not AB['no_xconv']:
         raise RuntimeError('xconv2d: convolution %r is not covered by the HIP kernels' % (conv,))
     y = conv(F.relu(x) if relu_in else x)
@@ -680,13 +812,13 @@ class XConv2d(nn.Conv2d):
         if xconv_supported(self, x):
             return _xconv(x, self.weight, self.bias, None, False, False, self.groups)
         k, st = self.kernel_size, self.stride
-        if (x.is_cuda and x.dtype == torch.float32 and k == (3, 3) and st[0] == st[1] and st[0] > 1 and
+        if (x.is_cuda and x.dtype in ACT_DTYPES and k == (3, 3) and st[0] == st[1] and st[0] > 1 and
                 tuple(self.padding) == (1, 1) and tuple(self.dilation) == (1, 1) and
                 (self.groups == 1 or self.in_channels // self.groups >= 32) and not AB['no_xconv']):
             # out[i][j] of a stride-s 'same' 3x3 convolution is out1[s*i][s*j] of the stride-1 one
             y = _xconv(x, self.weight, self.bias, None, False, False, self.groups)
             return _subsample(y, st[0])
-        if (x.is_cuda and x.dtype == torch.float32 and self.kernel_size == (1, 1) and self.groups == 1 and
+        if (x.is_cuda and x.dtype in ACT_DTYPES and self.kernel_size == (1, 1) and self.groups == 1 and
                 tuple(self.padding) == (0, 0) and self.stride[0] == self.stride[1] and self.stride[0] > 1 and
                 not AB['no_xconv']):
             st = self.stride[0]

@@ -16,16 +16,18 @@
 // sums of the backward are reduced per block, written as partials and summed in a fixed order by
 // a second kernel (deterministic).
 
+#include "dvd_io.h"
 #include "dvd_split.h"
 
 namespace dvd {
 
 constexpr int kBnChunk = 4096;   // elements of one plane handled by a block (1024 float4)
 
-__global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+template <class T>
+__global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
-                                                         float eps, float* __restrict__ y, int C, int HW, int chunks,
+                                                         float eps, T* __restrict__ y, int C, int HW, int chunks,
                                                          int relu) {
   const int chunk = blockIdx.x % chunks;
   const long long pl = blockIdx.x / chunks;   // n * C + c
@@ -36,13 +38,13 @@ __global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const float* __restrict
   const int lo = chunk * kBnChunk, hi = min(HW, lo + kBnChunk);
   if ((HW & 3) == 0) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-      float4 v = *reinterpret_cast<const float4*>(x + base + i);
+      float4 v = ld4(x + base + i);
       v.x = __builtin_fmaf(v.x, s, b);
       v.y = __builtin_fmaf(v.y, s, b);
       v.z = __builtin_fmaf(v.z, s, b);
       v.w = __builtin_fmaf(v.w, s, b);
       if (res) {
-        const float4 r = *reinterpret_cast<const float4*>(res + base + i);
+        const float4 r = ld4(res + base + i);
         v.x += r.x;
         v.y += r.y;
         v.z += r.z;
@@ -54,22 +56,23 @@ __global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const float* __restrict
         v.z = fmaxf(v.z, 0.0f);
         v.w = fmaxf(v.w, 0.0f);
       }
-      *reinterpret_cast<float4*>(y + base + i) = v;
+      st4(y + base + i, v);
     }
   } else {
     for (int i = lo + threadIdx.x; i < hi; i += 256) {
-      float v = __builtin_fmaf(x[base + i], s, b);
-      if (res) v += res[base + i];
-      y[base + i] = relu ? fmaxf(v, 0.0f) : v;
+      float v = __builtin_fmaf(ldf(x + base + i), s, b);
+      if (res) v += ldf(res + base + i);
+      stf(y + base + i, relu ? fmaxf(v, 0.0f) : v);
     }
   }
 }
 
 // partial[(c * N + n) * chunks + chunk] = (sum g, sum g * (x - mean[c])) of the block
-__global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                         const float* __restrict__ x, const float* __restrict__ gamma,
+template <class T>
+__global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y,
+                                                         const T* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
-                                                         float eps, float* __restrict__ gx, float* __restrict__ gres,
+                                                         float eps, T* __restrict__ gx, T* __restrict__ gres,
                                                          float2* __restrict__ partial, int N, int C, int HW,
                                                          int chunks, int relu, float* __restrict__ pmax, int npb) {
   // npb > 1 (small planes, chunks == 1): a block owns the planes of npb consecutive images of one channel -- the deep
@@ -96,9 +99,9 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
   const long long base = ((long long)n * C + c) * HW;
   if ((HW & 3) == 0) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
-      float4 g = *reinterpret_cast<const float4*>(gy + base + i);
+      float4 g = ld4(gy + base + i);
       if (relu) {
-        const float4 o = *reinterpret_cast<const float4*>(y + base + i);
+        const float4 o = ld4(y + base + i);
         g.x = o.x > 0.0f ? g.x : 0.0f;
         g.y = o.y > 0.0f ? g.y : 0.0f;
         g.z = o.z > 0.0f ? g.z : 0.0f;
@@ -107,22 +110,22 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const float* __restrict
       sg += (g.x + g.y) + (g.z + g.w);
       gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
       if (x) {
-        const float4 v = *reinterpret_cast<const float4*>(x + base + i);
+        const float4 v = ld4(x + base + i);
         sgx = __builtin_fmaf(g.x, v.x - mu,
                              __builtin_fmaf(g.y, v.y - mu, __builtin_fmaf(g.z, v.z - mu, __builtin_fmaf(g.w, v.w - mu, sgx))));
       }
-      if (gres) *reinterpret_cast<float4*>(gres + base + i) = g;
-      if (gx) *reinterpret_cast<float4*>(gx + base + i) = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+      if (gres) st4(gres + base + i, g);
+      if (gx) st4(gx + base + i, make_float4(g.x * s, g.y * s, g.z * s, g.w * s));
     }
   } else {
     for (int i = lo + threadIdx.x; i < hi; i += 256) {
-      float g = gy[base + i];
-      if (relu) g = y[base + i] > 0.0f ? g : 0.0f;
+      float g = ldf(gy + base + i);
+      if (relu) g = ldf(y + base + i) > 0.0f ? g : 0.0f;
       sg += g;
       gmax = fmaxf(gmax, fabsf(g));
-      if (x) sgx = __builtin_fmaf(g, x[base + i] - mu, sgx);
-      if (gres) gres[base + i] = g;
-      if (gx) gx[base + i] = g * s;
+      if (x) sgx = __builtin_fmaf(g, ldf(x + base + i) - mu, sgx);
+      if (gres) stf(gres + base + i, g);
+      if (gx) stf(gx + base + i, g * s);
     }
   }
   }
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(64) void bnrelu_param_grad_kernel(const float2* __r
                                                                const float* __restrict__ var, float eps,
                                                                float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                                int C, int records, const float* __restrict__ pmax,
-                                                               float* g_amax) {
+                                                               float* g_amax, const float* __restrict__ out_scale) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   double sg = 0.0, sgx = 0.0;
   float m = 0.0f;
@@ -163,8 +166,10 @@ __global__ __launch_bounds__(64) void bnrelu_param_grad_kernel(const float2* __r
       sgx += v.y;
       if (pmax) m = fmaxf(m, pmax[(size_t)c * records + r]);
     }
-    if (gbeta) gbeta[c] = (float)sg;
-    if (ggamma) ggamma[c] = (float)(sgx / sqrt((double)var[c] + (double)eps));
+    // out_scale: fp16 gradient storage -- the sums carry the step's loss scale, the PARAMETER gradients must not
+    const double os = out_scale ? (double)out_scale[0] : 1.0;
+    if (gbeta) gbeta[c] = (float)(sg * os);
+    if (ggamma) ggamma[c] = (float)(sgx * os / sqrt((double)var[c] + (double)eps));
   }
   if (g_amax) wave_amax_to(m, g_amax);      // C / 64 waves: a handful of atomics
 }
@@ -205,13 +210,19 @@ extern "C" {
 
 int dvd_bnrelu_fwd(const float* x, const float* residual, const float* gamma, const float* beta, const float* mean,
                    const float* var, float eps, float* y, int N, int C, int HW, int relu, dvd_stream_t stream) {
+  return dvd_bnrelu_fwd_t(x, residual, gamma, beta, mean, var, eps, y, 0, N, C, HW, relu, stream);
+}
+
+int dvd_bnrelu_fwd_t(const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
+                     const float* var, float eps, void* y, int f16, int N, int C, int HW, int relu, dvd_stream_t stream) {
   DVD_REQUIRE(x && gamma && beta && mean && var && y, "bnrelu fwd: null pointer");
   DVD_REQUIRE(N > 0 && C > 0 && HW > 0, "bnrelu fwd: bad shape");
   const int chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
   const long long blocks = (long long)N * C * chunks;
   DVD_REQUIRE(blocks < (1LL << 31), "bnrelu fwd: grid too large");
-  hipLaunchKernelGGL(dvd::bnrelu_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     residual, gamma, beta, mean, var, eps, y, C, HW, chunks, relu);
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::bnrelu_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(x), static_cast<const T*>(residual),
+                                         gamma, beta, mean, var, eps, static_cast<T*>(y), C, HW, chunks, relu));
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -225,6 +236,14 @@ size_t dvd_bnrelu_bwd_workspace_bytes(int N, int C, int HW) {
 int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float* gamma, const float* mean,
                    const float* var, float eps, float* gx, float* g_residual, float* g_gamma, float* g_beta,
                    void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu, float* g_amax, dvd_stream_t stream) {
+  return dvd_bnrelu_bwd_t(gy, y, x, gamma, mean, var, eps, gx, g_residual, g_gamma, g_beta, workspace, workspace_bytes, 0, nullptr, N,
+                          C, HW, relu, g_amax, stream);
+}
+
+int dvd_bnrelu_bwd_t(const void* gy, const void* y, const void* x, const float* gamma, const float* mean, const float* var,
+                     float eps, void* gx, void* g_residual, float* g_gamma, float* g_beta, void* workspace,
+                     size_t workspace_bytes, int f16, const float* out_scale, int N, int C, int HW, int relu, float* g_amax,
+                     dvd_stream_t stream) {
   DVD_REQUIRE(gy && gamma && mean && var && workspace, "bnrelu bwd: null pointer");
   DVD_REQUIRE(x || !g_gamma, "bnrelu bwd: the gamma gradient needs the BatchNorm input");
   DVD_REQUIRE(!relu || y, "bnrelu bwd: the ReLU mask needs the forward output");
@@ -247,12 +266,14 @@ int dvd_bnrelu_bwd(const float* gy, const float* y, const float* x, const float*
   DVD_REQUIRE(blocks < (1LL << 31), "bnrelu bwd: grid too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* pmax = g_amax ? reinterpret_cast<float*>(static_cast<float2*>(workspace) + (size_t)N * C * chunks) : nullptr;
-  hipLaunchKernelGGL(dvd::bnrelu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, gy, y, x, gamma, mean, var, eps, gx,
-                     g_residual, static_cast<float2*>(workspace), N, C, HW, chunks, relu, pmax, npb);
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::bnrelu_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s,
+                                         static_cast<const T*>(gy), static_cast<const T*>(y), static_cast<const T*>(x), gamma, mean,
+                                         var, eps, static_cast<T*>(gx), static_cast<T*>(g_residual),
+                                         static_cast<float2*>(workspace), N, C, HW, chunks, relu, pmax, npb));
   DVD_LAUNCH_OK();
   if (g_gamma || g_beta || g_amax) {
     hipLaunchKernelGGL(dvd::bnrelu_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, s,
-                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, records, pmax, g_amax);
+                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, records, pmax, g_amax, out_scale);
     DVD_LAUNCH_OK();
   }
   return DVD_OK;

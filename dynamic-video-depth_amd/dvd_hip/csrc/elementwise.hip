@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g1, float sa,
                                                    const float* __restrict__ sa_ptr, const float* __restrict__ g2,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
-                                                   float b1, float b2, float eps, float step_size, float inv_sqrt_bc2) {
+                                                   float b1, float b2, float eps, float step_size, float inv_sqrt_bc2,
+                                                   const float* __restrict__ skip) {
+  if (skip && skip[0] != 0.0f) return;       // fp16 gradient overflow in this step (csrc/a16.hip): no update, moments untouched
   const float s = sa * (sa_ptr ? sa_ptr[0] : 1.0f);
   const long long n4 = n >> 2;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -190,6 +192,13 @@ int dvd_acc_reg(const float* sf0, const float* sf1, float coef, float* g_sf1, vo
 int dvd_adam_step(float* param, const float* grad1, float scale, const float* scale_ptr, const float* grad2,
                   float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2, float eps,
                   int step, dvd_stream_t stream) {
+  return dvd_adam_step_guarded(param, grad1, scale, scale_ptr, grad2, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, nullptr,
+                               stream);
+}
+
+int dvd_adam_step_guarded(float* param, const float* grad1, float scale, const float* scale_ptr, const float* grad2,
+                          float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2, float eps,
+                          int step, const float* skip_flag, dvd_stream_t stream) {
   using namespace dvd;
   DVD_REQUIRE(param && grad1 && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad argument");
   DVD_REQUIRE(al16(param) && al16(grad1) && al16(grad2) && al16(exp_avg) && al16(exp_avg_sq),
@@ -199,7 +208,7 @@ int dvd_adam_step(float* param, const float* grad1, float scale, const float* sc
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad1,
-                     scale, scale_ptr, grad2, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_sqrt_bc2);
+                     scale, scale_ptr, grad2, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_sqrt_bc2, skip_flag);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -23,7 +23,7 @@
 //     sums go to a workspace and are reduced in a fixed order by a second kernel
 //     (deterministic, no atomics).  Algorithmic bytes: 8 B per pixel-channel (read x, gy).
 
-#include "dvd_common.h"
+#include "dvd_io.h"
 
 namespace dvd {
 
@@ -33,9 +33,9 @@ constexpr int kWT_W = 64, kWT_H = 8;    // wgrad tile
 
 // y[n, g*8+co, :, :] = sum_{ci,ky,kx} x[n, g*8+ci, y+ky-1, x+kx-1] * w[g*8+co, ci, ky, kx]      (TRANSPOSED = false)
 // gx[n, g*8+ci, :, :] = sum_{co,ky,kx} gy[n, g*8+co, y+1-ky, x+1-kx] * w[g*8+co, ci, ky, kx]    (TRANSPOSED = true)
-template <bool TRANSPOSED>
-__global__ __launch_bounds__(256) void gconv3x3_c8_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                          float* __restrict__ out, int C, int H, int W, int tiles_x) {
+template <bool TRANSPOSED, class T>
+__global__ __launch_bounds__(256) void gconv3x3_c8_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                          T* __restrict__ out, int C, int H, int W, int tiles_x) {
   constexpr int IW = kFT_W + 2 + 2;   // +2 halo, +2 pad: row stride 68 floats (16-byte multiple)
   constexpr int IH = kFT_H + 2;
   __shared__ __attribute__((aligned(16))) float s_in[kCPG][IH][IW];
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_kernel(const float* __restric
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int x0 = tx * kFT_W, y0 = ty * kFT_H;
   const size_t plane = (size_t)H * W;
-  const float* inb = in + ((size_t)n * C + (size_t)g * kCPG) * plane;
-  float* outb = out + ((size_t)n * C + (size_t)g * kCPG) * plane;
+  const T* inb = in + ((size_t)n * C + (size_t)g * kCPG) * plane;
+  T* outb = out + ((size_t)n * C + (size_t)g * kCPG) * plane;
   // weights of the group -> LDS in [src][ky][kx][dst] order
   for (int i = threadIdx.x; i < kCPG * kCPG * 9; i += 256) {
     const int co = i / (kCPG * 9), r = i - co * (kCPG * 9), ci = r / 9, t = r - ci * 9, ky = t / 3, kx = t - ky * 3;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_kernel(const float* __restric
         const int i = i0 + u * 256;
         const int c = i / (IH * kRow), r = i - c * (IH * kRow), yy = r / kRow, xx = r - yy * kRow;
         const int gy = y0 + yy - 1, gx = x0 + xx - 1;
-        v[u] = (i < kTot && gy >= 0 && gy < H && gx >= 0 && gx < W) ? inb[(size_t)c * plane + (size_t)gy * W + gx] : 0.0f;
+        v[u] = (i < kTot && gy >= 0 && gy < H && gx >= 0 && gx < W) ? ldf(inb + (size_t)c * plane + (size_t)gy * W + gx) : 0.0f;
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
@@ -110,20 +110,21 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_kernel(const float* __restric
     const bool vec = ((W & 3) == 0) && (ox + 3 < W);
 #pragma unroll
     for (int d = 0; d < kCPG; ++d) {
-      float* dst = outb + (size_t)d * plane + (size_t)oy * W + ox;
+      T* dst = outb + (size_t)d * plane + (size_t)oy * W + ox;
       if (vec) {
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[d][0], acc[d][1], acc[d][2], acc[d][3]);
+        st4(dst, make_float4(acc[d][0], acc[d][1], acc[d][2], acc[d][3]));
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (ox + j < W) dst[j] = acc[d][j];
+          if (ox + j < W) stf(dst + j, acc[d][j]);
       }
     }
   }
 }
 
 // partial[tile][g][co][ci][9] = sum over the tile's pixels of gy[co, p] * x[ci, p + tap]
-__global__ __launch_bounds__(256) void gconv3x3_c8_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+template <class T>
+__global__ __launch_bounds__(256) void gconv3x3_c8_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                                 float* __restrict__ partial, int C, int H, int W,
                                                                 int tiles_x, int tiles_per_img, int G) {
   constexpr int IW = kWT_W + 2 + 2;
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_wgrad_kernel(const float* __r
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   const int x0 = tx * kWT_W, y0 = ty * kWT_H;
   const size_t plane = (size_t)H * W;
-  const float* xb = x + ((size_t)n * C + (size_t)g * kCPG) * plane;
-  const float* gb = gy + ((size_t)n * C + (size_t)g * kCPG) * plane;
+  const T* xb = x + ((size_t)n * C + (size_t)g * kCPG) * plane;
+  const T* gb = gy + ((size_t)n * C + (size_t)g * kCPG) * plane;
   {
     constexpr int kU = 8, kRow = kWT_W + 2, kTot = kCPG * IH * kRow;
     for (int i0 = threadIdx.x; i0 < kTot; i0 += 256 * kU) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_wgrad_kernel(const float* __r
         const int i = i0 + u * 256;
         const int c = i / (IH * kRow), r = i - c * (IH * kRow), yy = r / kRow, xx = r - yy * kRow;
         const int py = y0 + yy - 1, px = x0 + xx - 1;
-        v[u] = (i < kTot && py >= 0 && py < H && px >= 0 && px < W) ? xb[(size_t)c * plane + (size_t)py * W + px] : 0.0f;
+        v[u] = (i < kTot && py >= 0 && py < H && px >= 0 && px < W) ? ldf(xb + (size_t)c * plane + (size_t)py * W + px) : 0.0f;
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_wgrad_kernel(const float* __r
         const int i = i0 + u * 256;
         const int c = i / (kWT_H * kWT_W), r = i - c * (kWT_H * kWT_W), yy = r / kWT_W, xx = r - yy * kWT_W;
         const int py = y0 + yy, px = x0 + xx;
-        v[u] = (py < H && px < W) ? gb[(size_t)c * plane + (size_t)py * W + px] : 0.0f;
+        v[u] = (py < H && px < W) ? ldf(gb + (size_t)c * plane + (size_t)py * W + px) : 0.0f;
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(256) void gconv3x3_c8_wgrad_kernel(const float* __r
 
 // gw[i] (+)= sum over records r of partial[r][i], r ascending; i over G*64*9 weights
 __global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
-                                                                 int n_records, int n_weights, int accumulate) {
+                                                                 int n_records, int n_weights, int accumulate,
+                                                                 const float* __restrict__ out_scale) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_weights) return;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __
     s3 += partial[(size_t)(r + 3) * n_weights + i];
   }
   for (; r < n_records; ++r) s0 += partial[(size_t)r * n_weights + i];
-  const float s = (s0 + s1) + (s2 + s3);
+  const float s = ((s0 + s1) + (s2 + s3)) * (out_scale ? out_scale[0] : 1.0f);     // fp16 gradients carry the loss scale
   gw[i] = accumulate ? gw[i] + s : s;
 }
 
@@ -247,22 +249,35 @@ static int check_shape(int N, int C, int H, int W) {
 extern "C" {
 
 int dvd_gconv3x3_c8_fwd(const float* x, const float* w, float* y, int N, int C, int H, int W, dvd_stream_t stream) {
+  return dvd_gconv3x3_c8_fwd_t(x, w, y, 0, N, C, H, W, stream);
+}
+int dvd_gconv3x3_c8_bwd_data(const float* gy, const float* w, float* gx, int N, int C, int H, int W, dvd_stream_t stream) {
+  return dvd_gconv3x3_c8_bwd_data_t(gy, w, gx, 0, N, C, H, W, stream);
+}
+int dvd_gconv3x3_c8_bwd_weight(const float* x, const float* gy, float* gw, int accumulate, void* workspace,
+                               size_t workspace_bytes, int N, int C, int H, int W, dvd_stream_t stream) {
+  return dvd_gconv3x3_c8_bwd_weight_t(x, gy, gw, accumulate, workspace, workspace_bytes, 0, nullptr, N, C, H, W, stream);
+}
+
+int dvd_gconv3x3_c8_fwd_t(const void* x, const float* w, void* y, int f16, int N, int C, int H, int W, dvd_stream_t stream) {
   if (int e = dvd::check_shape(N, C, H, W)) return e;
   DVD_REQUIRE(x && w && y, "gconv fwd: null pointer");
   const int tx = (W + dvd::kFT_W - 1) / dvd::kFT_W, ty = (H + dvd::kFT_H - 1) / dvd::kFT_H;
-  hipLaunchKernelGGL(dvd::gconv3x3_c8_kernel<false>, dim3(tx * ty, C / dvd::kCPG, N), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, w, y, C, H, W, tx);
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL((dvd::gconv3x3_c8_kernel<false, T>), dim3(tx * ty, C / dvd::kCPG, N), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(x), w, static_cast<T*>(y), C, H, W,
+                                         tx));
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
 
-int dvd_gconv3x3_c8_bwd_data(const float* gy, const float* w, float* gx, int N, int C, int H, int W,
-                             dvd_stream_t stream) {
+int dvd_gconv3x3_c8_bwd_data_t(const void* gy, const float* w, void* gx, int f16, int N, int C, int H, int W,
+                               dvd_stream_t stream) {
   if (int e = dvd::check_shape(N, C, H, W)) return e;
   DVD_REQUIRE(gy && w && gx, "gconv bwd_data: null pointer");
   const int tx = (W + dvd::kFT_W - 1) / dvd::kFT_W, ty = (H + dvd::kFT_H - 1) / dvd::kFT_H;
-  hipLaunchKernelGGL(dvd::gconv3x3_c8_kernel<true>, dim3(tx * ty, C / dvd::kCPG, N), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), gy, w, gx, C, H, W, tx);
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL((dvd::gconv3x3_c8_kernel<true, T>), dim3(tx * ty, C / dvd::kCPG, N), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(gy), w, static_cast<T*>(gx), C, H,
+                                         W, tx));
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -273,8 +288,9 @@ size_t dvd_gconv3x3_c8_wgrad_workspace_bytes(int N, int C, int H, int W) {
   return tiles * N * (size_t)C * dvd::kCPG * 9 * sizeof(float);
 }
 
-int dvd_gconv3x3_c8_bwd_weight(const float* x, const float* gy, float* gw, int accumulate, void* workspace,
-                               size_t workspace_bytes, int N, int C, int H, int W, dvd_stream_t stream) {
+int dvd_gconv3x3_c8_bwd_weight_t(const void* x, const void* gy, float* gw, int accumulate, void* workspace,
+                                 size_t workspace_bytes, int f16, const float* out_scale, int N, int C, int H, int W,
+                                 dvd_stream_t stream) {
   if (int e = dvd::check_shape(N, C, H, W)) return e;
   DVD_REQUIRE(x && gy && gw && workspace, "gconv bwd_weight: null pointer");
   const size_t need = dvd_gconv3x3_c8_wgrad_workspace_bytes(N, C, H, W);
@@ -284,13 +300,14 @@ int dvd_gconv3x3_c8_bwd_weight(const float* x, const float* gy, float* gw, int a
   }
   const int tx = (W + dvd::kWT_W - 1) / dvd::kWT_W, ty = (H + dvd::kWT_H - 1) / dvd::kWT_H;
   const int G = C / dvd::kCPG;
-  hipLaunchKernelGGL(dvd::gconv3x3_c8_wgrad_kernel, dim3(tx * ty, G, N), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, gy, static_cast<float*>(workspace), C, H, W, tx, tx * ty, G);
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::gconv3x3_c8_wgrad_kernel<T>, dim3(tx * ty, G, N), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(x), static_cast<const T*>(gy),
+                                         static_cast<float*>(workspace), C, H, W, tx, tx * ty, G));
   DVD_LAUNCH_OK();
   const int n_weights = C * dvd::kCPG * 9;
   hipLaunchKernelGGL(dvd::gconv_wgrad_reduce_kernel, dim3((n_weights + 255) / 256), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<const float*>(workspace), gw, tx * ty * N, n_weights,
-                     accumulate);
+                     accumulate, out_scale);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

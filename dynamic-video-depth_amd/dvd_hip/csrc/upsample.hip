@@ -16,7 +16,7 @@
 // Backward: a GATHER over the (at most 3x3) output pixels that read an input pixel, so it is
 // deterministic and needs neither atomics nor a memset.
 
-#include "dvd_common.h"
+#include "dvd_io.h"
 
 namespace dvd {
 
@@ -48,7 +48,8 @@ __device__ __forceinline__ void src_index(const Axis& a, int dst, int& i0, int& 
 // first").  Round 2's kernel re-loaded and re-blended both source rows for every output row and ran at 1.7 TB/s.
 // Row index = plane * n_out_y + oy, 32-bit arithmetic only.
 constexpr int kRows = 8;
-__global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <class T>
+__global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                     Axis ay, Axis ax, unsigned rows) {
   const unsigned quads = (unsigned)(ax.n_out + 3) >> 2;
   const unsigned idx = blockIdx.x * 256 + threadIdx.x;          // (row group, quad), quads fastest: no idle lanes in
@@ -69,9 +70,9 @@ __global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float*
   unsigned c0 = 0xffffffffu, c1 = 0xffffffffu;   // source rows (plane * n_in_y + y) whose blends h0 / h1 hold
   float h0[4], h1[4];
   auto blend = [&](unsigned g, float (&h)[4]) {
-    const float* rp = x + (size_t)g * ax.n_in;
+    const T* rp = x + (size_t)g * ax.n_in;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = wx0[j] * rp[x0[j]] + wx1[j] * rp[x1[j]];
+    for (int j = 0; j < 4; ++j) h[j] = wx0[j] * ldf(rp + x0[j]) + wx1[j] * ldf(rp + x1[j]);
   };
 #pragma unroll 2
   for (int k = 0; k < kRows; ++k) {
@@ -102,13 +103,13 @@ __global__ __launch_bounds__(256) void upsample_bilinear_fwd_kernel(const float*
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = wy0 * h0[j] + wy1 * h1[j];
-    float* dst = y + (size_t)r * ax.n_out + q * 4;
+    T* dst = y + (size_t)r * ax.n_out + q * 4;
     if (vec) {
-      *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+      st4(dst, make_float4(o[0], o[1], o[2], o[3]));
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if ((int)q * 4 + j < ax.n_out) dst[j] = o[j];
+        if ((int)q * 4 + j < ax.n_out) stf(dst + j, o[j]);
     }
     if (++oy == ay.n_out) {
       oy = 0;
@@ -147,8 +148,8 @@ __device__ __forceinline__ void axis_weights(const Axis& a, int i, int lo, float
 // per thread; row index = plane * n_in_y + iy.  (General gather: any factor up to 3, any width.  The decoder's x2 maps
 // take upsample_bilinear_bwd_sep_kernel below.)
 constexpr int kBRows = 4;
-template <int kCand>
-__global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+template <int kCand, class T>
+__global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx,
                                                                     Axis ay, Axis ax, unsigned rows) {
   const unsigned idx = blockIdx.x * 256 + threadIdx.x;          // (row group, input column), columns fastest
   const unsigned rg = idx / (unsigned)ax.n_in;
@@ -168,19 +169,19 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float*
     const int ylo = dst_lo(ay, iy);
     float wy[kCand];
     axis_weights<kCand>(ay, iy, ylo, wy);
-    const float* g = gy + (size_t)p * ay.n_out * ax.n_out;
+    const T* g = gy + (size_t)p * ay.n_out * ax.n_out;
     float acc = 0.0f;
 #pragma unroll
     for (int a = 0; a < kCand; ++a) {
       if (wy[a] == 0.0f) continue;
-      const float* grow = g + (size_t)(ylo + a) * ax.n_out + xlo;
+      const T* grow = g + (size_t)(ylo + a) * ax.n_out + xlo;
       float row = 0.0f;
 #pragma unroll
       for (int b = 0; b < kCand; ++b)
-        if (wx[b] != 0.0f) row = __builtin_fmaf(wx[b], grow[b], row);
+        if (wx[b] != 0.0f) row = __builtin_fmaf(wx[b], ldf(grow + b), row);
       acc = __builtin_fmaf(wy[a], row, acc);
     }
-    gx[(size_t)r * ax.n_in + ix] = acc;
+    stf(gx + (size_t)r * ax.n_in + ix, acc);
   }
 }
 
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float*
 // the walk has passed its last reader.  Per input element ~3.3 16-byte loads instead of the gather's 16 scalar loads;
 // the summation order (output rows ascending, columns ascending inside) is fixed: deterministic, no atomics, no memset.
 constexpr int kSegRows = 16, kSepCand = 12;
-__global__ __launch_bounds__(256) void upsample_bilinear_bwd_sep_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+template <class T>
+__global__ __launch_bounds__(256) void upsample_bilinear_bwd_sep_kernel(const T* __restrict__ gy, T* __restrict__ gx,
                                                                         Axis ay, Axis ax, unsigned segs, unsigned nseg) {
   const unsigned pairs = (unsigned)(ax.n_in + 1) >> 1;
   const unsigned idx = blockIdx.x * 256 + threadIdx.x;          // (plane, segment, column pair), pairs fastest
@@ -217,8 +219,8 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_sep_kernel(const fl
     wa[k] = in ? (i0 == ix ? w0 : 0.0f) + (i1 == ix ? w1 : 0.0f) : 0.0f;
     wb[k] = in && two ? (i0 == ix + 1 ? w0 : 0.0f) + (i1 == ix + 1 ? w1 : 0.0f) : 0.0f;
   }
-  const float* g = gy + (size_t)p * ay.n_out * ax.n_out + a0;
-  float* out = gx + (size_t)p * ay.n_in * ax.n_in + ix;
+  const T* g = gy + (size_t)p * ay.n_out * ax.n_out + a0;
+  T* out = gx + (size_t)p * ay.n_in * ax.n_in + ix;
   const bool ld0 = a0 < ax.n_out, ld1 = a0 + 4 < ax.n_out, ld2 = a0 + 8 < ax.n_out;   // W_out % 4 == 0: all or nothing
   int oy = dst_lo(ay, m0);
   int A;                                   // the input row acc_a belongs to (acc_b: A + 1)
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_sep_kernel(const fl
   float a_a = 0.0f, a_b = 0.0f, b_a = 0.0f, b_b = 0.0f;      // [column a / b]_[row A / A + 1]
   auto flush = [&]() {
     if (A >= m0 && A < m1) {
-      out[(size_t)A * ax.n_in] = a_a;
-      if (two) out[(size_t)A * ax.n_in + 1] = b_a;
+      stf(out + (size_t)A * ax.n_in, a_a);
+      if (two) stf(out + (size_t)A * ax.n_in + 1, b_a);
     }
     a_a = a_b;
     b_a = b_b;
@@ -241,10 +243,10 @@ __global__ __launch_bounds__(256) void upsample_bilinear_bwd_sep_kernel(const fl
   const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   float4 n0 = z, n1 = z, n2 = z;           // the NEXT output row's three quads: requested one row ahead of their use
   auto request = [&](int r) {
-    const float4* row = reinterpret_cast<const float4*>(g + (size_t)r * ax.n_out);
-    n0 = ld0 ? row[0] : z;
-    n1 = ld1 ? row[1] : z;
-    n2 = ld2 ? row[2] : z;
+    const T* row = g + (size_t)r * ax.n_out;
+    n0 = ld0 ? ld4(row) : z;
+    n1 = ld1 ? ld4(row + 4) : z;
+    n2 = ld2 ? ld4(row + 8) : z;
   };
   if (oy < ay.n_out) request(oy);
   for (; oy < ay.n_out; ++oy) {
@@ -293,6 +295,11 @@ extern "C" {
 
 int dvd_upsample_bilinear_fwd(const float* x, float* y, long long planes, int H_in, int W_in, int H_out, int W_out,
                               int align_corners, dvd_stream_t stream) {
+  return dvd_upsample_bilinear_fwd_t(x, y, 0, planes, H_in, W_in, H_out, W_out, align_corners, stream);
+}
+
+int dvd_upsample_bilinear_fwd_t(const void* x, void* y, int f16, long long planes, int H_in, int W_in, int H_out, int W_out,
+                                int align_corners, dvd_stream_t stream) {
   DVD_REQUIRE(x && y, "upsample fwd: null pointer");
   DVD_REQUIRE(planes > 0 && H_in > 0 && W_in > 0 && H_out > 0 && W_out > 0, "upsample fwd: bad shape");
   const dvd::Axis ay = dvd::make_axis(H_in, H_out, align_corners), ax = dvd::make_axis(W_in, W_out, align_corners);
@@ -301,14 +308,20 @@ int dvd_upsample_bilinear_fwd(const float* x, float* y, long long planes, int H_
   const unsigned quads = (unsigned)(W_out + 3) / 4;
   const long long total = (rows + dvd::kRows - 1) / dvd::kRows * quads;
   DVD_REQUIRE(total < (1LL << 32) - 256, "upsample fwd: too large");
-  hipLaunchKernelGGL(dvd::upsample_bilinear_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, y, ay, ax, (unsigned)rows);
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::upsample_bilinear_fwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(x), static_cast<T*>(y), ay, ax,
+                                         (unsigned)rows));
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
 
 int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int H_in, int W_in, int H_out, int W_out,
                               int align_corners, dvd_stream_t stream) {
+  return dvd_upsample_bilinear_bwd_t(gy, gx, 0, planes, H_in, W_in, H_out, W_out, align_corners, stream);
+}
+
+int dvd_upsample_bilinear_bwd_t(const void* gy, void* gx, int f16, long long planes, int H_in, int W_in, int H_out, int W_out,
+                                int align_corners, dvd_stream_t stream) {
   DVD_REQUIRE(gy && gx, "upsample bwd: null pointer");
   DVD_REQUIRE(planes > 0 && H_in > 0 && W_in > 0 && H_out > 0 && W_out > 0, "upsample bwd: bad shape");
   const dvd::Axis ay = dvd::make_axis(H_in, H_out, align_corners), ax = dvd::make_axis(W_in, W_out, align_corners);
@@ -325,16 +338,19 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
     const long long nseg = (H_in + dvd::kSegRows - 1) / dvd::kSegRows, segs = planes * nseg;
     const long long threads = segs * ((W_in + 1) / 2);
     DVD_REQUIRE(threads < (1LL << 32) - 256, "upsample bwd: too large");
-    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_sep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, gy, gx,
-                       ay, ax, (unsigned)segs, (unsigned)nseg);
+    DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_sep_kernel<T>, dim3((unsigned)((threads + 255) / 256)),
+                                           dim3(256), 0, s, static_cast<const T*>(gy), static_cast<T*>(gx), ay, ax, (unsigned)segs,
+                                           (unsigned)nseg));
     DVD_LAUNCH_OK();
     return DVD_OK;
   }
   const dim3 grid((unsigned)((total + 255) / 256));
   if (covered(ay, 6, 0.4f) && covered(ax, 6, 0.4f))
-    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<6>, grid, dim3(256), 0, s, gy, gx, ay, ax, (unsigned)rows);
+    DVD_DISPATCH_T(f16, hipLaunchKernelGGL((dvd::upsample_bilinear_bwd_kernel<6, T>), grid, dim3(256), 0, s,
+                                           static_cast<const T*>(gy), static_cast<T*>(gx), ay, ax, (unsigned)rows));
   else
-    hipLaunchKernelGGL(dvd::upsample_bilinear_bwd_kernel<8>, grid, dim3(256), 0, s, gy, gx, ay, ax, (unsigned)rows);
+    DVD_DISPATCH_T(f16, hipLaunchKernelGGL((dvd::upsample_bilinear_bwd_kernel<8, T>), grid, dim3(256), 0, s,
+                                           static_cast<const T*>(gy), static_cast<T*>(gx), ay, ax, (unsigned)rows));
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -28,10 +28,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static int g_w1_variant = 0;      // test / A-B hook (dvd_xwgrad_select): 0 auto, 1 always the 128 x 128 blocks
 
 struct Wg3Args {
-  const float* __restrict__ x;
-  const float* __restrict__ gy;
-  const float* __restrict__ x_amax;   // device scalars: max|x|, max|gy| (or upper bounds) of the whole tensors
+  const void* __restrict__ x;         // float, or _Float16 in the H16 kernels (fp16 activation storage, BASELINE configs[4])
+  const void* __restrict__ gy;
+  const float* __restrict__ x_amax;   // device scalars: max|x|, max|gy| (or upper bounds) of the whole tensors (fp32 kernels)
   const float* __restrict__ g_amax;
+  const float* __restrict__ out_scale;  // H16: device scalar the result is multiplied by (1 / loss scale of the fp16 gradients), or null
   float* __restrict__ partial;   // [S][9][Cout][Cin]
   int N, Cin, Cout, H, W;        // Cin / Cout per group
   int G, nco;                    // groups, output-channel blocks per group
@@ -39,19 +40,87 @@ struct Wg3Args {
   int relu_in;
 };
 
+
+// ---- fp16 operands (H16 kernels): both tensors are stored as _Float16 and ARE the matrix operands -- one term each, no scale,
+// no split: the staging is a copy and a product is ONE MFMA instead of three.  The fp16 gradients carry the step's loss scale;
+// the kernels multiply their result by *out_scale (its inverse).
+template <bool H16>
+struct Quad {
+  typedef float4 type;
+};
+template <>
+struct Quad<true> {
+  typedef uint2 type;
+};
+__device__ __forceinline__ unsigned relu_h2(unsigned v) {
+  const f16x2 z = {(_Float16)0.0f, (_Float16)0.0f};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, v), z));
+}
+// elements p[px .. px + 3] of a row of n elements (zero outside [0, n)); vec: the quad is inside the row and 4-element aligned
+template <bool H16>
+__device__ __forceinline__ typename Quad<H16>::type load_quad(const void* row, int px, int n, bool vec, bool relu) {
+  if constexpr (H16) {
+    const unsigned short* p = static_cast<const unsigned short*>(row);
+    uint2 v = make_uint2(0u, 0u);
+    if (vec) {
+      v = *reinterpret_cast<const uint2*>(p + px);
+    } else {
+      unsigned e0 = (px >= 0 && px < n) ? p[px] : 0u, e1 = (px + 1 >= 0 && px + 1 < n) ? p[px + 1] : 0u;
+      unsigned e2 = (px + 2 >= 0 && px + 2 < n) ? p[px + 2] : 0u, e3 = (px + 3 >= 0 && px + 3 < n) ? p[px + 3] : 0u;
+      v = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+    }
+    if (relu) v = make_uint2(relu_h2(v.x), relu_h2(v.y));
+    return v;
+  } else {
+    const float* p = static_cast<const float*>(row);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec) {
+      v = *reinterpret_cast<const float4*>(p + px);
+    } else {
+      if (px >= 0 && px < n) v.x = p[px];
+      if (px + 1 >= 0 && px + 1 < n) v.y = p[px + 1];
+      if (px + 2 >= 0 && px + 2 < n) v.z = p[px + 2];
+      if (px + 3 >= 0 && px + 3 < n) v.w = p[px + 3];
+    }
+    if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    return v;
+  }
+}
+template <bool H16>
+__device__ __forceinline__ typename Quad<H16>::type zero_quad() {
+  if constexpr (H16) return make_uint2(0u, 0u);
+  else return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// split (fp32) or copy (fp16) a staged quad into the LDS row(s): 8 bytes per term
+template <bool H16>
+__device__ __forceinline__ void store_quad(unsigned char* dst, int tstride, const typename Quad<H16>::type& q, float sc) {
+  if constexpr (H16) {
+    *reinterpret_cast<uint2*>(dst) = q;
+  } else {
+    unsigned h0, l0, h1, l1;
+    split_pair_f16(q.x * sc, q.y * sc, h0, l0);
+    split_pair_f16(q.z * sc, q.w * sc, h1, l1);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(l0, l1);
+  }
+}
+
 constexpr int kW3Strip = 64;                  // pixels per row step
 constexpr int kW3GPitch = 128 + 16;           // bytes per gy row in LDS (64 fp16 + pad: conflict-free 16-byte reads across rows)
 constexpr int kW3XPitch = 160 + 16;           // bytes per x row in LDS (80 fp16 + pad)
 constexpr int kW3CB = 64;                     // channels per block, both operands
 constexpr int kW3NT = 768;                    // 12 waves: 2 x 2 tile pairs x 3 kernel rows
 
+template <bool H16>
 __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
+  constexpr int EB = H16 ? 2 : 4;                // bytes per element in HBM
+  constexpr int NTERM = H16 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   // sG [buffer 2][term 2][co 64][kW3GPitch], sX [term 2][slot 4][ci 64][kW3XPitch] (slot-major: a channel stride of
   // 44 dwords keeps the 16-byte fragment reads of 32 channels conflict free; 4 x 44 did not)
   unsigned char* sG = smem3;
   unsigned char* sX = smem3 + 2 * 2 * kW3CB * kW3GPitch;
-  const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
+  const float sx = H16 ? 1.0f : pow2_scale(a.x_amax[0]), sg = H16 ? 1.0f : pow2_scale(a.g_amax[0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ky = wave % 3, pn = (wave / 3) & 1, pm = wave / 6;
   const int grp = blockIdx.z / a.nco;                      // group of a grouped convolution (0 for dense)
@@ -62,54 +131,39 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   // staging assignment: a thread stages 4 consecutive pixels of one channel row.
   //   gy row: 64 channels x 16 quads = 1024 quads;  x row: 64 channels x 20 quads = 1280 quads  -> 3 per thread
   constexpr int GQ = kW3CB * 16, XQ = kW3CB * 20, NQ = (GQ + XQ + kW3NT - 1) / kW3NT;
-  float4 stg[NQ];
+  typename Quad<H16>::type stg[NQ];
+  const bool wvec = (a.W & 3) == 0;
   auto stage_load = [&](int n, int c0, int r, bool with_g) {   // gy row r (if with_g) and x row r + 1
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int q = i * kW3NT + tid;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      typename Quad<H16>::type v = zero_quad<H16>();
       if (q < GQ) {
         const int ch = q >> 4, px = c0 + ((q & 15) << 2);
         if (with_g && (co0 + ch) < a.Cout && r < a.H) {
-          const float* p = a.gy + (((size_t)n * a.G + grp) * a.Cout + co0 + ch) * plane + (size_t)r * a.W;
-          if (px + 3 < a.W && ((a.W & 3) == 0)) {
-            v = *reinterpret_cast<const float4*>(p + px);
-          } else {
-            if (px < a.W) v.x = p[px];
-            if (px + 1 < a.W) v.y = p[px + 1];
-            if (px + 2 < a.W) v.z = p[px + 2];
-            if (px + 3 < a.W) v.w = p[px + 3];
-          }
+          const unsigned char* p = static_cast<const unsigned char*>(a.gy) +
+                                   ((((size_t)n * a.G + grp) * a.Cout + co0 + ch) * plane + (size_t)r * a.W) * EB;
+          v = load_quad<H16>(p, px, a.W, wvec && px + 3 < a.W, false);
         }
       } else if (q < GQ + XQ) {
         const int qq = q - GQ;
         const int ch = qq / 20, px = c0 - 8 + ((qq - ch * 20) << 2);
         const int row = r + 1;
         if ((ci0 + ch) < a.Cin && row >= 0 && row < a.H) {
-          const float* p = a.x + (((size_t)n * a.G + grp) * a.Cin + ci0 + ch) * plane + (size_t)row * a.W;
-          if (px >= 0 && px + 3 < a.W && ((a.W & 3) == 0)) {
-            v = *reinterpret_cast<const float4*>(p + px);
-          } else {
-            if (px >= 0 && px < a.W) v.x = p[px];
-            if (px + 1 >= 0 && px + 1 < a.W) v.y = p[px + 1];
-            if (px + 2 >= 0 && px + 2 < a.W) v.z = p[px + 2];
-            if (px + 3 >= 0 && px + 3 < a.W) v.w = p[px + 3];
-          }
-          if (a.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+          const unsigned char* p = static_cast<const unsigned char*>(a.x) +
+                                   ((((size_t)n * a.G + grp) * a.Cin + ci0 + ch) * plane + (size_t)row * a.W) * EB;
+          v = load_quad<H16>(p, px, a.W, wvec && px >= 0 && px + 3 < a.W, a.relu_in != 0);
         }
       }
       stg[i] = v;
     }
   };
-  auto stage_store = [&](int xslot, int gbuf) {      // split and write: 4 pixels = 8 bytes per term
+  auto stage_store = [&](int xslot, int gbuf) {      // split (fp32) or copy (fp16) and write: 4 pixels = 8 bytes per term
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int q = i * kW3NT + tid;
       if (q >= GQ + XQ) continue;
-      unsigned h0, l0, h1, l1;
       const float sc = q < GQ ? sg : sx;
-      split_pair_f16(stg[i].x * sc, stg[i].y * sc, h0, l0);
-      split_pair_f16(stg[i].z * sc, stg[i].w * sc, h1, l1);
       unsigned char* dst;
       int tstride;
       if (q < GQ) {
@@ -120,8 +174,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
         dst = sX + (xslot * kW3CB + ch) * kW3XPitch + ((qq - ch * 20) << 3);
         tstride = kW3CB * 4 * kW3XPitch;
       }
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(l0, l1);
+      store_quad<H16>(dst, tstride, stg[i], sc);
     }
   };
 
@@ -159,9 +212,9 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       const unsigned char* gr = ga + (r & 1) * (2 * kW3CB * kW3GPitch);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                // four K steps of 16 pixels
-        f16x8 A[2], B[3][2];
+        f16x8 A[NTERM], B[3][NTERM];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTERM; ++t) {
           A[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(gr + t * (kW3CB * kW3GPitch) + s * 32));
           const unsigned char* xc = xr + t * (kW3CB * 4 * kW3XPitch) + s * 32;
           const u32x4 cur = *reinterpret_cast<const u32x4*>(xc);
@@ -177,8 +230,10 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
 #define DVD_W3TERM(SA, SB)                                                                                  \
   _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[kx] =                                                \
       __builtin_amdgcn_mfma_f32_32x32x16_f16(A[SA], B[kx][SB], acc[kx], 0, 0, 0);
-        DVD_W3TERM(1, 0)
-        DVD_W3TERM(0, 1)
+        if constexpr (!H16) {
+          DVD_W3TERM(NTERM - 1, 0)
+          DVD_W3TERM(0, NTERM - 1)
+        }
         DVD_W3TERM(0, 0)
 #undef DVD_W3TERM
       }
@@ -186,7 +241,7 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   }
   // partial[s][tap][G * Cout][Cin]
   float* dst = a.partial + (size_t)blockIdx.x * 9 * a.G * a.Cout * a.Cin;
-  const float unscale = 1.0f / (sx * sg);          // exact power of two
+  const float unscale = H16 ? (a.out_scale ? a.out_scale[0] : 1.0f) : 1.0f / (sx * sg);          // fp32: exact power of two
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) {
     const int tap = ky * 3 + kx;
@@ -227,11 +282,14 @@ constexpr int kW1Pitch = 64 + 16;             // bytes per channel row in LDS (3
 constexpr int kW1CB = 128;
 constexpr int kW1NT = 512;
 
+template <bool H16>
 __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
+  constexpr int EB = H16 ? 2 : 4;
+  constexpr int NTERM = H16 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   unsigned char* sG = smem3;                               // [term 2][co 128][kW1Pitch]
   unsigned char* sX = smem3 + 2 * kW1CB * kW1Pitch;        // [term 2][ci 128][kW1Pitch]
-  const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
+  const float sx = H16 ? 1.0f : pow2_scale(a.x_amax[0]), sg = H16 ? 1.0f : pow2_scale(a.g_amax[0]);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pn = wave & 1, pm = wave >> 1;
   const int co0 = blockIdx.z * kW1CB, ci0 = blockIdx.y * kW1CB;
@@ -240,7 +298,8 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
   const int cpi = (HW + kW1Chunk - 1) / kW1Chunk;          // chunks per image
   const int items = a.N * cpi;
   // staging: 128 channels x 8 quads per operand = 2048 quads -> 4 per thread (2 gy + 2 x)
-  float4 stg[4];
+  typename Quad<H16>::type stg[4];
+  const bool hvec = (HW & 3) == 0;
   auto stage_load = [&](int item) {
     const int n = item / cpi, p0 = (item - n * cpi) * kW1Chunk;
 #pragma unroll
@@ -249,18 +308,10 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
       const int ch = q >> 3, px = p0 + ((q & 7) << 2);
       const bool isx = i >= 2;
       const int C = isx ? a.Cin : a.Cout, c = (isx ? ci0 : co0) + ch;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      typename Quad<H16>::type v = zero_quad<H16>();
       if (c < C) {
-        const float* p = (isx ? a.x : a.gy) + ((size_t)n * C + c) * plane;
-        if (px + 3 < HW && ((HW & 3) == 0)) {
-          v = *reinterpret_cast<const float4*>(p + px);
-        } else {
-          if (px < HW) v.x = p[px];
-          if (px + 1 < HW) v.y = p[px + 1];
-          if (px + 2 < HW) v.z = p[px + 2];
-          if (px + 3 < HW) v.w = p[px + 3];
-        }
-        if (isx && a.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        const unsigned char* p = static_cast<const unsigned char*>(isx ? a.x : a.gy) + ((size_t)n * C + c) * plane * EB;
+        v = load_quad<H16>(p, px, HW, hvec && px + 3 < HW, isx && a.relu_in);
       }
       stg[i] = v;
     }
@@ -269,14 +320,10 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = (i & 1) * kW1NT + tid;
-      unsigned h0, l0, h1, l1;
       const float sc = i >= 2 ? sx : sg;
-      split_pair_f16(stg[i].x * sc, stg[i].y * sc, h0, l0);
-      split_pair_f16(stg[i].z * sc, stg[i].w * sc, h1, l1);
       unsigned char* dst = (i >= 2 ? sX : sG) + (q >> 3) * kW1Pitch + ((q & 7) << 3);
       constexpr int tstride = kW1CB * kW1Pitch;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(l0, l1);
+      store_quad<H16>(dst, tstride, stg[i], sc);
     }
   };
   f32x16 acc[2];
@@ -295,9 +342,9 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
     if (item + a.S < items) stage_load(item + a.S);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      f16x8 A[2], B[2][2];
+      f16x8 A[NTERM], B[2][NTERM];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NTERM; ++t) {
         A[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ga + t * (kW1CB * kW1Pitch) + s * 32));
         B[0][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(xa + t * (kW1CB * kW1Pitch) + s * 32));
         B[1][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(xa + 32 * kW1Pitch + t * (kW1CB * kW1Pitch) + s * 32));
@@ -305,14 +352,16 @@ __global__ __launch_bounds__(kW1NT, 2) void xwgrad1s_kernel(const Wg3Args a) {
 #define DVD_W1TERM(SA, SB)                                                                                \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[j] =                                                  \
       __builtin_amdgcn_mfma_f32_32x32x16_f16(A[SA], B[j][SB], acc[j], 0, 0, 0);
-      DVD_W1TERM(1, 0)
-      DVD_W1TERM(0, 1)
+      if constexpr (!H16) {
+        DVD_W1TERM(NTERM - 1, 0)
+        DVD_W1TERM(0, NTERM - 1)
+      }
       DVD_W1TERM(0, 0)
 #undef DVD_W1TERM
     }
   }
   float* dst = a.partial + (size_t)blockIdx.x * a.Cout * a.Cin;       // partial[s][co][ci]
-  const float unscale = 1.0f / (sx * sg);
+  const float unscale = H16 ? (a.out_scale ? a.out_scale[0] : 1.0f) : 1.0f / (sx * sg);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -335,7 +384,10 @@ constexpr int kWbTerm = 256 * kWbPitch;            // one split term of one oper
 constexpr int kWbBuf = 2 * 2 * kWbTerm;            // gy terms, then x terms
 constexpr size_t kWbLds = 2 * (size_t)kWbBuf;      // double buffered: 98 304
 
+template <bool H16>
 __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
+  constexpr int EB = H16 ? 2 : 4;
+  constexpr int NTERM = H16 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 1, wc = w & 1;
@@ -347,7 +399,7 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
   const long long items = (long long)a.N * cpi;
   const long long t0 = items * s / a.S, t1 = items * (s + 1) / a.S;
   const int n_it = (int)(t1 - t0);
-  const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
+  const float sx = H16 ? 1.0f : pow2_scale(a.x_amax[0]), sg = H16 ? 1.0f : pow2_scale(a.g_amax[0]);
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -356,8 +408,9 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
     for (int c = 0; c < 4; ++c) acc[r][c] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread; q = i * 512 + tid, row = q >> 2 (0..255 gy, 256..511 x)
-  float4 sg0[4], sg1[4];
-  auto stage_load = [&](int it, float4 (&st)[4]) {
+  typedef typename Quad<H16>::type QT;
+  QT sg0[4], sg1[4];
+  auto stage_load = [&](int it, QT (&st)[4]) {
     const long long item = t0 + it;
     const int n = (int)(item / cpi), p0 = (int)(item - (long long)n * cpi) * 16;
 #pragma unroll
@@ -367,25 +420,21 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
       const int r = row & 255;
       const int C = isx ? a.Cin : a.Cout, c = (isx ? ci0 : co0) + r;
       const int px = p0 + quad * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      QT v = zero_quad<H16>();
       if (c < C && px < HW)                                      // HW % 4 == 0 (host): a quad is inside or outside as a whole
-        v = *reinterpret_cast<const float4*>((isx ? a.x : a.gy) + ((size_t)n * C + c) * plane + px);
-      if (isx && a.relu_in) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        v = load_quad<H16>(static_cast<const unsigned char*>(isx ? a.x : a.gy) + ((size_t)n * C + c) * plane * EB, px, HW, true,
+                           isx && a.relu_in);
       st[i] = v;
     }
   };
-  auto stage_store = [&](int buf, const float4 (&st)[4]) {
+  auto stage_store = [&](int buf, const QT (&st)[4]) {
     unsigned char* base = smem3 + buf * kWbBuf;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = i * 128 + (tid >> 2), quad = tid & 3;
-      unsigned h0, l0, h1, l1;
       const float sc = i >= 2 ? sx : sg;
-      split_pair_f16(st[i].x * sc, st[i].y * sc, h0, l0);
-      split_pair_f16(st[i].z * sc, st[i].w * sc, h1, l1);
       unsigned char* dst = base + (i >= 2 ? 2 * kWbTerm : 0) + (row & 255) * kWbPitch + quad * 8;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + kWbTerm) = make_uint2(l0, l1);
+      store_quad<H16>(dst, kWbTerm, st[i], sc);
     }
   };
   // Fragments of chunk it + 1 are read from LDS DURING the MFMAs of chunk it (the rolling prefetch of csrc/xconv.hip: one
@@ -395,18 +444,18 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
   // during step it - 2 (into the buffer whose fragments were read during step it - 3), read during step it - 1.
   const unsigned char* gb0 = smem3 + (64 * wr + i32) * kWbPitch + hh * 16;
   const unsigned char* hb0 = smem3 + 2 * kWbTerm + (128 * wc + i32) * kWbPitch + hh * 16;
-  u32x4 Bf[4][2];
-  auto read_a = [&](int buf, u32x4 (&A)[2][2]) {
+  u32x4 Bf[4][NTERM];
+  auto read_a = [&](int buf, u32x4 (&A)[2][NTERM]) {
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) A[r][t] = *reinterpret_cast<const u32x4*>(gb0 + buf * kWbBuf + t * kWbTerm + r * 32 * kWbPitch);
+      for (int t = 0; t < NTERM; ++t) A[r][t] = *reinterpret_cast<const u32x4*>(gb0 + buf * kWbBuf + t * kWbTerm + r * 32 * kWbPitch);
   };
   auto read_b = [&](int buf, int c) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) Bf[c][t] = *reinterpret_cast<const u32x4*>(hb0 + buf * kWbBuf + t * kWbTerm + c * 32 * kWbPitch);
+    for (int t = 0; t < NTERM; ++t) Bf[c][t] = *reinterpret_cast<const u32x4*>(hb0 + buf * kWbBuf + t * kWbTerm + c * 32 * kWbPitch);
   };
-  auto mfma_roll = [&](int nbuf, const u32x4 (&A)[2][2], u32x4 (&An)[2][2]) {    // MFMAs on (A, Bf); next fragments from nbuf
+  auto mfma_roll = [&](int nbuf, const u32x4 (&A)[2][NTERM], u32x4 (&An)[2][NTERM]) {    // MFMAs on (A, Bf); next fragments from nbuf
     read_a(nbuf, An);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -414,8 +463,10 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
 #define DVD_WB_TERM(SA, SB)                                                                                   \
   _Pragma("unroll") for (int r = 0; r < 2; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(           \
       __builtin_bit_cast(f16x8, A[r][SA]), __builtin_bit_cast(f16x8, Bf[c][SB]), acc[r][c], 0, 0, 0);
-      DVD_WB_TERM(1, 0)
-      DVD_WB_TERM(0, 1)
+      if constexpr (!H16) {
+        DVD_WB_TERM(NTERM - 1, 0)
+        DVD_WB_TERM(0, NTERM - 1)
+      }
       DVD_WB_TERM(0, 0)
 #undef DVD_WB_TERM
       __builtin_amdgcn_sched_barrier(0);           // the reload stays behind this column tile's MFMAs
@@ -433,7 +484,7 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
     stage_store(1, sg0);
     stage_load(clamp(2), sg0);
     __syncthreads();
-    u32x4 A0[2][2], A1[2][2];
+    u32x4 A0[2][NTERM], A1[2][NTERM];
     read_a(0, A0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) read_b(0, c);
@@ -451,7 +502,7 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
     }
   }
   float* dst = a.partial + (size_t)s * a.Cout * a.Cin;       // partial[s][co][ci]
-  const float unscale = 1.0f / (sx * sg);
+  const float unscale = H16 ? (a.out_scale ? a.out_scale[0] : 1.0f) : 1.0f / (sx * sg);
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
@@ -523,11 +574,11 @@ size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W, int g
   return (size_t)p.S * 9 * Cout * (Cin / groups) * sizeof(float);
 }
 
-int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
-                size_t workspace_bytes, int N, int Cin_total, int Cout_total, int H, int W, int groups, int relu_in,
-                dvd_stream_t stream) {
+static int xwgrad3_impl(const void* x, const float* x_amax, const void* gy, const float* gy_amax, float* gw, void* workspace,
+                        size_t workspace_bytes, int N, int Cin_total, int Cout_total, int H, int W, int groups, int relu_in,
+                        bool h16, const float* out_scale, dvd_stream_t stream) {
   DVD_REQUIRE(x && gy && gw && workspace, "xwgrad3: null pointer");
-  DVD_REQUIRE(x_amax && gy_amax, "xwgrad3: the operands' max|.| scalars are missing (dvd_amax)");
+  DVD_REQUIRE(h16 || (x_amax && gy_amax), "xwgrad3: the operands' max|.| scalars are missing (dvd_amax)");
   DVD_REQUIRE(N > 0 && Cin_total > 0 && Cout_total > 0 && H > 0 && W > 0, "xwgrad3: bad shape");
   DVD_REQUIRE(groups > 0 && Cin_total % groups == 0 && Cout_total % groups == 0, "xwgrad3: %d groups do not divide the channels", groups);
   DVD_REQUIRE((long long)H * W * (long long)(Cin_total > Cout_total ? Cin_total : Cout_total) < (1ll << 31),
@@ -551,16 +602,36 @@ int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const floa
   a.G = groups; a.nco = p.nco;
   a.nstrips = p.nstrips; a.RS = p.RS; a.nrseg = p.nrseg; a.S = p.S;
   a.relu_in = relu_in ? 1 : 0;
+  a.out_scale = out_scale;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)p.lds));
-  hipLaunchKernelGGL(dvd::xwgrad3_kernel, dim3(p.S, p.nci, p.nco * groups), dim3(dvd::kW3NT), p.lds, s, a);
+  if (h16) {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad3_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(dvd::xwgrad3_kernel<true>, dim3(p.S, p.nci, p.nco * groups), dim3(dvd::kW3NT), p.lds, s, a);
+  } else {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad3_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(dvd::xwgrad3_kernel<false>, dim3(p.S, p.nci, p.nco * groups), dim3(dvd::kW3NT), p.lds, s, a);
+  }
   DVD_LAUNCH_OK();
   const long long per = (long long)9 * Cout_total * Cin;
   hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
                      static_cast<const float*>(workspace), gw, p.S, 9, Cout_total, Cin);
   DVD_LAUNCH_OK();
   return DVD_OK;
+}
+
+int dvd_xwgrad3(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
+                size_t workspace_bytes, int N, int Cin_total, int Cout_total, int H, int W, int groups, int relu_in,
+                dvd_stream_t stream) {
+  return xwgrad3_impl(x, x_amax, gy, gy_amax, gw, workspace, workspace_bytes, N, Cin_total, Cout_total, H, W, groups, relu_in, false,
+                      nullptr, stream);
+}
+
+int dvd_xwgrad3_h(const void* x, const void* gy, const float* out_scale, float* gw, void* workspace, size_t workspace_bytes, int N,
+                  int Cin_total, int Cout_total, int H, int W, int groups, int relu_in, dvd_stream_t stream) {
+  return xwgrad3_impl(x, nullptr, gy, nullptr, gw, workspace, workspace_bytes, N, Cin_total, Cout_total, H, W, groups, relu_in, true,
+                      out_scale, stream);
 }
 
 size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
@@ -578,6 +649,10 @@ int dvd_xwgrad_select(int variant) {
   return DVD_OK;
 }
 
+static int xwgrad1s_impl(const void* x, const float* x_amax, const void* gy, const float* gy_amax, float* gw, void* workspace,
+                         size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, bool h16,
+                         const float* out_scale, dvd_stream_t stream);
+
 int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, float* gy_rowsum,
                         void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in,
                         dvd_stream_t stream) {
@@ -591,8 +666,19 @@ int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, co
 
 int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
                  size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
+  return xwgrad1s_impl(x, x_amax, gy, gy_amax, gw, workspace, workspace_bytes, N, Cin, Cout, H, W, relu_in, false, nullptr, stream);
+}
+
+int dvd_xwgrad1s_h(const void* x, const void* gy, const float* out_scale, float* gw, void* workspace, size_t workspace_bytes, int N,
+                   int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream) {
+  return xwgrad1s_impl(x, nullptr, gy, nullptr, gw, workspace, workspace_bytes, N, Cin, Cout, H, W, relu_in, true, out_scale, stream);
+}
+
+static int xwgrad1s_impl(const void* x, const float* x_amax, const void* gy, const float* gy_amax, float* gw, void* workspace,
+                         size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in, bool h16,
+                         const float* out_scale, dvd_stream_t stream) {
   DVD_REQUIRE(x && gy && gw && workspace, "xwgrad1s: null pointer");
-  DVD_REQUIRE(x_amax && gy_amax, "xwgrad1s: the operands' max|.| scalars are missing (dvd_amax)");
+  DVD_REQUIRE(h16 || (x_amax && gy_amax), "xwgrad1s: the operands' max|.| scalars are missing (dvd_amax)");
   DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgrad1s: bad shape");
   DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgrad1s: image too large for 32-bit offsets");
   if (dvd::wg1_wide(Cin, Cout, H * W)) {
@@ -612,10 +698,18 @@ int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const flo
     a.G = 1; a.nco = (Cout + 255) / 256;
     a.nstrips = 0; a.RS = 0; a.nrseg = 0; a.S = S;
     a.relu_in = relu_in ? 1 : 0;
+    a.out_scale = out_scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1b_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)dvd::kWbLds));
-    hipLaunchKernelGGL(dvd::xwgrad1b_kernel, dim3(S, (Cin + 255) / 256, (Cout + 255) / 256), dim3(512), dvd::kWbLds, s, a);
+    const dim3 grid(S, (Cin + 255) / 256, (Cout + 255) / 256);
+    if (h16) {
+      DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1b_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dvd::kWbLds));
+      hipLaunchKernelGGL(dvd::xwgrad1b_kernel<true>, grid, dim3(512), dvd::kWbLds, s, a);
+    } else {
+      DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1b_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dvd::kWbLds));
+      hipLaunchKernelGGL(dvd::xwgrad1b_kernel<false>, grid, dim3(512), dvd::kWbLds, s, a);
+    }
     DVD_LAUNCH_OK();
     const long long per = (long long)Cout * Cin;
     hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
@@ -645,11 +739,18 @@ int dvd_xwgrad1s(const float* x, const float* x_amax, const float* gy, const flo
   a.G = 1; a.nco = nco;
   a.nstrips = 0; a.RS = 0; a.nrseg = 0; a.S = S;
   a.relu_in = relu_in ? 1 : 0;
+  a.out_scale = out_scale;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)2 * 2 * dvd::kW1CB * dvd::kW1Pitch;
-  DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
-  hipLaunchKernelGGL(dvd::xwgrad1s_kernel, dim3(S, nci, nco), dim3(dvd::kW1NT), lds, s, a);
+  if (h16) {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1s_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(dvd::xwgrad1s_kernel<true>, dim3(S, nci, nco), dim3(dvd::kW1NT), lds, s, a);
+  } else {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1s_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(dvd::xwgrad1s_kernel<false>, dim3(S, nci, nco), dim3(dvd::kW1NT), lds, s, a);
+  }
   DVD_LAUNCH_OK();
   const long long per = (long long)Cout * Cin;
   hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,

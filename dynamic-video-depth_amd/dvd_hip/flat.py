@@ -77,26 +77,26 @@ class FlatNet(object):
         parallel.all_reduce_sum_(self.grad)
         return None
 
-    def all_reduce_and_adam_step(self, n_buckets=4):
+    def all_reduce_and_adam_step(self, n_buckets=4, skip_ptr=None):
         """Gradient exchange pipelined with the optimiser: the flat gradient goes out as `n_buckets` large
         all-reduces issued back to back; the Adam kernel of bucket i runs as soon as that bucket has arrived, while
         buckets i+1.. are still being reduced (RCCL runs them on its own stream; `work.wait()` only makes the compute
         stream wait, the host never blocks).  Single process: one Adam launch over the whole buffer."""
         if not parallel.is_distributed():
-            return self.adam_step()
+            return self.adam_step(skip_ptr=skip_ptr)
         pending = parallel.all_reduce_sum_buckets_async_(self.grad, n_buckets)
         self.step_count += 1
         for lo, hi, work in pending:
             if work is not None:
                 work.wait()
             ops.adam_step(self.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.step_count,
-                          self.lr, self.betas[0], self.betas[1], self.eps)
+                          self.lr, self.betas[0], self.betas[1], self.eps, skip_ptr=skip_ptr)
 
-    def adam_step(self, extra_grad=None, scale=1.0, scale_ptr=None):
-        """param -= Adam(scale * (*scale_ptr) * grad + extra_grad)."""
+    def adam_step(self, extra_grad=None, scale=1.0, scale_ptr=None, skip_ptr=None):
+        """param -= Adam(scale * (*scale_ptr) * grad + extra_grad); nothing happens if *skip_ptr != 0."""
         self.step_count += 1
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
-                      self.betas[1], self.eps, scale=scale, scale_ptr=scale_ptr, grad2=extra_grad)
+                      self.betas[1], self.eps, scale=scale, scale_ptr=scale_ptr, grad2=extra_grad, skip_ptr=skip_ptr)
 
     # Checkpoints carry `optimizer.state_dict()` of a torch.optim.Adam (netinterface.py:528-536, written by
     # ModelSaveLogger with save_optimizer=True); emit and accept exactly that layout -- per-parameter

@@ -37,7 +37,7 @@ from os.path import join
 import numpy as np
 import torch
 
-from .. import configs, flat, ops, parallel
+from .. import configs, conv, flat, ops, parallel
 from ..losses.scene_flow_projection import BackwardWarp, flow_by_depth, scene_flow_projection_slack, unproject_ptcld
 from ..networks.sceneflow_field import SceneFlowFieldNet
 from ..third_party.hourglass import HourglassModel_Embed
@@ -91,6 +91,10 @@ class Model(NetInterface):
                                  '(phase 1) and its backward (phase 3), chunk by chunk, in HIP graphs: a kept chunk is not '
                                  'recomputed (MiDaS at 384x672: 1 GB per image, 95 GB for 48 pairs).  Chunks beyond the budget, '
                                  'or beyond what the MLP stashes leave free, take the no-graph forward + recompute path')
+        parser.add_argument('--act_fp16', action='store_true',
+                            help='BASELINE configs[4]: store the depth net\'s activations (and their gradients) as fp16 in HBM -- '
+                                 'fp32 parameters, fp32 accumulation, fp32 loss sums; gradients carry a power-of-two loss scale kept on '
+                                 'the device (csrc/a16.hip); a step whose fp16 gradients overflow skips its depth-net update.  MiDaS only')
         parser.add_argument('--grad_buckets', type=int, default=4,
                             help='data parallel: the depth-net gradient (421 MB for MiDaS) is all-reduced as this many large '
                                  'buckets in flight at once, the Adam launch of a bucket overlapping the reduction of the next')
@@ -153,6 +157,12 @@ class Model(NetInterface):
         self._optimizers = [self._flat_depth, self._flat_sf]
         self._sf_grad_main = torch.zeros_like(self._flat_sf.grad)
         self._mlp = self.net_sceneflow.kernels(self.device)
+        self._gscale = None
+        if getattr(self.opt, 'act_fp16', False):
+            if not self.opt.midas:
+                raise NotImplementedError('--act_fp16 covers the MiDaS depth net (BASELINE configs[4])')
+            self.net_depth.act_dtype = torch.float16
+            self._gscale = ops.gscale_new(self.device)       # lives as long as the model: captured graphs hold its address
         if self._pending_optimizer_state is not None:      # checkpoint restored before .to() (train.py:256,279)
             self._apply_optimizer_state(self._pending_optimizer_state)
             self._pending_optimizer_state = None
@@ -434,6 +444,7 @@ class Model(NetInterface):
     def _train_on_batch(self, epoch, batch_ind, batch):
         opt = self.opt
         self._step_no += 1
+        conv.set_grad_scale_state(self._gscale)      # the loss-scale state of THIS model's fp16 gradients (None: fp32 storage)
         self.warm = warm = epoch <= opt.warm_sf
         self.net_depth.eval()                        # BN statistics are never updated (:157,168 / hourglass.py:200-208)
         for p in self.net_depth.parameters():
@@ -694,7 +705,15 @@ class Model(NetInterface):
             self._depth_backward(inp.img_2, fid2, g_d2, slot0=n_slots)
             # 421 MB (MiDaS) in --grad_buckets large all-reduces, each bucket's Adam launch overlapping the next
             # bucket's reduction
-            self._flat_depth.all_reduce_and_adam_step(getattr(opt, 'grad_buckets', 4))
+            skip = None
+            if self._gscale is not None:
+                # fp16 gradients: did this step stay inside fp16 range?  (device-side decision; with several ranks an
+                # overflow anywhere skips the update everywhere)
+                if parallel.is_distributed():
+                    torch.distributed.all_reduce(self._gscale[3:4], op=torch.distributed.ReduceOp.MAX)
+                ops.gscale_end(self._gscale)
+                skip = self._gscale[4:5]
+            self._flat_depth.all_reduce_and_adam_step(getattr(opt, 'grad_buckets', 4), skip_ptr=skip)
         if capturing:
             k.all_reduce_grads()
         if h_sf is not None:

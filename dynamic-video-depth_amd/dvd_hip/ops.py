@@ -439,9 +439,21 @@ WEIGHT_EPOCH = [0]
 
 
 def adam_step(param, grad1, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps=1e-8, scale=1.0, scale_ptr=None,
-              grad2=None):
+              grad2=None, skip_ptr=None):
+    """skip_ptr: device scalar; the update is skipped when it is non-zero (fp16 gradient overflow, csrc/a16.hip)."""
     WEIGHT_EPOCH[0] += 1
     lib = _lib.load()
-    _lib.check(lib.dvd_adam_step(_p(param), _p(grad1), float(scale), _p(scale_ptr), _p(grad2), _p(exp_avg),
-                                 _p(exp_avg_sq), param.numel(), float(lr), float(beta1), float(beta2), float(eps),
-                                 int(step), _stream()), 'dvd_adam_step')
+    _lib.check(lib.dvd_adam_step_guarded(_p(param), _p(grad1), float(scale), _p(scale_ptr), _p(grad2), _p(exp_avg),
+                                         _p(exp_avg_sq), param.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                         int(step), _p(skip_ptr), _stream()), 'dvd_adam_step')
+
+
+def gscale_new(device, target_exponent=10.0):
+    """The loss-scale state of the fp16 gradients (8 floats on the device; layout: include/dvd_hip.h, policy: csrc/a16.hip)."""
+    st = torch.empty(8, device=device, dtype=torch.float32)
+    _lib.check(_lib.load().dvd_gscale_init(_p(st), float(target_exponent), _stream()), 'dvd_gscale_init')
+    return st
+
+
+def gscale_end(state):
+    _lib.check(_lib.load().dvd_gscale_end(_p(state), _stream()), 'dvd_gscale_end')

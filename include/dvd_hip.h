@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DVD_ABI_VERSION 3
+#define DVD_ABI_VERSION 4
 
 typedef void* dvd_stream_t; /* hipStream_t */
 
@@ -392,6 +392,63 @@ int dvd_xwgrad_select(int variant);
  * Same fp32 operation order as the reference's numpy / ATen path: the integer masks are bit-identical. */
 int dvd_flow_consistency_mask(const float* flow_a, const float* flow_b, float* mask, int B, int H, int W,
                               dvd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * fp16 ACTIVATION STORAGE (round 4; BASELINE.json configs[4]: "fp16 activations with fp32 loss accumulation").
+ * Reference: the same layers as the fp32 entry points above (third_party/MiDaS.py:186-246, third_party/midas_blocks.py:35-168);
+ * the reference itself has no reduced-precision mode.  Every tensor between the encoder stem and the depth head is stored as
+ * _Float16 in HBM; the image, the depth map, parameters, parameter gradients, loss sums and optimiser state stay fp32 and every
+ * accumulation is fp32.  An fp16 activation IS the matrix operand (one term, no scale): activation x two-term weight = 2 MFMAs per
+ * product instead of 3, activation x activation (weight gradients) = 1 instead of 3.
+ *   "_h" entry points: activations / gradients are _Float16 (void*).
+ *   "_t" entry points: `f16` selects the storage (0 = float, 1 = _Float16) of the activation / gradient tensors.
+ *   out_scale: device scalar the PARAMETER gradients are multiplied by -- 1 / (loss scale of the fp16 gradients), state[1] of the
+ *   loss-scale state below (null = 1). */
+/* dvd_xconv_fwd with fp16 input; out_f16 = 0 writes fp32 (then residual / mask_src are fp32 too).  Needs Cin / groups % 16 == 0. */
+int dvd_xconv_fwd_h(const void* x, const void* packed, const float* bias, const void* residual, const void* mask_src,
+                    const dvd_bn_params* bn, void* y, float* y_amax, int N, int Cin_total, int Cout_total, int H, int W, int KS,
+                    int groups, int flags, int out_f16, dvd_stream_t stream);
+int dvd_xwgrad3_h(const void* x, const void* gy, const float* out_scale, float* gw, void* workspace, size_t workspace_bytes, int N,
+                  int Cin_total, int Cout_total, int H, int W, int groups, int relu_in, dvd_stream_t stream);
+int dvd_xwgrad1s_h(const void* x, const void* gy, const float* out_scale, float* gw, void* workspace, size_t workspace_bytes, int N,
+                   int Cin, int Cout, int H, int W, int relu_in, dvd_stream_t stream);
+int dvd_bnrelu_fwd_t(const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
+                     const float* var, float eps, void* y, int f16, int N, int C, int HW, int relu, dvd_stream_t stream);
+int dvd_bnrelu_bwd_t(const void* gy, const void* y, const void* x, const float* gamma, const float* mean, const float* var,
+                     float eps, void* gx, void* g_residual, float* g_gamma, float* g_beta, void* workspace,
+                     size_t workspace_bytes, int f16, const float* out_scale, int N, int C, int HW, int relu, float* g_amax,
+                     dvd_stream_t stream);
+int dvd_upsample_bilinear_fwd_t(const void* x, void* y, int f16, long long planes, int H_in, int W_in, int H_out, int W_out,
+                                int align_corners, dvd_stream_t stream);
+int dvd_upsample_bilinear_bwd_t(const void* gy, void* gx, int f16, long long planes, int H_in, int W_in, int H_out, int W_out,
+                                int align_corners, dvd_stream_t stream);
+int dvd_gconv3x3_c8_fwd_t(const void* x, const float* w, void* y, int f16, int N, int C, int H, int W, dvd_stream_t stream);
+int dvd_gconv3x3_c8_bwd_data_t(const void* gy, const float* w, void* gx, int f16, int N, int C, int H, int W,
+                               dvd_stream_t stream);
+int dvd_gconv3x3_c8_bwd_weight_t(const void* x, const void* gy, float* gw, int accumulate, void* workspace,
+                                 size_t workspace_bytes, int f16, const float* out_scale, int N, int C, int H, int W,
+                                 dvd_stream_t stream);
+/* The depth head `ReLU -> Conv2d(C, 1, 1)` (third_party/MiDaS.py:192-194), the fp16 / fp32 boundary: y fp32 [N,1,H,W] from
+ * x [N,C,H,W] (C <= 64, H * W % 4 == 0); backward: gx = S * w[c] * gy * [x > 0] (storage of x), gw [C], gb [1] fp32 from the
+ * unscaled fp32 gy; gscale_state: the loss-scale state (null: S = 1).  Deterministic (fixed-order partial sums). */
+int dvd_head1x1_fwd(const void* x, int f16, const float* w, const float* bias, float* y, int N, int C, int HW, int relu_in,
+                    dvd_stream_t stream);
+size_t dvd_head1x1_bwd_workspace_bytes(int C);
+int dvd_head1x1_bwd(const void* x, int f16, const float* w, const float* gy, const float* gscale_state, void* gx, float* gw,
+                    float* gb, void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu_in, dvd_stream_t stream);
+/* Loss scale of the fp16 gradients, kept on the device (state: 8 floats; [0] = S, [1] = 1 / S, [2] = target exponent,
+ * [3] = observed max |S g| this step, [4] = skip flag, [5] = skipped steps).  begin: S = 2^(target - ceil(log2(max|g| * max|w|)))
+ * from the device scalar max|g_out| and the n_w head weights; end (once per step, before the optimiser): overflow -> skip flag +
+ * back-off, small observed maximum -> raise the target.  Policy and thresholds: csrc/a16.hip. */
+int dvd_gscale_init(float* state, float target_exponent, dvd_stream_t stream);
+int dvd_gscale_begin(float* state, const float* g_amax, const float* w, int n_w, dvd_stream_t stream);
+int dvd_gscale_end(float* state, dvd_stream_t stream);
+/* out[i] = scale[0] * in[i] as fp32 (n % 4 == 0): the gradient leaving the fp16 region towards the fp32 stem. */
+int dvd_cast_scale_f32(const void* in, int f16, float* out, long long n, const float* scale, dvd_stream_t stream);
+/* dvd_adam_step that does nothing when skip_flag[0] != 0 (state[4] above): the GradScaler "skipped step". */
+int dvd_adam_step_guarded(float* param, const float* grad1, float scale, const float* scale_ptr, const float* grad2,
+                          float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2, float eps,
+                          int step, const float* skip_flag, dvd_stream_t stream);
 
 #ifdef __cplusplus
 }

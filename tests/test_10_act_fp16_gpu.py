@@ -1,0 +1,353 @@
+"""fp16 ACTIVATION storage (BASELINE configs[4]: "fp16 activations with fp32 loss accumulation") -- the kernels.
+
+What is checked, and against what:
+  * helper kernels (BatchNorm+ReLU, bilinear up-sampling, the 8-per-group 3x3) with fp16 storage do the SAME fp32 arithmetic as
+    their fp32 versions and only round when they store: out16 == fp16(out32 of the same fp16-valued inputs), BIT-EXACT;
+  * the matrix kernels (csrc/xconv.hip IN16 / OUT16, csrc/xwgrad3.hip H16) against float64 convolutions (the reference's
+    nn.Conv2d, third_party/midas_blocks.py:102-168) of the SAME fp16-valued inputs: what remains is the two-term weight split
+    (2^-22 per product) and, for activations, the fp16 rounding of the stored result: |err| <= 2^-11 |y| + 4e-6 max|y|;
+    weight gradients (fp32 out) 2e-5 of max, the bound of the fp32 path;
+  * the depth head / loss-scale boundary (csrc/a16.hip) against torch, and the loss-scale policy's transitions;
+  * the MiDaS net with fp16 activations against the same net with fp32 activations: depth to 2e-3, parameter-gradient norms to
+    2e-2 (the error budget of fp16 storage pinned by tests/test_split_bf16_cpu.py::test_fp16_activation_arithmetic_error_budget:
+    2e-4 of max|y| per K = 2304 layer)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import log_measured, seeded_fill_
+
+pytestmark = pytest.mark.gpu
+
+H_EPS = 2.0 ** -11
+
+
+def _h(t):
+    """fp16-valued fp32 tensor (what the fp16 kernels see) and its fp16 copy on the GPU."""
+    t16 = t.half()
+    return t16.float(), t16.cuda()
+
+
+def _state():
+    from dvd_hip import conv as C, ops
+    st = ops.gscale_new(torch.device('cuda'))
+    C.set_grad_scale_state(st)
+    return st
+
+
+@pytest.fixture(autouse=True)
+def _reset_state():
+    yield
+    from dvd_hip import conv as C
+    C.set_grad_scale_state(None)
+
+
+# ---- helper kernels: same arithmetic, rounded once at the store -------------------------------------------------------
+def test_bnrelu_fp16_storage_is_the_fp32_kernel_rounded_once():
+    from dvd_hip import conv as C
+    torch.manual_seed(0)
+    st = _state()
+    for (N, Cc, H, W, res, relu) in ((2, 24, 12, 20, True, True), (3, 16, 7, 9, False, True), (2, 8, 64, 70, True, False)):
+        bn = seeded_fill_(torch.nn.BatchNorm2d(Cc), 3).cuda().eval()
+        x32, x16 = _h(torch.randn(N, Cc, H, W))
+        r32, r16 = _h(torch.randn(N, Cc, H, W))
+        g32, g16 = _h(torch.randn(N, Cc, H, W))
+        outs = []
+        for x, r, g in ((x32.cuda(), r32.cuda(), g32.cuda()), (x16, r16, g16)):
+            x = x.requires_grad_(True)
+            r = r.requires_grad_(True)
+            bn.zero_grad()
+            y = C.bn_eval_relu(bn, x, residual=r if res else None, relu=relu)
+            y.backward(g)
+            outs.append((y.detach(), x.grad, r.grad if res else None, bn.weight.grad.clone(), bn.bias.grad.clone()))
+        (y32, gx32, gr32, gw32, gb32), (y16, gx16, gr16, gw16, gb16) = outs
+        assert y16.dtype == torch.float16 and torch.equal(y16, y32.half())
+        # backward: the ReLU mask comes from the STORED y (fp16 in one run, fp32 in the other): identical signs unless y32 is a
+        # positive value that rounds to 0 in fp16 (none at these magnitudes)
+        assert torch.equal(gx16, gx32.half())
+        if res:
+            assert torch.equal(gr16, gr32.half())
+        # parameter gradients: fp32 sums of the same values (1 / S = 1 here: the state is fresh)
+        assert torch.allclose(gw16, gw32, rtol=1e-5, atol=1e-5) and torch.allclose(gb16, gb32, rtol=1e-5, atol=1e-5)
+    assert float(st[0]) == 1.0
+
+
+@pytest.mark.parametrize('align', [False, True])
+def test_upsample_fp16_storage_is_the_fp32_kernel_rounded_once(align):
+    from dvd_hip import conv as C
+    torch.manual_seed(1)
+    for (N, Cc, H, W) in ((2, 8, 12, 20), (1, 5, 7, 10), (1, 3, 24, 42)):
+        x32, x16 = _h(torch.randn(N, Cc, H, W))
+        g32, g16 = _h(torch.randn(N, Cc, 2 * H, 2 * W))
+        a = x32.cuda().requires_grad_(True)
+        b = x16.requires_grad_(True)
+        ya, yb = C.upsample_bilinear2x(a, align), C.upsample_bilinear2x(b, align)
+        ya.backward(g32.cuda())
+        yb.backward(g16)
+        assert yb.dtype == torch.float16 and torch.equal(yb.detach(), ya.detach().half())
+        assert torch.equal(b.grad, a.grad.half())
+
+
+def test_gconv_c8_fp16_storage_is_the_fp32_kernel_rounded_once():
+    from dvd_hip import conv as C
+    torch.manual_seed(2)
+    _state()
+    for (N, Cc, H, W) in ((2, 32, 12, 20), (1, 64, 17, 70)):
+        m = C.GroupedConv3x3C8(Cc).cuda()
+        x32, x16 = _h(torch.randn(N, Cc, H, W))
+        g32, g16 = _h(torch.randn(N, Cc, H, W))
+        res = []
+        for x, g in ((x32.cuda(), g32.cuda()), (x16, g16)):
+            x = x.requires_grad_(True)
+            m.zero_grad()
+            y = m(x)
+            y.backward(g)
+            res.append((y.detach(), x.grad, m.weight.grad.clone()))
+        assert torch.equal(res[1][0], res[0][0].half()) and torch.equal(res[1][1], res[0][1].half())
+        assert torch.allclose(res[1][2], res[0][2], rtol=1e-5, atol=1e-5)
+
+
+# ---- matrix kernels against float64 -----------------------------------------------------------------------------------
+XCASES = [
+    # N, Cin, Cout, H, W, KS, groups
+    (2, 256, 256, 24, 42, 3, 1),
+    (2, 64, 256, 24, 42, 1, 1),
+    (1, 1024, 256, 12, 21, 3, 1),
+    (1, 256, 128, 20, 36, 3, 1),
+    (1, 128, 32, 30, 70, 3, 1),
+    (1, 512, 512, 13, 22, 1, 1),
+    (2, 256, 256, 12, 20, 3, 8),      # grouped, 32 per group (ResNeXt stage 3)
+    (1, 512, 512, 9, 14, 3, 8),       # 64 per group (stage 4)
+    (2, 16, 256, 7, 9, 3, 1),
+    (2, 256, 256, 96, 128, 1, 1),
+]
+
+
+def _chk(name, got, want, rel, of_max):
+    d = (got.double().cpu() - want).abs()
+    bound = rel * want.abs() + of_max * float(want.abs().max())
+    worst = float((d / bound).max())
+    log_measured(name, worst, 1.0)
+    assert worst <= 1.0, '%s: worst error / bound = %.3g' % (name, worst)
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H,W,KS,G', XCASES)
+def test_conv_fp16_activations_forward_input_and_weight_gradient(N, Cin, Cout, H, W, KS, G):
+    from dvd_hip import conv as C
+    torch.manual_seed(Cin + Cout + KS + G)
+    st = _state()
+    conv = torch.nn.Conv2d(Cin, Cout, KS, padding=KS // 2, groups=G, bias=True)
+    x32, x16 = _h(torch.randn(N, Cin, H, W))
+    g32, g16 = _h(torch.randn(N, Cout, H, W))
+    r32, r16 = _h(torch.randn(N, Cout, H, W))
+    xd = x32.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    bd = conv.bias.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd.relu(), wd, bd, padding=KS // 2, groups=G) + r32.double()
+    yd.backward(g32.double())
+    conv = conv.cuda()
+    xg = x16.requires_grad_(True)
+    y = C.xconv2d(conv, xg, relu_in=True, residual=r16)
+    assert y.dtype == torch.float16
+    y.backward(g16)
+    tag = 'a16 conv %s' % ((N, Cin, Cout, H, W, KS, G),)
+    _chk(tag + ' y', y.detach(), yd.detach(), 1.01 * H_EPS, 4e-6)
+    _chk(tag + ' gx', xg.grad, xd.grad, 1.01 * H_EPS, 4e-6)
+    _chk(tag + ' gw', conv.weight.grad, wd.grad, 0.0, 2e-5)
+    _chk(tag + ' gb', conv.bias.grad, bd.grad, 0.0, 2e-5)
+    # the backward-data epilogue reported the largest gradient magnitude it wrote to the loss-scale state
+    assert float(st[3]) >= 0.99 * float(xg.grad.float().abs().max())
+
+
+def test_conv_bn_relu_fused_fp16():
+    """conv + eval-mode BatchNorm + residual + ReLU in one launch, fp16 in / out, and its backward through the masked pass."""
+    from dvd_hip import conv as C
+    torch.manual_seed(5)
+    _state()
+    N, Cin, Cout, H, W = 2, 64, 256, 12, 20
+    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=False)
+    bn = seeded_fill_(torch.nn.BatchNorm2d(Cout), 7).eval()
+    x32, x16 = _h(torch.randn(N, Cin, H, W))
+    g32, g16 = _h(torch.randn(N, Cout, H, W))
+    r32, r16 = _h(torch.randn(N, Cout, H, W))
+    cd, bd = conv.double(), bn.double()
+    xd = x32.double().requires_grad_(True)
+    yd = F.relu(bd(cd(xd)) + r32.double())
+    yd.backward(g32.double())
+    want = {k: v.grad.clone() for k, v in (('w', cd.weight), ('gamma', bd.weight), ('beta', bd.bias))}
+    conv, bn = conv.float().cuda(), bn.float().cuda()
+    conv.zero_grad(), bn.zero_grad()
+    xg = x16.requires_grad_(True)
+    y = C.conv_bn_act(conv, bn, xg, residual=r16, relu=True)
+    y.backward(g16)
+    _chk('a16 convbn y', y.detach(), yd.detach(), 1.01 * H_EPS, 4e-6)
+    # ReLU' is taken from the fp16 y: elements whose float64 value is within fp16 rounding of 0 may flip; compare where |y| is clear
+    clear = (yd.detach().abs() > 1e-3) | (yd.detach() == 0)
+    d = ((xg.grad.double().cpu() - xd.grad).abs())
+    assert float(d.max()) <= 3e-3 * float(xd.grad.abs().max())
+    for k, p in (('w', conv.weight), ('gamma', bn.weight), ('beta', bn.bias)):
+        err = float((p.grad.double().cpu() - want[k]).abs().max() / want[k].abs().max())
+        assert err <= 2e-3, (k, err)
+    assert bool(clear.any())
+
+
+def test_weight_gradient_is_unscaled_by_the_loss_scale():
+    """The fp16 gradients carry S; every parameter gradient is multiplied by state[1] = 1 / S where it is produced."""
+    from dvd_hip import conv as C
+    torch.manual_seed(6)
+    st = _state()
+    S = 256.0
+    st[0], st[1] = S, 1.0 / S
+    N, Cin, Cout, H, W = 2, 64, 64, 12, 20
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=True).cuda()
+    x32, x16 = _h(torch.randn(N, Cin, H, W))
+    g32, _ = _h(1e-3 * torch.randn(N, Cout, H, W))
+    g16 = (g32 * S).half().cuda()                                  # what the backward hands around: S * g
+    xd, wd = x32.double(), conv.weight.detach().double().cpu().requires_grad_(True)
+    bd = conv.bias.detach().double().cpu().requires_grad_(True)
+    F.conv2d(xd, wd, bd, padding=1).backward((g16.float().cpu() / S).double())
+    y = C.xconv2d(conv, x16.requires_grad_(True))
+    y.backward(g16)
+    assert float((conv.weight.grad.double().cpu() - wd.grad).abs().max() / wd.grad.abs().max()) < 2e-5
+    assert float((conv.bias.grad.double().cpu() - bd.grad).abs().max() / bd.grad.abs().max()) < 1e-3   # (fp16 torch.sum inputs)
+
+
+# ---- the boundary and the loss-scale policy --------------------------------------------------------------------------
+def test_head_boundary_forward_backward_and_scale():
+    from dvd_hip import conv as C
+    torch.manual_seed(7)
+    st = _state()
+    N, Cc, H, W = 2, 32, 12, 20
+    conv = torch.nn.Conv2d(Cc, 1, 1).cuda()
+    x32, x16 = _h(torch.randn(N, Cc, H, W))
+    gy = (1e-6 * torch.randn(N, 1, H, W)).cuda()                    # tiny output gradient: would underflow fp16 unscaled
+    xr = x32.cuda().requires_grad_(True)
+    ref = F.conv2d(F.relu(xr), conv.weight, conv.bias)
+    ref.backward(gy)
+    want_w, want_b = conv.weight.grad.clone(), conv.bias.grad.clone()
+    conv.zero_grad()
+    xg = x16.requires_grad_(True)
+    y = C.head1x1(conv, xg, relu_in=True)
+    assert y.dtype == torch.float32 and torch.allclose(y, ref.detach(), rtol=1e-5, atol=1e-6)
+    y.backward(gy)
+    S = float(st[0])
+    m = float(gy.abs().max() * conv.weight.abs().max())
+    assert S == 2.0 ** round(np.log2(S)) and 2.0 ** 9 < m * S <= 2.0 ** 10 and float(st[1]) == 1.0 / S
+    got = xg.grad.float() / S
+    assert float((got - xr.grad).abs().max()) <= 1.01 * H_EPS * float(xr.grad.abs().max())
+    assert torch.allclose(conv.weight.grad, want_w, rtol=1e-4, atol=1e-12) and torch.allclose(conv.bias.grad, want_b, rtol=1e-4)
+    assert abs(float(st[3]) - float(xg.grad.float().abs().max())) <= 1e-3 * float(st[3])
+
+
+def test_loss_scale_policy_transitions_and_guarded_adam():
+    from dvd_hip import ops
+    st = ops.gscale_new(torch.device('cuda'))
+    assert st.tolist() == [1.0, 1.0, 10.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    p = torch.ones(8, device='cuda')
+    g, m, v = torch.ones(8, device='cuda'), torch.zeros(8, device='cuda'), torch.zeros(8, device='cuda')
+    st[3] = 5000.0                                   # inside the band: nothing changes, no skip
+    ops.gscale_end(st)
+    assert st[2:6].tolist() == [10.0, 0.0, 0.0, 0.0]
+    ops.adam_step(p, g, m, v, 1, 0.1, 0.5, 0.9, skip_ptr=st[4:5])
+    assert float(p[0]) < 1.0
+    st[3] = 100.0                                    # far below: raise the target
+    ops.gscale_end(st)
+    assert st[2:6].tolist() == [11.0, 0.0, 0.0, 0.0]
+    st[3] = 60000.0                                  # overflow territory: skip + back off
+    ops.gscale_end(st)
+    assert st[2:6].tolist() == [8.0, 0.0, 1.0, 1.0]
+    before = (p.clone(), m.clone(), v.clone())
+    ops.adam_step(p, g, m, v, 2, 0.1, 0.5, 0.9, skip_ptr=st[4:5])
+    assert torch.equal(p, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
+    st[3] = float('inf')
+    ops.gscale_end(st)
+    assert st[2:6].tolist() == [5.0, 0.0, 1.0, 2.0]
+    st[3] = 20000.0
+    ops.gscale_end(st)
+    assert st[4].item() == 0.0
+
+
+# ---- the network ------------------------------------------------------------------------------------------------------
+def test_midas_fp16_activations_against_fp32_activations():
+    from dvd_hip import conv as C, ops
+    from dvd_hip.third_party.MiDaS import MidasNet, calibrate_head_for_random_init
+    torch.manual_seed(0)
+    net = calibrate_head_for_random_init(MidasNet(non_negative=True, normalize_input=True)).cuda().eval()
+    x = torch.rand(2, 3, 64, 96, device='cuda')
+    gd = torch.randn(2, 1, 64, 96, device='cuda') * 1e-3
+    res = []
+    for dt in (torch.float32, torch.float16):
+        net.act_dtype = dt
+        C.set_grad_scale_state(ops.gscale_new(x.device) if dt == torch.float16 else None)
+        net.zero_grad()
+        d = net(x)
+        d.backward(gd)
+        res.append((d.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+    (d32, g32), (d16, g16) = res
+    assert d16.dtype == torch.float32
+    e_d = float((d16 - d32).abs().max() / d32.abs().max())
+    worst, name = 0.0, None
+    for k in g32:
+        n32 = float(g32[k].double().norm())
+        if n32 == 0.0:
+            continue
+        r = abs(float(g16[k].double().norm()) - n32) / n32
+        if r > worst:
+            worst, name = r, k
+    log_measured('midas fp16 activations vs fp32: depth rel', e_d, 2e-3)
+    log_measured('midas fp16 activations vs fp32: worst gradient-norm rel (%s)' % name, worst, 2e-2)
+    print('fp16 activations: depth %.2e, worst gradient norm %.2e (%s)' % (e_d, worst, name))
+    assert e_d < 2e-3 and worst < 2e-2
+
+
+# ---- the step ---------------------------------------------------------------------------------------------------------
+def test_full_step_fp16_activations_against_the_reference_fixture():
+    """`--act_fp16` step against the REAL reference's fp32 CPU step (tests/golden/fullstep_midas_b2_192x384_train.npz, the
+    BASELINE configs[0] shape): stated tolerance of the fp16-activation mode -- losses rtol 2e-3, per-parameter gradient norms
+    5e-2 (the fp32-storage step meets 1e-5 / 1.5e-3 on the same fixture, tests/test_30_full_step_gpu.py); no skipped step."""
+    import test_30_full_step_gpu as T30
+    import helpers
+    gd = helpers.load_golden('fullstep_midas_b2_192x384_train')
+    model, opt, batch = T30._build(gd, act_fp16=True)
+    log = model._train_on_batch(int(gd['epoch']), 0, helpers.loader_batch(batch))
+    torch.cuda.synchronize()
+    st = model._gscale.tolist()
+    assert st[4] == 0.0 and st[5] == 0.0, 'the step overflowed fp16: %s' % (st,)
+    loss_rel = max(abs(log[k] - float(gd['log_' + k])) / abs(float(gd['log_' + k]))
+                   for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss'))
+    names = [str(n) for n in gd['param_names']]
+    want_g = dict(zip(names, gd['grad_norms']))
+    worst, wname = 0.0, None
+    for prefix, net in (('depth', model.net_depth), ('sf', model.net_sceneflow)):
+        for k, p in net.named_parameters():
+            w = want_g[prefix + '/' + k]
+            if w == 0.0:
+                continue
+            r = abs(float(p.grad.double().norm()) - w) / w
+            if r > worst:
+                worst, wname = r, prefix + '/' + k
+    log_measured('fp16-activation step vs reference fixture: loss rel', loss_rel, 2e-3)
+    log_measured('fp16-activation step vs reference fixture: worst gradient-norm rel (%s)' % wname, worst, 5e-2)
+    print('fp16-activation step: loss rel %.2e, worst gradient norm %.2e (%s), loss scale 2^%d, observed max %.0f' % (
+        loss_rel, worst, wname, int(np.log2(st[0])), st[3]))
+    assert loss_rel < 2e-3 and worst < 5e-2
+
+
+def test_fp16_step_graph_replay_matches_eager():
+    """Two steps with captured graphs (kept slots) equal two steps run eagerly: the loss-scale state, the head boundary and the
+    fp16 kernels are all capture-safe (every scalar they read is written inside the same graph or lives in the persistent state)."""
+    import test_30_full_step_gpu as T30
+    import helpers
+    gd = helpers.load_golden('fullstep_midas_b1_64x96_train')
+    logs = []
+    for graphs in (0, 1):
+        model, opt, batch = T30._build(gd, act_fp16=True, depth_graphs=graphs)
+        for i in range(3):
+            log = model._train_on_batch(int(gd['epoch']), i, helpers.loader_batch(dict(batch)))
+        torch.cuda.synchronize()
+        logs.append((log['loss'], float(model._flat_depth.grad.double().norm())))
+        del model
+    assert abs(logs[0][0] - logs[1][0]) <= 1e-6 * abs(logs[0][0]) and abs(logs[0][1] - logs[1][1]) <= 1e-5 * logs[0][1], logs

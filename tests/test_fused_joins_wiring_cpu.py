@@ -16,8 +16,9 @@ class _FakeLib(object):
     def dvd_bnrelu_bwd_workspace_bytes(self, N, C, HW):
         return 16
 
-    def dvd_bnrelu_bwd(self, gy, y, x, gamma, mean, var, eps, gx, gres, ggamma, gbeta, ws, ws_bytes, N, C, HW, relu, g_amax,
-                       stream):
+    def dvd_bnrelu_bwd_t(self, gy, y, x, gamma, mean, var, eps, gx, gres, ggamma, gbeta, ws, ws_bytes, f16, out_scale, N, C, HW,
+                         relu, g_amax, stream):
+        assert not f16 and out_scale is None          # fp32 storage here (the fp16 variants: tests/test_10_act_fp16_gpu.py)
         g = gy * (y > 0).to(gy.dtype) if relu else gy
         if gres is not None:
             gres.copy_(g)

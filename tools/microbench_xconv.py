@@ -44,6 +44,10 @@ def main():
     from dvd_hip import _lib
     _lib.check(_lib.load().dvd_xconv_select(cfg), 'dvd_xconv_select')
     skip_wgrad = bool(os.environ.get('XCONV_NO_WGRAD'))
+    half = bool(os.environ.get('XCONV_FP16'))                 # fp16 activation storage (configs[4] kernels)
+    if half:
+        from dvd_hip import ops
+        C.set_grad_scale_state(ops.gscale_new(torch.device('cuda')))
     for (N, Cin, Cout, H, W, KS) in shapes:
         N *= nmul
         torch.manual_seed(0)
@@ -54,8 +58,10 @@ def main():
         gy = torch.randn(N, Cout, H, W, device='cuda')
         if os.environ.get('XCONV_ZERO_INPUT'):
             gy.zero_()
+        if half:
+            x, gy = x.half(), gy.half()
         flop = 2.0 * N * Cin * Cout * H * W * KS * KS
-        rec = {'shape': [N, Cin, Cout, H, W, KS], 'gflop': flop / 1e9}
+        rec = {'shape': [N, Cin, Cout, H, W, KS], 'gflop': flop / 1e9, 'act': 'fp16' if half else 'fp32'}
         pk, pkT = C.xconv_packed(conv.weight, False), C.xconv_packed(conv.weight, True)
         it = 10
         rec['xconv_fwd_ms'] = timeit(lambda: C._xconv_run(x, pk, Cout, KS, bias=conv.bias), it)
@@ -64,7 +70,7 @@ def main():
             rec['xconv_wgrad_ms'] = timeit(lambda: C.xconv_wgrad(x, gy, conv.weight.shape, False), it)
         rec['cfg'] = cfg
         rec['pack_ms'] = timeit(lambda: (conv.weight._dvd_xpack.clear(), C.xconv_packed(conv.weight, False)), it)
-        if 'nomiopen' not in only:
+        if 'nomiopen' not in only and not half:
             with torch.no_grad():
                 rec['miopen_fwd_ms'] = timeit(lambda: F.conv2d(x, conv.weight, conv.bias, padding=KS // 2), it)
             rec['miopen_dgrad_ms'] = timeit(lambda: torch.ops.aten.convolution_backward(
