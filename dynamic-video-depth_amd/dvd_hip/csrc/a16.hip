@@ -13,13 +13,13 @@
 //   * the loss-scale policy, entirely on the device (no host read-back anywhere in the step):
 //       state[0] = S, state[1] = 1 / S          set by dvd_gscale_begin at the start of every depth-net backward pass: the power
 //                                               of two that puts max|g_out| * max|w_head| at 2^target
-//       state[2] = target exponent              (initially 10: 2^10 at the head leaves 6 octaves of head room below fp16's
-//                                               65504 and 34 octaves above its smallest subnormal)
+//       state[2] = target exponent              (initially 4: gradients may grow by 2^11 between the head and the deepest layer
+//                                               before the first step overflows; re-centred after every step)
 //       state[3] = observed max |S g| of the fp16 gradient tensors of this step (the backward-data epilogues fold it in)
 //       state[4] = skip flag of this step, state[5] = steps skipped so far
-//     dvd_gscale_end (once per step, before the optimiser): an observed maximum of 2^15.5 or more (or Inf) means fp16 range
-//     was exceeded somewhere -> the step's depth-net update is SKIPPED (dvd_adam_step_guarded) and the target drops by 3;
-//     below 2^11 the target rises by 1 (at most 14).  Every kernel that produces a PARAMETER gradient from fp16 gradients
+//     dvd_gscale_end (once per step, before the optimiser): an observed maximum of 2^15.5 or more means fp16 range was
+//     exceeded somewhere -> the step's depth-net update is SKIPPED (dvd_adam_step_guarded); in either case the target moves
+//     by the whole number of octaves that puts the observed maximum at 2^13 (upwards by at most 4 per step).  Every kernel that produces a PARAMETER gradient from fp16 gradients
 //     multiplies by state[1] (`out_scale`), so the flat gradient buffers always hold true gradients.
 #include "dvd_io.h"
 
@@ -27,7 +27,6 @@ namespace dvd {
 
 constexpr int kHeadMaxC = 64;
 constexpr float kGsOverflow = 46340.95f;      // 2^15.5
-constexpr float kGsLow = 2048.0f;             // 2^11
 
 __global__ void gscale_init_kernel(float* __restrict__ st, float target) {
   if (threadIdx.x < 8) st[threadIdx.x] = threadIdx.x == 0 || threadIdx.x == 1 ? 1.0f : (threadIdx.x == 2 ? target : 0.0f);
@@ -55,17 +54,27 @@ __global__ __launch_bounds__(64) void gscale_begin_kernel(float* __restrict__ st
   }
 }
 
+// Once per step.  obs = the largest |S g| any monitored fp16 gradient tensor was ABOUT to store (computed in fp32 before the
+// conversion, so it is finite and exact even when the fp16 value became Inf).  The target is re-centred so that the same
+// network state would put obs at 2^13 next step (three octaves below fp16's maximum): gradient growth between the head and
+// the deepest layer is a property of the weights and changes slowly.
 __global__ void gscale_end_kernel(float* __restrict__ st) {
   if (threadIdx.x != 0) return;
   const float obs = st[3];
-  if (!(obs < kGsOverflow)) {          // overflow (or Inf / NaN): skip this step's update, back off
+  float target = st[2];
+  if (!(obs < kGsOverflow)) {          // fp16 range exceeded (or Inf / NaN): skip this step's update, back off
     st[4] = 1.0f;
     st[5] += 1.0f;
-    st[2] = fmaxf(st[2] - 3.0f, -20.0f);
+    target -= (obs < 3.0e38f) ? ceilf(log2f(obs) - 13.0f) : 8.0f;
   } else {
     st[4] = 0.0f;
-    if (obs > 0.0f && obs < kGsLow) st[2] = fminf(st[2] + 1.0f, 14.0f);
+    if (obs > 0.0f) {
+      float d = rintf(13.0f - log2f(obs));     // (whole octaves; within half an octave of 2^13 nothing moves)
+      d = d > 4.0f ? 4.0f : d;                 // rise by at most 4 octaves per step
+      target += d;
+    }
   }
+  st[2] = fminf(fmaxf(target, -24.0f), 14.0f);
   st[3] = 0.0f;
 }
 

@@ -265,9 +265,10 @@ class Model(NetInterface):
             del self._depth_graphs[k]
         entry = None
         # bytes a slot will hold: measured on the slots captured so far (per image and pixel), a-priori figure (MiDaS with
-        # fused epilogues: ~4.1 KB per pixel) for the first one, + packed weights
+        # fused epilogues: ~4.1 KB per pixel, ~2.2 KB with fp16 activations) for the first one, + packed weights
         n_px = chunk.shape[0] * chunk.shape[2] * chunk.shape[3]
-        est = int(n_px * max(4400.0, self._keep_per_px) + 1.5 * 2 ** 30)
+        apriori = 2400.0 if self._gscale is not None else 4400.0        # fp16 activation storage halves the kept state
+        est = int(n_px * max(apriori, self._keep_per_px) + 1.5 * 2 ** 30)
         free, total = self._free_hbm(chunk.device)
         budget = float(getattr(self.opt, 'depth_keep_gb', 150.0)) * 2 ** 30
         # room that must stay free: the MLP stashes of phase 2 + 8 % head room + (unless this is the last slot of a step

@@ -448,7 +448,7 @@ def adam_step(param, grad1, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps=1e-
                                          int(step), _p(skip_ptr), _stream()), 'dvd_adam_step')
 
 
-def gscale_new(device, target_exponent=10.0):
+def gscale_new(device, target_exponent=4.0):
     """The loss-scale state of the fp16 gradients (8 floats on the device; layout: include/dvd_hip.h, policy: csrc/a16.hip)."""
     st = torch.empty(8, device=device, dtype=torch.float32)
     _lib.check(_lib.load().dvd_gscale_init(_p(st), float(target_exponent), _stream()), 'dvd_gscale_init')

@@ -234,8 +234,8 @@ def test_head_boundary_forward_backward_and_scale():
     assert y.dtype == torch.float32 and torch.allclose(y, ref.detach(), rtol=1e-5, atol=1e-6)
     y.backward(gy)
     S = float(st[0])
-    m = float(gy.abs().max() * conv.weight.abs().max())
-    assert S == 2.0 ** round(np.log2(S)) and 2.0 ** 9 < m * S <= 2.0 ** 10 and float(st[1]) == 1.0 / S
+    m = float(gy.abs().max() * conv.weight.detach().abs().max())
+    assert S == 2.0 ** round(np.log2(S)) and 2.0 ** 3 < m * S <= 2.0 ** 4 and float(st[1]) == 1.0 / S
     got = xg.grad.float() / S
     assert float((got - xr.grad).abs().max()) <= 1.01 * H_EPS * float(xr.grad.abs().max())
     assert torch.allclose(conv.weight.grad, want_w, rtol=1e-4, atol=1e-12) and torch.allclose(conv.bias.grad, want_b, rtol=1e-4)
@@ -245,29 +245,35 @@ def test_head_boundary_forward_backward_and_scale():
 def test_loss_scale_policy_transitions_and_guarded_adam():
     from dvd_hip import ops
     st = ops.gscale_new(torch.device('cuda'))
-    assert st.tolist() == [1.0, 1.0, 10.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    assert st.tolist() == [1.0, 1.0, 4.0, 0.0, 0.0, 0.0, 0.0, 0.0]
     p = torch.ones(8, device='cuda')
     g, m, v = torch.ones(8, device='cuda'), torch.zeros(8, device='cuda'), torch.zeros(8, device='cuda')
-    st[3] = 5000.0                                   # inside the band: nothing changes, no skip
+    st[3] = 10000.0                                  # 2^13.3: centred, nothing changes, no skip
     ops.gscale_end(st)
-    assert st[2:6].tolist() == [10.0, 0.0, 0.0, 0.0]
+    assert st[2:6].tolist() == [4.0, 0.0, 0.0, 0.0]
     ops.adam_step(p, g, m, v, 1, 0.1, 0.5, 0.9, skip_ptr=st[4:5])
     assert float(p[0]) < 1.0
-    st[3] = 100.0                                    # far below: raise the target
+    st[3] = 1000.0                                   # 2^9.97: three octaves of unused range -> +3
+    ops.gscale_end(st)
+    assert st[2:6].tolist() == [7.0, 0.0, 0.0, 0.0]
+    st[3] = 1.0                                      # far below: at most +4 per step
     ops.gscale_end(st)
     assert st[2:6].tolist() == [11.0, 0.0, 0.0, 0.0]
-    st[3] = 60000.0                                  # overflow territory: skip + back off
+    st[3] = 40000.0                                  # 2^15.3: still representable, but only 0.7 octaves left -> -2, no skip
     ops.gscale_end(st)
-    assert st[2:6].tolist() == [8.0, 0.0, 1.0, 1.0]
+    assert st[2:6].tolist() == [9.0, 0.0, 0.0, 0.0]
+    st[3] = 2.0 ** 20                                # seven octaves over 2^13: skip + back off by exactly that
+    ops.gscale_end(st)
+    assert st[2:6].tolist() == [2.0, 0.0, 1.0, 1.0]
     before = (p.clone(), m.clone(), v.clone())
     ops.adam_step(p, g, m, v, 2, 0.1, 0.5, 0.9, skip_ptr=st[4:5])
     assert torch.equal(p, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
     st[3] = float('inf')
     ops.gscale_end(st)
-    assert st[2:6].tolist() == [5.0, 0.0, 1.0, 2.0]
-    st[3] = 20000.0
+    assert st[2:6].tolist() == [-6.0, 0.0, 1.0, 2.0]
+    st[3] = 8192.0
     ops.gscale_end(st)
-    assert st[4].item() == 0.0
+    assert st[2:6].tolist() == [-6.0, 0.0, 0.0, 2.0]
 
 
 # ---- the network ------------------------------------------------------------------------------------------------------
@@ -279,15 +285,26 @@ def test_midas_fp16_activations_against_fp32_activations():
     x = torch.rand(2, 3, 64, 96, device='cuda')
     gd = torch.randn(2, 1, 64, 96, device='cuda') * 1e-3
     res = []
-    for dt in (torch.float32, torch.float16):
+    for dt in (torch.float32, torch.float16, torch.float16):
         net.act_dtype = dt
         C.set_grad_scale_state(ops.gscale_new(x.device) if dt == torch.float16 else None)
         net.zero_grad()
         d = net(x)
         d.backward(gd)
-        res.append((d.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
-    (d32, g32), (d16, g16) = res
+        # (refinenet4.resConfUnit1 is never used -- refinenet4 has one input, third_party/MiDaS.py:228 -- in either mode)
+        missing = sorted(k for k, p in net.named_parameters() if p.grad is None)
+        assert all(k.startswith('scratch.refinenet4.resConfUnit1.') for k in missing), (dt, missing[:8])
+        res.append((d.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}))
+    (d32, g32), (d16, g16), (d16b, g16b) = res
     assert d16.dtype == torch.float32
+    # the fp16 kernels are deterministic: two passes give bit-identical depths and parameter gradients (the 7x7 stem's weight
+    # gradient runs on MIOpen, whose reduction order is not fixed: compared to 1e-5)
+    assert torch.equal(d16, d16b)
+    for k in g16:
+        if k.startswith('pretrained.layer1.0.'):
+            assert torch.allclose(g16[k], g16b[k], rtol=1e-5, atol=1e-5 * float(g16[k].abs().max())), k
+        else:
+            assert torch.equal(g16[k], g16b[k]), k
     e_d = float((d16 - d32).abs().max() / d32.abs().max())
     worst, name = 0.0, None
     for k in g32:
@@ -343,11 +360,22 @@ def test_fp16_step_graph_replay_matches_eager():
     import helpers
     gd = helpers.load_golden('fullstep_midas_b1_64x96_train')
     logs = []
-    for graphs in (0, 1):
+    for graphs in (0, 0, 1):                  # eager twice (the mode itself is deterministic), then replayed graphs
         model, opt, batch = T30._build(gd, act_fp16=True, depth_graphs=graphs)
+        trace = []
         for i in range(3):
             log = model._train_on_batch(int(gd['epoch']), i, helpers.loader_batch(dict(batch)))
+            trace.append((log['loss'], [round(v, 3) for v in model._gscale.tolist()[:6]]))
         torch.cuda.synchronize()
-        logs.append((log['loss'], float(model._flat_depth.grad.double().norm())))
+        logs.append((log['loss'], float(model._flat_depth.grad.double().norm()), trace))
         del model
-    assert abs(logs[0][0] - logs[1][0]) <= 1e-6 * abs(logs[0][0]) and abs(logs[0][1] - logs[1][1]) <= 1e-5 * logs[0][1], logs
+    print('\n'.join(str(l) for l in logs))
+    # Steps 1 and 2 (same weights up to Adam's sign-like first update) are identical in all three runs; from step 3 on two EAGER
+    # runs differ by ~1e-4 themselves: the stem's MIOpen weight gradient is not bitwise reproducible (1e-7), and fp16 STORAGE
+    # is a discontinuous function of the weights -- a 1e-7 perturbation moves some activations across an fp16 rounding boundary
+    # (2^-11 each).  The replayed graphs must agree with eager execution to that same noise level, and exactly in the loss-scale
+    # decisions.
+    for a, b in ((0, 1), (0, 2)):
+        assert [t[0] for t in logs[a][2][:2]] == [t[0] for t in logs[b][2][:2]], (a, b)
+        assert [t[1] for t in logs[a][2]] == [t[1] for t in logs[b][2]], 'loss-scale decisions differ'
+        assert abs(logs[a][0] - logs[b][0]) <= 5e-4 * abs(logs[a][0]) and abs(logs[a][1] - logs[b][1]) <= 2e-2 * logs[a][1], logs
