@@ -39,7 +39,7 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import torch  # noqa: E402
 
 H, W, PAIRS, GAP = 384, 672, 48, 1
-PAIRS_CFG4 = 16                  # BASELINE configs[4] (768x1344, fp16 activations): frame pairs per GPU that fit one MI355X
+PAIRS_CFG4 = 24                  # BASELINE configs[4] (768x1344, fp16 activations): frame pairs per GPU whose depth-net state stays resident (2 x 59 GB of kept slots + 119 GB of MLP stashes); more pairs run with recomputed chunks
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 WARP_BYTES_PER_PIXEL = 52        # fused fwd+bwd, unique bytes
 

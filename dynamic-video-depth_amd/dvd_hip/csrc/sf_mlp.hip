@@ -65,6 +65,7 @@ constexpr int kXBytes = 2 * kTermStride;     // 65 536
 
 struct Geometry {
   int n_freq_xyz, n_freq_t, time_dependent;
+  int s16;               // stash_f16 of the descriptor
   int c_in, c_in16;      // input channels, padded to the K step
   int ks0, rt0;          // K steps of the input layer, row tiles of W_0^T
   int t_base, xyz_base;  // channel of t / of x in the input layer
@@ -75,6 +76,7 @@ static Geometry make_geometry(const dvd_mlp_desc* d) {
   g.n_freq_xyz = d->n_freq_xyz;
   g.n_freq_t = d->time_dependent ? d->n_freq_t : 0;
   g.time_dependent = d->time_dependent;
+  g.s16 = d->stash_f16 ? 1 : 0;
   const int ct = d->time_dependent ? 1 + 2 * d->n_freq_t : 0;
   g.c_in = ct + 3 + 6 * d->n_freq_xyz;
   g.c_in16 = (g.c_in + 15) & ~15;
@@ -184,12 +186,16 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const PackArgs a) {
 // stash : embedding [c_in16][64], h_0 .. h_4 [256][64] each, sign words [5][512] (one bit per unit of the lane's
 //         32 outputs of that layer, bit = 16 ct + r)
 // gstash: pre-activation gradients G_0 .. G_4 [256][64] each; after all tiles: the dW workspace
-__host__ __device__ inline size_t stash_floats_per_tile(int c_in16) {
-  return (size_t)(c_in16 + kHidden * kWidth) * kTM + (size_t)kHidden * kNT;
+// s16 (round 4, dvd_mlp_desc.stash_f16): h_0 .. h_4 are stored as _Float16 -- half the floats per layer, everything else as
+// before.  The stash is what the WEIGHT-GRADIENT kernel contracts against (and h_4 what the dX kernel takes dW_5 from); the
+// forward arithmetic keeps its two-term activations in LDS either way, so losses and dX are untouched by the stash's storage.
+__host__ __device__ inline size_t stash_h_floats(bool s16) { return (size_t)kWidth * kTM / (s16 ? 2 : 1); }   // one h_l, in floats
+__host__ __device__ inline size_t stash_floats_per_tile(int c_in16, bool s16) {
+  return (size_t)c_in16 * kTM + kHidden * stash_h_floats(s16) + (size_t)kHidden * kNT;
 }
-__host__ __device__ inline size_t stash_h_off(int c_in16, int l) { return (size_t)(c_in16 + l * kWidth) * kTM; }   // h_l
-__host__ __device__ inline size_t stash_sign_off(int c_in16, int l) {
-  return (size_t)(c_in16 + kHidden * kWidth) * kTM + (size_t)l * kNT;
+__host__ __device__ inline size_t stash_h_off(int c_in16, int l, bool s16) { return (size_t)c_in16 * kTM + l * stash_h_floats(s16); }   // h_l
+__host__ __device__ inline size_t stash_sign_off(int c_in16, int l, bool s16) {
+  return (size_t)c_in16 * kTM + kHidden * stash_h_floats(s16) + (size_t)l * kNT;
 }
 __host__ __device__ inline size_t gstash_floats_per_tile() { return (size_t)kHidden * kWidth * kTM; }
 // After the tiles of a stash: 16 floats of per-layer maxima over ALL tiles (atomic max by the forward / dX kernels, read by
@@ -347,7 +353,7 @@ __device__ __forceinline__ void build_embedding(const Geometry& g, const float* 
   }
 }
 
-template <bool STASH>
+template <bool STASH, bool S16>
 __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* X = smem;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const Fwd
   const u32x4* P4 = static_cast<const u32x4*>(a.packed);
   for (int i = tid; i < 3 * kWidth + 4; i += kNT) w5[i] = pf[i < 3 * kWidth ? a.L.w5 + i : a.L.bias[5] + (i - 3 * kWidth)];
   const unsigned char* Xl = X + hh * 1024 + j * 16;
-  float* tail = STASH ? a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16) : nullptr;   // per-layer maxima
+  float* tail = STASH ? a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;   // per-layer maxima
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long n0 = (long long)tile * kTM;
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const Fwd
       psm[c * kTM + lane] = v;
     }
     __syncthreads();
-    float* st = STASH ? a.stash + (size_t)tile * stash_floats_per_tile(a.g.c_in16) : nullptr;
+    float* st = STASH ? a.stash + (size_t)tile * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;
     // operand scale of the embedding: the largest input magnitude of the tile (every wave sees all 64 pixels in its lanes)
     const float emax = wave_max_all(fmaxf(fmaxf(fabsf(psm[lane]), fabsf(psm[kTM + lane])),
                                           fmaxf(fmaxf(fabsf(psm[2 * kTM + lane]), fabsf(psm[3 * kTM + lane])), 1.0f)));
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const Fwd
       const float hmax = tile_max(tmx);
       sx = pow2_scale(hmax);                           // scale of the next layer's input
       if (STASH && tid == 0) fold_amax(tail + 1 + l, hmax);
-      float* sh = STASH ? st + stash_h_off(a.g.c_in16, l) : nullptr;
+      float* sh = STASH ? st + stash_h_off(a.g.c_in16, l, S16) : nullptr;
       unsigned sw = 0;
       float po[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
@@ -432,11 +438,19 @@ __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const Fwd
           const int m = 32 * ct + j;
           if (l < kHidden - 1) store_split4(X, 4 * w + q, m, hh, sx, v0, v1, v2, v3);   // the next layer's input
           if (STASH) {
-            float* sp = sh + (size_t)n4 * kTM + m;
-            sp[0] = v0;
-            sp[kTM] = v1;
-            sp[2 * kTM] = v2;
-            sp[3 * kTM] = v3;
+            if constexpr (S16) {
+              _Float16* sp = reinterpret_cast<_Float16*>(sh) + (size_t)n4 * kTM + m;
+              sp[0] = (_Float16)v0;
+              sp[kTM] = (_Float16)v1;
+              sp[2 * kTM] = (_Float16)v2;
+              sp[3 * kTM] = (_Float16)v3;
+            } else {
+              float* sp = sh + (size_t)n4 * kTM + m;
+              sp[0] = v0;
+              sp[kTM] = v1;
+              sp[2 * kTM] = v2;
+              sp[3 * kTM] = v3;
+            }
             const int b0 = 16 * ct + 4 * q;
             sw |= (v0 > 0.f ? 1u : 0u) << b0 | (v1 > 0.f ? 1u : 0u) << (b0 + 1) | (v2 > 0.f ? 1u : 0u) << (b0 + 2) |
                   (v3 > 0.f ? 1u : 0u) << (b0 + 3);
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const Fwd
             }
           }
         }
-      if (STASH) reinterpret_cast<unsigned*>(st + stash_sign_off(a.g.c_in16, l))[tid] = sw;
+      if (STASH) reinterpret_cast<unsigned*>(st + stash_sign_off(a.g.c_in16, l, S16))[tid] = sw;
       if (l == kHidden - 1) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -503,6 +517,7 @@ struct BwdArgs {
 // LDS: X (gradient tile, split; at the end fp32 g_in [<= 256][64]) | gz5 [4][64] | w5 [3][256] | tmx [8]
 constexpr size_t kBwdLds = (size_t)kXBytes + 4 * kTM * 4 + 3 * kWidth * 4 + 8 * 4;
 
+template <bool S16>
 __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* X = smem;
@@ -516,7 +531,7 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
   const u32x4* P4 = static_cast<const u32x4*>(a.packed);
   for (int i = tid; i < 3 * kWidth; i += kNT) w5[i] = pf[a.L.w5 + i];
   // per-layer maxima of the pre-activation gradients over all tiles (for the weight-gradient kernel): stash tail [8 + l]
-  float* gtail = const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16) + 8;
+  float* gtail = const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, S16) + 8;
   const float s1 = a.gscale * (a.scale_ptr ? a.scale_ptr[0] : 1.0f);
   const unsigned char* Xl = X + hh * 1024 + j * 16;
   float sx = 1.0f;                                         // operand scale of what X currently holds
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
 #pragma unroll
     for (int i = 0; i < 16; ++i) dw5[c][i] = 0.0f;
   float db5 = 0.0f;
-  const size_t spt = stash_floats_per_tile(a.g.c_in16), gpt = gstash_floats_per_tile();
+  const size_t spt = stash_floats_per_tile(a.g.c_in16, S16), gpt = gstash_floats_per_tile();
 
   for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
     const long long n0 = (long long)tile * kTM;
@@ -551,8 +566,8 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
     }
     __syncthreads();
     {  // layer 5 (256 -> 3): g_z4 = (W5^T g_z5) * LeakyReLU'(h4); dW5 += g_z5 h4^T -- in the epilogue mapping
-      const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4))[tid];
-      const float* h4 = st + stash_h_off(a.g.c_in16, 4);
+      const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4, S16))[tid];
+      const float* h4 = st + stash_h_off(a.g.c_in16, 4, S16);
       float* g4 = gs + (size_t)4 * kWidth * kTM;
       // g_z4 of (pixel m, channels n4 .. n4 + 3): three FMAs and the slope per value -- evaluated twice (first for the
       // tile maximum, the stash and dW5, then for the split store) rather than kept in 32 registers across the barrier
@@ -581,7 +596,8 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
           gz4(ct, q, v);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float hv = h4[(size_t)(n4 + e) * kTM + m];
+            const float hv = S16 ? (float)reinterpret_cast<const _Float16*>(h4)[(size_t)(n4 + e) * kTM + m]
+                                 : h4[(size_t)(n4 + e) * kTM + m];
             vmax = fmaxf(vmax, fabsf(v[e]));
             g4[(size_t)(n4 + e) * kTM + m] = v[e];
             dw5[0][4 * q + e] = __builtin_fmaf(ga, hv, dw5[0][4 * q + e]);
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
     for (int l = 4; l >= 1; --l) {
       f32x16 acc[2];
       zero2(acc);
-      const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, l - 1))[tid];
+      const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, l - 1, S16))[tid];
       gemm_rows32(P4 + a.L.bwd[l] + (size_t)w * 16 * 128 + lane, 16, Xl, acc);
       const float unscale = 1.0f / (sx * pow2_scale(pf[a.L.wamax + l]));
       float vmax = 0.0f;
@@ -714,8 +730,11 @@ constexpr int kDwBuf = 2 * 2 * kDwTerm;            // 49 152: G terms, then H te
 constexpr size_t kDwLds = 2 * (size_t)kDwBuf;      // double buffered
 
 // FULL: every H row and every column tile is live (layers 1..4) -- no predicates in the chunk loop
-template <bool FULL>
+// H16: the H operand (h_{layer-1}, layers 1..4) comes from an fp16 stash -- one term, no scale: G (two terms) x H = 2 MFMAs
+template <bool FULL, bool H16>
 __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
+  static_assert(FULL || !H16, "the embedding (layer 0's H) is always fp32");
+  const bool s16 = a.g.s16 != 0;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 1, wc = w & 1;               // rows [64 wr, +64), columns [128 wc, +128)
   const int i32 = lane & 31, hh = lane >> 5;
@@ -724,8 +743,8 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
   const int n_it = (t1 - t0) * 4;                  // 16-pixel chunks
   const int hrows = FULL ? kWidth : a.g.c_in16;
   const int nct = FULL ? 4 : ((a.g.c_in16 + 31) / 32 - 4 * wc);   // column tiles of this wave that hold anything
-  const size_t spt = stash_floats_per_tile(a.g.c_in16), gpt = gstash_floats_per_tile();
-  const size_t hoff = layer == 0 ? 0 : stash_h_off(a.g.c_in16, layer - 1);
+  const size_t spt = stash_floats_per_tile(a.g.c_in16, s16), gpt = gstash_floats_per_tile();
+  const size_t hoff = layer == 0 ? 0 : stash_h_off(a.g.c_in16, layer - 1, s16);
   const size_t goff = (size_t)layer * kWidth * kTM;
 
   f32x16 acc[2][4];
@@ -738,7 +757,8 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
   float rs[2] = {0.f, 0.f};                        // row sums of G (bias gradient): rows (tid >> 2) and 128 + (tid >> 2)
   // per-launch operand scales from the maxima the forward / dX kernels left behind the stash's tiles
   const float* tail = a.stash + (size_t)a.n_tiles * spt;
-  const float scg = pow2_scale(tail[8 + layer]), sch = pow2_scale(tail[layer]);   // G_layer; H = embedding (0) or h_{layer-1}
+  const float scg = pow2_scale(tail[8 + layer]);                                  // G_layer
+  const float sch = H16 ? 1.0f : pow2_scale(tail[layer]);                         // H = embedding (0) or h_{layer-1}
 
   // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread; q = i * 512 + tid, row = q >> 2, quad = q & 3.
   // Two register sets: the chunk loaded during step `it` is split and stored during step it + 1 and consumed by the
@@ -752,6 +772,12 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
       const bool isH = i >= 2;
       const int r = row & 255;
       const bool valid = FULL || !isH || r < hrows;
+      if (H16 && isH) {      // four fp16 values = 8 bytes, carried in the first two lanes of the float4 as raw bits
+        const _Float16* src = reinterpret_cast<const _Float16*>(a.stash + (size_t)tile * spt + hoff) + (size_t)r * kTM;
+        const float2 raw = *reinterpret_cast<const float2*>(src + chunk * 16 + quad * 4);
+        sg[i] = make_float4(raw.x, raw.y, 0.f, 0.f);
+        continue;
+      }
       const float* src = isH ? a.stash + (size_t)tile * spt + hoff + (size_t)(valid ? r : 0) * kTM
                              : a.gstash + (size_t)tile * gpt + goff + (size_t)r * kTM;
       const float4 v = *reinterpret_cast<const float4*>(src + chunk * 16 + quad * 4);
@@ -764,6 +790,11 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
     for (int i = 0; i < 4; ++i) {
       const int row = i * 128 + (tid >> 2), quad = tid & 3;
       if (i < 2) rs[i] += count ? (sg[i].x + sg[i].y) + (sg[i].z + sg[i].w) : 0.0f;
+      if (H16 && i >= 2) {
+        unsigned char* dst16 = base + 2 * kDwTerm + (row & 255) * kDwPitch + quad * 8;
+        *reinterpret_cast<u32x2*>(dst16) = (u32x2){__float_as_uint(sg[i].x), __float_as_uint(sg[i].y)};
+        continue;
+      }
       unsigned h0, l0, h1, l1;
       const float sc = i >= 2 ? sch : scg;
       split_pair_f16(sg[i].x * sc, sg[i].y * sc, h0, l0);
@@ -786,12 +817,12 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
       if (FULL || c < nct) {
         u32x4 B[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) B[t] = *reinterpret_cast<const u32x4*>(hb + t * kDwTerm + c * 32 * kDwPitch);
+        for (int t = 0; t < (H16 ? 1 : 2); ++t) B[t] = *reinterpret_cast<const u32x4*>(hb + t * kDwTerm + c * 32 * kDwPitch);
 #define DVD_DW_TERM(SA, SB)                                                                                     \
   _Pragma("unroll") for (int r = 0; r < 2; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(             \
       __builtin_bit_cast(f16x8, A[r][SA]), __builtin_bit_cast(f16x8, B[SB]), acc[r][c], 0, 0, 0);
         DVD_DW_TERM(1, 0)
-        DVD_DW_TERM(0, 1)
+        if constexpr (!H16) { DVD_DW_TERM(0, 1) }
         DVD_DW_TERM(0, 0)
 #undef DVD_DW_TERM
       }
@@ -841,12 +872,13 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
   }
 }
 
+template <bool S16>
 __global__ __launch_bounds__(kNT) void mlp_bwd_dw_kernel(const DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (blockIdx.y == 0)
-    dw_body<false>(a, smem);
+    dw_body<false, false>(a, smem);
   else
-    dw_body<true>(a, smem);
+    dw_body<true, S16>(a, smem);
 }
 
 // gW_l[n][k] += sum_s partial[l][s][n][k] (ascending s), gb_l[n] += sum_s rowsum[l][s][n]
@@ -911,7 +943,7 @@ size_t dvd_sf_mlp_packed_bytes(const dvd_mlp_desc* d) {
 size_t dvd_sf_mlp_stash_bytes(const dvd_mlp_desc* d, long long n_pix) {
   if (!d || n_pix <= 0) return 0;
   const long long tiles = (n_pix + dvd::kTM - 1) / dvd::kTM;
-  return ((size_t)tiles * dvd::stash_floats_per_tile(dvd::make_geometry(d).c_in16) + dvd::kStashTail) * 4;
+  return ((size_t)tiles * dvd::stash_floats_per_tile(dvd::make_geometry(d).c_in16, d->stash_f16 != 0) + dvd::kStashTail) * 4;
 }
 
 size_t dvd_sf_mlp_gstash_bytes(long long n_pix) {
@@ -977,15 +1009,18 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   const int grid = persistent_grid(a.n_tiles, DVD_MLP_FWD_OCC);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (stash)   // per-layer maxima behind the tiles (embedding, h_0 .. h_4; the dX kernel zeroes its own half)
-    if (int e = zero_words(a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16), kStashTail, s)) return e;
-  if (stash) {
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
-    hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(grid), dim3(kNT), kFwdLds, s, a);
+    if (int e = zero_words(a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, a.g.s16 != 0), kStashTail, s)) return e;
+  auto go = [&](auto kern) -> int {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), kFwdLds, s, a);
+    return DVD_OK;
+  };
+  if (stash && a.g.s16) {
+    if (int e = go(mlp_fwd_kernel<true, true>)) return e;
+  } else if (stash) {
+    if (int e = go(mlp_fwd_kernel<true, false>)) return e;
   } else {
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
-    hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(grid), dim3(kNT), kFwdLds, s, a);
+    if (int e = go(mlp_fwd_kernel<false, false>)) return e;
   }
   DVD_LAUNCH_OK();
   return DVD_OK;
@@ -1021,12 +1056,18 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
   a.gscale = gscale;
   const int grid = persistent_grid(a.n_tiles, DVD_MLP_DX_OCC);
   // maxima of G_0 .. G_4 over all tiles, folded in by the kernel: floats [8, 16) behind the stash's tiles
-  if (int e = zero_words(const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16) + 8, 8,
+  if (int e = zero_words(const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, a.g.s16 != 0) + 8, 8,
                          static_cast<hipStream_t>(stream)))
     return e;
-  DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
-  hipLaunchKernelGGL(mlp_bwd_dx_kernel, dim3(grid), dim3(kNT), kBwdLds, static_cast<hipStream_t>(stream), a);
+  if (a.g.s16) {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
+    hipLaunchKernelGGL(mlp_bwd_dx_kernel<true>, dim3(grid), dim3(kNT), kBwdLds, static_cast<hipStream_t>(stream), a);
+  } else {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
+    hipLaunchKernelGGL(mlp_bwd_dx_kernel<false>, dim3(grid), dim3(kNT), kBwdLds, static_cast<hipStream_t>(stream), a);
+  }
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -1053,9 +1094,15 @@ int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, void* gstash, lo
   r.S = a.S;
   r.c_in = a.g.c_in;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)kDwLds));
-  hipLaunchKernelGGL(mlp_bwd_dw_kernel, dim3(a.S, kHidden), dim3(kNT), kDwLds, s, a);
+  if (a.g.s16) {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kDwLds));
+    hipLaunchKernelGGL(mlp_bwd_dw_kernel<true>, dim3(a.S, kHidden), dim3(kNT), kDwLds, s, a);
+  } else {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kDwLds));
+    hipLaunchKernelGGL(mlp_bwd_dw_kernel<false>, dim3(a.S, kHidden), dim3(kNT), kDwLds, s, a);
+  }
   DVD_LAUNCH_OK();
   hipLaunchKernelGGL(mlp_dw_reduce_kernel, dim3((unsigned)((kDwPartial + 255) / 256), kHidden), dim3(256), 0, s, r);
   DVD_LAUNCH_OK();

@@ -95,6 +95,10 @@ class Model(NetInterface):
                             help='BASELINE configs[4]: store the depth net\'s activations (and their gradients) as fp16 in HBM -- '
                                  'fp32 parameters, fp32 accumulation, fp32 loss sums; gradients carry a power-of-two loss scale kept on '
                                  'the device (csrc/a16.hip); a step whose fp16 gradients overflow skips its depth-net update.  MiDaS only')
+        parser.add_argument('--mlp_stash_fp16', action='store_true',
+                            help='store the hidden activations of the scene-flow MLP stash as fp16 (3.2 instead of 5.7 KB per pixel and '
+                                 'Euler step; the MLP weight gradients then see fp16-rounded activations, losses and input gradients '
+                                 'are unchanged).  Implied by --act_fp16')
         parser.add_argument('--grad_buckets', type=int, default=4,
                             help='data parallel: the depth-net gradient (421 MB for MiDaS) is all-reduced as this many large '
                                  'buckets in flight at once, the Adam launch of a bucket overlapping the reduction of the next')
@@ -156,7 +160,8 @@ class Model(NetInterface):
         self.optimizer_depth, self.optimizer_scene = self._flat_depth, self._flat_sf
         self._optimizers = [self._flat_depth, self._flat_sf]
         self._sf_grad_main = torch.zeros_like(self._flat_sf.grad)
-        self._mlp = self.net_sceneflow.kernels(self.device)
+        self._mlp = self.net_sceneflow.kernels(self.device, stash_f16=bool(getattr(self.opt, 'mlp_stash_fp16', False) or
+                                                                           getattr(self.opt, 'act_fp16', False)))
         self._gscale = None
         if getattr(self.opt, 'act_fp16', False):
             if not self.opt.midas:

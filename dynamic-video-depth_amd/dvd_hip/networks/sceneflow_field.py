@@ -81,10 +81,11 @@ class SceneFlowFieldNet(nn.Module):
         self.n_freq_xyz, self.n_freq_t = N_freq_xyz, N_freq_t
         self._kernels = {}
 
-    def kernels(self, device):
-        key = str(device)
+    def kernels(self, device, stash_f16=False):
+        key = (str(device), bool(stash_f16))
         if key not in self._kernels:
-            self._kernels[key] = ops.SceneFlowMLPKernels(device, self.n_freq_xyz, self.n_freq_t, self.time_dependent)
+            self._kernels[key] = ops.SceneFlowMLPKernels(device, self.n_freq_xyz, self.n_freq_t, self.time_dependent,
+                                                         stash_f16=stash_f16)
         return self._kernels[key]
 
     def parameter_list(self):

@@ -318,16 +318,19 @@ class SceneFlowMLPKernels(object):
     """Host-side handle of the fused MLP kernels for one network configuration:
     owns the frequency tables, the packed-weight buffer and the scratch stashes."""
 
-    def __init__(self, device, n_freq_xyz=16, n_freq_t=16, time_dependent=True):
+    def __init__(self, device, n_freq_xyz=16, n_freq_t=16, time_dependent=True, stash_f16=False):
         if torch.device(device).type != 'cuda':
             raise RuntimeError('SceneFlowMLPKernels needs a GPU device (dvd_hip has no CPU path)')
         self.device = torch.device(device)
         self.n_freq_xyz, self.n_freq_t, self.time_dependent = int(n_freq_xyz), int(n_freq_t), bool(time_dependent)
         self.fx = embed_frequencies(self.n_freq_xyz).to(self.device) if self.n_freq_xyz > 0 else None
         self.ft = embed_frequencies(self.n_freq_t).to(self.device) if (self.time_dependent and self.n_freq_t > 0) else None
+        # stash_f16: the five hidden activations of the stash as fp16 (3.2 instead of 5.7 KB per pixel-evaluation; only the
+        # weight gradients see the rounding -- include/dvd_hip.h, dvd_mlp_desc)
+        self.stash_f16 = bool(stash_f16)
         self.desc = _lib.MlpDesc(self.n_freq_xyz, self.n_freq_t, int(self.time_dependent),
                                  self.fx.data_ptr() if self.fx is not None else 0,
-                                 self.ft.data_ptr() if self.ft is not None else 0)
+                                 self.ft.data_ptr() if self.ft is not None else 0, int(self.stash_f16))
         lib = _lib.load()
         self.c_in = lib.dvd_sf_mlp_in_channels(ctypes.byref(self.desc))
         self.packed = torch.empty(lib.dvd_sf_mlp_packed_bytes(ctypes.byref(self.desc)) // 4, device=self.device,

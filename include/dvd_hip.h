@@ -149,6 +149,9 @@ typedef struct dvd_mlp_desc {
   int time_dependent;  /* 1: input = [embed(t), embed(xyz)] */
   const float* freqs_xyz; /* device [n_freq_xyz] = linspace(1, n+1, n) as torch computes it */
   const float* freqs_t;   /* device [n_freq_t] */
+  int stash_f16;          /* ABI 4: 1 = the five hidden activations of the stash are stored as _Float16 (3.2 KB per pixel instead of
+                           * 5.7): the weight-gradient kernel then contracts fp32 gradients (two terms) against fp16 activations (one
+                           * term, 2 MFMAs per product).  Losses and the input gradient do not depend on it. */
 } dvd_mlp_desc;
 
 int dvd_sf_mlp_in_channels(const dvd_mlp_desc* d);             /* 132 for the shipped config */

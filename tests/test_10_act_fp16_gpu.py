@@ -379,3 +379,41 @@ def test_fp16_step_graph_replay_matches_eager():
         assert [t[0] for t in logs[a][2][:2]] == [t[0] for t in logs[b][2][:2]], (a, b)
         assert [t[1] for t in logs[a][2]] == [t[1] for t in logs[b][2]], 'loss-scale decisions differ'
         assert abs(logs[a][0] - logs[b][0]) <= 5e-4 * abs(logs[a][0]) and abs(logs[a][1] - logs[b][1]) <= 2e-2 * logs[a][1], logs
+
+
+# ---- the scene-flow MLP's fp16 stash ----------------------------------------------------------------------------------
+def test_mlp_fp16_stash_changes_only_the_weight_gradients():
+    """dvd_mlp_desc.stash_f16: the hidden activations h_0 .. h_4 of the stash are stored as fp16 (networks/sceneflow_field.py:43-53
+    is the layer stack they belong to).  The forward output and the input gradient are BIT-identical to the fp32 stash (neither
+    reads the stored activations: the dX chain uses the sign bits); the weight gradients contract fp32 gradients against
+    fp16-rounded activations: <= 8e-4 of max|g| per tensor (measured on MI355X: 3.3e-4 worst, layer 3), biases exact."""
+    from dvd_hip import ops
+    from oracle import sceneflow_mlp as M
+    sd = M.init_params(seed=4)
+    B, H, W = 2, 24, 40
+    g = torch.Generator().manual_seed(11)
+    p = (2.0 * torch.randn(B, 3, H, W, generator=g)).cuda()
+    ts = torch.rand(B, 1, 1, 1, generator=g).expand(B, 1, H, W).contiguous().cuda()
+    gout = torch.randn(B, 3, H, W, generator=g).cuda()
+    n_pix = B * H * W
+    res = []
+    for s16 in (False, True):
+        k = ops.SceneFlowMLPKernels('cuda', 16, 16, True, stash_f16=s16)
+        k.pack([sd['convs.%d.conv.weight' % i].cuda() for i in range(6)], [sd['convs.%d.conv.bias' % i].cuda() for i in range(6)])
+        stash, gst = k.new_stash(n_pix), k.new_gstash(n_pix)
+        sf, g_p = torch.empty_like(p), torch.empty_like(p)
+        k.forward(p, ts, 0.0, 0.01, sf_out=sf, stash=stash)
+        dims = [k.c_in] + [256] * 5
+        gW = [torch.zeros(256 if i < 5 else 3, dims[i], device='cuda') for i in range(6)]
+        gb = [torch.zeros(256 if i < 5 else 3, device='cuda') for i in range(6)]
+        k.backward_dx(stash, 0.01, gout, g_p, gst, gW[5], gb[5], (B, H, W))
+        k.backward_dw(stash, gst, n_pix, gW[:5], gb[:5])
+        res.append((sf, g_p, gW, gb, stash.numel()))
+    (sf32, gp32, gW32, gb32, n32), (sf16, gp16, gW16, gb16, n16) = res
+    assert n16 < 0.6 * n32
+    assert torch.equal(sf32, sf16) and torch.equal(gp32, gp16)
+    for i in range(6):
+        assert torch.allclose(gb32[i], gb16[i], rtol=1e-6, atol=1e-7 * float(gb32[i].abs().max()))      # (layer 5: atomics)
+        e = float((gW32[i] - gW16[i]).abs().max() / gW32[i].abs().max())
+        log_measured('mlp fp16 stash: dW_%d vs fp32 stash, of max' % i, e, 8e-4)
+        assert e <= (1e-6 if i == 0 else 8e-4), (i, e)          # layer 0 contracts against the fp32 embedding
