@@ -147,6 +147,8 @@ SIGNATURES = {
     'dvd_gscale_begin': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'dvd_gscale_end': (c_int, [c_void_p, c_void_p]),
     'dvd_cast_scale_f32': (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_void_p, c_void_p]),
+    'dvd_maxpool3s2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    'dvd_maxpool3s2_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     'dvd_adam_step_guarded': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,
                                       c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
 }

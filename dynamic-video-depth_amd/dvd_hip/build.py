@@ -37,6 +37,7 @@ SOURCES = [
     ('xwgrad3.hip', []),
     ('consistency.hip', ['-ffp-contract=off']),
     ('a16.hip', []),
+    ('pool.hip', []),
 ]
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
           '-I' + INCLUDE, '-I' + CSRC]

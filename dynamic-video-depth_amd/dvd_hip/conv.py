@@ -313,6 +313,96 @@ class GroupedConv3x3C32(nn.Conv2d):
         return gconv3x3_c32(x, self.weight)
 
 
+# ---- the ResNeXt stem natively (round 4) ------------------------------------------------------------------------------
+# `conv1 = Conv2d(3, 64, 7, stride 2, padding 3)` + `bn1` + ReLU + `MaxPool2d(3, 2, 1)` (torchvision's ResNet stem, reached
+# through third_party/midas_blocks.py:35-45).  Round 3 left all four to ATen / MIOpen.  A stride-2 7x7 convolution is a
+# STRIDE-1 convolution over the 2x2 space-to-depth image: with x'[4c + 2py + px][Y][X] = x[c][2Y + py][2X + px] and
+# ky - 3 = 2a + py (a in -2..1), out[y][x] = sum w[c][ky][kx] x'[4c + 2py + px][y + a][x + b] -- a 4x4 kernel, embedded in a
+# 5x5 "same" one (zero taps at a = 2 / b = 2).  That runs on the kernels this package already has: xconv (csrc/xconv.hip) with
+# the eval-mode BatchNorm + ReLU in its epilogue, and the exact-fp32 weight gradient (csrc/xwgrad.hip, KS = 5); the image needs
+# no gradient.  The rearranged weight is a gather of the module's [64,3,7,7] parameter, so its gradient flows back through
+# autograd's index backward and the state_dict keeps the reference's key and shape.
+_S2D_IDX = {}
+
+
+def _s2d_index(device):
+    key = str(device)
+    if key not in _S2D_IDX:
+        idx = torch.full((2, 2, 5, 5), 49, dtype=torch.long)
+        for py in range(2):
+            for a in range(-2, 3):
+                ky = 2 * a + py + 3
+                if not 0 <= ky <= 6:
+                    continue
+                for px in range(2):
+                    for b in range(-2, 3):
+                        kx = 2 * b + px + 3
+                        if 0 <= kx <= 6:
+                            idx[py, px, a + 2, b + 2] = ky * 7 + kx
+        _S2D_IDX[key] = idx.reshape(-1).to(device)
+    return _S2D_IDX[key]
+
+
+def s2d_weight(w):
+    """[Cout, C, 7, 7] (stride 2, padding 3) -> the equivalent [Cout, 4C, 5, 5] (stride 1, padding 2) over pixel_unshuffle(x, 2)."""
+    Co, C = w.shape[0], w.shape[1]
+    w_ext = torch.cat([w.reshape(Co, C, 49), w.new_zeros(Co, C, 1)], 2)
+    return w_ext.index_select(2, _s2d_index(w.device)).reshape(Co, C * 4, 5, 5)
+
+
+def stem_conv_bn_relu(conv, bn, x):
+    """relu(bn(conv(x))) for the 7x7 / stride 2 / padding 3 stem convolution and its eval-mode BatchNorm, GPU fp32 tensors."""
+    if not (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.groups == 1 and
+            not bn.training and bn.track_running_stats):
+        raise RuntimeError('stem_conv_bn_relu: not the ResNet stem (%r)' % (conv,))
+    H, W = x.shape[2], x.shape[3]
+    if H % 2 or W % 2:                    # the zero row / column the convolution's padding would have supplied
+        x = F.pad(x, (0, W % 2, 0, H % 2))
+    x4 = F.pixel_unshuffle(x, 2).contiguous()
+    w5 = s2d_weight(conv.weight)
+    gamma, beta = (bn.weight, bn.bias) if bn.affine else (None, None)
+    out_site = _Site()
+    y, y_amax = _XConvBn.apply(x4, amax_of(x4), w5, conv.bias, gamma, beta, bn.running_mean, bn.running_var, bn.eps, None, True,
+                               1, False, None, out_site)
+    y._dvd_site = out_site
+    return set_amax(y, y_amax)
+
+
+class _MaxPool3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on csrc/pool.hip (ATen's tie rule; deterministic gather backward).  to_half: the output is
+    written as fp16 -- the fp32 / fp16 boundary of fp16 activation storage, fused into the pooling; the backward then hands
+    the fp32 stem the TRUE gradient (fp16 gradient times 1 / loss scale)."""
+
+    @staticmethod
+    def forward(ctx, x, to_half):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.float16 if to_half else torch.float32)
+        idx = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.uint8)
+        _lib.check(_lib.load().dvd_maxpool3s2_fwd(_p(x), _p(y), int(bool(to_half)), _p(idx), ctypes.c_longlong(N * C), H, W,
+                                                  _stream()), 'dvd_maxpool3s2_fwd')
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        idx, = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        h16 = _is16(gy)
+        gx = torch.empty(N, C, H, W, device=gy.device, dtype=torch.float32)
+        _lib.check(_lib.load().dvd_maxpool3s2_bwd(_p(gy), int(h16), _p(idx), _p(gx), _p(_gs(1)) if h16 else None,
+                                                  ctypes.c_longlong(N * C), H, W, _stream()), 'dvd_maxpool3s2_bwd')
+        return gx, None
+
+
+def maxpool3s2(x, to_half=False):
+    y = _MaxPool3s2.apply(x, bool(to_half))
+    return y if to_half else set_amax(y, known_amax(x))      # a maximum of inputs never exceeds the largest input magnitude
+
+
 def add_bounded(a, b):
     """a + b; when both operands carry a max|.| scalar the sum's bound is their sum (one tiny kernel instead of a reduction
     pass over the sum when it feeds a convolution)."""
@@ -636,7 +726,9 @@ def xconv_wgrad(x, gy, wshape, relu_in, groups=1, x_amax=None, g_amax=None, rows
                                                ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W, int(bool(relu_in)), _stream()),
                        'dvd_xwgrad1s_rowsum')
         return gw
-    if wshape[2] in (1, 3) and not AB['no_xwgrad']:
+    if (wshape[2] in (1, 3) and not AB['no_xwgrad']) or wshape[2] in (5, 7, 11):
+        # exact-fp32 MFMA kernel (csrc/xwgrad.hip): the A/B fall-back of the small kernels, and -- round 4 -- THE weight gradient
+        # of the hourglass's 5x5 / 7x7 / 11x11 inception branches and of the stem's 5x5 space-to-depth form (round 3: MIOpen)
         N, Cin, H, W = x.shape
         Cout, _, KS, _ = wshape
         gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
@@ -645,11 +737,12 @@ def xconv_wgrad(x, gy, wshape, relu_in, groups=1, x_amax=None, g_amax=None, rows
         _lib.check(lib.dvd_xwgrad(_p(x), _p(gy), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W, KS,
                                   int(bool(relu_in)), _stream()), 'dvd_xwgrad')
         return gw
-    # larger kernels (hourglass inception branches): MIOpen's weight-gradient kernels
-    xin = torch.relu(x) if relu_in else x
-    KS = wshape[2]
-    return torch.ops.aten.convolution_backward(gy, xin, torch.empty(wshape, device=x.device), None, [1, 1],
-                                               [KS // 2, KS // 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    if AB['no_xwgrad'] and wshape[2] in (1, 3):            # A/B only: MIOpen's weight-gradient kernels
+        xin = torch.relu(x) if relu_in else x
+        KS = wshape[2]
+        return torch.ops.aten.convolution_backward(gy, xin, torch.empty(wshape, device=x.device), None, [1, 1],
+                                                   [KS // 2, KS // 2], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    raise RuntimeError('xconv: no weight-gradient kernel for a %dx%d convolution (1, 3, 5, 7, 11 are covered)' % (wshape[2], wshape[3]))
 
 
 class _XConvBn(torch.autograd.Function):

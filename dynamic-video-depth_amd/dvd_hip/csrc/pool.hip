@@ -1,0 +1,114 @@
+// 3x3 / stride 2 / padding 1 max-pooling of the ResNeXt stem, forward and backward (gfx950).
+//
+// What it replaces (reference, /root/reference): `pretrained.layer1[3]` = torchvision's nn.MaxPool2d(3, 2, 1) behind the 7x7
+// stem (third_party/midas_blocks.py:35-45 builds `layer1 = Sequential(conv1, bn1, relu, maxpool, layer1)`); round 3 ran it
+// on ATen (max_pool2d_with_indices / its backward, 6 ms of a step).
+//
+// Semantics = ATen's: the window of output (oy, ox) covers input rows 2 oy - 1 .. 2 oy + 1 (clipped to the image: padding
+// never wins), scanned row-major; a later element replaces the maximum only if it is strictly greater (or NaN), so the FIRST
+// maximum of a window takes the gradient -- after the stem's ReLU whole windows are 0 and the tie rule decides where the
+// gradient goes.  The forward stores the winner's window position (0..8) in one byte per output; the backward is a gather
+// over the (at most four) windows that contain an input pixel: deterministic, no atomics, no memset.
+//
+// HBM bound.  The forward writes the storage the network continues in (fp32, or _Float16 with fp16 activation storage -- the
+// cast of BASELINE configs[4] is fused here); the backward reads that storage and writes the fp32 gradient of the stem times
+// *out_scale (1 / loss scale of the fp16 gradients, csrc/a16.hip).
+#include "dvd_io.h"
+
+namespace dvd {
+
+template <class T>
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* __restrict__ x, T* __restrict__ y,
+                                                             unsigned char* __restrict__ idx, int H, int W, int Ho, int Wo,
+                                                             long long total) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= total) return;
+  const int ox = (int)(i % Wo);
+  const long long r = i / Wo;
+  const int oy = (int)(r % Ho);
+  const long long pl = r / Ho;
+  const float* xp = x + pl * H * W;
+  float best = -INFINITY;
+  int bi = 0;
+  bool any = false;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = 2 * ox - 1 + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const float v = xp[(size_t)iy * W + ix];
+        if (!any || v > best || v != v) {
+          best = v;
+          bi = ky * 3 + kx;
+          any = true;
+        }
+      }
+    }
+  }
+  stf(y + i, best);
+  idx[i] = (unsigned char)bi;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const T* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                                             float* __restrict__ gx, int H, int W, int Ho, int Wo,
+                                                             long long total, const float* __restrict__ out_scale) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W);
+  const long long r = i / W;
+  const int y = (int)(r % H);
+  const long long pl = r / H;
+  const T* gp = gy + pl * Ho * Wo;
+  const unsigned char* ip = idx + pl * Ho * Wo;
+  const int oy0 = y >> 1, ox0 = x >> 1;              // windows: oy0 (and oy0 + 1 for odd y), likewise in x
+  float s = 0.0f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const int oy = oy0 + dy;
+    if (oy >= Ho || (dy == 1 && !(y & 1))) continue;
+    const int ky = y - (2 * oy - 1);
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int ox = ox0 + dx;
+      if (ox >= Wo || (dx == 1 && !(x & 1))) continue;
+      const int kx = x - (2 * ox - 1);
+      const size_t o = (size_t)oy * Wo + ox;
+      if (ip[o] == ky * 3 + kx) s += ldf(gp + o);
+    }
+  }
+  gx[i] = s * (out_scale ? out_scale[0] : 1.0f);
+}
+
+}  // namespace dvd
+
+extern "C" {
+
+int dvd_maxpool3s2_fwd(const float* x, void* y, int y_f16, unsigned char* index, long long planes, int H, int W,
+                       dvd_stream_t stream) {
+  DVD_REQUIRE(x && y && index && planes > 0 && H > 0 && W > 0, "maxpool fwd: bad arguments");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = planes * Ho * Wo;
+  DVD_REQUIRE((total + 255) / 256 < (1LL << 31), "maxpool fwd: too large");
+  DVD_DISPATCH_T(y_f16, hipLaunchKernelGGL(dvd::maxpool3s2_fwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                                           static_cast<hipStream_t>(stream), x, static_cast<T*>(y), index, H, W, Ho, Wo, total));
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_maxpool3s2_bwd(const void* gy, int gy_f16, const unsigned char* index, float* gx, const float* out_scale,
+                       long long planes, int H, int W, dvd_stream_t stream) {
+  DVD_REQUIRE(gy && index && gx && planes > 0 && H > 0 && W > 0, "maxpool bwd: bad arguments");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = planes * H * W;
+  DVD_REQUIRE((total + 255) / 256 < (1LL << 31), "maxpool bwd: too large");
+  DVD_DISPATCH_T(gy_f16, hipLaunchKernelGGL(dvd::maxpool3s2_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                                            static_cast<hipStream_t>(stream), static_cast<const T*>(gy), index, gx, H, W, Ho, Wo,
+                                            total, out_scale));
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+}  // extern "C"

@@ -1,4 +1,5 @@
-// Backward-weight of the dense stride-1 "same" convolutions (3x3 and 1x1), NCHW fp32, on fp32 MFMA for gfx950:
+// Backward-weight of the dense stride-1 "same" convolutions (1x1, 3x3 and -- round 4 -- 5x5, 7x7, 11x11), NCHW fp32, on fp32
+// MFMA for gfx950:
 //   dW[co][ci][ky][kx] = sum_{n, r, c} gy[n][co][r][c] * act(x)[n][ci][r + ky - pad][c + kx - pad]
 // (act = identity or the ReLU that csrc/xconv.hip applies to its input).  Deterministic: no atomics.
 //
@@ -15,6 +16,11 @@
 // pitches (the 32 lanes of a half wave read 32 channels at one pixel: 32 different banks); the next tile's rows
 // are requested into registers before the MFMAs of the current one.  Every block writes its partial sums to
 // the workspace; `xwgrad_reduce_kernel` adds them in slice order.
+// The 3x3 / 1x1 convolutions of the depth nets run on the faster split-operand kernels of csrc/xwgrad3.hip; this exact-fp32
+// kernel serves the large kernels of the hourglass's inception branches (third_party/hourglass.py:21-57: 5x5, 7x7, 11x11 --
+// round 3 left those to MIOpen) and the 5x5 space-to-depth form of the ResNeXt stem (third_party/midas_blocks.py:35-45,
+// dvd_hip/third_party/MiDaS.py): COB = CIB = 32 channels, one wave per kernel row, an 11-wide kernel row split over two
+// blocks (KXN columns each) so that the accumulators fit the register file.
 #include "dvd_common.h"
 
 namespace dvd {
@@ -28,11 +34,12 @@ struct WgArgs {
   int N, Cin, Cout, H, W;
   int TC, ntr, ntc, S;
   int relu_in;
+  int nkxb;                      // blocks per kernel row (column ranges of KXN taps)
 };
 
 // KS = 3: TR = 3 rows x TC <= 62 columns (x rows of TC + 2 <= 64 pixels: one wave-wide load per row).
 // KS = 1: the image is one row of H * W pixels; a tile is TR = 2 "rows" of TC = 64 consecutive pixels.
-template <int KS, int PM, int PN, int TR>
+template <int KS, int PM, int PN, int TR, int KXN = KS, int UN = 8>
 __global__ __launch_bounds__(64 * PM * PN * KS) void xwgrad_kernel(const WgArgs a) {
   constexpr int NW = PM * PN * KS;
   constexpr int PAD = KS / 2;
@@ -51,6 +58,8 @@ __global__ __launch_bounds__(64 * PM * PN * KS) void xwgrad_kernel(const WgArgs 
   const size_t plane = (size_t)a.H * a.W;
   const int tiles_per_img = a.ntr * a.ntc;
   const int total = a.N * tiles_per_img;
+  const int slice = KXN == KS ? blockIdx.x : blockIdx.x / a.nkxb;
+  const int kx0 = KXN == KS ? 0 : (blockIdx.x - slice * a.nkxb) * KXN;     // first kernel column of this block
 
   float rg[NG], rx[NX];
   auto load_tile = [&](int t) {
@@ -96,14 +105,15 @@ __global__ __launch_bounds__(64 * PM * PN * KS) void xwgrad_kernel(const WgArgs 
     }
   };
 
-  f32x16 acc[KS];
+  f32x16 acc[KXN];
 #pragma unroll
-  for (int k = 0; k < KS; ++k) acc[k] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < KXN; ++k) acc[k] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const float* ga = sG + (pm * 32 + (lane & 31)) * PG + (lane >> 5);
-  const float* xa = sX + (pn * 32 + (lane & 31)) * PX + ky * XC + (lane >> 5);
+  // (a column range past the kernel's last column reads in-range LDS cells of the next row; those accumulators are dropped)
+  const float* xa = sX + (pn * 32 + (lane & 31)) * PX + ky * XC + (lane >> 5) + kx0;
   const int pw = TC >> 1;                             // pixel pairs per row (TC is even)
 
-  int t = blockIdx.x;
+  int t = slice;
   if (t < total) load_tile(t);
   for (; t < total; t += a.S) {
     __syncthreads();                                  // the previous tile's MFMAs have read their operands
@@ -114,33 +124,34 @@ __global__ __launch_bounds__(64 * PM * PN * KS) void xwgrad_kernel(const WgArgs 
     for (int rr = 0; rr < TR; ++rr) {
       const float* gr = ga + rr * TC;
       const float* xr = xa + rr * XC;
-      // eight pixel pairs per trip: their LDS reads are issued together, ahead of the MFMAs that use them
+      // UN pixel pairs per trip: their LDS reads are issued together, ahead of the MFMAs that use them
       int q = 0;
-      for (; q + 8 <= pw; q += 8) {
-        float av[8], bv[8][KS];
+      for (; q + UN <= pw; q += UN) {
+        float av[UN], bv[UN][KXN];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UN; ++u) {
           av[u] = gr[2 * (q + u)];
 #pragma unroll
-          for (int kx = 0; kx < KS; ++kx) bv[u][kx] = xr[2 * (q + u) + kx];
+          for (int kx = 0; kx < KXN; ++kx) bv[u][kx] = xr[2 * (q + u) + kx];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-          for (int kx = 0; kx < KS; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][kx], acc[kx], 0, 0, 0);
+          for (int kx = 0; kx < KXN; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][kx], acc[kx], 0, 0, 0);
       }
       for (; q < pw; ++q) {
         const float av = gr[2 * q];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xr[2 * q + kx], acc[kx], 0, 0, 0);
+        for (int kx = 0; kx < KXN; ++kx) acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xr[2 * q + kx], acc[kx], 0, 0, 0);
       }
     }
   }
   // partial[s][tap][co][ci]
-  float* dst = a.partial + (size_t)blockIdx.x * (KS * KS) * a.Cout * a.Cin;
+  float* dst = a.partial + (size_t)slice * (KS * KS) * a.Cout * a.Cin;
 #pragma unroll
-  for (int kx = 0; kx < KS; ++kx) {
-    const int tap = ky * KS + kx;
+  for (int kx = 0; kx < KXN; ++kx) {
+    if (kx0 + kx >= KS) break;
+    const int tap = ky * KS + kx0 + kx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + pm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256) void xwgrad_reduce_kernel(const float* __restr
 }
 
 struct WgPlan {
-  int KS, TR, TC, ntr, ntc, S, cob, cib, nco, nci;
+  int KS, TR, TC, ntr, ntc, S, cob, cib, nco, nci, nkxb;
   size_t lds;
 };
 static bool wg_plan(int N, int Cin, int Cout, int H, int W, int KS, WgPlan& p) {
@@ -191,9 +202,20 @@ static bool wg_plan(int N, int Cin, int Cout, int H, int W, int KS, WgPlan& p) {
     p.cob = p.cib = 64;
     p.ntr = (Hh + p.TR - 1) / p.TR;
     p.ntc = (Ww + p.TC - 1) / p.TC;
+  } else if (KS == 5 || KS == 7 || KS == 11) {
+    // x rows of TC + 2 pad <= 64 pixels (one wave-wide load per row), TC even; 32 x 32 channels per block
+    p.TR = KS == 11 ? 2 : 3;
+    const int tcmax = (64 - 2 * (KS / 2)) & ~1;
+    const int nct = (Ww + tcmax - 1) / tcmax;
+    p.TC = ((Ww + nct - 1) / nct + 1) & ~1;
+    if (p.TC > tcmax) p.TC = tcmax;
+    p.cob = p.cib = 32;
+    p.ntr = (Hh + p.TR - 1) / p.TR;
+    p.ntc = (Ww + p.TC - 1) / p.TC;
   } else {
     return false;
   }
+  p.nkxb = KS == 11 ? 2 : 1;
   p.nco = (Cout + p.cob - 1) / p.cob;
   p.nci = (Cin + p.cib - 1) / p.cib;
   const int total = N * p.ntr * p.ntc;
@@ -203,7 +225,7 @@ static bool wg_plan(int N, int Cin, int Cout, int H, int W, int KS, WgPlan& p) {
   if (S > total) S = total;
   p.S = S;
   const int pad = KS / 2, XR = p.TR + 2 * pad, XC = p.TC + 2 * pad;
-  p.lds = ((size_t)p.cob * ((p.TR * p.TC) | 1) + (size_t)p.cib * ((XR * XC) | 1)) * sizeof(float);
+  p.lds = ((size_t)p.cob * ((p.TR * p.TC) | 1) + (size_t)p.cib * ((XR * XC) | 1) + 16) * sizeof(float);   // (+ slack: see kx0)
   return p.lds <= 160 * 1024;
 }
 
@@ -223,7 +245,7 @@ int dvd_xwgrad(const float* x, const float* gy, float* gw, void* workspace, size
   DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgrad: bad shape");
   DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgrad: image too large for 32-bit offsets");
   dvd::WgPlan p;
-  DVD_REQUIRE(dvd::wg_plan(N, Cin, Cout, H, W, KS, p), "xwgrad: kernel size %d is not covered (1 and 3 are)", KS);
+  DVD_REQUIRE(dvd::wg_plan(N, Cin, Cout, H, W, KS, p), "xwgrad: kernel size %d is not covered (1, 3, 5, 7, 11 are)", KS);
   const size_t need = (size_t)p.S * KS * KS * Cout * Cin * sizeof(float);
   if (workspace_bytes < need) {
     dvd::set_error("xwgrad: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -238,10 +260,22 @@ int dvd_xwgrad(const float* x, const float* gy, float* gw, void* workspace, size
   a.W = KS == 1 ? H * W : W;
   a.TC = p.TC; a.ntr = p.ntr; a.ntc = p.ntc; a.S = p.S;
   a.relu_in = relu_in ? 1 : 0;
+  a.nkxb = p.nkxb;
   DVD_REQUIRE(p.nco <= 65535 && p.nci <= 65535, "xwgrad: too many channel blocks");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid(p.S, p.nci, p.nco);
-  if (KS == 3) {
+  const dim3 grid(p.S * p.nkxb, p.nci, p.nco);
+  auto go = [&](auto kern, int waves) -> int {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(kern, grid, dim3(64 * waves), p.lds, s, a);
+    return DVD_OK;
+  };
+  if (KS == 5) {
+    if (int e = go(dvd::xwgrad_kernel<5, 1, 1, 3>, 5)) return e;
+  } else if (KS == 7) {
+    if (int e = go(dvd::xwgrad_kernel<7, 1, 1, 3>, 7)) return e;
+  } else if (KS == 11) {
+    if (int e = go(dvd::xwgrad_kernel<11, 1, 1, 2, 6, 4>, 11)) return e;
+  } else if (KS == 3) {
     auto kern = dvd::xwgrad_kernel<3, 2, 2, 3>;
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     hipLaunchKernelGGL(kern, grid, dim3(64 * 12), p.lds, s, a);

@@ -453,6 +453,15 @@ int dvd_adam_step_guarded(float* param, const float* grad1, float scale, const f
                           float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2, float eps,
                           int step, const float* skip_flag, dvd_stream_t stream);
 
+/* nn.MaxPool2d(3, stride 2, padding 1) of the ResNeXt stem (third_party/midas_blocks.py:35-45), ATen's semantics (the first
+ * maximum of a window takes the gradient).  x fp32 [planes][H][W] -> y [planes][Ho][Wo] (Ho = (H - 1) / 2 + 1) in fp32 or
+ * _Float16 (y_f16: the fp32 -> fp16 boundary of fp16 activation storage), index: one byte per output (winner's window position).
+ * Backward: gx fp32 = out_scale[0] * (gather of gy over the windows that contain the pixel); deterministic. */
+int dvd_maxpool3s2_fwd(const float* x, void* y, int y_f16, unsigned char* index, long long planes, int H, int W,
+                       dvd_stream_t stream);
+int dvd_maxpool3s2_bwd(const void* gy, int gy_f16, const unsigned char* index, float* gx, const float* out_scale,
+                       long long planes, int H, int W, dvd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
