@@ -112,26 +112,33 @@ def _cpu_model():
     return 'unknown'
 
 
-def oracle_first_step(pairs=1):
+def oracle_first_step(pairs=1, gap=None, warm=False, depth='midas'):
     """The oracle's first optimisation step (seeded weights) on `pairs` frame pairs of the benchmark workload at 384x672:
     returns everything the cpu_baseline leg continues from and the parity leg compares with -- the initial weights,
-    the batch, the step's log and the gradients its Adam steps consumed."""
+    the batch, the step's log and the gradients its Adam steps consumed.  gap / warm / depth: the other schedules of the
+    shipped run at the same image size (frame gap = Euler steps, the warm-up phase, the hourglass depth net)."""
     from dvd_hip import synthetic
+    from dvd_hip.third_party.hourglass import HourglassModel_Embed
     from dvd_hip.third_party.MiDaS import MidasNet, calibrate_head_for_random_init
     from oracle import sceneflow_mlp as M
     from oracle import train_step as T
     from oracle.losses import default_opt
+    gap = GAP if gap is None else gap
     torch.manual_seed(0)
-    net = calibrate_head_for_random_init(MidasNet(non_negative=True, normalize_input=True)).eval()
+    if depth == 'midas':
+        net = calibrate_head_for_random_init(MidasNet(non_negative=True, normalize_input=True)).eval()
+    else:
+        net = HourglassModel_Embed(noexp=False, use_embedding=False).eval()
     sd = M.init_params(seed=0)
     init = ({k: v.detach().clone() for k, v in net.state_dict().items()}, {k: v.clone() for k, v in sd.items()})
-    opt = default_opt()
-    batch = synthetic.make_batch(pairs, H, W, gap=GAP, seed=1234)
+    opt = default_opt(midas=depth == 'midas')
+    batch = synthetic.make_batch(pairs, H, W, gap=gap, seed=1234)
     state = {}
     t0 = time.time()
-    log, tm = T.train_step(opt, net, sd, batch, warm=False, lr_depth=1e-6, lr_mlp=1e-3, adam_state=state, return_grads=True)
-    return {'net': net, 'sd': sd, 'opt': opt, 'batch': batch, 'state': state, 'init': init, 'log': log,
-            'mlp_grads': tm['mlp_grads'], 'depth_grad_norms': tm['depth_grad_norms'], 'seconds': time.time() - t0}
+    log, tm = T.train_step(opt, net, sd, batch, warm=warm, lr_depth=1e-6, lr_mlp=1e-3, adam_state=state, return_grads=True)
+    return {'net': net, 'sd': sd, 'opt': opt, 'batch': batch, 'state': state, 'init': init, 'log': log, 'gap': gap, 'warm': warm,
+            'depth': depth, 'mlp_grads': tm['mlp_grads'], 'depth_grad_norms': tm['depth_grad_norms'],
+            'seconds': time.time() - t0}
 
 
 def hip_parity(first, device):
@@ -140,23 +147,25 @@ def hip_parity(first, device):
     per-parameter gradient norms of the depth net and the worst element of the MLP gradients (relative to each
     tensor's largest element)."""
     from dvd_hip import synthetic
-    opt = make_opt(depth_chunk=1)
+    opt = make_opt(depth_chunk=1, midas=first.get('depth', 'midas') == 'midas')
     model = build_model(opt, torch.device('cpu'), seed=0, to_device=False)
     model.net_depth.load_state_dict(first['init'][0])
     model.net_sceneflow.load_state_dict(first['init'][1])
     model.to(device)
     b = {k: (v.to(device) if torch.is_tensor(v) and k != 'time_step' else v) for k, v in first['batch'].items()}
-    log = model._train_on_batch(opt.warm_sf + 1, 0, synthetic.with_loader_dim(b))
+    warm = bool(first.get('warm', False))
+    log = model._train_on_batch(opt.warm_sf + (0 if warm else 1), 0, synthetic.with_loader_dim(b))
     torch.cuda.synchronize()
     rel = lambda a, c: abs(a - c) / max(abs(c), 1e-30)       # noqa: E731
-    out = {'sample': '%d frame pair(s) at %dx%d, gap %d, seeded weights, one step' % (first['batch']['img_1'].shape[0], H, W, GAP),
+    out = {'sample': '%d frame pair(s) at %dx%d, gap %d, %s depth net, %s phase, seeded weights, one step' % (
+               first['batch']['img_1'].shape[0], H, W, first.get('gap', GAP), first.get('depth', 'midas'), 'warm-up' if warm else 'main'),
            'loss_cpu': first['log']['loss'], 'loss_hip': log['loss'], 'rel': rel(log['loss'], first['log']['loss'])}
     for k in ('flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
         out[k + '_rel'] = rel(log[k], first['log'][k])
     worst, worst_name = 0.0, None
     for k, p in model.net_depth.named_parameters():
         want = first['depth_grad_norms'].get(k)
-        if not want:
+        if not want or p.grad is None:
             continue
         r = rel(float(p.grad.double().norm()), want)
         if r > worst:

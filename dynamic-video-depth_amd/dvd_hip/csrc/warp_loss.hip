@@ -566,6 +566,7 @@ struct TileArgs {
   const int2* offs;   // per pair: window offset (multiple of 4 in x), written by warp_prep_kernel
   int ntx, nty;
   int direct;         // 1: window cells no neighbouring window covers go straight to g_depth_2 (needs W % 4 == 0)
+  int tile0;          // global index of this launch's first tile (a launch covers a contiguous run of pairs)
 };
 
 // The windows of adjacent tiles overlap by the halo: cell (wx, wy) of a tile's window is covered by that tile ALONE when
@@ -575,6 +576,48 @@ struct TileArgs {
 template <int TW, int TH, int R>
 __device__ __forceinline__ bool tile_exclusive(int wx, int wy) {
   return wx >= 2 * R + 4 && wx < TW && wy >= 2 * R + 1 && wy < TH;
+}
+
+// g_depth_2[b,y,x .. x+3] = sum over the tiles whose window covers the quad, fixed order (dj outer, di inner): the ONE
+// definition of the combine, used by combine_slabs_kernel and by the in-kernel combine of the tile kernel.
+template <int TW, int TH, int R>
+__device__ __forceinline__ void combine_quad(const float* __restrict__ slabs, int2 off, float* __restrict__ g_d2, int H, int W,
+                                             int ntx, int nty, int b, int y, int x, int direct) {
+  constexpr int WW = TW + 2 * R + 4;
+  constexpr int WH = TH + 2 * R + 1;
+  static_assert(2 * R + 4 <= TW && 2 * R + 1 <= TH, "only adjacent tiles may overlap a pixel");
+  const int xs = x - off.x, ys = y - off.y;          // coordinates in the pair's shifted tile grid
+  const int ti = xs >= 0 ? xs / TW : -((TW - 1 - xs) / TW), tj = ys >= 0 ? ys / TH : -((TH - 1 - ys) / TH);
+  // written by the pixel's own tile (tile_exclusive; a quad is exclusive as a whole: every bound is a multiple of 4)
+  if (direct && ti >= 0 && ti < ntx && tj >= 0 && tj < nty && tile_exclusive<TW, TH, R>(xs - ti * TW + R, ys - tj * TH + R)) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int dj = -1; dj <= 1; ++dj) {
+    const int j = tj + dj;
+    const int wy = ys - (j * TH - R);
+    if (j < 0 || j >= nty || wy < 0 || wy >= WH) continue;
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+      const int i = ti + di;
+      const int wx = xs - (i * TW - R);
+      if (i < 0 || i >= ntx || wx < 0 || wx + 3 >= WW) continue;
+      const float4 v =
+          *reinterpret_cast<const float4*>(slabs + ((size_t)(b * nty + j) * ntx + i) * (WW * WH) + wy * WW + wx);
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+  }
+  float* dst = g_d2 + ((size_t)b * H + y) * W + x;
+  if ((W & 3) == 0) {
+    *reinterpret_cast<float4*>(dst) = s;
+  } else {
+    dst[0] = s.x;
+    if (x + 1 < W) dst[1] = s.y;
+    if (x + 2 < W) dst[2] = s.z;
+    if (x + 3 < W) dst[3] = s.w;
+  }
 }
 
 __device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
@@ -605,7 +648,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);  // [WH][WW] u64 first (8-byte aligned)
   float* win = smem + 2 * WW * WH;
 
-  const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const int logical = ta.tile0 + xcd_contiguous_block(blockIdx.x, gridDim.x);      // global tile index
   const int tiles = ta.ntx * ta.nty;
   const int b = logical / tiles;
   const int t = logical - b * tiles;
@@ -825,53 +868,17 @@ __global__ __launch_bounds__(64) void warp_prep_kernel(const float* __restrict__
   offs[b] = make_int2(ox, oy);
 }
 
-// g_depth_2[b,y,x] = sum over the tiles whose window covers (x,y), fixed order.
 template <int TW, int TH, int R>
 __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restrict__ slabs, const int2* __restrict__ offs,
                                                             float* __restrict__ g_d2, int H, int W, int ntx,
-                                                            int nty, int total_quads, int direct) {
-  constexpr int WW = TW + 2 * R + 4;
-  constexpr int WH = TH + 2 * R + 1;
-  static_assert(2 * R + 4 <= TW && 2 * R + 1 <= TH, "only adjacent tiles may overlap a pixel");
+                                                            int nty, int total_quads, int direct, int b0) {
   const int qid = blockIdx.x * 256 + threadIdx.x;
   if (qid >= total_quads) return;
   const int qpr = (W + 3) >> 2;  // quads per row
   const int row = qid / qpr;
   const int x = (qid - row * qpr) * 4;
-  const int b = row / H, y = row - b * H;
-  const int2 off = offs[b];
-  const int xs = x - off.x, ys = y - off.y;          // coordinates in the pair's shifted tile grid
-  const int ti = xs >= 0 ? xs / TW : -((TW - 1 - xs) / TW), tj = ys >= 0 ? ys / TH : -((TH - 1 - ys) / TH);
-  // written by the pixel's own tile (tile_exclusive; a quad is exclusive as a whole: every bound is a multiple of 4)
-  if (direct && ti >= 0 && ti < ntx && tj >= 0 && tj < nty && tile_exclusive<TW, TH, R>(xs - ti * TW + R, ys - tj * TH + R)) return;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int dj = -1; dj <= 1; ++dj) {
-    const int j = tj + dj;
-    const int wy = ys - (j * TH - R);
-    if (j < 0 || j >= nty || wy < 0 || wy >= WH) continue;
-#pragma unroll
-    for (int di = -1; di <= 1; ++di) {
-      const int i = ti + di;
-      const int wx = xs - (i * TW - R);
-      if (i < 0 || i >= ntx || wx < 0 || wx + 3 >= WW) continue;
-      const float4 v =
-          *reinterpret_cast<const float4*>(slabs + ((size_t)(b * nty + j) * ntx + i) * (WW * WH) + wy * WW + wx);
-      s.x += v.x;
-      s.y += v.y;
-      s.z += v.z;
-      s.w += v.w;
-    }
-  }
-  float* dst = g_d2 + ((size_t)b * H + y) * W + x;
-  if ((W & 3) == 0) {
-    *reinterpret_cast<float4*>(dst) = s;
-  } else {
-    dst[0] = s.x;
-    if (x + 1 < W) dst[1] = s.y;
-    if (x + 2 < W) dst[2] = s.z;
-    if (x + 3 < W) dst[3] = s.w;
-  }
+  const int b = b0 + row / H, y = row - (row / H) * H;      // this launch covers the pairs b0 ...
+  combine_quad<TW, TH, R>(slabs, offs[b], g_d2, H, W, ntx, nty, b, y, x, direct);
 }
 
 // Second stage: fixed-order sum of the per-block partials (deterministic).
@@ -972,7 +979,7 @@ constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 // Variant selection: the production path is the tiled kernel with the auto-chosen tile shape.  The parity tests
 // also drive the other shapes, the 4-pixels-per-step mapping and the global-atomics reference variant through
 // dvd_warp_loss_select() -- a process-wide test hook, not an environment switch read on every call.
-static int g_variant = 0;   // 0 tiled, 1 direct (global gathers + hardware atomics)
+static int g_variant = 0;   // 0 tiled (production), 1 direct (global gathers + hardware atomics)
 static int g_tile = -1;     // -1 auto, else index into kShapes
 static int g_px = 0;        // 0 auto, 2 or 4 pixels per thread-step
 
@@ -1026,6 +1033,13 @@ static Plan make_plan(int B, int H, int W) {
   return p;
 }
 
+// Launch sequence: prep (counters + window offsets) -> tile kernel -> slab combine -> finish, on one stream.
+// Round 4 tried to take the combine (34 us at 48 x 384 x 672) off the serial tail twice; both lost and are not kept:
+//   * combine inside the tile kernel by the block that stores the LAST slab of a 3 x 3 tile neighbourhood (bit-identical
+//     results, tests green): 2.9 ms instead of 0.24 -- the release / acquire fences the hand-over needs are agent-scope, and on
+//     a multi-XCD part an agent-scope fence writes back / invalidates the XCD's whole L2;
+//   * two tile launches cut where the full rounds of blocks end, the first cut's combine on a side stream under the second
+//     launch: 0.252-0.263 ms against 0.234-0.238 -- the event record / wait pair costs more than the overlap returns.
 template <int TW, int TH, int NT>
 static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, hipStream_t stream) {
   constexpr int WW = TW + 2 * kR + 4, WH = TH + 2 * kR + 1;
@@ -1039,42 +1053,52 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.ntx = p.ntx;
   ta.nty = p.nty;
   ta.direct = ((a.W & 3) == 0 && DVD_WARP_DIRECT_INTERIOR) ? 1 : 0;
-  const int nblocks = p.ntx * p.nty * a.B;
+  ta.tile0 = 0;
+  const int tiles = p.ntx * p.nty, nblocks = tiles * a.B;
   const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
-  // launch sequence: prep (counter + window offsets) -> tile kernel -> slab combine -> finish
   hipLaunchKernelGGL(warp_prep_kernel, dim3(a.B), dim3(64), 0, stream, a.flow, a.H, a.W, offs, ta.ovf.count);
   DVD_LAUNCH_OK();
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
   // 2 pixels per thread-step when that splits the tile evenly over the block and 4 does not
   constexpr bool kEven4 = ((TW / 4) * TH) % NT == 0, kEven2 = ((TW / 2) * TH) % NT == 0;
   const bool px2 = (g_px ? g_px : ((kEven2 && !kEven4) ? 2 : 4)) == 2;
+  auto tile_launch = [&](int pair0, int npairs) -> int {
+    TileArgs t2 = ta;
+    t2.tile0 = pair0 * tiles;
+    const int nb = npairs * tiles;
 #define DVD_TILED_LAUNCH(G, S)                                                                            \
   do {                                                                                                    \
     auto k = px2 ? warp_loss_tiled_kernel<TW, TH, kR, NT, G, S, 2> : warp_loss_tiled_kernel<TW, TH, kR, NT, G, S, 4>; \
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                      \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-    hipLaunchKernelGGL(k, dim3(nblocks), dim3(NT), lds, stream, a, ta);                                   \
+    hipLaunchKernelGGL(k, dim3(nb), dim3(NT), lds, stream, a, t2);                                        \
   } while (0)
-  if (grads) {
-    if (shipped)
-      DVD_TILED_LAUNCH(true, true);
-    else
-      DVD_TILED_LAUNCH(true, false);
-  } else {
-    if (shipped)
-      DVD_TILED_LAUNCH(false, true);
-    else
-      DVD_TILED_LAUNCH(false, false);
-  }
+    if (grads) {
+      if (shipped)
+        DVD_TILED_LAUNCH(true, true);
+      else
+        DVD_TILED_LAUNCH(true, false);
+    } else {
+      if (shipped)
+        DVD_TILED_LAUNCH(false, true);
+      else
+        DVD_TILED_LAUNCH(false, false);
+    }
 #undef DVD_TILED_LAUNCH
-  DVD_LAUNCH_OK();
-  if (grads) {
-    const int qpr = (a.W + 3) / 4;
-    const int total_quads = qpr * a.H * a.B;
-    hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, stream,
-                       ta.slabs, (const int2*)offs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads, ta.direct);
     DVD_LAUNCH_OK();
-  }
+    return DVD_OK;
+  };
+  auto combine_launch = [&](int pair0, int npairs, hipStream_t st) -> int {
+    const int qpr = (a.W + 3) / 4;
+    const int total_quads = qpr * a.H * npairs;
+    hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, st, ta.slabs,
+                       (const int2*)offs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads, ta.direct, pair0);
+    DVD_LAUNCH_OK();
+    return DVD_OK;
+  };
+  if (int e = tile_launch(0, a.B)) return e;
+  if (grads)
+    if (int e = combine_launch(0, a.B, stream)) return e;
   // partial-sum reduction and overflow records in one launch
   hipLaunchKernelGGL(warp_finish_kernel, dim3(grads ? 129 : 1), dim3(1024), 0, stream, a.partial, nblocks, a.sums,
                      ta.ovf.count, ta.ovf.rec, ta.ovf.cap, grads ? a.g_d2 : (float*)nullptr);

@@ -59,7 +59,11 @@ def _compare(module, x, gy):
         worst[k] = (e64, eab)
         tol = 1e-4 if (k.startswith('g_') and k.endswith('weight') and want[k].dim() == 4) else 2e-5
         assert e64 < tol, '%s: %.2e of max against float64' % (k, e64)
-        assert eab < 1e-6, '%s: fused and unfused joins differ by %.2e of max' % (k, eab)
+        # the fused joins / masks are the SAME roundings in another launch (epilogue add = ATen add, mask = mask): bit-identical;
+        # only the opt-in row-sum variant (another summation order for the per-channel sums) is compared within 1e-6 of max
+        assert torch.equal(fused[k], plain[k]) and torch.equal(fused[k], nomask[k]), \
+            '%s: fused and unfused joins differ (%.2e / %.2e of max)' % (k, _rel(fused[k], plain[k]), _rel(fused[k], nomask[k]))
+        assert eab < 1e-6, '%s: the row-sum variant differs by %.2e of max' % (k, eab)
     print('worst vs float64 %.2e, fused vs unfused %.2e, sites %s' % (max(v[0] for v in worst.values()),
                                                                     max(v[1] for v in worst.values()), taken))
     return taken
