@@ -316,6 +316,12 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     dist_on = parallel.is_distributed()
     dist_backend = torch.distributed.get_backend() if dist_on else None
+    try:
+        rccl_version = '.'.join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                      # noqa: BLE001 -- informational only
+        rccl_version = None
+    from dvd_hip.models.scene_flow_motion_field import head_room_fraction
+    head_room_gb = head_room_fraction(world) * torch.cuda.get_device_properties(device).total_memory / 2 ** 30
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -353,6 +359,8 @@ def main():
         # the consuming convolution's epilogue (conv._Site) and how many ran their own mask pass
         'bn_relu_sites': dict(__import__('dvd_hip.conv', fromlist=['STATS']).STATS),
         'dist_backend': dist_backend, 'ranks_seen': world,
+        # the collective library behind torch.distributed's 'nccl' backend on ROCm (RCCL) and the planner's head room
+        'rccl_version': rccl_version, 'hbm_head_room_GB': head_room_gb,
     }
     if warp is not None:
         # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 --pmc passes of

@@ -47,12 +47,20 @@ from .netinterface import NetInterface
 CAM_KEYS = ops.CAM_KEYS
 
 
-def keep_slot_fits(est, free, total, reserve, spare, kept, budget):
+def head_room_fraction(world):
+    """Fraction of the device the memory planner leaves untouched: allocator fragmentation, and -- with several ranks --
+    RCCL's channel / staging buffers and the workspaces its collectives allocate while the step runs.  Single process: 8 %
+    (23 GB of 288); data parallel: 14 % (40 GB), derated automatically (round 4: the 8 % of a 251 GB-reserved step was all an
+    8-rank run would have had)."""
+    return 0.08 if world <= 1 else 0.14
+
+
+def keep_slot_fits(est, free, total, reserve, spare, kept, budget, head_room=0.08):
     """May one more kept-activation slot of `est` bytes be captured?  `free` = HBM available to ordinary allocations,
     `reserve` = what phase 2 (the MLP stashes) will allocate, `spare` = room for the recompute graph of a chunk that is not
     kept (0 if this slot completes the step), `kept` = bytes already held by slots, `budget` = --depth_keep_gb.
-    8 % of the device stays free as head room (allocator fragmentation, RCCL buffers)."""
-    return kept + est <= budget and free - est >= reserve + 0.08 * total + spare
+    `head_room` (head_room_fraction) of the device stays free."""
+    return kept + est <= budget and free - est >= reserve + head_room * total + spare
 
 
 class Model(NetInterface):
@@ -281,9 +289,11 @@ class Model(NetInterface):
         spare = 0 if last_and_all_kept else est
         if os.environ.get('DVD_KEEP_DEBUG'):
             print('keep slot %d: est %.1f GB, free %.1f, reserve %.1f + %.1f + spare %.1f, kept so far %.1f, pools %.1f' % (
-                slot, est / 2 ** 30, free / 2 ** 30, reserve_bytes / 2 ** 30, 0.08 * total / 2 ** 30, spare / 2 ** 30,
+                slot, est / 2 ** 30, free / 2 ** 30, reserve_bytes / 2 ** 30,
+                head_room_fraction(parallel.world_size()) * total / 2 ** 30, spare / 2 ** 30,
                 self._keep_bytes / 2 ** 30, self._pool_bytes / 2 ** 30), file=sys.stderr, flush=True)
-        if not keep_slot_fits(est, free, total, reserve_bytes, spare, self._keep_bytes, budget):
+        hr = head_room_fraction(parallel.world_size())
+        if not keep_slot_fits(est, free, total, reserve_bytes, spare, self._keep_bytes, budget, hr):
             self._depth_graphs[key] = None
             self._keep_denied[key] = self._step_no
             return None
@@ -355,7 +365,7 @@ class Model(NetInterface):
             print('after phase 1: free %.1f GB, phase 2 needs %.1f, pools %.1f' % (free / 2 ** 30, need_bytes / 2 ** 30,
                                                                                self._pool_bytes / 2 ** 30), file=sys.stderr, flush=True)
         kept = [k for k, v in self._depth_graphs.items() if k[0] == 'keep' and v is not None]
-        while kept and free < need_bytes + 0.04 * total:
+        while kept and free < need_bytes + 0.5 * head_room_fraction(parallel.world_size()) * total:
             key = kept.pop()
             self._keep_bytes -= self._depth_graphs[key][5]
             self._pool_bytes -= self._depth_graphs[key][5]
