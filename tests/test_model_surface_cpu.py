@@ -83,11 +83,12 @@ def test_kept_activation_slot_planning_arithmetic():
     assert not keep_slot_fits(60 * G, 166 * G, total, reserve, 60 * G, 116 * G, 300 * G)       # a third would starve phase 2
     assert not keep_slot_fits(84 * G, 200 * G, total, reserve, 0, 82 * G, 150 * G)             # 82 GB slots: the second does not fit
     assert not keep_slot_fits(60 * G, 285 * G, total, 0, 0, 116 * G, 150 * G)                  # budget
-    # data-parallel runs leave RCCL 14 % of the device instead of 8 %: the second slot no longer fits next to 130 GB of stashes
+    # data-parallel runs leave 10 % of the device free instead of 8 %: the benchmark's second slot still fits, a tighter one does not
     from dvd_hip.models.scene_flow_motion_field import head_room_fraction
-    assert head_room_fraction(1) == 0.08 and head_room_fraction(8) == 0.14
-    assert keep_slot_fits(60 * G, 225 * G, total, reserve, 0, 58 * G, 150 * G, head_room_fraction(1))
-    assert not keep_slot_fits(60 * G, 225 * G, total, reserve, 0, 58 * G, 150 * G, head_room_fraction(8))
+    assert head_room_fraction(1) == 0.08 and head_room_fraction(8) == 0.10
+    assert keep_slot_fits(60 * G, 225 * G, total, reserve, 0, 58 * G, 150 * G, head_room_fraction(8))
+    assert keep_slot_fits(60 * G, 215 * G, total, reserve, 0, 58 * G, 150 * G, head_room_fraction(1))
+    assert not keep_slot_fits(60 * G, 215 * G, total, reserve, 0, 58 * G, 150 * G, head_room_fraction(8))
 
 
 def test_grouped_conv_modules_on_cpu_are_plain_convolutions():
