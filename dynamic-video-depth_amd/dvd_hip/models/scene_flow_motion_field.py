@@ -39,6 +39,7 @@ import torch
 
 from .. import configs, conv, flat, ops, parallel
 from ..losses.scene_flow_projection import BackwardWarp, flow_by_depth, scene_flow_projection_slack, unproject_ptcld
+from ..networks.FCNUnet import FCNUnet
 from ..networks.sceneflow_field import SceneFlowFieldNet
 from ..third_party.hourglass import HourglassModel_Embed
 from ..third_party.MiDaS import MidasNet
@@ -121,9 +122,6 @@ class Model(NetInterface):
                             'time_stamp_1', 'time_stamp_2', 'frame_id_1', 'frame_id_2', 'time_step']
         self.gt_names = []
         self.requires = list(set().union(self.input_names, self.gt_names))
-        if opt.use_cnn:
-            raise NotImplementedError('--use_cnn (FCNUnet scene-flow net) is outside the accelerated path '
-                                      '(SURVEY.md section 2 row 16)')
         if opt.midas:
             resize = [224, 384] if any(k in opt.dataset for k in ('real_video', 'korean', 'mctest', 'cube')) else None
             path = configs.midas_pretrain_path if os.path.exists(configs.midas_pretrain_path) else None
@@ -136,8 +134,13 @@ class Model(NetInterface):
                 self.net_depth.net_depth.load_state_dict(torch.load(configs.depth_pretrain_path, map_location='cpu'))
             else:
                 warnings.warn('depth checkpoint %s not found: random weights' % configs.depth_pretrain_path)
-        self.net_sceneflow = SceneFlowFieldNet(net_width=256, n_layers=4, time_dependent=opt.time_dependent,
-                                               N_freq_xyz=opt.n_freq_xyz, N_freq_t=opt.n_freq_t)
+        if opt.use_cnn:      # the U-Net scene-flow network (:102-105), on the convolution kernels under autograd
+            conv_setup = {'norm': 'none', 'activation': 'lrelu', 'pad_type': 'reflect', 'stride': 1}
+            self.net_sceneflow = FCNUnet(conv_setup, n_down=getattr(opt, 'n_down', 3), feat=32, block_type='double_conv',
+                                         in_channel=4 if opt.time_dependent else 3, out_channel=3)
+        else:
+            self.net_sceneflow = SceneFlowFieldNet(net_width=256, n_layers=4, time_dependent=opt.time_dependent,
+                                                   N_freq_xyz=opt.n_freq_xyz, N_freq_t=opt.n_freq_t)
         self.bkwarp = BackwardWarp()
         self.unproject_points = unproject_ptcld()
         self.global_rank = getattr(opt, 'global_rank', 0)
@@ -169,8 +172,8 @@ class Model(NetInterface):
         self.optimizer_depth, self.optimizer_scene = self._flat_depth, self._flat_sf
         self._optimizers = [self._flat_depth, self._flat_sf]
         self._sf_grad_main = torch.zeros_like(self._flat_sf.grad)
-        self._mlp = self.net_sceneflow.kernels(self.device, stash_f16=bool(getattr(self.opt, 'mlp_stash_fp16', False) or
-                                                                           getattr(self.opt, 'act_fp16', False)))
+        self._mlp = None if self.opt.use_cnn else self.net_sceneflow.kernels(
+            self.device, stash_f16=bool(getattr(self.opt, 'mlp_stash_fp16', False) or getattr(self.opt, 'act_fp16', False)))
         self._gscale = None
         if getattr(self.opt, 'act_fp16', False):
             if not self.opt.midas:
@@ -446,11 +449,15 @@ class Model(NetInterface):
         return int((gap / time_step).round().long().item()), time_step
 
     def _pairs_per_chunk(self, B, HW, steps, with_reg):
+        if self._mlp is None:            # --use_cnn: the whole batch goes through the U-Net at once
+            return B
         per_pair = self._mlp.stash_floats(HW) * 4 * max(steps, 2 if with_reg else 1) + self._mlp.gstash_floats(HW) * 4
         return int(max(1, min(B, (self.opt.mlp_stash_gb * 2 ** 30) // per_pair)))
 
     def _whole_batch_fits(self, B, Bc, HW, steps, with_reg):
         """Forward stashes of all B pairs + the backward / regulariser scratch of one chunk."""
+        if self._mlp is None:
+            return True
         stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
         # (merged backward: the regulariser's second evaluation needs a stash of its own only at gap 1; from gap 2 on it is
         #  Euler evaluation 1)
@@ -491,9 +498,12 @@ class Model(NetInterface):
             depth_2 = self._depths_nograd(inp.img_2, fid2)
         else:
             Bc0 = self._pairs_per_chunk(B, HW, steps, do_reg)
-            stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
-            mlp_need = min(B * steps * stash + Bc0 * (gstash + (stash if (do_reg and steps == 1) else 0)),
-                           float(getattr(opt, 'mlp_whole_batch_gb', 160.0)) * 2 ** 30) + 24 * B * HW * 4
+            if self._mlp is None:        # --use_cnn: ~2.6 KB of autograd state per pixel and U-Net evaluation
+                mlp_need = B * HW * 2600 * (steps + (1 if do_reg else 0)) + 24 * B * HW * 4
+            else:
+                stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
+                mlp_need = min(B * steps * stash + Bc0 * (gstash + (stash if (do_reg and steps == 1) else 0)),
+                               float(getattr(opt, 'mlp_whole_batch_gb', 160.0)) * 2 ** 30) + 24 * B * HW * 4
             depth_1 = self._depths_keep(inp.img_1, fid1, 0, mlp_need, 2 * n_slots)
             depth_2 = self._depths_keep(inp.img_2, fid2, n_slots, mlp_need, 2 * n_slots)
             self._trim_keep_slots(dev, mlp_need)
@@ -506,6 +516,9 @@ class Model(NetInterface):
         g_d2_main = torch.empty_like(depth_2)
         g_d1_reg = None                              # allocated only by the per-chunk fallback path
         mlp, k = self._mlp, self._flat_sf
+        if opt.use_cnn:
+            return self._finish_step_cnn(epoch, batch_ind, batch, inp, depth_1, depth_2, steps, time_step, warm, do_reg, n_slots,
+                                         fid1, fid2, mul, disp_mode, sums, g_d1_main, g_d2_main)
         mlp.pack([p for p in self.net_sceneflow.parameter_list()[0::2]], self.net_sceneflow.parameter_list()[1::2])
         gW_main = [k.view(self._sf_grad_main, 2 * i) for i in range(6)]
         gb_main = [k.view(self._sf_grad_main, 2 * i + 1) for i in range(6)]
@@ -747,6 +760,84 @@ class Model(NetInterface):
         self._export_train_visuals(epoch, batch_ind, batch)
         return batch_log
 
+    # -- --use_cnn: phases 2 and 3 with the U-Net scene-flow network ------------------------------------------------------
+    def _sf_net_cnn(self, p, t):
+        """Model.forward_sf_net with --use_cnn (:346-357)."""
+        x = torch.cat([p, t], 1) if self.opt.time_dependent else p
+        return self.net_sceneflow(x) / self.opt.sf_mag_div
+
+    def _finish_step_cnn(self, epoch, batch_ind, batch, inp, depth_1, depth_2, steps, time_step, warm, do_reg, n_slots, fid1,
+                         fid2, mul, disp_mode, sums, g_d1_main, g_d2_main):
+        """Everything downstream of the depth maps when the scene-flow network is the U-Net (networks/FCNUnet.py): the
+        network runs under PyTorch autograd on this package's convolution kernels, the geometry and the losses stay the ONE
+        fused warp+loss launch -- its scene-flow gradient is what the U-Net's backward starts from, with the batch-global
+        normaliser applied as a device scalar.  The regulariser's first evaluation is Euler evaluation 0, as in the MLP path."""
+        opt, dev = self.opt, self.device
+        B, _, H, W = inp.img_1.shape
+        HW = H * W
+        k = self._flat_sf
+        cams = {kk: getattr(inp, kk) for kk in CAM_KEYS}
+        mask_2 = inp.mask_2.reshape(B, H, W)
+        mseg = inp.motion_seg_1.reshape(B, H, W) if opt.use_motion_seg else None
+        cfg = ops.warp_cfg(B, H, W, midas_mask=opt.midas, crit_l2=warm, disp_mode=disp_mode, loss_on_sf=not opt.use_disp,
+                           flow_mul=opt.flow_mul * mul, disp_mul=opt.disp_mul * mul)
+        _late, n_global, capturing = parallel.agree_on_step_plan(dev, False, B, False)
+        reg_coef = opt.acc_mul / (3.0 * n_global * HW + 1e-6)
+        P1 = ops.unproject(depth_1, inp.R_1, inp.t_1, inp.K_inv, planar=True).requires_grad_(True)
+        ts = inp.time_stamp_1
+        with torch.enable_grad():
+            sf_acc, p, t, sf0 = None, P1, ts, None
+            for i in range(steps):
+                s_i = self._sf_net_cnn(p, t)
+                sf0 = s_i if i == 0 else sf0
+                sf_acc = s_i if sf_acc is None else sf_acc + s_i
+                p, t = p + s_i, t + time_step
+        sf_all = sf_acc.detach().contiguous()
+        sf_used = ops.mul_mask(torch.empty_like(sf_all), sf_all, mseg) if mseg is not None else sf_all
+        csum, g_sf = torch.empty(4, device=dev), torch.empty_like(sf_all)
+        ops.warp_loss_fused(cfg, depth_1, depth_2, inp.flow_1_2, mask_2, sf_used, cams, out=(csum, g_d1_main, g_d2_main, g_sf))
+        if mseg is not None:
+            ops.mul_mask(g_sf, g_sf, mseg)
+        sums[:4] += csum
+        parallel.all_reduce_sum_(sums[:4])
+        scalars = ops.loss_finalize(cfg, sums)
+        inv = scalars[0:1]
+        ops.scale_add(g_d1_main, g_d1_main, scale_ptr=inv)
+        ops.scale_add(g_sf, g_sf, scale_ptr=inv)
+        sf_acc.backward(g_sf, retain_graph=bool(do_reg))        # parameter gradients land in the flat buffer's views
+        if do_reg:
+            with torch.enable_grad():
+                sf1 = self._sf_net_cnn(P1 + sf0, ts + time_step)
+                dsum = (sf1 - sf0).abs().sum()
+            sums[4:5] += dsum.detach()
+            (dsum * reg_coef).backward()
+        parallel.all_reduce_sum_(sums[4:])
+        ops.unproject_backward(P1.grad.contiguous(), True, cams['R_1'], cams['K_inv'], out=g_d1_main, accumulate=True)
+        h_sf = None if capturing else k.all_reduce_grads(async_op=True)
+        if not warm:
+            g_d2 = ops.scale_add(g_d2_main, g_d2_main, scale_ptr=inv)
+            self._depth_backward(inp.img_1, fid1, g_d1_main, slot0=0)
+            self._depth_backward(inp.img_2, fid2, g_d2, slot0=n_slots)
+            skip = None
+            if self._gscale is not None:
+                if parallel.is_distributed():
+                    torch.distributed.all_reduce(self._gscale[3:4], op=torch.distributed.ReduceOp.MAX)
+                ops.gscale_end(self._gscale)
+                skip = self._gscale[4:5]
+            self._flat_depth.all_reduce_and_adam_step(getattr(opt, 'grad_buckets', 4), skip_ptr=skip)
+        if capturing:
+            k.all_reduce_grads()
+        if h_sf is not None:
+            h_sf.wait()
+        k.adam_step()
+        host = torch.cat([scalars, sums[4:5]]).tolist()
+        acc_reg = opt.acc_mul * host[8] / (3.0 * n_global * HW + 1e-6) if do_reg else 0
+        batch_log = {'size': opt.batch_size, 'loss': host[1] / mul, 'total_loss': host[1] / mul, 'flow_loss_1_2': host[2],
+                     'disp_loss_1_2': host[3], 'sf_loss': host[4], 'acc_reg': acc_reg}
+        self._last = {'depth_1': depth_1, 'depth_2': depth_2, 'mask_sum': host[5], 'sf_all': sf_all, 'mseg': mseg}
+        self._export_train_visuals(epoch, batch_ind, batch)
+        return batch_log
+
     # -- the reference's `pred` dict and its export (scene_flow_motion_field.py:201-225, video_base.py:105-126) ----
     def _export_train_visuals(self, epoch, batch_ind, batch):
         opt = self.opt
@@ -796,6 +887,9 @@ class Model(NetInterface):
         fid = inp.frame_id_1 if not self.opt.midas else None
         depth = self._depths_nograd(inp.img, fid)
         P = ops.unproject(depth, inp.R_1, inp.t_1, inp.K_inv, planar=True)
+        if self.opt.use_cnn:
+            with torch.no_grad():
+                return {'depth': depth, 'sf_1_2': self._sf_net_cnn(P, inp.time_stamp_1)}
         sf = torch.empty_like(P)
         self._mlp.pack(self.net_sceneflow.parameter_list()[0::2], self.net_sceneflow.parameter_list()[1::2])
         ts = inp.time_stamp_1 if self.opt.time_dependent else None

@@ -22,7 +22,7 @@ def default_opt(**over):
     o = dict(midas=True, use_disp=True, use_disp_ratio=False, time_dependent=True,
              flow_mul=1.0, disp_mul=1.0, acc_mul=1.0, sf_mag_div=100.0, interp_steps=5,
              warm_reg=False, weight_steps=False, use_motion_seg=False,
-             n_freq_xyz=16, n_freq_t=16)
+             n_freq_xyz=16, n_freq_t=16, use_cnn=False, n_down=3)
     o.update(over)
     return SimpleNamespace(**o)
 
@@ -83,7 +83,13 @@ def predict_train(opt, sd_mlp, batch, depth_1, depth_2):
     steps = integer_steps(batch['time_stamp_1'], batch['time_stamp_2'], time_step)
     kw = dict(n_freq_xyz=opt.n_freq_xyz, n_freq_t=opt.n_freq_t)
     ts = batch['time_stamp_1'] if opt.time_dependent else None
-    if opt.time_dependent:
+    if getattr(opt, 'use_cnn', False):                 # the U-Net scene-flow network (oracle/fcn_unet.py), same Euler loop
+        from . import fcn_unet as U
+        sf, p, tcur = 0, P1, batch['time_stamp_1']
+        for _ in range(steps):
+            s = U.sf_net(opt, sd_mlp, p, tcur)
+            sf, p, tcur = sf + s, p + s, tcur + time_step
+    elif opt.time_dependent:
         sf = M.sf_multi_step(sd_mlp, P1, ts, time_step, steps, opt.sf_mag_div, **kw)
     else:
         sf = 0
@@ -116,6 +122,12 @@ def acceleration_reg(opt, sd_mlp, batch, P1):
     kw = dict(n_freq_xyz=opt.n_freq_xyz, n_freq_t=opt.n_freq_t)
     time_step = float(batch['time_step'].squeeze().item())
     ts = batch['time_stamp_1'] if opt.time_dependent else None
+    if getattr(opt, 'use_cnn', False):
+        from . import fcn_unet as U
+        sf0 = U.sf_net(opt, sd_mlp, P1, batch['time_stamp_1'])
+        sf1 = U.sf_net(opt, sd_mlp, P1 + sf0, batch['time_stamp_1'] + time_step)
+        ones = torch.ones_like(sf0)
+        return (ones * torch.abs(sf1 - sf0)).sum() / (ones.sum() + 1e-6) * opt.acc_mul
     sf0 = M.mlp_forward(sd_mlp, P1, ts, **kw) / opt.sf_mag_div
     ones = torch.ones_like(sf0)
     ts1 = (ts + time_step) if ts is not None else None

@@ -251,7 +251,9 @@ def case_full_step(name, midas, B, H, W, gap, epoch, seed, over=None):
     out['param_names'] = np.array(names)
     out['grad_norms'] = np.array(gnorm)
     out['param_norms_after'] = np.array(pnorm)
-    keep = ['convs.0.conv.weight', 'convs.3.conv.bias', 'convs.5.conv.weight', 'convs.5.conv.bias']
+    keep = ['convs.0.conv.weight', 'convs.3.conv.bias', 'convs.5.conv.weight', 'convs.5.conv.bias',
+            'down_00.model.0.conv.weight', 'mid_conv.model.1.conv.weight', 'up_0002.model.0.conv.weight',
+            'output_conv.conv.weight', 'output_conv.conv.bias']                 # (--use_cnn: the U-Net's keys)
     for k, p in model.net_sceneflow.named_parameters():
         if k in keep:
             out['g_sf/' + k] = p.grad.numpy()
@@ -295,6 +297,10 @@ def main():
         case_full_step('fullstep_midas_b1_64x96_train', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=107)
         case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'use_cnn':             # the U-Net scene-flow network (round 4)
+        case_full_step('fullstep_hourglass_b2_32x48_usecnn_gap2', midas=False, B=2, H=32, W=48, gap=2, epoch=6, seed=127,
+                       over=dict(use_cnn=True))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'midas_192x384':       # only the configs[0]-shape fixture (round 2)
         case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
         return
@@ -314,6 +320,8 @@ def main():
                    over=dict(use_motion_seg=True))
     # BASELINE configs[0] shape (192x384, the reference's training resolution of record), MiDaS, 2 pairs
     case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
+    case_full_step('fullstep_hourglass_b2_32x48_usecnn_gap2', midas=False, B=2, H=32, W=48, gap=2, epoch=6, seed=127,
+                   over=dict(use_cnn=True))
     case_flow_masks('flow_masks')
 
 

@@ -57,7 +57,8 @@ def _build(gd, **over):
 
 @pytest.mark.parametrize('name', ['fullstep_hourglass_b2_32x48_train', 'fullstep_hourglass_b2_32x48_warm',
                                   'fullstep_midas_b1_64x96_train', 'fullstep_hourglass_b2_32x48_mseg_gap2',
-                                  'fullstep_midas_b2_192x384_train'])      # BASELINE configs[0] shape, 2 pairs
+                                  'fullstep_midas_b2_192x384_train',       # BASELINE configs[0] shape, 2 pairs
+                                  'fullstep_hourglass_b2_32x48_usecnn_gap2'])   # --use_cnn: the U-Net scene-flow network
 def test_train_on_batch_matches_reference(name):
     gd = helpers.load_golden(name)
     model, opt, batch = _build(gd)

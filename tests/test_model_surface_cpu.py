@@ -67,8 +67,26 @@ def test_attribute_contract_after_construction():
     import torch
     with pytest.raises(RuntimeError, match='GPU only'):
         m.to(torch.device('cpu'))
-    with pytest.raises(NotImplementedError):
-        Model(SimpleNamespace(**dict(o, use_cnn=True)), None)
+    # --use_cnn: the U-Net scene-flow network of the reference (networks/FCNUnet.py:21-92), same state_dict keys
+    from dvd_hip.networks.FCNUnet import FCNUnet
+    with pytest.warns(UserWarning):
+        mc = Model(SimpleNamespace(**dict(o, use_cnn=True)), None)
+    assert type(mc.net_sceneflow) is FCNUnet and len(mc.net_sceneflow.state_dict()) == 30
+    if os.path.isdir(REF):
+        sys.path.insert(0, REF)
+        try:
+            from networks.FCNUnet import FCNUnet as RefUnet
+            ref = RefUnet({'norm': 'none', 'activation': 'lrelu', 'pad_type': 'reflect', 'stride': 1}, n_down=3, feat=32,
+                          block_type='double_conv', in_channel=4, out_channel=3)
+        finally:
+            sys.path.remove(REF)
+            for mod in [mm for mm in list(sys.modules) if getattr(sys.modules[mm], '__file__', None) and REF in sys.modules[mm].__file__]:
+                del sys.modules[mod]
+        assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == \
+            {k: tuple(v.shape) for k, v in mc.net_sceneflow.state_dict().items()}
+        ref.load_state_dict(mc.net_sceneflow.state_dict())
+        x = torch.randn(2, 4, 32, 48)
+        assert torch.equal(ref(x), mc.net_sceneflow(x))              # CPU tensors: the reference's own ATen arithmetic
 
 
 def test_kept_activation_slot_planning_arithmetic():

@@ -95,7 +95,7 @@ def test_step_losses_and_grads(name):
 
 
 @pytest.mark.parametrize('name', ['fullstep_hourglass_b2_32x48_train', 'fullstep_hourglass_b2_32x48_warm',
-                                  'fullstep_hourglass_b2_32x48_mseg_gap2'])
+                                  'fullstep_hourglass_b2_32x48_mseg_gap2', 'fullstep_hourglass_b2_32x48_usecnn_gap2'])
 def test_full_step_oracle_reproduces_the_reference_logs(name):
     """oracle.train_step (what bench.py times as cpu_baseline) against the batch_log the REAL reference
     Model._train_on_batch produced for the same seeded weights and batch (tests/golden/make_golden.py)."""
@@ -111,11 +111,15 @@ def test_full_step_oracle_reproduces_the_reference_logs(name):
                   for k, v in zip(gd['over_keys'], gd['over_vals'])})
     opt = L.default_opt(**{k: o[k] for k in ('midas', 'use_disp', 'use_disp_ratio', 'time_dependent', 'flow_mul', 'disp_mul',
                                              'acc_mul', 'sf_mag_div', 'interp_steps', 'warm_reg', 'weight_steps',
-                                             'use_motion_seg', 'n_freq_xyz', 'n_freq_t')})
+                                             'use_motion_seg', 'n_freq_xyz', 'n_freq_t', 'use_cnn', 'n_down')})
     seed = int(gd['seed'])
     depth = helpers.seeded_fill_(HourglassModel_Embed(noexp=False, use_embedding=False), seed)
-    mlp = helpers.seeded_fill_(SceneFlowFieldNet(net_width=256, n_layers=4, time_dependent=True, N_freq_xyz=16,
-                                                 N_freq_t=16), seed + 1)
+    if opt.use_cnn:          # the U-Net scene-flow network: oracle/fcn_unet.py, weights keyed like the reference state_dict
+        from dvd_hip.networks.FCNUnet import FCNUnet
+        mlp = helpers.seeded_fill_(FCNUnet(None, n_down=3, feat=32, block_type='double_conv', in_channel=4, out_channel=3), seed + 1)
+    else:
+        mlp = helpers.seeded_fill_(SceneFlowFieldNet(net_width=256, n_layers=4, time_dependent=True, N_freq_xyz=16,
+                                                     N_freq_t=16), seed + 1)
     sd = T.mlp_state_from_module(mlp)
     batch = synthetic.make_batch(int(gd['B']), int(gd['H']), int(gd['W']), gap=int(gd['gap']), seed=seed + 2)
     warm = int(gd['epoch']) <= o['warm_sf']
