@@ -141,13 +141,13 @@ def oracle_first_step(pairs=1, gap=None, warm=False, depth='midas'):
             'seconds': time.time() - t0}
 
 
-def hip_parity(first, device):
+def hip_parity(first, device, act_fp16=False):
     """One `_train_on_batch` of the HIP Model on the oracle's pair and initial weights; returns the `parity` object of
     the bench line: both losses, relative differences of every logged loss, the worst relative difference of the
     per-parameter gradient norms of the depth net and the worst element of the MLP gradients (relative to each
     tensor's largest element)."""
     from dvd_hip import synthetic
-    opt = make_opt(depth_chunk=1, midas=first.get('depth', 'midas') == 'midas')
+    opt = make_opt(depth_chunk=1, midas=first.get('depth', 'midas') == 'midas', act_fp16=bool(act_fp16))
     model = build_model(opt, torch.device('cpu'), seed=0, to_device=False)
     model.net_depth.load_state_dict(first['init'][0])
     model.net_sceneflow.load_state_dict(first['init'][1])
@@ -176,6 +176,11 @@ def hip_parity(first, device):
         g = first['mlp_grads'][k]
         wm = max(wm, float((p.grad.cpu() - g).abs().max() / g.abs().max().clamp_min(1e-30)))
     out['mlp_grad_worst_of_max'] = wm
+    if act_fp16:
+        st = model._gscale.tolist()
+        out['activations'] = 'fp16'
+        out['loss_scale_log2'] = __import__('math').log2(st[0]) if st[0] > 0 else None
+        out['step_skipped'] = bool(st[4])
     del model
     return out
 
@@ -391,14 +396,14 @@ def main():
         st = model._gscale.tolist()
         out['loss_scale'] = {'log2_S': __import__('math').log2(st[0]) if st[0] > 0 else None, 'target_exponent': st[2],
                              'steps_skipped': st[5]}
-    if world == 1 and not a.no_cpu_baseline and a.depth == 'midas' and a.gap == GAP and a.config == 2 and not a.act_fp16:
+    if world == 1 and not a.no_cpu_baseline and a.depth == 'midas' and a.gap == GAP and a.config == 2:
         # the 48-pair model's graph slots hold most of the HBM: release them before the 1-pair parity model is built
         import gc
         del model, batch
         gc.collect()
         torch.cuda.empty_cache()
         first = oracle_first_step()
-        out['parity'] = hip_parity(first, device)
+        out['parity'] = hip_parity(first, device, act_fp16=a.act_fp16)      # (fp16 activations: against the SAME fp32 oracle)
         out['cpu_baseline'] = cpu_baseline(first, timed_steps=max(1, a.cpu_steps))
     print(json.dumps(out))
 

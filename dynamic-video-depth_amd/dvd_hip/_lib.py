@@ -119,6 +119,8 @@ SIGNATURES = {
     'dvd_xwgrad3_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad1s_workspace_bytes': (c_size_t, [c_int] * 5),
     'dvd_xwgrad_select': (c_int, [c_int]),
+    'dvd_xwgradk_workspace_bytes': (c_size_t, [c_int] * 6),
+    'dvd_xwgradk': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     'dvd_xwgrad1s': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 6 + [c_void_p]),
     'dvd_xwgrad1s_rowsum': (c_int, [c_void_p] * 7 + [c_size_t] + [c_int] * 6 + [c_void_p]),
     'dvd_xwgrad3': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 7 + [c_void_p]),

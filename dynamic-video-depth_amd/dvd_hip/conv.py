@@ -726,6 +726,14 @@ def xconv_wgrad(x, gy, wshape, relu_in, groups=1, x_amax=None, g_amax=None, rows
                                                ctypes.c_size_t(ws.numel()), N, Cin, Cout, H, W, int(bool(relu_in)), _stream()),
                        'dvd_xwgrad1s_rowsum')
         return gw
+    if wshape[2] in (5, 7, 11) and not AB['no_xwgrad3']:      # split-operand MFMA with KS kernel rows (csrc/xwgrad3.hip xwgradk)
+        N, Cin, H, W = x.shape
+        Cout, _, KS, _ = wshape
+        gw = torch.empty(wshape, device=x.device, dtype=torch.float32)
+        ws = _workspace(lib.dvd_xwgradk_workspace_bytes(N, Cin, Cout, H, W, KS), x.device)
+        _lib.check(lib.dvd_xwgradk(_p(x), _p(x_amax), _p(gy), _p(g_amax), _p(gw), _p(ws), ctypes.c_size_t(ws.numel()), N, Cin, Cout,
+                                   H, W, KS, int(bool(relu_in)), _stream()), 'dvd_xwgradk')
+        return gw
     if (wshape[2] in (1, 3) and not AB['no_xwgrad']) or wshape[2] in (5, 7, 11):
         # exact-fp32 MFMA kernel (csrc/xwgrad.hip): the A/B fall-back of the small kernels, and -- round 4 -- THE weight gradient
         # of the hourglass's 5x5 / 7x7 / 11x11 inception branches and of the stem's 5x5 space-to-depth form (round 3: MIOpen)

@@ -254,6 +254,143 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   }
 }
 
+// ---- 5x5 / 7x7 / 11x11 (round 4): the same walk with KS kernel rows.  Replaces the weight gradient of the hourglass's large
+// inception branches (third_party/hourglass.py:21-57) -- MIOpen in round 3, the exact-fp32 MFMA kernel of csrc/xwgrad.hip at the
+// start of round 4 (37 % of an hourglass step: fp32 MFMAs run at the vector rate).  A block owns 32 output x 32 input channels;
+// wave ky keeps the KXN accumulators of kernel row ky for the columns [KX0, KX0 + KXN) (an 11-wide row takes two launches so
+// that the accumulators fit the register file); KS + 1 x-row slots roll through LDS (rows r - pad .. r + pad are read while
+// row r + pad + 1 is stored).  The fragment of column offset s is eight pixels starting s pixels off the lane's cell: the
+// lane reads the cell and both neighbours as 16-byte cells (conflict free) and takes the run out of the 12 dwords -- a plain
+// register selection for even s, v_alignbit for odd s (one shared chain of alignbits serves all odd offsets).
+template <int KS, int KX0, int KXN>
+__global__ __launch_bounds__(64 * KS) void xwgradk_kernel(const Wg3Args a) {
+  constexpr int PAD = KS / 2, NS = KS + 1, CB = 32, NT = 64 * KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  unsigned char* sG = smem3;                                   // [buffer 2][term 2][co 32][kW3GPitch]
+  unsigned char* sX = smem3 + 2 * 2 * CB * kW3GPitch;          // [term 2][slot NS][ci 32][kW3XPitch]
+  constexpr int kXTerm = NS * CB * kW3XPitch;
+  const float sx = pow2_scale(a.x_amax[0]), sg = pow2_scale(a.g_amax[0]);
+  const int tid = threadIdx.x, lane = tid & 63, ky = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int co0 = blockIdx.z * CB, ci0 = blockIdx.y * CB;
+  const size_t plane = (size_t)a.H * a.W;
+  const int items = a.N * a.nstrips * a.nrseg;
+  constexpr int GQ = CB * 16, XQ = CB * 20, NQ = (GQ + XQ + NT - 1) / NT;
+  float4 stg[NQ];
+  const bool wvec = (a.W & 3) == 0;
+  auto slot_of = [](int row) { return (row + 64) % NS; };      // rows >= -PAD
+  auto stage_load = [&](int n, int c0, int grow, int xrow) {   // gy row `grow` (< 0: none) and x row `xrow`
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = i * NT + tid;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < GQ) {
+        const int ch = q >> 4, px = c0 + ((q & 15) << 2);
+        if (grow >= 0 && (co0 + ch) < a.Cout && grow < a.H)
+          v = load_quad<false>(static_cast<const float*>(a.gy) + ((size_t)n * a.Cout + co0 + ch) * plane + (size_t)grow * a.W, px, a.W,
+                               wvec && px + 3 < a.W, false);
+      } else if (q < GQ + XQ) {
+        const int qq = q - GQ;
+        const int ch = qq / 20, px = c0 - 8 + ((qq - ch * 20) << 2);
+        if ((ci0 + ch) < a.Cin && xrow >= 0 && xrow < a.H)
+          v = load_quad<false>(static_cast<const float*>(a.x) + ((size_t)n * a.Cin + ci0 + ch) * plane + (size_t)xrow * a.W, px, a.W,
+                               wvec && px >= 0 && px + 3 < a.W, a.relu_in != 0);
+      }
+      stg[i] = v;
+    }
+  };
+  auto stage_store = [&](int xslot, int gbuf) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = i * NT + tid;
+      if (q >= GQ + XQ) continue;
+      if (q < GQ) {
+        store_quad<false>(sG + gbuf * (2 * CB * kW3GPitch) + (q >> 4) * kW3GPitch + ((q & 15) << 3), CB * kW3GPitch, stg[i], sg);
+      } else {
+        const int qq = q - GQ, ch = qq / 20;
+        store_quad<false>(sX + (xslot * CB + ch) * kW3XPitch + ((qq - ch * 20) << 3), kXTerm, stg[i], sx);
+      }
+    }
+  };
+  f32x16 acc[KXN];
+#pragma unroll
+  for (int k = 0; k < KXN; ++k) acc[k] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int half = lane >> 5;
+  const unsigned char* ga = sG + (lane & 31) * kW3GPitch + half * 16;
+  const unsigned char* xa = sX + (lane & 31) * kW3XPitch + 16 + half * 16;     // cell 1 + half of slot 0
+
+  for (int item = blockIdx.x; item < items; item += a.S) {
+    const int n = item / (a.nstrips * a.nrseg);
+    const int rem = item - n * (a.nstrips * a.nrseg);
+    const int strip = rem / a.nrseg, seg = rem - strip * a.nrseg;
+    const int c0 = strip * kW3Strip, r0 = seg * a.RS;
+    const int r1 = (r0 + a.RS) < a.H ? (r0 + a.RS) : a.H;
+    __syncthreads();                               // the previous item's MFMAs have read their operands
+    for (int j = -PAD; j < PAD; ++j) {             // x rows r0 - pad .. r0 + pad - 1 (the gy halves: zeros into the idle buffer)
+      stage_load(n, c0, -1, r0 + j);
+      stage_store(slot_of(r0 + j), (r0 + 1) & 1);
+    }
+    stage_load(n, c0, r0, r0 + PAD);
+    stage_store(slot_of(r0 + PAD), r0 & 1);        // gy row r0, x row r0 + pad
+    stage_load(n, c0, r0 + 1, r0 + 1 + PAD);       // in registers: the rows step r0 stores for step r0 + 1
+    for (int r = r0; r < r1; ++r) {
+      __syncthreads();                             // the rows of step r are complete; step r - 1 has been read by every wave
+      stage_store(slot_of(r + 1 + PAD), (r + 1) & 1);
+      stage_load(n, c0, r + 2, r + 2 + PAD);
+      const unsigned char* xr = xa + slot_of(r - PAD + ky) * (CB * kW3XPitch);
+      const unsigned char* gr = ga + (r & 1) * (2 * CB * kW3GPitch);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {                // four K steps of 16 pixels
+        f16x8 A[2];
+        unsigned d[2][12];                         // per term: previous cell, the lane's cell, next cell (24 pixels)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          A[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(gr + t * (CB * kW3GPitch) + s * 32));
+          const unsigned char* xc = xr + t * kXTerm + s * 32;
+          const u32x4 p = *reinterpret_cast<const u32x4*>(xc - 16), c = *reinterpret_cast<const u32x4*>(xc),
+                      nn = *reinterpret_cast<const u32x4*>(xc + 16);
+          d[t][0] = p.x; d[t][1] = p.y; d[t][2] = p.z; d[t][3] = p.w;
+          d[t][4] = c.x; d[t][5] = c.y; d[t][6] = c.z; d[t][7] = c.w;
+          d[t][8] = nn.x; d[t][9] = nn.y; d[t][10] = nn.z; d[t][11] = nn.w;
+        }
+#pragma unroll
+        for (int kx = 0; kx < KXN; ++kx) {
+          const int sh = KX0 + kx - PAD;           // column offset in pixels (compile-time after unrolling)
+          const int st = 8 + sh;                   // first pixel of the run inside the 24-pixel window (3 .. 13)
+          f16x8 B[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            u32x4 f;
+            if ((st & 1) == 0) {
+              const int j = st >> 1;
+              f = (u32x4){d[t][j], d[t][j + 1], d[t][j + 2], d[t][j + 3]};
+            } else {
+              const int j = (st - 1) >> 1;
+              f = (u32x4){__builtin_amdgcn_alignbit(d[t][j + 1], d[t][j], 16), __builtin_amdgcn_alignbit(d[t][j + 2], d[t][j + 1], 16),
+                          __builtin_amdgcn_alignbit(d[t][j + 3], d[t][j + 2], 16), __builtin_amdgcn_alignbit(d[t][j + 4], d[t][j + 3], 16)};
+            }
+            B[t] = __builtin_bit_cast(f16x8, f);
+          }
+          acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[1], B[0], acc[kx], 0, 0, 0);     // small terms first
+          acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[1], acc[kx], 0, 0, 0);
+          acc[kx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc[kx], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* dst = a.partial + (size_t)blockIdx.x * (KS * KS) * a.Cout * a.Cin;      // partial[s][tap][Cout][Cin]
+  const float unscale = 1.0f / (sx * sg);
+#pragma unroll
+  for (int kx = 0; kx < KXN; ++kx) {
+    const int tap = ky * KS + KX0 + kx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ci = ci0 + (lane & 31);
+      if (co < a.Cout && ci < a.Cin) dst[((size_t)tap * a.Cout + co) * a.Cin + ci] = acc[kx][r] * unscale;
+    }
+  }
+}
+
 // gw[co][ci][tap] = sum_s partial[s][tap][co][ci], ascending s (two interleaved chains)
 __global__ __launch_bounds__(256) void xwgrad3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int S,
                                                              int T, int Cout, int Cin) {
@@ -641,6 +778,78 @@ size_t dvd_xwgrad1s_workspace_bytes(int N, int Cin, int Cout, int H, int W) {
   const int Sw = dvd::wg1_wide_slices(N, Cin, Cout, H * W);      // (either kernel may serve the call)
   if (Sw > S) S = Sw;
   return (size_t)S * Cout * Cin * sizeof(float);
+}
+
+// ---- 5x5 / 7x7 / 11x11
+static bool wgk_plan(int N, int Cin, int Cout, int H, int W, int KS, dvd::Wg3Plan& p) {
+  if (KS != 5 && KS != 7 && KS != 11) return false;
+  p.nco = (Cout + 31) / 32;
+  p.nci = (Cin + 31) / 32;
+  p.nstrips = (W + dvd::kW3Strip - 1) / dvd::kW3Strip;
+  const int pairs = p.nco * p.nci;
+  int S = pairs >= 256 ? 1 : (256 + pairs - 1) / pairs;        // one block per CU is resident
+  int RS = H;
+  while (RS > 4 * KS && (long long)N * p.nstrips * ((H + RS - 1) / RS) < 4LL * S) RS = (RS + 1) / 2;   // (KS - 1 warm-up rows per item)
+  p.RS = RS;
+  p.nrseg = (H + RS - 1) / RS;
+  const long long items = (long long)N * p.nstrips * p.nrseg;
+  if (S > items) S = (int)items;
+  p.S = S;
+  p.lds = (size_t)2 * 2 * 32 * dvd::kW3GPitch + (size_t)2 * (KS + 1) * 32 * dvd::kW3XPitch;
+  return true;
+}
+
+size_t dvd_xwgradk_workspace_bytes(int N, int Cin, int Cout, int H, int W, int KS) {
+  dvd::Wg3Plan p;
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !wgk_plan(N, Cin, Cout, H, W, KS, p)) return 0;
+  return (size_t)p.S * KS * KS * Cout * Cin * sizeof(float);
+}
+
+int dvd_xwgradk(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
+                size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int KS, int relu_in, dvd_stream_t stream) {
+  DVD_REQUIRE(x && gy && gw && workspace && x_amax && gy_amax, "xwgradk: null pointer");
+  DVD_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "xwgradk: bad shape");
+  DVD_REQUIRE((long long)H * W * (long long)(Cin > Cout ? Cin : Cout) < (1ll << 31), "xwgradk: image too large for 32-bit offsets");
+  dvd::Wg3Plan p;
+  DVD_REQUIRE(wgk_plan(N, Cin, Cout, H, W, KS, p), "xwgradk: kernel size %d (5, 7 and 11 are covered)", KS);
+  const size_t need = (size_t)p.S * KS * KS * Cout * Cin * sizeof(float);
+  if (workspace_bytes < need) {
+    dvd::set_error("xwgradk: workspace %zu < %zu bytes", workspace_bytes, need);
+    return DVD_ENOSPC;
+  }
+  DVD_REQUIRE(p.nco <= 65535 && p.nci <= 65535, "xwgradk: too many channel blocks");
+  dvd::Wg3Args a;
+  a.x = x;
+  a.gy = gy;
+  a.x_amax = x_amax;
+  a.g_amax = gy_amax;
+  a.out_scale = nullptr;
+  a.partial = static_cast<float*>(workspace);
+  a.N = N; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+  a.G = 1; a.nco = p.nco;
+  a.nstrips = p.nstrips; a.RS = p.RS; a.nrseg = p.nrseg; a.S = p.S;
+  a.relu_in = relu_in ? 1 : 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(p.S, p.nci, p.nco);
+  auto go = [&](auto kern, int waves) -> int {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(kern, grid, dim3(64 * waves), p.lds, s, a);
+    DVD_LAUNCH_OK();
+    return DVD_OK;
+  };
+  if (KS == 5) {
+    if (int e = go(dvd::xwgradk_kernel<5, 0, 5>, 5)) return e;
+  } else if (KS == 7) {
+    if (int e = go(dvd::xwgradk_kernel<7, 0, 7>, 7)) return e;
+  } else {
+    if (int e = go(dvd::xwgradk_kernel<11, 0, 6>, 11)) return e;     // columns 0 .. 5
+    if (int e = go(dvd::xwgradk_kernel<11, 6, 5>, 11)) return e;     // columns 6 .. 10 (disjoint taps of the same partials)
+  }
+  const long long per = (long long)KS * KS * Cout * Cin;
+  hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
+                     static_cast<const float*>(workspace), gw, p.S, KS * KS, Cout, Cin);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
 }
 
 int dvd_xwgrad_select(int variant) {

@@ -384,6 +384,12 @@ int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, co
  * 1 = always 128 x 128.  Same products and the same per-element summation order within a slice; the number of slices
  * (partial sums added at the end) differs, so results agree to fp32 rounding, not bitwise. */
 int dvd_xwgrad_select(int variant);
+/* The same for dense 5x5 / 7x7 / 11x11 stride-1 "same" convolutions (round 4: third_party/hourglass.py:21-57, the inception
+ * branches; round 3 left their weight gradient to MIOpen): split-operand MFMA, 32 x 32 channels per block, one wave per kernel
+ * row, deterministic.  gw [Cout][Cin][KS][KS]. */
+size_t dvd_xwgradk_workspace_bytes(int N, int Cin, int Cout, int H, int W, int KS);
+int dvd_xwgradk(const float* x, const float* x_amax, const float* gy, const float* gy_amax, float* gw, void* workspace,
+                size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int KS, int relu_in, dvd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Flow-consistency (occlusion) + out-of-bounds mask of one direction of a frame pair.
