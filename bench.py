@@ -369,7 +369,7 @@ def main():
     }
     if warp is not None:
         # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 --pmc passes of
-        # the same launch at 48 x 384 x 672: tools/gpu_round.sh pmc -> tools/pmc_to_json.py); the committed summary of the
+        # the same launch at 48 x 384 x 672: tools/gpu_visit.sh, stage pmc -> tools/pmc_to_json.py); the committed summary of the
         # CURRENT kernel is read here and its provenance is stated next to the number
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, 'profiles', 'warp_loss_pmc.json')

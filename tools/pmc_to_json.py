@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turn the rocprofv3 --pmc summary of the warp+loss micro-benchmark (tools/gpu_round.sh, stage
+"""Turn the rocprofv3 --pmc summary of the warp+loss micro-benchmark (tools/gpu_visit.sh, stage
 pmc; FETCH_SIZE and WRITE_SIZE collected in separate passes) into profiles/warp_loss_pmc.json,
 which bench.py reports as roofline.traffic.
 
