@@ -24,9 +24,10 @@ What is different is HOW a step runs.  The reference builds one autograd graph o
      backward graph (or a forward+backward recompute graph); then one RCCL all-reduce per net over its flat gradient
      buffer and one fused Adam launch per net.
 
-Every convolution, BatchNorm+ReLU, up-sampling and the MLP run on this package's HIP kernels (csrc/); the matrix kernels
-evaluate fp32 products from two fp16 terms per operand (csrc/dvd_split.h).  Only the 7x7 stride-2 stem, its BatchNorm and
-the max-pool of the ResNeXt encoder are ATen / MIOpen calls (< 1 % of a step).
+Every convolution (the 7x7 stride-2 stem included, round 4), BatchNorm+ReLU, pooling, up-sampling and the MLP run on this
+package's HIP kernels (csrc/); the matrix kernels evaluate fp32 products from two fp16 terms per operand (csrc/dvd_split.h).
+`--act_fp16` (BASELINE configs[4]) stores the depth net's activations and their gradients as fp16 (csrc/a16.hip: the loss scale
+lives on the device); `--use_cnn` swaps the MLP for the reference's U-Net scene-flow network (networks/FCNUnet.py) under autograd.
 """
 import os
 import sys
