@@ -18,6 +18,8 @@
 // scaled and split into the two fp16 terms on the way in; the next step's rows are requested before the MFMAs of the
 // current one.  Wave (pm, pn, ky) of the 12 keeps the three accumulators of kernel row ky for its 32 x 32 pair.
 // Every block writes its partial sums; xwgrad3_reduce_kernel adds them in slice order.
+#include <type_traits>
+
 #include "dvd_split.h"
 
 namespace dvd {
@@ -104,6 +106,34 @@ __device__ __forceinline__ void store_quad(unsigned char* dst, int tstride, cons
     *reinterpret_cast<uint2*>(dst + tstride) = make_uint2(l0, l1);
   }
 }
+// fp16 rows are staged 8 pixels (16 bytes) per item: with 4-pixel items the H16 kernels issued twice the loads of the fp32
+// kernels per byte and sat on the load-instruction rate (3x3 256 -> 256: the matrix pipe 24 % busy at one MFMA per product).
+// p[px .. px + 7] of a row of n elements (zero outside); a8: rows are 16-byte aligned (n % 8 == 0), a4: 8-byte aligned
+__device__ __forceinline__ uint4 load_oct_h(const void* row, int px, int n, bool a8, bool a4, bool relu) {
+  const unsigned short* p = static_cast<const unsigned short*>(row);
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (a8 && px >= 0 && px + 7 < n) {
+    v = *reinterpret_cast<const uint4*>(p + px);
+  } else if (a4) {
+    if (px >= 0 && px + 3 < n) {
+      const uint2 t = *reinterpret_cast<const uint2*>(p + px);
+      v.x = t.x;
+      v.y = t.y;
+    }
+    if (px + 4 >= 0 && px + 7 < n) {
+      const uint2 t = *reinterpret_cast<const uint2*>(p + px + 4);
+      v.z = t.x;
+      v.w = t.y;
+    }
+  } else {
+    unsigned e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = (px + i >= 0 && px + i < n) ? p[px + i] : 0u;
+    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+  }
+  if (relu) v = make_uint4(relu_h2(v.x), relu_h2(v.y), relu_h2(v.z), relu_h2(v.w));
+  return v;
+}
 
 constexpr int kW3Strip = 64;                  // pixels per row step
 constexpr int kW3GPitch = 128 + 16;           // bytes per gy row in LDS (64 fp16 + pad: conflict-free 16-byte reads across rows)
@@ -128,31 +158,41 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   const size_t plane = (size_t)a.H * a.W;
   const int items = a.N * a.nstrips * a.nrseg;
 
-  // staging assignment: a thread stages 4 consecutive pixels of one channel row.
-  //   gy row: 64 channels x 16 quads = 1024 quads;  x row: 64 channels x 20 quads = 1280 quads  -> 3 per thread
-  constexpr int GQ = kW3CB * 16, XQ = kW3CB * 20, NQ = (GQ + XQ + kW3NT - 1) / kW3NT;
-  typename Quad<H16>::type stg[NQ];
-  const bool wvec = (a.W & 3) == 0;
+  // staging assignment: a thread stages QW consecutive pixels of one channel row (fp32: 4 = 16 bytes; fp16: 8 = 16 bytes).
+  //   fp32: gy row 64 channels x 16 items, x row 64 x 20 -> 3 per thread;  fp16: 64 x 8 and 64 x 10 -> 2 per thread
+  constexpr int QW = H16 ? 8 : 4, GPR = 64 / QW, XPR = 80 / QW;
+  constexpr int GQ = kW3CB * GPR, XQ = kW3CB * XPR, NQ = (GQ + XQ + kW3NT - 1) / kW3NT;
+  typedef std::conditional_t<H16, uint4, float4> StgT;
+  StgT stg[NQ];
+  const bool wvec = (a.W & 3) == 0, wvec8 = (a.W & 7) == 0;
+  auto zero_item = [&]() -> StgT {
+    if constexpr (H16) return make_uint4(0u, 0u, 0u, 0u);
+    else return make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto load_item = [&](const unsigned char* row, int px, bool relu) -> StgT {
+    if constexpr (H16) return load_oct_h(row, px, a.W, wvec8, wvec, relu);
+    else return load_quad<false>(row, px, a.W, wvec && px >= 0 && px + 3 < a.W, relu);
+  };
   auto stage_load = [&](int n, int c0, int r, bool with_g) {   // gy row r (if with_g) and x row r + 1
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
       const int q = i * kW3NT + tid;
-      typename Quad<H16>::type v = zero_quad<H16>();
+      StgT v = zero_item();
       if (q < GQ) {
-        const int ch = q >> 4, px = c0 + ((q & 15) << 2);
+        const int ch = q / GPR, px = c0 + (q - ch * GPR) * QW;
         if (with_g && (co0 + ch) < a.Cout && r < a.H) {
           const unsigned char* p = static_cast<const unsigned char*>(a.gy) +
                                    ((((size_t)n * a.G + grp) * a.Cout + co0 + ch) * plane + (size_t)r * a.W) * EB;
-          v = load_quad<H16>(p, px, a.W, wvec && px + 3 < a.W, false);
+          v = load_item(p, px, false);
         }
       } else if (q < GQ + XQ) {
         const int qq = q - GQ;
-        const int ch = qq / 20, px = c0 - 8 + ((qq - ch * 20) << 2);
+        const int ch = qq / XPR, px = c0 - 8 + (qq - ch * XPR) * QW;
         const int row = r + 1;
         if ((ci0 + ch) < a.Cin && row >= 0 && row < a.H) {
           const unsigned char* p = static_cast<const unsigned char*>(a.x) +
                                    ((((size_t)n * a.G + grp) * a.Cin + ci0 + ch) * plane + (size_t)row * a.W) * EB;
-          v = load_quad<H16>(p, px, a.W, wvec && px >= 0 && px + 3 < a.W, a.relu_in != 0);
+          v = load_item(p, px, a.relu_in != 0);
         }
       }
       stg[i] = v;
@@ -167,14 +207,16 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       unsigned char* dst;
       int tstride;
       if (q < GQ) {
-        dst = sG + gbuf * (2 * kW3CB * kW3GPitch) + (q >> 4) * kW3GPitch + ((q & 15) << 3);
+        const int ch = q / GPR;
+        dst = sG + gbuf * (2 * kW3CB * kW3GPitch) + ch * kW3GPitch + (q - ch * GPR) * (QW * 2);
         tstride = kW3CB * kW3GPitch;
       } else {
-        const int qq = q - GQ, ch = qq / 20;
-        dst = sX + (xslot * kW3CB + ch) * kW3XPitch + ((qq - ch * 20) << 3);
+        const int qq = q - GQ, ch = qq / XPR;
+        dst = sX + (xslot * kW3CB + ch) * kW3XPitch + (qq - ch * XPR) * (QW * 2);
         tstride = kW3CB * 4 * kW3XPitch;
       }
-      store_quad<H16>(dst, tstride, stg[i], sc);
+      if constexpr (H16) *reinterpret_cast<uint4*>(dst) = stg[i];
+      else store_quad<false>(dst, tstride, stg[i], sc);
     }
   };
 
@@ -545,6 +587,7 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
     for (int c = 0; c < 4; ++c) acc[r][c] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread; q = i * 512 + tid, row = q >> 2 (0..255 gy, 256..511 x)
+  // (16-byte staging items for fp16 rows, as in xwgrad3_kernel, were tried here too: 3-10 % slower on the 1x1 shapes; not kept)
   typedef typename Quad<H16>::type QT;
   QT sg0[4], sg1[4];
   auto stage_load = [&](int it, QT (&st)[4]) {
