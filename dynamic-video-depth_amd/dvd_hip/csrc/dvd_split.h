@@ -54,6 +54,15 @@ __device__ __forceinline__ void split8_f16(const float v[8], float s, uint4& h, 
   split_pair_f16(v[6] * s, v[7] * s, h.w, l.w);
 }
 
+// A pointer the compiler can see is wave-uniform (block indices divided by run-time values pass through VGPRs): buffer
+// resources must sit in SGPRs, a resource of unknown uniformity costs a waterfall loop around every load.
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
 // max over the wave, then AT MOST one atomic per wave: |x| as an unsigned integer is monotonic in |x|.  The scalar is read
 // first and the atomic only issued when it would raise it: tens of thousands of waves finishing together otherwise
 // serialise on the one address (~88 atomics per microsecond: a BatchNorm mask pass of 49 000 blocks took 1.4 ms instead of

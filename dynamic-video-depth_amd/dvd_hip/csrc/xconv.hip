@@ -43,15 +43,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of it stay in registers
 
-// A pointer the compiler can see is wave-uniform (block indices divided by run-time values pass through VGPRs): buffer
-// resources must sit in SGPRs, a resource of unknown uniformity costs a waterfall loop around every load.
-template <class T>
-__device__ __forceinline__ T* uniform_ptr(T* p) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
-}
-
 // Packed weights: a 256-byte header (float 0: max|A| over the whole tensor, written by xconv_wamax_kernel) followed by
 // frag[(((mt * nkc + kc) * T + tap) * 2 + term) * 64 + lane] : 8 fp16 of A * pow2_scale(max|A|)
 //   forward:    A[m][k] = w[co = m][ci = k][tap]
@@ -163,6 +154,7 @@ struct XArgs {
 // scale, no split (the staging is a transposing copy), so a product costs TWO MFMAs (two-term weight x one-term activation)
 // instead of three and the activation planes in LDS halve; the output (and the residual / mask operands of its epilogue) is
 // _Float16.  The weights stay fp32 in HBM and two-term in the packed buffer, accumulation stays fp32.
+constexpr int kXFitOne = 11;     // FIT value of the 1x1 kernels (see kOne)
 template <int TM, int TN, int WM, int WN, int FIT, bool FAST, bool B1 = false, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const XArgs a) {
   static_assert(!IN16 || FAST, "fp16 activations exist on the buffer-addressed main loop only");
@@ -173,7 +165,8 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   constexpr int XB = IN16 ? 2 : 4;               // bytes per activation element in HBM
   constexpr int NT = 64 * WM * WN;
   constexpr bool kDirect = FIT == 0;             // big halos (k >= 5): stage without the register prefetch
-  constexpr int FI = kDirect ? 1 : FIT;
+  constexpr bool kOne = FIT == kXFitOne;         // 1x1 convolutions, one staging item per thread: the two-chunk loop
+  constexpr int FI = (kDirect || kOne) ? 1 : FIT;
   constexpr int MT = WM * TM;                    // 32-channel tiles per block
   constexpr int AU = MT * 2 * 64;                // uint4 per A stage (all tiles, two terms)
   constexpr int AI = (AU + NT - 1) / NT;         // staging loads per thread
@@ -221,7 +214,8 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   for (int it = 0; it < FI; ++it) voff[it] = gok[it] ? (goff[it] + cig8[it] * (int)plane) * XB : (int)0x80000000;
   const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(const_cast<TX*>(xn)), 0, FAST ? a.Cin * planeB : 0, 0x00020000);
-  RawT raw[FI][8];
+  typedef RawT RawSet[FI][8];
+  RawSet raw, raw_b;        // raw_b: the second set of the 1x1 loop (two chunks in flight per block)
   // 8 fp16 channel values of one position -> one LDS cell (+ ReLU on packed halves): the whole "split" of the IN16 kernels
   auto cell16 = [&](const unsigned short (&r)[8]) {
     u32x4 c = {(unsigned)r[0] | ((unsigned)r[1] << 16), (unsigned)r[2] | ((unsigned)r[3] << 16),
@@ -234,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     }
     return c;
   };
-  auto load_raw = [&](int kc) {
+  auto load_raw_to = [&](RawSet& raw, int kc) {
     if constexpr (IN16) {
       const int s0 = kc * 16 * planeB;
 #pragma unroll
@@ -262,7 +256,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     }
     }
   };
-  auto split_write = [&](int buf, int kc) {
+  auto split_write_from = [&](const RawSet& raw, int buf, int kc) {
     u32x4* dst = sB + (B1 ? 0 : buf * 2 * BT * npos);
     if constexpr (IN16) {
 #pragma unroll
@@ -293,6 +287,9 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     }
     }
   };
+
+  auto load_raw = [&](int kc) { load_raw_to(raw, kc); };
+  auto split_write = [&](int buf, int kc) { split_write_from(raw, buf, kc); };
 
   // direct staging (kDirect): load, split and store item by item, nothing kept in registers across the MFMAs
   auto stage_direct = [&](int buf, int kc) {
@@ -530,9 +527,57 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       }
       advance();
     };
-    for (int kt = 0; kt < nkt; kt += 2) {
-      step_roll(kt, fb[0], fb[1]);
-      if (kt + 1 < nkt) step_roll(kt + 1, fb[1], fb[0]);
+    // 1x1 convolutions (one tap per chunk): a K step is 16 channels of activations from HBM, and with ONE chunk requested per
+    // step a block had 8 KB in flight for one step's MFMAs -- a third of the HBM latency: every step waited on its chunk,
+    // 3.1 TB/s at any block shape (round 4 counters: matrix pipe 34 % busy, 37 % of the wave cycles in s_waitcnt).  Two
+    // register sets keep two chunks in flight: chunk kt + 3 is requested at the TOP of step kt, BEHIND the step's weight
+    // request (loads return in order: the wait for A(kt + 2) at the end of the step must not drain the activation request),
+    // and split at the end of step kt + 1.
+    auto step_one = [&](int kt, f16x8 (&bc)[TN][BT], const RawSet& rs, RawSet& ro) {
+      __syncthreads();
+      load_a(ra, kt + 2 < nkt ? kt + 2 : kt);
+      load_raw_to(ro, kt + 3 < a.nkc ? kt + 3 : a.nkc - 1);
+      const u32x4* Ac = sA + ((kt + 1) & 1) * AS + al;
+      const u32x4* Bc = sB + ((kt + 1) & 1) * 2 * BT * npos + bl;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][1], bc[tn][0], acc[tm][tn], 0, 0, 0);
+        if constexpr (!IN16) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][0], bc[tn][1], acc[tm][tn], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm][0], bc[tn][0], acc[tm][tn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[tm][t] = __builtin_bit_cast(f16x8, Ac[(tm * 2 + t) * 64]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the activation fragments of step kt + 1 go into the registers this step's last MFMAs have read (one set: the second
+      // pays for the second raw set); their LDS round trip is covered by the staging below
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int t = 0; t < BT; ++t) bc[tn][t] = __builtin_bit_cast(f16x8, Bc[t * 2 * npos + qb[tn]]);
+      __builtin_amdgcn_sched_barrier(0);
+      write_a(ra, kt & 1);                           // A(kt + 2) over A(kt)
+      split_write_from(rs, kt & 1, kt + 2);          // chunk kt + 2 (requested at the top of step kt - 1) over chunk kt
+    };
+    if constexpr (kOne) {
+      for (int kt = 0; kt < nkt; kt += 2) {
+        step_one(kt, fb[0], raw, raw_b);
+        if (kt + 1 < nkt) step_one(kt + 1, fb[0], raw_b, raw);
+      }
+    } else {
+      for (int kt = 0; kt < nkt; kt += 2) {
+        step_roll(kt, fb[0], fb[1]);
+        if (kt + 1 < nkt) step_roll(kt + 1, fb[1], fb[0]);
+      }
     }
   } else {
   load_a(ra, 0);
@@ -696,7 +741,7 @@ struct XCfg {
 // positions in ONE 512-thread block per CU for k >= 3 (the haloed tile of 256 positions needs ~120 KB of LDS).
 static int g_xcfg = 0;    // test / A-B hook (dvd_xconv_select): 0 auto, 1 round-2 shapes only, 2 force 256x128, 3 force 256x256,
                           // 4 round-2 shapes on the generic (pointer-addressed) main loop, 5 128 x 128 blocks with one
-                          // activation stage at three blocks per CU
+                          // activation stage at three blocks per CU, 6 1x1 kernels without the two-chunk loop (kOne)
 static XCfg pick_cfg(int M, int KS) {
   if (M <= 32) return {1, 2, 1, 4};     // 32 channels x 256 positions
   if (M <= 64) return {2, 2, 1, 4};     // 64 x 256
@@ -769,6 +814,9 @@ static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t 
     DVD_LAUNCH_OK();
     return DVD_OK;
   };
+  if constexpr (TM >= 4 && !B1 && FAST && DVD_XCONV_ROLL != 0) {
+    if (a.T == 1 && FI == 1 && g_xcfg != 6) return go(xconv_kernel<TM, TN, WM, WN, kXFitOne, FAST, B1, IN16, OUT16>);
+  }
   switch (FI) {
     case 1: return go(xconv_kernel<TM, TN, WM, WN, 1, FAST, B1, IN16, OUT16>);
     case 2: return go(xconv_kernel<TM, TN, WM, WN, 2, FAST, B1, IN16, OUT16>);
@@ -832,7 +880,7 @@ int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int K
 }
 
 int dvd_xconv_select(int cfg) {
-  DVD_REQUIRE(cfg >= 0 && cfg <= 5, "xconv_select: cfg %d", cfg);
+  DVD_REQUIRE(cfg >= 0 && cfg <= 6, "xconv_select: cfg %d", cfg);
   dvd::g_xcfg = cfg;
   return DVD_OK;
 }

@@ -28,6 +28,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static int g_w1_variant = 0;      // test / A-B hook (dvd_xwgrad_select): 0 auto, 1 always the 128 x 128 blocks
+static int g_w3_variant = 0;      // 1 (hook value 2): the 3x3 kernel's round-3 row step (staging ahead of the MFMAs) on every shape
 
 struct Wg3Args {
   const void* __restrict__ x;         // float, or _Float16 in the H16 kernels (fp16 activation storage, BASELINE configs[4])
@@ -140,8 +141,15 @@ constexpr int kW3GPitch = 128 + 16;           // bytes per gy row in LDS (64 fp1
 constexpr int kW3XPitch = 160 + 16;           // bytes per x row in LDS (80 fp16 + pad)
 constexpr int kW3CB = 64;                     // channels per block, both operands
 constexpr int kW3NT = 768;                    // 12 waves: 2 x 2 tile pairs x 3 kernel rows
+constexpr int kW3LdsBytes = 2 * 2 * kW3CB * kW3GPitch + 2 * kW3CB * 4 * kW3XPitch;   // + 16 spare bytes (idle staging items)
 
-template <bool H16>
+// FW (host: W a multiple of the staging item, 4 pixels fp32 / 8 fp16): every staging item is a whole 16-byte run of one row or
+// nothing, so the loads are raw BUFFER loads with a per-thread offset computed once per work item (channels past the tensor
+// and columns outside the image fall out of the resource's range and read 0) -- no branch in the row step.  With the body one
+// basic block, the staging work of item i (split + LDS store of the row loaded a step ago, request of the row two steps ahead)
+// sits between the MFMAs of K step i: round 3 ran `barrier | all staging | all MFMAs` in every wave, the 12 waves in lock step
+// behind the barrier, and the counters showed matrix pipe and VALU taking turns (55 % busy at 5.5 VALU per MFMA).
+template <bool H16, bool FW>
 __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   constexpr int EB = H16 ? 2 : 4;                // bytes per element in HBM
   constexpr int NTERM = H16 ? 1 : 2;
@@ -227,28 +235,114 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   const unsigned char* ga = sG + (pm * 32 + (lane & 31)) * kW3GPitch + half * 16;
   const unsigned char* xa = sX + (pn * 32 + (lane & 31)) * kW3XPitch + 16 + half * 16;   // cell 1 + half of slot 0
 
+  // ---- FW staging (see the kernel's header): per-thread constants of the NQ staging items
+  bool f_isg[NQ];          // wave-uniform: the item is a gy run (else an x run)
+  int f_ch[NQ], f_pq[NQ], f_lds[NQ];
+  if constexpr (FW) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int q = i * kW3NT + tid;
+      f_isg[i] = __builtin_amdgcn_readfirstlane(q < GQ ? 1 : 0) != 0;          // GQ is a multiple of 64
+      const int qq = f_isg[i] ? q : q - GQ;
+      const int pr = f_isg[i] ? GPR : XPR;
+      f_ch[i] = qq / pr;
+      const int cell = qq - f_ch[i] * pr;
+      f_pq[i] = cell * QW - (f_isg[i] ? 0 : 8);
+      // items past the two rows (fp16: the last six waves of item 1) load nothing and store into the spare 16 bytes
+      f_lds[i] = q >= GQ + XQ ? kW3LdsBytes
+                              : (f_isg[i] ? f_ch[i] * kW3GPitch : (int)(sX - smem3) + f_ch[i] * kW3XPitch) + cell * (QW * 2);
+      if (q >= GQ + XQ) f_ch[i] = 1 << 20;                                       // beyond any resource's range
+    }
+  }
+  u32x4 fstg[NQ];
+  int f_voff[NQ];
+  __amdgpu_buffer_rsrc_t srdX, srdG;
+  const float relu_lo = a.relu_in ? 0.0f : -__builtin_inff();
+  const unsigned relu_lo_h = a.relu_in ? 0u : 0xfc00fc00u;                      // packed halves: 0 | -inf
+  auto f_load = [&](int i, int rg, bool with_g) {                               // item i of (gy row rg, x row rg + 1)
+    const int row = f_isg[i] ? rg : rg + 1;
+    const bool ok = row >= 0 && row < a.H && (with_g || !f_isg[i]);              // wave-uniform
+    const int vo = ok ? f_voff[i] : (int)0x80000000;
+    const int so = ok ? row * a.W * EB : 0;
+    fstg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(f_isg[i] ? srdG : srdX, vo, so, 0));
+  };
+  auto f_store = [&](int i, int xslot, int gbuf) {
+    unsigned char* dst = smem3 + f_lds[i] + (f_isg[i] ? gbuf * (2 * kW3CB * kW3GPitch) : xslot * (kW3CB * kW3XPitch));
+    if constexpr (H16) {
+      u32x4 v = fstg[i];
+      if (!f_isg[i]) {                                                           // ReLU of the activations (no-op against -inf)
+        const f16x2 lo = __builtin_bit_cast(f16x2, relu_lo_h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, (unsigned)v[j]), lo));
+      }
+      *reinterpret_cast<u32x4*>(dst) = v;
+    } else {
+      const float sc = f_isg[i] ? sg : sx;
+      const float lo = f_isg[i] ? -__builtin_inff() : relu_lo;
+      const float v0 = fmaxf(__uint_as_float(fstg[i][0]), lo) * sc, v1 = fmaxf(__uint_as_float(fstg[i][1]), lo) * sc;
+      const float v2 = fmaxf(__uint_as_float(fstg[i][2]), lo) * sc, v3 = fmaxf(__uint_as_float(fstg[i][3]), lo) * sc;
+      unsigned h0, l0, h1, l1;
+      split_pair_f16(v0, v1, h0, l0);
+      split_pair_f16(v2, v3, h1, l1);
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + (f_isg[i] ? kW3CB * kW3GPitch : kW3CB * 4 * kW3XPitch)) = make_uint2(l0, l1);
+    }
+  };
+
   for (int item = blockIdx.x; item < items; item += a.S) {
     const int n = item / (a.nstrips * a.nrseg);
     const int rem = item - n * (a.nstrips * a.nrseg);
     const int strip = rem / a.nrseg, seg = rem - strip * a.nrseg;
     const int c0 = strip * kW3Strip, r0 = seg * a.RS;
     const int r1 = (r0 + a.RS) < a.H ? (r0 + a.RS) : a.H;
+    if constexpr (FW) {
+      // this image's 64 channels of either tensor as buffer resources: channels past the tensor are out of range
+      const int nci = (a.Cin - ci0) < kW3CB ? (a.Cin - ci0) : kW3CB, nco = (a.Cout - co0) < kW3CB ? (a.Cout - co0) : kW3CB;
+      const unsigned char* xb = static_cast<const unsigned char*>(a.x) + (((size_t)n * a.G + grp) * a.Cin + ci0) * plane * EB;
+      const unsigned char* gb = static_cast<const unsigned char*>(a.gy) + (((size_t)n * a.G + grp) * a.Cout + co0) * plane * EB;
+      srdX = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(xb)), 0, nci * (int)plane * EB, 0x00020000);
+      srdG = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(gb)), 0, nco * (int)plane * EB, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int px = c0 + f_pq[i];
+        f_voff[i] = (px >= 0 && px + QW <= a.W && f_ch[i] < kW3CB) ? (f_ch[i] * (int)plane + px) * EB : (int)0x80000000;
+      }
+    }
+    auto load_all = [&](int rg, bool with_g) {
+      if constexpr (FW) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) f_load(i, rg, with_g);
+      } else {
+        stage_load(n, c0, rg, with_g);
+      }
+    };
+    auto store_all = [&](int xslot, int gbuf) {
+      if constexpr (FW) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) f_store(i, xslot, gbuf);
+      } else {
+        stage_store(xslot, gbuf);
+      }
+    };
     // Four x-row slots (row & 3) and two gy buffers (row & 1): step r reads x rows r - 1 .. r + 1 and gy row r while the
     // rows of step r + 1 (x row r + 2, gy row r + 1: loaded during step r - 1) are split and stored and the rows of step
     // r + 2 are requested -- ONE barrier per step, and no phase in which every wave of the block does staging work while
     // the matrix pipe idles (round 2 stored between two barriers).
     __syncthreads();                               // the previous item's MFMAs have read their operands
-    stage_load(n, c0, r0 - 2, false);
-    stage_store((r0 - 1) & 3, (r0 + 1) & 1);       // x row r0 - 1 (the gy half of these two stores is zeros into the idle buffer)
-    stage_load(n, c0, r0 - 1, false);
-    stage_store(r0 & 3, (r0 + 1) & 1);             // x row r0
-    stage_load(n, c0, r0, true);
-    stage_store((r0 + 1) & 3, r0 & 1);             // gy row r0, x row r0 + 1
-    stage_load(n, c0, r0 + 1, true);               // gy row r0 + 1, x row r0 + 2 in registers
+    load_all(r0 - 2, false);
+    store_all((r0 - 1) & 3, (r0 + 1) & 1);         // x row r0 - 1 (the gy half of these two stores is zeros into the idle buffer)
+    load_all(r0 - 1, false);
+    store_all(r0 & 3, (r0 + 1) & 1);               // x row r0
+    load_all(r0, true);
+    store_all((r0 + 1) & 3, r0 & 1);               // gy row r0, x row r0 + 1
+    load_all(r0 + 1, true);                        // gy row r0 + 1, x row r0 + 2 in registers
     for (int r = r0; r < r1; ++r) {
       __syncthreads();                             // the rows of step r are complete; step r - 1 has been read by every wave
-      stage_store((r + 2) & 3, (r + 1) & 1);       // for step r + 1 (x row r - 2 / gy row r - 1 are no longer needed)
-      stage_load(n, c0, r + 2, true);              // for step r + 2: in flight under this step's MFMAs
+      if constexpr (!FW) {
+        stage_store((r + 2) & 3, (r + 1) & 1);     // for step r + 1 (x row r - 2 / gy row r - 1 are no longer needed)
+        stage_load(n, c0, r + 2, true);            // for step r + 2: in flight under this step's MFMAs
+      }
       const int slot = (r - 1 + ky) & 3;           // x row r - 1 + ky
       const unsigned char* xr = xa + slot * (kW3CB * kW3XPitch);
       const unsigned char* gr = ga + (r & 1) * (2 * kW3CB * kW3GPitch);
@@ -278,6 +372,15 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
         }
         DVD_W3TERM(0, 0)
 #undef DVD_W3TERM
+        if constexpr (FW) {
+          // staging item s rides behind the MFMAs of K step s: store the run loaded a step ago (for step r + 1), then
+          // request the same run two rows further down (for step r + 2)
+          if (s < NQ) {
+            f_store(s, (r + 2) & 3, (r + 1) & 1);
+            f_load(s, r + 2, true);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
@@ -740,7 +843,7 @@ static void wg3_plan(int N, int Cin, int Cout, int H, int W, int G, Wg3Plan& p) 
   const long long items = (long long)N * p.nstrips * p.nrseg;
   if (S > items) S = (int)items;
   p.S = S;
-  p.lds = (size_t)2 * 2 * kW3CB * kW3GPitch + (size_t)2 * kW3CB * 4 * kW3XPitch;
+  p.lds = (size_t)kW3LdsBytes + 16;
 }
 
 }  // namespace dvd
@@ -784,15 +887,17 @@ static int xwgrad3_impl(const void* x, const float* x_amax, const void* gy, cons
   a.relu_in = relu_in ? 1 : 0;
   a.out_scale = out_scale;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (h16) {
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad3_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    hipLaunchKernelGGL(dvd::xwgrad3_kernel<true>, dim3(p.S, p.nci, p.nco * groups), dim3(dvd::kW3NT), p.lds, s, a);
-  } else {
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad3_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    hipLaunchKernelGGL(dvd::xwgrad3_kernel<false>, dim3(p.S, p.nci, p.nco * groups), dim3(dvd::kW3NT), p.lds, s, a);
-  }
+  auto go = [&](auto kern) -> int {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(kern, dim3(p.S, p.nci, p.nco * groups), dim3(dvd::kW3NT), p.lds, s, a);
+    return DVD_OK;
+  };
+  // whole 16-byte staging items (and 64 channels of one image within a 31-bit buffer range): the branch-free row step
+  const bool fw = W % (h16 ? 8 : 4) == 0 && (long long)64 * H * W * (h16 ? 2 : 4) < (1ll << 31) && dvd::g_w3_variant != 1;
+  int e;
+  if (h16) e = fw ? go(dvd::xwgrad3_kernel<true, true>) : go(dvd::xwgrad3_kernel<true, false>);
+  else e = fw ? go(dvd::xwgrad3_kernel<false, true>) : go(dvd::xwgrad3_kernel<false, false>);
+  if (e) return e;
   DVD_LAUNCH_OK();
   const long long per = (long long)9 * Cout_total * Cin;
   hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,
@@ -896,8 +1001,9 @@ int dvd_xwgradk(const float* x, const float* x_amax, const float* gy, const floa
 }
 
 int dvd_xwgrad_select(int variant) {
-  DVD_REQUIRE(variant == 0 || variant == 1, "xwgrad_select: variant %d", variant);
-  dvd::g_w1_variant = variant;
+  DVD_REQUIRE(variant >= 0 && variant <= 2, "xwgrad_select: variant %d", variant);
+  dvd::g_w1_variant = variant == 1 ? 1 : 0;
+  dvd::g_w3_variant = variant == 2 ? 1 : 0;
   return DVD_OK;
 }
 

@@ -9,6 +9,7 @@
 #   trace   rocprofv3 --kernel-trace --stats of bench.py variants (TRACES="name:args;name:args", default fp32 / fp16 / hourglass)
 #   pmc     HBM-traffic counters of the warp+loss launch sequence (separate --pmc passes) -> warp_loss_pmc.json
 #   sq      SQ counters of the warp+loss tile kernel
+#   xsq     SQ counters of the convolution / weight-gradient kernels (3x3 256 -> 256 and the wide 1x1), fp32 and fp16 storage
 #   micro   micro-benchmarks: warp+loss, scene-flow MLP, convolutions in both activation storages
 #   a16     only the fp16-activation kernel tests
 set -u
@@ -71,6 +72,23 @@ fi
 if has sq; then
   bash tools/warp_pmc_sq.sh ${TAG:-visit}/warp_sq > /dev/null 2>&1
   cat $OUT/warp_sq/sq_summary.txt | cut -c1-200 | head -12
+fi
+if has xsq; then
+  # SQ counters of the convolution / weight-gradient kernels at 3x3 256 -> 256, 96x168 (shape 4) and the wide 1x1 (shape 8),
+  # in both activation storages
+  for mode in fp32 fp16; do
+    i=0
+    for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+               "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" \
+               "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM"; do
+      i=$((i+1))
+      ( cd /tmp && XCONV_ONLY=${XSQ_SHAPES:-4,8} XCONV_NMUL=3 XCONV_FP16=$([ $mode = fp16 ] && echo 1) timeout 300 rocprofv3 --pmc $grp --output-format csv \
+          -d $ROOT/$OUT/xsq_${mode}_$i -o pmc -- python $ROOT/tools/microbench_xconv.py nomiopen > $ROOT/$OUT/xsq_${mode}_$i.log 2>&1 )
+    done
+    python tools/pmc_summary.py "$OUT/xsq_${mode}_*/" 2>&1 | grep -E "xconv_kernel|xwgrad3_kernel|xwgrad1b_kernel" > $OUT/xconv_sq_summary_$mode.txt
+    rm -rf $OUT/xsq_${mode}_*/
+    cut -c1-200 $OUT/xconv_sq_summary_$mode.txt | head -6
+  done
 fi
 if has micro; then
   timeout 300 python tools/microbench_warp.py > $OUT/micro_warp.log 2>&1; tail -1 $OUT/micro_warp.log | cut -c1-300

@@ -44,6 +44,7 @@ def main():
     from dvd_hip import _lib
     _lib.check(_lib.load().dvd_xconv_select(cfg), 'dvd_xconv_select')
     skip_wgrad = bool(os.environ.get('XCONV_NO_WGRAD'))
+    _lib.check(_lib.load().dvd_xwgrad_select(int(os.environ.get('XWGRAD_VARIANT', '0'))), 'dvd_xwgrad_select')   # 2: round-3 row step
     half = bool(os.environ.get('XCONV_FP16'))                 # fp16 activation storage (configs[4] kernels)
     if half:
         from dvd_hip import ops
