@@ -136,6 +136,7 @@ struct XArgs {
   int TR, TC, P, ntr, ntc, NV;
   int nkc, npos, nfi;     // nfi: B staging items per thread (FI == 0 kernels loop over them at run time)
   int relu_in, relu_out, res_relu;
+  int vec_out;            // 1x1 kernels: positions are pixels in runs of 8 and every pointer is 16-byte aligned (wide epilogue)
 };
 
 // One block = WM x WN waves, each wave TM x TN tiles of 32 x 32; A and B double buffered in LDS, one barrier per
@@ -645,6 +646,119 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   // kernel's VGPR count and cost the 1x1 kernels their third block per CU).
   const float unscale = 1.0f / (sx * sw);
   float ymax = 0.0f;
+  if constexpr (kOne) {
+    // Wide epilogue of the 1x1 kernels.  In the accumulator layout a lane holds ONE pixel of 16 channels per tile: 128 dword
+    // stores per wave (and as many dword loads per residual / mask operand) -- the epilogue was a quarter of a 1x1 kernel's
+    // time, store-issue bound.  Here a tile row (32 channels x 64 pixels of the wave) goes through LDS once and comes back with
+    // a lane holding 4 (fp32) / 8 (fp16 output) consecutive pixels of one channel: 16-byte loads and stores, one bias /
+    // BatchNorm pair per run.  Same arithmetic per element in the same order as the narrow epilogue below.
+    if (a.vec_out) {                               // block-uniform
+      constexpr int PXL = OUT16 ? 8 : 4;           // pixels per lane and run
+      constexpr int LPR = 64 / PXL;                // lanes per channel row of the wave's 64 positions
+      constexpr int RPI = 64 / LPR;                // channel rows per pass
+      constexpr int kTP = 68;                      // floats per LDS row (64 + 4: 16-byte aligned rows, conflict-free both ways)
+      __syncthreads();                             // every wave has read its last fragments: the stages are free
+      float* Tw = reinterpret_cast<float*>(smem) + wave * (32 * kTP);
+      const int j = lane & 31, hh = lane >> 5;
+      const int px = (lane % LPR) * PXL, rl = lane / LPR;
+      const int q0 = wn * TN * 32;                 // the wave's first position in the block's tile (TN = 2: 64 positions)
+      const bool pok = q0 + px < TCv;              // whole runs: TC and H * W are multiples of 8
+      float my_sc[TM], my_sh[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        my_sc[tm] = 1.0f;
+        my_sh[tm] = 0.0f;
+        if (a.bn_var) {
+          const int co = (mt0 + wm * TM + tm) * 32 + (lane & 31);
+          const int cg = grp * a.Cout + (co < a.Cout ? co : a.Cout - 1);
+          my_sc[tm] = (a.bn_gamma ? a.bn_gamma[cg] : 1.0f) / sqrtf(a.bn_var[cg] + a.bn_eps);
+          my_sh[tm] = (a.bn_beta ? a.bn_beta[cg] : 0.0f) - a.bn_mean[cg] * my_sc[tm];
+        }
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * kTP + tn * 32 + j] = acc[tm][tn][r] * unscale;      // exact: 2^-(e_x + e_w)
+        __builtin_amdgcn_wave_barrier();           // LDS operations of one wave complete in order
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+          const int cl = rl + RPI * i;             // channel within the tile row
+          const int co = (mt0 + wm * TM + tm) * 32 + cl;
+          const bool ok = pok && co < a.Cout;
+          float v[PXL];
+#pragma unroll
+          for (int e4 = 0; e4 < PXL; e4 += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(Tw + cl * kTP + px + e4);
+            v[e4] = t.x; v[e4 + 1] = t.y; v[e4 + 2] = t.z; v[e4 + 3] = t.w;
+          }
+          const int cg = grp * a.Cout + (co < a.Cout ? co : a.Cout - 1);
+          if (a.bias) {
+            const float b = a.bias[cg];
+#pragma unroll
+            for (int e = 0; e < PXL; ++e) v[e] += b;
+          }
+          if (a.bn_var) {
+            const float sc = __shfl(my_sc[tm], cl, 64), sh = __shfl(my_sh[tm], cl, 64);
+#pragma unroll
+            for (int e = 0; e < PXL; ++e) v[e] = __builtin_fmaf(v[e], sc, sh);
+          }
+          const int o = ok ? co * iplane + c0 + q0 + px : 0;        // idle lanes read the image's first run
+          auto load_run = [&](const void* base, float (&d)[PXL]) {
+            const TY* __restrict__ p = static_cast<const TY*>(base) + ibase + o;
+            if constexpr (OUT16) {
+              const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const f16x2 h2 = __builtin_bit_cast(f16x2, (unsigned)t[e]);
+                d[2 * e] = (float)h2[0];
+                d[2 * e + 1] = (float)h2[1];
+              }
+            } else {
+              const float4 t = *reinterpret_cast<const float4*>(p);
+              d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+            }
+          };
+          if (a.res) {
+            float rv[PXL];
+            load_run(a.res, rv);
+#pragma unroll
+            for (int e = 0; e < PXL; ++e) v[e] += a.res_relu ? fmaxf(rv[e], 0.0f) : rv[e];
+          }
+          if (a.mask_src) {
+            float mv[PXL];
+            load_run(a.mask_src, mv);
+#pragma unroll
+            for (int e = 0; e < PXL; ++e) v[e] = mv[e] > 0.0f ? v[e] : 0.0f;
+          }
+          if (a.relu_out) {
+#pragma unroll
+            for (int e = 0; e < PXL; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+          if (ok) {
+            if constexpr (OUT16) {
+              u32x4 t;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const f16x2 h2 = {(_Float16)v[2 * e], (_Float16)v[2 * e + 1]};
+                t[e] = __builtin_bit_cast(unsigned, h2);
+              }
+              *reinterpret_cast<u32x4*>(yb + o) = t;
+            } else {
+              *reinterpret_cast<float4*>(yb + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int e = 0; e < PXL; ++e) ymax = fmaxf(ymax, fabsf(v[e]));
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (a.y_amax) wave_amax_to(ymax, a.y_amax);
+      return;
+    }
+  }
   float my_sc[TM], my_sh[TM];
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
@@ -741,7 +855,7 @@ struct XCfg {
 // positions in ONE 512-thread block per CU for k >= 3 (the haloed tile of 256 positions needs ~120 KB of LDS).
 static int g_xcfg = 0;    // test / A-B hook (dvd_xconv_select): 0 auto, 1 round-2 shapes only, 2 force 256x128, 3 force 256x256,
                           // 4 round-2 shapes on the generic (pointer-addressed) main loop, 5 128 x 128 blocks with one
-                          // activation stage at three blocks per CU, 6 1x1 kernels without the two-chunk loop (kOne)
+                          // activation stage at three blocks per CU, 6 1x1 kernels without the two-chunk loop (kOne), 7 kOne with the narrow epilogue
 static XCfg pick_cfg(int M, int KS) {
   if (M <= 32) return {1, 2, 1, 4};     // 32 channels x 256 positions
   if (M <= 64) return {2, 2, 1, 4};     // 64 x 256
@@ -772,7 +886,8 @@ static bool pick_tile_budget(int H, int W, int KS, const XCfg& c, XTile& best, i
   const int pad = KS / 2, NQ = c.NQ(), NT = c.NT();
   double best_eff = -1.0;
   for (int nct = 1; nct <= W; ++nct) {
-    const int TC = (W + nct - 1) / nct;
+    int TC = (W + nct - 1) / nct;
+    if (KS == 1) TC = (TC + 7) & ~7;                     // whole 16-byte runs per lane in the wide epilogue of the 1x1 kernels
     const int P = TC + 2 * pad;
     if (P > NQ) continue;
     const int ntc = (W + TC - 1) / TC;
@@ -880,7 +995,7 @@ int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int K
 }
 
 int dvd_xconv_select(int cfg) {
-  DVD_REQUIRE(cfg >= 0 && cfg <= 6, "xconv_select: cfg %d", cfg);
+  DVD_REQUIRE(cfg >= 0 && cfg <= 7, "xconv_select: cfg %d", cfg);
   dvd::g_xcfg = cfg;
   return DVD_OK;
 }
@@ -942,7 +1057,12 @@ static int xconv_fwd_impl(const void* x, const float* x_amax, const void* packed
   a.mbpg = mblocks;
   DVD_REQUIRE((long long)mblocks * groups <= 65535, "xconv: too many channel blocks");
   const dim3 grid(t.ntr * t.ntc, mblocks * groups, N);
-  const size_t lds = t.lds;
+  // wide epilogue of the 1x1 kernels: whole 16-byte runs of pixels behind 16-byte aligned pointers
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  a.vec_out = (KS == 1 && ((long long)H * W) % 8 == 0 && t.TC % 8 == 0 && al16(y) && al16(residual) && al16(mask_src) &&
+               dvd::g_xcfg != 7) ? 1 : 0;
+  size_t lds = t.lds;
+  if (a.vec_out && lds < (size_t)c.NT() / 64 * 32 * 68 * 4) lds = (size_t)c.NT() / 64 * 32 * 68 * 4;   // one tile row per wave
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define DVD_XGO(TM_, TN_, WM_, WN_)                                                                                      \
   do {                                                                                                                   \

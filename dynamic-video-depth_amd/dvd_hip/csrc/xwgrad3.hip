@@ -26,6 +26,7 @@ namespace dvd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 
 static int g_w1_variant = 0;      // test / A-B hook (dvd_xwgrad_select): 0 auto, 1 always the 128 x 128 blocks
 static int g_w3_variant = 0;      // 1 (hook value 2): the 3x3 kernel's round-3 row step (staging ahead of the MFMAs) on every shape
@@ -666,7 +667,11 @@ constexpr int kWbTerm = 256 * kWbPitch;            // one split term of one oper
 constexpr int kWbBuf = 2 * 2 * kWbTerm;            // gy terms, then x terms
 constexpr size_t kWbLds = 2 * (size_t)kWbBuf;      // double buffered: 98 304
 
-template <bool H16>
+// FW (host: H * W a multiple of 16, so every 16-pixel chunk is whole): the staging loads are raw buffer loads (channel rows past
+// the tensor fall out of the resource's range and read 0), a column tile's MFMAs are followed by the split + LDS store of ONE
+// staging item and the request of the same item two chunks ahead -- round 3 ran `barrier | requests | all MFMAs | all splits`
+// with both waves of a SIMD in the same phase (matrix pipe 37 % busy) and one chunk of latency cover for the HBM request.
+template <bool H16, bool FW>
 __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
   constexpr int EB = H16 ? 2 : 4;
   constexpr int NTERM = H16 ? 1 : 2;
@@ -758,6 +763,105 @@ __global__ __launch_bounds__(512) void xwgrad1b_kernel(const Wg3Args a) {
     }
   };
 
+  if constexpr (FW) {
+    if (n_it > 0) {
+      const int nco = (a.Cout - co0) < 256 ? (a.Cout - co0) : 256, nci = (a.Cin - ci0) < 256 ? (a.Cin - ci0) : 256;
+      // item i of a thread: channel row i * 128 + (tid >> 2) (0..255 gy, 256..511 x), quad tid & 3 of the chunk's 16 pixels
+      int voff[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) voff[h] = ((h * 128 + (tid >> 2)) * (int)plane + (tid & 3) * 4) * EB;
+      u32x4 f0[4], f1[4];                                              // fp16 rows: 8 bytes per item, in the low half
+      const float relu_lo = a.relu_in ? 0.0f : -__builtin_inff();
+      const unsigned relu_lo_h = a.relu_in ? 0u : 0xfc00fc00u;
+      auto f_load = [&](int it, int i, u32x4 (&st)[4]) {
+        // chunks past the slice's end read zeros (an offset beyond the range): the loop always runs whole pairs of chunks
+        const bool live = it < n_it;
+        const long long item = t0 + (live ? it : 0);
+        const int n = (int)(item / cpi), p0 = (int)(item - (long long)n * cpi) * 16;     // wave-uniform
+        const int vo = live ? voff[i & 1] : (int)0x80000000;
+        const bool isx = i >= 2;
+        const unsigned char* base = static_cast<const unsigned char*>(isx ? a.x : a.gy) +
+                                    ((size_t)n * (isx ? a.Cin : a.Cout) + (isx ? ci0 : co0)) * plane * EB;
+        const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(const_cast<unsigned char*>(base)), 0, (isx ? nci : nco) * (int)plane * EB, 0x00020000);
+        if constexpr (H16) {
+          const u32x2v v = __builtin_bit_cast(u32x2v, __builtin_amdgcn_raw_buffer_load_b64(srd, vo, p0 * EB, 0));
+          st[i] = (u32x4){v[0], v[1], 0u, 0u};
+        } else {
+          st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, vo, p0 * EB, 0));
+        }
+      };
+      auto f_store = [&](int buf, int i, const u32x4 (&st)[4]) {
+        const bool isx = i >= 2;
+        const int row = i * 128 + (tid >> 2), quad = tid & 3;
+        unsigned char* dst = smem3 + buf * kWbBuf + (isx ? 2 * kWbTerm : 0) + (row & 255) * kWbPitch + quad * 8;
+        if constexpr (H16) {
+          unsigned v0 = st[i][0], v1 = st[i][1];
+          if (isx) {
+            const f16x2 lo = __builtin_bit_cast(f16x2, relu_lo_h);
+            v0 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, v0), lo));
+            v1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, v1), lo));
+          }
+          *reinterpret_cast<uint2*>(dst) = make_uint2(v0, v1);
+        } else {
+          const float sc = isx ? sx : sg;
+          const float lo = isx ? relu_lo : -__builtin_inff();
+          const float v0 = fmaxf(__uint_as_float(st[i][0]), lo) * sc, v1 = fmaxf(__uint_as_float(st[i][1]), lo) * sc;
+          const float v2 = fmaxf(__uint_as_float(st[i][2]), lo) * sc, v3 = fmaxf(__uint_as_float(st[i][3]), lo) * sc;
+          unsigned h0, l0, h1, l1;
+          split_pair_f16(v0, v1, h0, l0);
+          split_pair_f16(v2, v3, h1, l1);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dst + kWbTerm) = make_uint2(l0, l1);
+        }
+      };
+      // MFMAs of one chunk on (A, Bf), next fragments from nbuf; behind column tile c: item c of `st` is stored into buffer
+      // sbuf (chunk `it_st`, requested two chunks ago) and requested again for chunk it_ld
+      auto mfma_fw = [&](int nbuf, const u32x4 (&A)[2][NTERM], u32x4 (&An)[2][NTERM], int sbuf, u32x4 (&st)[4], int it_ld) {
+        read_a(nbuf, An);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#define DVD_WB_TERM(SA, SB)                                                                                   \
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(           \
+      __builtin_bit_cast(f16x8, A[r][SA]), __builtin_bit_cast(f16x8, Bf[c][SB]), acc[r][c], 0, 0, 0);
+          if constexpr (!H16) {
+            DVD_WB_TERM(NTERM - 1, 0)
+            DVD_WB_TERM(0, NTERM - 1)
+          }
+          DVD_WB_TERM(0, 0)
+#undef DVD_WB_TERM
+          read_b(nbuf, c);
+          f_store(sbuf, c, st);
+          f_load(it_ld, c, st);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f_load(0, i, f0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f_load(1, i, f1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f_store(0, i, f0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f_load(2, i, f0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f_store(1, i, f1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f_load(3, i, f1);
+      __syncthreads();
+      u32x4 A0[2][NTERM], A1[2][NTERM];
+      read_a(0, A0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) read_b(0, c);
+      for (int it = 0; it < n_it; it += 2) {
+        __syncthreads();                   // chunk it + 1 is complete in buffer 1; buffer 0 has been read by every wave
+        mfma_fw(1, A0, A1, 0, f0, it + 4);                  // chunk it; chunk it + 2 -> buffer 0; request chunk it + 4
+        __syncthreads();
+        mfma_fw(0, A1, A0, 1, f1, it + 5);                         // chunk it + 1 (zeros past the end); it + 3 -> buffer 1
+      }
+    }
+  } else
   if (n_it > 0) {
     const int last = n_it - 1;
     auto clamp = [&](int i) { return i < last ? i : last; };
@@ -1059,15 +1163,17 @@ static int xwgrad1s_impl(const void* x, const float* x_amax, const void* gy, con
     a.out_scale = out_scale;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid(S, (Cin + 255) / 256, (Cout + 255) / 256);
-    if (h16) {
-      DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1b_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dvd::kWbLds));
-      hipLaunchKernelGGL(dvd::xwgrad1b_kernel<true>, grid, dim3(512), dvd::kWbLds, s, a);
-    } else {
-      DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1b_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dvd::kWbLds));
-      hipLaunchKernelGGL(dvd::xwgrad1b_kernel<false>, grid, dim3(512), dvd::kWbLds, s, a);
-    }
+    auto go = [&](auto kern) -> int {
+      DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dvd::kWbLds));
+      hipLaunchKernelGGL(kern, grid, dim3(512), dvd::kWbLds, s, a);
+      return DVD_OK;
+    };
+    // whole 16-pixel chunks, 256 channel rows of one image inside a 31-bit buffer range
+    const bool fw = (H * W) % 16 == 0 && (long long)256 * H * W * (h16 ? 2 : 4) < (1ll << 31) && dvd::g_w3_variant != 1;
+    int e;
+    if (h16) e = fw ? go(dvd::xwgrad1b_kernel<true, true>) : go(dvd::xwgrad1b_kernel<true, false>);
+    else e = fw ? go(dvd::xwgrad1b_kernel<false, true>) : go(dvd::xwgrad1b_kernel<false, false>);
+    if (e) return e;
     DVD_LAUNCH_OK();
     const long long per = (long long)Cout * Cin;
     hipLaunchKernelGGL(dvd::xwgrad3_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s,

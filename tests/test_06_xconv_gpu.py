@@ -188,7 +188,7 @@ def test_block_shapes_give_identical_results(KS):
     lib = _lib.load()
     outs = []
     try:
-        for cfg in (0, 1, 2, 3, 4, 5):
+        for cfg in (0, 1, 2, 3, 4, 5, 6, 7):     # 6 / 7: the 1x1 kernels without their two-chunk loop / wide epilogue
             _lib.check(lib.dvd_xconv_select(cfg), 'dvd_xconv_select')
             xg = x.clone().requires_grad_(True)
             y = C.xconv2d(conv, xg, relu_in=True, residual=res, res_relu=True)

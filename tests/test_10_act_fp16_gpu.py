@@ -194,6 +194,33 @@ def test_conv_bn_relu_fused_fp16():
     assert bool(clear.any())
 
 
+def test_wide_epilogue_of_the_1x1_kernels_is_bitwise_the_narrow_one_fp16():
+    """dvd_xconv_select 6 / 7 switch the 1x1 kernels' two-chunk loop / LDS-transposed 16-byte epilogue off: same fp16 bits, with
+    BatchNorm, residual and ReLU fused (forward) and on the masked backward-data pass."""
+    from dvd_hip import _lib, conv as C
+    torch.manual_seed(77)
+    _state()
+    N, Cin, Cout, H, W = 2, 256, 512, 12, 20
+    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=False).cuda()
+    bn = seeded_fill_(torch.nn.BatchNorm2d(Cout), 9).eval().cuda()
+    _, x16 = _h(torch.randn(N, Cin, H, W))
+    _, g16 = _h(torch.randn(N, Cout, H, W))
+    _, r16 = _h(torch.randn(N, Cout, H, W))
+    lib = _lib.load()
+    outs = []
+    try:
+        for cfg in (0, 6, 7):
+            _lib.check(lib.dvd_xconv_select(cfg), 'dvd_xconv_select')
+            xg = x16.clone().requires_grad_(True)
+            y = C.conv_bn_act(conv, bn, xg, residual=r16, relu=True)
+            y.backward(g16)
+            outs.append((y.detach().clone(), xg.grad.clone()))
+    finally:
+        _lib.check(lib.dvd_xconv_select(0), 'dvd_xconv_select')
+    for y, gx in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(gx, outs[0][1])
+
+
 def test_weight_gradient_is_unscaled_by_the_loss_scale():
     """The fp16 gradients carry S; every parameter gradient is multiplied by state[1] = 1 / S where it is produced."""
     from dvd_hip import conv as C

@@ -10,6 +10,7 @@
 #   pmc     HBM-traffic counters of the warp+loss launch sequence (separate --pmc passes) -> warp_loss_pmc.json
 #   sq      SQ counters of the warp+loss tile kernel
 #   xsq     SQ counters of the convolution / weight-gradient kernels (3x3 256 -> 256 and the wide 1x1), fp32 and fp16 storage
+#   msq     SQ counters of the scene-flow MLP kernels
 #   micro   micro-benchmarks: warp+loss, scene-flow MLP, convolutions in both activation storages
 #   a16     only the fp16-activation kernel tests
 set -u
@@ -89,6 +90,20 @@ if has xsq; then
     rm -rf $OUT/xsq_${mode}_*/
     cut -c1-200 $OUT/xconv_sq_summary_$mode.txt | head -6
   done
+fi
+if has msq; then
+  # SQ counters of the scene-flow MLP kernels (tools/microbench_mlp.py)
+  i=0
+  for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+             "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" \
+             "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 300 rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/msq_$i -o pmc -- \
+        python $ROOT/tools/microbench_mlp.py > $ROOT/$OUT/msq_$i.log 2>&1 )
+  done
+  python tools/pmc_summary.py "$OUT/msq_*/" 2>&1 | grep -E "mlp_" > $OUT/mlp_sq_summary.txt
+  rm -rf $OUT/msq_*/
+  wc -l $OUT/mlp_sq_summary.txt
 fi
 if has micro; then
   timeout 300 python tools/microbench_warp.py > $OUT/micro_warp.log 2>&1; tail -1 $OUT/micro_warp.log | cut -c1-300

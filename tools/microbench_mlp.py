@@ -1,10 +1,11 @@
 """Times the three scene-flow MLP kernels at the step's launch size (16 pairs of 384x672) through the C ABI."""
 import json
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, 'dynamic-video-depth_amd')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'dynamic-video-depth_amd'))
 from dvd_hip import ops  # noqa: E402
 
 
