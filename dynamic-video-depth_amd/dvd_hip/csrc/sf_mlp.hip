@@ -269,6 +269,55 @@ __device__ __forceinline__ void store_split4(unsigned char* X, int ko, int m, in
   *reinterpret_cast<u32x2*>(dst + kTermStride) = (u32x2){l0, l1};
 }
 
+// 4 x 4 transpose inside every quad of lanes (two DPP exchanges): on return lane p of a quad holds in v[i] what lane i held
+// in v[p].  The accumulator layout gives a lane ONE pixel of four consecutive channels; the stashes are [channel][64 pixels]
+// rows, so storing (or loading) them register by register costs four dword instructions per lane where the transposed quad
+// needs one 16-byte instruction -- the dX kernel spent 20 % of its time issuing gstash stores, the forward 25 % on the stash.
+__device__ __forceinline__ float quad_swap1(float v) {     // from lane ^ 1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float quad_swap2(float v) {     // from lane ^ 2
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], int lane) {
+  const bool odd = lane & 1, hi = lane & 2;
+  const float r01 = quad_swap1(odd ? v[0] : v[1]), r23 = quad_swap1(odd ? v[2] : v[3]);
+  v[0] = odd ? r01 : v[0];
+  v[1] = odd ? v[1] : r01;
+  v[2] = odd ? r23 : v[2];
+  v[3] = odd ? v[3] : r23;
+  const float r02 = quad_swap2(hi ? v[0] : v[2]), r13 = quad_swap2(hi ? v[1] : v[3]);
+  v[0] = hi ? r02 : v[0];
+  v[2] = hi ? v[2] : r02;
+  v[1] = hi ? r13 : v[1];
+  v[3] = hi ? v[3] : r13;
+}
+// rows = first of the four channel rows [.][kTM] the lane's values v0 .. v3 belong to, m = the lane's pixel: one 16-byte
+// (fp16 rows: 8-byte) store per lane
+__device__ __forceinline__ void store_rows4(float* rows, int m, int lane, float v0, float v1, float v2, float v3) {
+  float v[4] = {v0, v1, v2, v3};
+  quad_transpose4(v, lane);
+  *reinterpret_cast<float4*>(rows + (size_t)(lane & 3) * kTM + (m & ~3)) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store_rows4(_Float16* rows, int m, int lane, float v0, float v1, float v2, float v3) {
+  float v[4] = {v0, v1, v2, v3};
+  quad_transpose4(v, lane);
+  const f16x2 a = {(_Float16)v[0], (_Float16)v[1]}, b = {(_Float16)v[2], (_Float16)v[3]};
+  *reinterpret_cast<u32x2*>(rows + (size_t)(lane & 3) * kTM + (m & ~3)) = (u32x2){__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+}
+// the reverse: the lane's pixel m of the four channel rows, from one 16-byte (8-byte) load per lane
+__device__ __forceinline__ void load_rows4(const float* rows, int m, int lane, float (&v)[4]) {
+  const float4 t = *reinterpret_cast<const float4*>(rows + (size_t)(lane & 3) * kTM + (m & ~3));
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  quad_transpose4(v, lane);
+}
+__device__ __forceinline__ void load_rows4(const _Float16* rows, int m, int lane, float (&v)[4]) {
+  const u32x2 t = *reinterpret_cast<const u32x2*>(rows + (size_t)(lane & 3) * kTM + (m & ~3));
+  const f16x2 a = __builtin_bit_cast(f16x2, (unsigned)t[0]), b = __builtin_bit_cast(f16x2, (unsigned)t[1]);
+  v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)b[0]; v[3] = (float)b[1];
+  quad_transpose4(v, lane);
+}
+
 // max over the wave's lanes, in every lane
 __device__ __forceinline__ float wave_max_all(float m) {
 #pragma unroll
@@ -438,19 +487,8 @@ __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const Fwd
           const int m = 32 * ct + j;
           if (l < kHidden - 1) store_split4(X, 4 * w + q, m, hh, sx, v0, v1, v2, v3);   // the next layer's input
           if (STASH) {
-            if constexpr (S16) {
-              _Float16* sp = reinterpret_cast<_Float16*>(sh) + (size_t)n4 * kTM + m;
-              sp[0] = (_Float16)v0;
-              sp[kTM] = (_Float16)v1;
-              sp[2 * kTM] = (_Float16)v2;
-              sp[3 * kTM] = (_Float16)v3;
-            } else {
-              float* sp = sh + (size_t)n4 * kTM + m;
-              sp[0] = v0;
-              sp[kTM] = v1;
-              sp[2 * kTM] = v2;
-              sp[3 * kTM] = v3;
-            }
+            if constexpr (S16) store_rows4(reinterpret_cast<_Float16*>(sh) + (size_t)n4 * kTM, m, lane, v0, v1, v2, v3);
+            else store_rows4(sh + (size_t)n4 * kTM, m, lane, v0, v1, v2, v3);
             const int b0 = 16 * ct + 4 * q;
             sw |= (v0 > 0.f ? 1u : 0u) << b0 | (v1 > 0.f ? 1u : 0u) << (b0 + 1) | (v2 > 0.f ? 1u : 0u) << (b0 + 2) |
                   (v3 > 0.f ? 1u : 0u) << (b0 + 3);
@@ -592,14 +630,15 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n4 = 32 * w + 8 * q + 4 * hh;
-          float v[4];
+          float v[4], hq[4];
           gz4(ct, q, v);
+          if constexpr (S16) load_rows4(reinterpret_cast<const _Float16*>(h4) + (size_t)n4 * kTM, m, lane, hq);
+          else load_rows4(h4 + (size_t)n4 * kTM, m, lane, hq);
+          store_rows4(g4 + (size_t)n4 * kTM, m, lane, v[0], v[1], v[2], v[3]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float hv = S16 ? (float)reinterpret_cast<const _Float16*>(h4)[(size_t)(n4 + e) * kTM + m]
-                                 : h4[(size_t)(n4 + e) * kTM + m];
+            const float hv = hq[e];
             vmax = fmaxf(vmax, fabsf(v[e]));
-            g4[(size_t)(n4 + e) * kTM + m] = v[e];
             dw5[0][4 * q + e] = __builtin_fmaf(ga, hv, dw5[0][4 * q + e]);
             dw5[1][4 * q + e] = __builtin_fmaf(gb, hv, dw5[1][4 * q + e]);
             dw5[2][4 * q + e] = __builtin_fmaf(gc, hv, dw5[2][4 * q + e]);
@@ -652,8 +691,7 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int n4 = 32 * w + 8 * q + 4 * hh, m = 32 * ct + j;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) gl[(size_t)(n4 + e) * kTM + m] = acc[ct][4 * q + e];
+          store_rows4(gl + (size_t)n4 * kTM, m, lane, acc[ct][4 * q + 0], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]);
           store_split4(X, 4 * w + q, m, hh, sx, acc[ct][4 * q + 0], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]);
         }
       __syncthreads();
