@@ -537,6 +537,185 @@ __global__ __launch_bounds__(64 * KS) void xwgradk_kernel(const Wg3Args a) {
   }
 }
 
+// ---- grouped 3x3 with at most 32 channels per group on either side (ResNeXt stages 2 and 3: 16 / 32 per group) -----------
+// On xwgrad3_kernel's 64 x 64 channel blocks only one of the four 32 x 32 tile pairs of a block holds data (16 per group: a
+// quarter of that pair): three of twelve waves did useful MFMAs while all twelve staged zeros -- 0.42 ms per stage-3 layer
+// at 48 x 1024 x 24 x 42 against 0.1 ms of HBM traffic, 4 % of a step for 1 % of its FLOPs.  Here a block is one 32 x 32
+// pair and three waves (one per kernel row); two blocks share a CU.  Same walk, same row step as xwgrad3_kernel<., FW>
+// (buffer loads, the staging of item i between the MFMAs), same per-element products in the same order: bit-identical sums.
+// Rows need not be whole staging items: a run that crosses the end of its row is loaded anyway (dword-aligned 16-byte buffer
+// loads) and the elements past the row are zeroed on the way to LDS -- for fp32 by the per-element operand scale the split
+// multiplies by anyway (0 instead of 2^e), for fp16 by a mask -- so the 42- and 21-pixel rows of stages 3 and 4 take the
+// same path as the rest.
+constexpr int kWgCB = 32, kWgNT = 192;
+constexpr int kWgLdsBytes = 2 * 2 * kWgCB * kW3GPitch + 2 * kWgCB * 4 * kW3XPitch;    // 63 488
+
+template <bool H16>
+__global__ __launch_bounds__(kWgNT) void xwgrad3g_kernel(const Wg3Args a) {
+  constexpr int EB = H16 ? 2 : 4, NTERM = H16 ? 1 : 2, CB = kWgCB;
+  constexpr int QW = H16 ? 8 : 4, GPR = 64 / QW, XPR = 80 / QW, GQ = CB * GPR, XQ = CB * XPR, NQ = (GQ + XQ) / kWgNT;
+  static_assert((GQ + XQ) % kWgNT == 0 && GQ % 64 == 0, "staging items divide evenly over the threads, wave-uniform kind");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  unsigned char* sG = smem3;                                   // [buffer 2][term 2][co 32][kW3GPitch]
+  unsigned char* sX = smem3 + 2 * 2 * CB * kW3GPitch;          // [term 2][slot 4][ci 32][kW3XPitch]
+  const float sx = H16 ? 1.0f : pow2_scale(a.x_amax[0]), sg = H16 ? 1.0f : pow2_scale(a.g_amax[0]);
+  const int tid = threadIdx.x, lane = tid & 63, ky = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = blockIdx.z / a.nco;
+  const int co0 = (blockIdx.z - grp * a.nco) * CB, ci0 = blockIdx.y * CB;
+  const size_t plane = (size_t)a.H * a.W;
+  const int items = a.N * a.nstrips * a.nrseg;
+
+  bool isg[NQ];
+  int f_ch[NQ], f_pq[NQ], f_lds[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = i * kWgNT + tid;
+    isg[i] = __builtin_amdgcn_readfirstlane(q < GQ ? 1 : 0) != 0;
+    const int qq = isg[i] ? q : q - GQ, pr = isg[i] ? GPR : XPR;
+    f_ch[i] = qq / pr;
+    const int cell = qq - f_ch[i] * pr;
+    f_pq[i] = cell * QW - (isg[i] ? 0 : 8);
+    f_lds[i] = (isg[i] ? f_ch[i] * kW3GPitch : (int)(sX - smem3) + f_ch[i] * kW3XPitch) + cell * (QW * 2);
+  }
+  u32x4 fstg[NQ];
+  int f_voff[NQ];
+  float f_sc[H16 ? 1 : NQ][4];          // fp32: the operand scale per element of the run, 0 past the row's end
+  unsigned f_msk[H16 ? NQ : 1][4];      // fp16: all-ones / zero halves
+  __amdgpu_buffer_rsrc_t srdX, srdG;
+  const float relu_lo = a.relu_in ? 0.0f : -__builtin_inff();
+  const unsigned relu_lo_h = a.relu_in ? 0u : 0xfc00fc00u;
+  auto f_load = [&](int i, int rg, bool with_g) {
+    const int row = isg[i] ? rg : rg + 1;
+    const bool ok = row >= 0 && row < a.H && (with_g || !isg[i]);
+    const int vo = ok ? f_voff[i] : (int)0x80000000;
+    const int so = ok ? row * a.W * EB : 0;
+    fstg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(isg[i] ? srdG : srdX, vo, so, 0));
+  };
+  auto f_store = [&](int i, int xslot, int gbuf) {
+    unsigned char* dst = smem3 + f_lds[i] + (isg[i] ? gbuf * (2 * CB * kW3GPitch) : xslot * (CB * kW3XPitch));
+    if constexpr (H16) {
+      u32x4 v = fstg[i];
+      const f16x2 lo = __builtin_bit_cast(f16x2, isg[i] ? 0xfc00fc00u : relu_lo_h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, (unsigned)v[j]), lo)) & f_msk[i][j];
+      *reinterpret_cast<u32x4*>(dst) = v;
+    } else {
+      const float lo = isg[i] ? -__builtin_inff() : relu_lo;
+      const float v0 = fmaxf(__uint_as_float(fstg[i][0]), lo) * f_sc[i][0], v1 = fmaxf(__uint_as_float(fstg[i][1]), lo) * f_sc[i][1];
+      const float v2 = fmaxf(__uint_as_float(fstg[i][2]), lo) * f_sc[i][2], v3 = fmaxf(__uint_as_float(fstg[i][3]), lo) * f_sc[i][3];
+      unsigned h0, l0, h1, l1;
+      split_pair_f16(v0, v1, h0, l0);
+      split_pair_f16(v2, v3, h1, l1);
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + (isg[i] ? CB * kW3GPitch : CB * 4 * kW3XPitch)) = make_uint2(l0, l1);
+    }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc[k] = (f32x16){0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int half = lane >> 5;
+  const unsigned char* ga = sG + (lane & 31) * kW3GPitch + half * 16;
+  const unsigned char* xa = sX + (lane & 31) * kW3XPitch + 16 + half * 16;     // cell 1 + half of slot 0
+
+  for (int item = blockIdx.x; item < items; item += a.S) {
+    const int n = item / (a.nstrips * a.nrseg);
+    const int rem = item - n * (a.nstrips * a.nrseg);
+    const int strip = rem / a.nrseg, seg = rem - strip * a.nrseg;
+    const int c0 = strip * kW3Strip, r0 = seg * a.RS;
+    const int r1 = (r0 + a.RS) < a.H ? (r0 + a.RS) : a.H;
+    {
+      const int nci = (a.Cin - ci0) < CB ? (a.Cin - ci0) : CB, nco = (a.Cout - co0) < CB ? (a.Cout - co0) : CB;
+      const unsigned char* xb = static_cast<const unsigned char*>(a.x) + (((size_t)n * a.G + grp) * a.Cin + ci0) * plane * EB;
+      const unsigned char* gb = static_cast<const unsigned char*>(a.gy) + (((size_t)n * a.G + grp) * a.Cout + co0) * plane * EB;
+      srdX = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(xb)), 0, nci * (int)plane * EB, 0x00020000);
+      srdG = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(gb)), 0, nco * (int)plane * EB, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int px = c0 + f_pq[i];
+        const int nv = px < 0 ? 0 : ((a.W - px) < QW ? (a.W - px) : QW);       // elements of the run inside the row (<= 0: none)
+        f_voff[i] = nv > 0 ? (f_ch[i] * (int)plane + px) * EB : (int)0x80000000;
+        if constexpr (H16) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f_msk[i][j] = (2 * j < nv ? 0xffffu : 0u) | (2 * j + 1 < nv ? 0xffff0000u : 0u);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f_sc[i][e] = e < nv ? (isg[i] ? sg : sx) : 0.0f;
+        }
+      }
+    }
+    auto load_all = [&](int rg, bool with_g) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) f_load(i, rg, with_g);
+    };
+    auto store_all = [&](int xslot, int gbuf) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) f_store(i, xslot, gbuf);
+    };
+    __syncthreads();                               // the previous item's MFMAs have read their operands
+    load_all(r0 - 2, false);
+    store_all((r0 - 1) & 3, (r0 + 1) & 1);         // x row r0 - 1 (the gy half: zeros into the idle buffer)
+    load_all(r0 - 1, false);
+    store_all(r0 & 3, (r0 + 1) & 1);               // x row r0
+    load_all(r0, true);
+    store_all((r0 + 1) & 3, r0 & 1);               // gy row r0, x row r0 + 1
+    load_all(r0 + 1, true);                        // gy row r0 + 1, x row r0 + 2 in registers
+    for (int r = r0; r < r1; ++r) {
+      __syncthreads();                             // the rows of step r are complete; step r - 1 has been read by every wave
+      const int slot = (r - 1 + ky) & 3;           // x row r - 1 + ky
+      const unsigned char* xr = xa + slot * (CB * kW3XPitch);
+      const unsigned char* gr = ga + (r & 1) * (2 * CB * kW3GPitch);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {                // four K steps of 16 pixels
+        f16x8 A[NTERM], B[3][NTERM];
+#pragma unroll
+        for (int t = 0; t < NTERM; ++t) {
+          A[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(gr + t * (CB * kW3GPitch) + s * 32));
+          const unsigned char* xc = xr + t * (CB * 4 * kW3XPitch) + s * 32;
+          const u32x4 cur = *reinterpret_cast<const u32x4*>(xc);
+          const unsigned prev3 = *reinterpret_cast<const unsigned*>(xc - 4);
+          const unsigned next0 = *reinterpret_cast<const unsigned*>(xc + 16);
+          const unsigned t0 = __builtin_amdgcn_alignbit(cur.x, prev3, 16), t1 = __builtin_amdgcn_alignbit(cur.y, cur.x, 16),
+                         t2 = __builtin_amdgcn_alignbit(cur.z, cur.y, 16), t3 = __builtin_amdgcn_alignbit(cur.w, cur.z, 16),
+                         t4 = __builtin_amdgcn_alignbit(next0, cur.w, 16);
+          B[0][t] = __builtin_bit_cast(f16x8, (u32x4){t0, t1, t2, t3});
+          B[1][t] = __builtin_bit_cast(f16x8, cur);
+          B[2][t] = __builtin_bit_cast(f16x8, (u32x4){t1, t2, t3, t4});
+        }
+#define DVD_W3TERM(SA, SB)                                                                                  \
+  _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) acc[kx] =                                                \
+      __builtin_amdgcn_mfma_f32_32x32x16_f16(A[SA], B[kx][SB], acc[kx], 0, 0, 0);
+        if constexpr (!H16) {
+          DVD_W3TERM(NTERM - 1, 0)
+          DVD_W3TERM(0, NTERM - 1)
+        }
+        DVD_W3TERM(0, 0)
+#undef DVD_W3TERM
+        // the staging items i = s, s + 4 ride behind the MFMAs of K step s (for step r + 1 / r + 2, as in xwgrad3_kernel)
+#pragma unroll
+        for (int i = s; i < NQ; i += 4) {
+          f_store(i, (r + 2) & 3, (r + 1) & 1);
+          f_load(i, r + 2, true);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float* dst = a.partial + (size_t)blockIdx.x * 9 * a.G * a.Cout * a.Cin;        // partial[s][tap][G * Cout][Cin]
+  const float unscale = H16 ? (a.out_scale ? a.out_scale[0] : 1.0f) : 1.0f / (sx * sg);
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int tap = ky * 3 + kx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int ci = ci0 + (lane & 31);
+      if (co < a.Cout && ci < a.Cin) dst[((size_t)tap * a.G * a.Cout + grp * a.Cout + co) * a.Cin + ci] = acc[kx][r] * unscale;
+    }
+  }
+}
+
 // gw[co][ci][tap] = sum_s partial[s][tap][co][ci], ascending s (two interleaved chains)
 __global__ __launch_bounds__(256) void xwgrad3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int S,
                                                              int T, int Cout, int Cin) {
@@ -950,6 +1129,24 @@ static void wg3_plan(int N, int Cin, int Cout, int H, int W, int G, Wg3Plan& p) 
   p.lds = (size_t)kW3LdsBytes + 16;
 }
 
+// 32 x 32 channel blocks of three waves (xwgrad3g_kernel): grouped layers with at most 32 channels per group on both sides
+static bool wg3_small(int Cin, int Cout, int G) { return G > 1 && Cin <= kWgCB && Cout <= kWgCB && g_w3_variant != 1; }
+static void wg3g_plan(int N, int Cin, int Cout, int H, int W, int G, Wg3Plan& p) {
+  p.nco = (Cout + kWgCB - 1) / kWgCB;
+  p.nci = (Cin + kWgCB - 1) / kWgCB;
+  p.nstrips = (W + kW3Strip - 1) / kW3Strip;
+  const int pairs = p.nco * p.nci * G;
+  int S = pairs >= 512 ? 1 : (512 + pairs - 1) / pairs;        // two blocks per CU are resident
+  int RS = H;
+  while (RS > 8 && (long long)N * p.nstrips * ((H + RS - 1) / RS) < 4LL * S) RS = (RS + 1) / 2;
+  p.RS = RS;
+  p.nrseg = (H + RS - 1) / RS;
+  const long long items = (long long)N * p.nstrips * p.nrseg;
+  if (S > items) S = (int)items;
+  p.S = S;
+  p.lds = (size_t)kWgLdsBytes;
+}
+
 }  // namespace dvd
 
 extern "C" {
@@ -958,7 +1155,12 @@ size_t dvd_xwgrad3_workspace_bytes(int N, int Cin, int Cout, int H, int W, int g
   if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cin % groups || Cout % groups) return 0;
   dvd::Wg3Plan p;
   dvd::wg3_plan(N, Cin / groups, Cout / groups, H, W, groups, p);
-  return (size_t)p.S * 9 * Cout * (Cin / groups) * sizeof(float);
+  int S = p.S;
+  if (dvd::wg3_small(Cin / groups, Cout / groups, groups)) {      // (the larger of the two plans: the launch may take either)
+    dvd::wg3g_plan(N, Cin / groups, Cout / groups, H, W, groups, p);
+    if (p.S > S) S = p.S;
+  }
+  return (size_t)S * 9 * Cout * (Cin / groups) * sizeof(float);
 }
 
 static int xwgrad3_impl(const void* x, const float* x_amax, const void* gy, const float* gy_amax, float* gw, void* workspace,
@@ -972,7 +1174,10 @@ static int xwgrad3_impl(const void* x, const float* x_amax, const void* gy, cons
               "xwgrad3: image too large for 32-bit offsets");
   const int Cin = Cin_total / groups, Cout = Cout_total / groups;
   dvd::Wg3Plan p;
-  dvd::wg3_plan(N, Cin, Cout, H, W, groups, p);
+  // rows of fp16 elements must start dword-aligned for the 32 x 32 kernel's buffer loads: even widths
+  const bool small = dvd::wg3_small(Cin, Cout, groups) && (!h16 || W % 2 == 0) && (long long)32 * H * W * (h16 ? 2 : 4) < (1ll << 31);
+  if (small) dvd::wg3g_plan(N, Cin, Cout, H, W, groups, p);
+  else dvd::wg3_plan(N, Cin, Cout, H, W, groups, p);
   const size_t need = (size_t)p.S * 9 * Cout_total * Cin * sizeof(float);
   if (workspace_bytes < need) {
     dvd::set_error("xwgrad3: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -993,13 +1198,14 @@ static int xwgrad3_impl(const void* x, const float* x_amax, const void* gy, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto go = [&](auto kern) -> int {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    hipLaunchKernelGGL(kern, dim3(p.S, p.nci, p.nco * groups), dim3(dvd::kW3NT), p.lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(p.S, p.nci, p.nco * groups), dim3(small ? dvd::kWgNT : dvd::kW3NT), p.lds, s, a);
     return DVD_OK;
   };
   // whole 16-byte staging items (and 64 channels of one image within a 31-bit buffer range): the branch-free row step
   const bool fw = W % (h16 ? 8 : 4) == 0 && (long long)64 * H * W * (h16 ? 2 : 4) < (1ll << 31) && dvd::g_w3_variant != 1;
   int e;
-  if (h16) e = fw ? go(dvd::xwgrad3_kernel<true, true>) : go(dvd::xwgrad3_kernel<true, false>);
+  if (small) e = h16 ? go(dvd::xwgrad3g_kernel<true>) : go(dvd::xwgrad3g_kernel<false>);
+  else if (h16) e = fw ? go(dvd::xwgrad3_kernel<true, true>) : go(dvd::xwgrad3_kernel<true, false>);
   else e = fw ? go(dvd::xwgrad3_kernel<false, true>) : go(dvd::xwgrad3_kernel<false, false>);
   if (e) return e;
   DVD_LAUNCH_OK();
