@@ -345,7 +345,9 @@ int dvd_xconv_fwd(const float* x, const float* x_amax, const void* packed, const
 /* Test / A-B hook (process wide, like dvd_warp_loss_select): block shape of dvd_xconv_fwd for >= 256 output channels.
  * 0 = automatic (256 channels x 128 positions for 1x1 kernels, 256 x 256 for k >= 3), 1 = round 2's 128 x 128 blocks,
  * 2 / 3 = force 256 x 128 / 256 x 256, 4 = round 2's blocks on the generic pointer-addressed main loop (the path shapes
- * with Cin % 16 != 0 take).  Results are identical in every setting (same products, same K order). */
+ * with Cin % 16 != 0 take), 5 = 128 x 128 blocks with one activation stage at three blocks per CU, 6 = 1x1 kernels without
+ * their two-chunk loop, 7 = 1x1 kernels with the narrow (dword) epilogue instead of the LDS-transposed 16-byte one.
+ * Results are identical in every setting (same products, same K order). */
 int dvd_xconv_select(int cfg);
 /* Transposed / forward packing with every weight of output channel co scaled by gamma[co] / sqrt(var[co] + eps): the
  * backward-data pass through a fused BatchNorm is dvd_xconv_fwd on the masked, UNSCALED output gradient. */
@@ -381,8 +383,9 @@ int dvd_xwgrad1s_rowsum(const float* x, const float* x_amax, const float* gy, co
                         void* workspace, size_t workspace_bytes, int N, int Cin, int Cout, int H, int W, int relu_in,
                         dvd_stream_t stream);
 /* Test / A-B hook (process wide): 0 = automatic (256 x 256-channel workgroups for wide 1x1 layers, 128 x 128 otherwise),
- * 1 = always 128 x 128.  Same products and the same per-element summation order within a slice; the number of slices
- * (partial sums added at the end) differs, so results agree to fp32 rounding, not bitwise. */
+ * 1 = always 128 x 128, 2 = round 3's row step everywhere (no buffer-load / interleaved-staging instantiations of the 3x3 and
+ * wide 1x1 kernels, grouped layers on the 64 x 64 channel blocks).  Same products and the same per-element summation order
+ * within a slice; the number of slices (partial sums added at the end) differs, so results agree to fp32 rounding, not bitwise. */
 int dvd_xwgrad_select(int variant);
 /* The same for dense 5x5 / 7x7 / 11x11 stride-1 "same" convolutions (round 4: third_party/hourglass.py:21-57, the inception
  * branches; round 3 left their weight gradient to MIOpen): split-operand MFMA, 32 x 32 channels per block, one wave per kernel
