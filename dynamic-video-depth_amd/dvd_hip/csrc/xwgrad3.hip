@@ -144,8 +144,9 @@ constexpr int kW3CB = 64;                     // channels per block, both operan
 constexpr int kW3NT = 768;                    // 12 waves: 2 x 2 tile pairs x 3 kernel rows
 constexpr int kW3LdsBytes = 2 * 2 * kW3CB * kW3GPitch + 2 * kW3CB * 4 * kW3XPitch;   // + 16 spare bytes (idle staging items)
 
-// FW (host: W a multiple of the staging item, 4 pixels fp32 / 8 fp16): every staging item is a whole 16-byte run of one row or
-// nothing, so the loads are raw BUFFER loads with a per-thread offset computed once per work item (channels past the tensor
+// FW (host: rows of fp16 elements start dword-aligned, i.e. W even; any W for fp32): every staging item is a 16-byte run of one
+// row (a run crossing the row's end is loaded whole and its tail zeroed on the way to LDS, as in xwgrad3g_kernel) or nothing,
+// so the loads are raw BUFFER loads with a per-thread offset computed once per work item (channels past the tensor
 // and columns outside the image fall out of the resource's range and read 0) -- no branch in the row step.  With the body one
 // basic block, the staging work of item i (split + LDS store of the row loaded a step ago, request of the row two steps ahead)
 // sits between the MFMAs of K step i: round 3 ran `barrier | all staging | all MFMAs` in every wave, the 12 waves in lock step
@@ -257,6 +258,8 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
   }
   u32x4 fstg[NQ];
   int f_voff[NQ];
+  float f_sc[H16 ? 1 : NQ][4];          // fp32: the operand scale per element of the run, 0 past the row's end (xwgrad3g_kernel)
+  unsigned f_msk[H16 ? NQ : 1][4];      // fp16: all-ones / zero halves
   __amdgpu_buffer_rsrc_t srdX, srdG;
   const float relu_lo = a.relu_in ? 0.0f : -__builtin_inff();
   const unsigned relu_lo_h = a.relu_in ? 0u : 0xfc00fc00u;                      // packed halves: 0 | -inf
@@ -271,18 +274,15 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
     unsigned char* dst = smem3 + f_lds[i] + (f_isg[i] ? gbuf * (2 * kW3CB * kW3GPitch) : xslot * (kW3CB * kW3XPitch));
     if constexpr (H16) {
       u32x4 v = fstg[i];
-      if (!f_isg[i]) {                                                           // ReLU of the activations (no-op against -inf)
-        const f16x2 lo = __builtin_bit_cast(f16x2, relu_lo_h);
+      const f16x2 lo = __builtin_bit_cast(f16x2, f_isg[i] ? 0xfc00fc00u : relu_lo_h);   // ReLU of the activations (no-op against -inf)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          v[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, (unsigned)v[j]), lo));
-      }
+      for (int j = 0; j < 4; ++j)
+        v[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, (unsigned)v[j]), lo)) & f_msk[i][j];
       *reinterpret_cast<u32x4*>(dst) = v;
     } else {
-      const float sc = f_isg[i] ? sg : sx;
       const float lo = f_isg[i] ? -__builtin_inff() : relu_lo;
-      const float v0 = fmaxf(__uint_as_float(fstg[i][0]), lo) * sc, v1 = fmaxf(__uint_as_float(fstg[i][1]), lo) * sc;
-      const float v2 = fmaxf(__uint_as_float(fstg[i][2]), lo) * sc, v3 = fmaxf(__uint_as_float(fstg[i][3]), lo) * sc;
+      const float v0 = fmaxf(__uint_as_float(fstg[i][0]), lo) * f_sc[i][0], v1 = fmaxf(__uint_as_float(fstg[i][1]), lo) * f_sc[i][1];
+      const float v2 = fmaxf(__uint_as_float(fstg[i][2]), lo) * f_sc[i][2], v3 = fmaxf(__uint_as_float(fstg[i][3]), lo) * f_sc[i][3];
       unsigned h0, l0, h1, l1;
       split_pair_f16(v0, v1, h0, l0);
       split_pair_f16(v2, v3, h1, l1);
@@ -306,8 +306,17 @@ __global__ __launch_bounds__(kW3NT) void xwgrad3_kernel(const Wg3Args a) {
       srdG = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<unsigned char*>(gb)), 0, nco * (int)plane * EB, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
+        // a run that crosses the end of its row is loaded anyway and the elements past the row are zeroed on the way to LDS
         const int px = c0 + f_pq[i];
-        f_voff[i] = (px >= 0 && px + QW <= a.W && f_ch[i] < kW3CB) ? (f_ch[i] * (int)plane + px) * EB : (int)0x80000000;
+        const int nv = px < 0 ? 0 : ((a.W - px) < QW ? (a.W - px) : QW);
+        f_voff[i] = (nv > 0 && f_ch[i] < kW3CB) ? (f_ch[i] * (int)plane + px) * EB : (int)0x80000000;
+        if constexpr (H16) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f_msk[i][j] = (2 * j < nv ? 0xffffu : 0u) | (2 * j + 1 < nv ? 0xffff0000u : 0u);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f_sc[i][e] = e < nv ? (f_isg[i] ? sg : sx) : 0.0f;
+        }
       }
     }
     auto load_all = [&](int rg, bool with_g) {
@@ -1202,7 +1211,7 @@ static int xwgrad3_impl(const void* x, const float* x_amax, const void* gy, cons
     return DVD_OK;
   };
   // whole 16-byte staging items (and 64 channels of one image within a 31-bit buffer range): the branch-free row step
-  const bool fw = W % (h16 ? 8 : 4) == 0 && (long long)64 * H * W * (h16 ? 2 : 4) < (1ll << 31) && dvd::g_w3_variant != 1;
+  const bool fw = (!h16 || W % 2 == 0) && (long long)64 * H * W * (h16 ? 2 : 4) < (1ll << 31) && dvd::g_w3_variant != 1;
   int e;
   if (small) e = h16 ? go(dvd::xwgrad3g_kernel<true>) : go(dvd::xwgrad3g_kernel<false>);
   else if (h16) e = fw ? go(dvd::xwgrad3_kernel<true, true>) : go(dvd::xwgrad3_kernel<true, false>);
