@@ -18,6 +18,10 @@
 // scaled and split into the two fp16 terms on the way in; the next step's rows are requested before the MFMAs of the
 // current one.  Wave (pm, pn, ky) of the 12 keeps the three accumulators of kernel row ky for its 32 x 32 pair.
 // Every block writes its partial sums; xwgrad3_reduce_kernel adds them in slice order.
+// Round 4: the row step exists in two instantiations -- FW (buffer loads, no branch, the staging of item i
+// between the MFMAs of K step i; taken whenever rows start dword-aligned) and the round-3 one (per-element guarded loads ahead
+// of the MFMAs; what is left for it: fp16 rows of odd width); xwgrad3g_kernel is the same walk on 32 x 32 channel blocks of
+// three waves for grouped layers with at most 32 channels per group; xwgrad1b_kernel (1x1, wide layers) has an FW form too.
 #include <type_traits>
 
 #include "dvd_split.h"
