@@ -36,6 +36,24 @@
 #ifndef DVD_WARP_PINHOLE
 #define DVD_WARP_PINHOLE 1      // 0: A/B builds without the pinhole-intrinsics instantiation (tools/build_variant.sh)
 #endif
+#ifndef DVD_WARP_V5
+#define DVD_WARP_V5 1           // 0: A/B builds without the two-pixel lockstep loop of round 5 (tools/build_variant.sh)
+#endif
+#ifndef DVD_WARP_V5_PREFETCH
+#define DVD_WARP_V5_PREFETCH 0  // 1: inputs of thread-step i + 1 requested between the phases of step i (measured: 159.7 vs 156.1 us without)
+#endif
+#ifndef DVD_WARP_COMBINE_TILES
+#define DVD_WARP_COMBINE_TILES 1
+#endif
+#ifndef DVD_WARP_V5_EARLY
+#define DVD_WARP_V5_EARLY 0
+#endif
+#ifndef DVD_WARP_V5_SCHED
+#define DVD_WARP_V5_SCHED 1     // scheduling barriers at the forward / backward boundary of the lockstep pixel pair
+#endif
+#ifndef DVD_WARP_CAM_VGPR
+#define DVD_WARP_CAM_VGPR 0     // bit mask of the camera matrices pinned into VGPRs: 1 R1, 2 R2, 4 K, 8 R2T (round 4: 15)
+#endif
 #include <type_traits>
 
 namespace dvd {
@@ -510,6 +528,9 @@ struct TileIO {
     } else {
       DirectIO g{d2b, nullptr, W, 1.0f};
       g.fetch(o_n, x0, y0, in_e, in_s, dnw, dne, dsw, dse);
+      // consumed here: the wait for these rare gathers must not land at the merge with the LDS path, where it is
+      // s_waitcnt vmcnt(0) for EVERY pixel and also waits for the previous step's stores (round 5)
+      asm volatile("" : "+v"(dnw), "+v"(dne), "+v"(dsw), "+v"(dse));
     }
   }
   // (index, value) record for a tap the window cannot take; applied with global atomics after the slab combine.
@@ -559,6 +580,272 @@ struct TileIO {
     }
   }
 };
+
+// ---------------------------------------------------------------------------
+// Round 5: TWO horizontally adjacent pixels of a thread-step evaluated in lockstep, the lanes of a float2 holding the
+// two pixels, so that every multiply / add / fma of pixel() issues ONCE as v_pk_{mul,add,fma}_f32 for both (gfx950's
+// vector fp32 peak is the packed rate; the one-pixel loop ran 369 VALU instructions per pixel and was issue bound).
+// Shipped flag set (--midas --use_disp) and pinhole intrinsics only -- every other case stays on pixel().
+// Each lane of a packed instruction rounds like the scalar instruction, so the EXACT class is unchanged: the operation
+// sequence below is pixel<GRADS, true, true>'s, statement by statement (masks and tap indices stay bit-identical; the
+// parity tests run it against the oracle and against the one-pixel variants).  What differs, FAST class only:
+//   * the sign of a residual is med3(e * 2^126, -1, 1) (two instructions instead of four; exact for |e| >= 2^-126);
+//   * branches that only skipped work for masked / behind-camera pixels are arithmetic (a zeroed reciprocal / factor):
+//     with finite inputs a masked pixel's gradients are products with an exact 0;
+//   * the four sums are accumulated per lane and the lanes added at the end.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f fma2(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, (v2f){b, b}, c); }
+__device__ __forceinline__ v2f fma2(v2f a, float b, float c) { return __builtin_elementwise_fma(a, (v2f){b, b}, (v2f){c, c}); }
+__device__ __forceinline__ v2f abs2(v2f a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ v2f rcp2(v2f a) { return (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ v2f sgn2(v2f e) {
+  const v2f t = e * 0x1p126f;
+  return (v2f){__builtin_amdgcn_fmed3f(t.x, -1.0f, 1.0f), __builtin_amdgcn_fmed3f(t.y, -1.0f, 1.0f)};
+}
+// div_exact1 / rowvec_mat3 / sample_coord on two pixels: the same operations in the same order, per lane
+__device__ __forceinline__ v2f div_exact2(v2f a, v2f b, v2f y) {
+  v2f q = a * y;
+  v2f r = fma2(-b, q, a);
+  q = fma2(r, y, q);
+  r = fma2(-b, q, a);
+  return fma2(r, y, q);
+}
+__device__ __forceinline__ void rowvec_mat3_2(v2f v0, v2f v1, v2f v2, const float* __restrict__ M, v2f& o0, v2f& o1, v2f& o2) {
+  o0 = (v0 * M[0] + v1 * M[3]) + v2 * M[6];
+  o1 = (v0 * M[1] + v1 * M[4]) + v2 * M[7];
+  o2 = (v0 * M[2] + v1 * M[5]) + v2 * M[8];
+}
+__device__ __forceinline__ v2f sample_coord2(v2f pix, v2f fl, float half, float yhalf, float maxv) {
+  v2f g = pix + fl;
+  g = div_exact2(g, (v2f){half, half}, (v2f){yhalf, yhalf});
+  g = g - 1.0f;
+  const v2f i = (g + 1.0f) * half;
+  return (v2f){fminf(maxv, fmaxf(i.x, 0.0f)), fminf(maxv, fmaxf(i.y, 0.0f))};
+}
+// Q31.32 from a float with |v| < 2^30 in four instructions: v_fract (v - floor(v), kept below 1), * 2^32, v_cvt_u32,
+// v_cvt_flr_i32 (floor and convert in one).  Differs from to_fixed() only for -2^-24 < v < 0, where v_fract's clamp
+// gives 1 - 2^-24 instead of 1: an absolute error of 6e-8 * 2^-24 in a gradient accumulator -- FAST class.
+__device__ __forceinline__ unsigned long long to_fixed_fast(float v, float v_scaled_fract) {
+  int hi;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(hi) : "v"(v));
+  const unsigned lo = (unsigned)v_scaled_fract;
+  return ((unsigned long long)(unsigned)hi << 32) | lo;
+}
+// accumulator cell -> float: float(hi) + float(lo) * 2^-32 in one fma (three instructions; the compiler's signed 64-bit
+// conversion is a 13-instruction sequence with a 64-bit shift, and a tile converts 1.85 cells per pixel)
+__device__ __forceinline__ float from_fixed(long long c) {
+  return __builtin_fmaf((float)(unsigned)c, kFixInv, (float)(int)(c >> 32));
+}
+
+// The lockstep loop keeps the pair's camera in LDS (32 floats behind the windows, written once per block) and reads it
+// as 16-byte BROADCASTS right where a phase needs it: a packed instruction takes a scalar from either half of a VGPR pair
+// through op_sel, but a scalar REGISTER operand occupies an aligned SGPR pair of its own (the instruction selector builds
+// {s, undef}), so 32 camera scalars in SGPRs cost 64 registers and spilled into vector lanes (217 spilled SGPRs, a
+// v_readlane pair + s_nop in front of most packed instructions); pinned in VGPRs they cost 32 registers for the whole
+// pixel pair.  Layout (float4 index): 0-2 columns of R1 | t1;  3 t2 | K[0];  4-6 columns of R2T | K[4], K[6], K[7];
+// 7 Ki[0], Ki[4], Ki[6], Ki[7].
+constexpr int kCamLdsFloats = 32;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const volatile v4f* lds_quad_ptr;     // explicitly LDS: ds_read_b128, not a flat load
+__device__ __forceinline__ v4f ldq(const float* cam, int i) {
+  return ((lds_quad_ptr)cam)[i];                    // volatile: a read per phase, not one hoisted set
+}
+__device__ __forceinline__ float cam_lds_value(const Cam& c, int i) {
+  const int q = i >> 2, k = i & 3;
+  if (q < 3) return k < 3 ? c.R1[3 * k + q] : c.t1[q];
+  if (q == 3) return k < 3 ? c.t2[k] : c.K[0];
+  if (q < 7) return k < 3 ? c.R2T[3 * k + (q - 4)] : (q == 4 ? c.K[4] : (q == 5 ? c.K[6] : c.K[7]));
+  return k == 0 ? c.Ki[0] : (k == 1 ? c.Ki[4] : (k == 2 ? c.Ki[6] : c.Ki[7]));
+}
+
+template <bool GRADS, bool CRIT_L2, int WW, int WH, class MID, class ST>
+__device__ __forceinline__ void pixel2(const WarpArgs& a, const float* cam, const TileIO<WW, WH>& io, int y, int x, v2f d1,
+                                       v2f fx, v2f fy, v2f mk, v2f s0, v2f s1, v2f s2, float yhw, float yhh, float acc[4],
+                                       MID&& between_phases, ST&& store) {
+  const float xf = (float)x, yf = (float)y;
+  const v2f X = {xf, xf + 1.0f};
+  // --- EXACT: ray, p1c, P1
+  const v4f ki = ldq(cam, 7);                  // Ki[0], Ki[4], Ki[6], Ki[7]
+  const v2f r0 = X * ki.x + ki.z;
+  const float r1 = yf * ki.y + ki.w;
+  const v2f pc0 = d1 * r0, pc1 = d1 * r1;
+  v2f P0, P1, P2;
+  {
+    const v4f c0 = ldq(cam, 0), c1 = ldq(cam, 1), c2 = ldq(cam, 2);   // columns of R1 | t1
+    P0 = ((pc0 * c0.x + pc1 * c0.y) + d1 * c0.z) + c0.w;
+    P1 = ((pc0 * c1.x + pc1 * c1.y) + d1 * c1.z) + c1.w;
+    P2 = ((pc0 * c2.x + pc1 * c2.y) + d1 * c2.z) + c2.w;
+  }
+  const v2f mk1 = {d1.x < 100.0f ? mk.x : 0.0f, d1.y < 100.0f ? mk.y : 0.0f};   // [depth_1 < 100] * mask_2
+  // --- EXACT: bilinear taps of frame 2 at (x,y)+flow
+  const v2f ix = sample_coord2(X, fx, a.half_w, yhw, a.wmax);
+  const v2f iy = sample_coord2((v2f){yf, yf}, fy, a.half_h, yhh, a.hmax);
+  const v2f x0f = {floorf(ix.x), floorf(ix.y)}, y0f = {floorf(iy.x), floorf(iy.y)};
+  const v2f ww = ix - x0f, we = 1.0f - ww;
+  const v2f wn = iy - y0f, ws = 1.0f - wn;
+  const v2f w_nw = ws * we, w_ne = ws * ww, w_sw = wn * we, w_se = wn * ww;
+  const int x0A = (int)x0f.x, x0B = (int)x0f.y, y0A = (int)y0f.x, y0B = (int)y0f.y;
+  const int lxA = x0A - io.wx0, lyA = y0A - io.wy0, lxB = x0B - io.wx0, lyB = y0B - io.wy0;
+  const bool inside = ((unsigned)lxA < (unsigned)(WW - 1)) & ((unsigned)lyA < (unsigned)(WH - 1)) &
+                      ((unsigned)lxB < (unsigned)(WW - 1)) & ((unsigned)lyB < (unsigned)(WH - 1));
+  const int cellA = lyA * WW + lxA, cellB = lyB * WW + lxB;
+  v2f dnw, dne, dsw, dse;
+  if (inside) {
+    const float* pA = io.win + cellA;
+    const float* pB = io.win + cellB;
+    dnw = (v2f){pA[0], pB[0]};
+    dne = (v2f){pA[1], pB[1]};
+    dsw = (v2f){pA[WW], pB[WW]};
+    dse = (v2f){pA[WW + 1], pB[WW + 1]};
+  } else {
+#ifdef DVD_WARP_NO_SLOW
+    dnw = dne = dsw = dse = (v2f){0.f, 0.f};
+    return;
+#endif
+    float t0, t1, t2, t3, u0, u1, u2, u3;
+    io.fetch(y0A * a.W + x0A, x0A, y0A, (x0A + 1) < a.W, (y0A + 1) < a.H, t0, t1, t2, t3);
+    io.fetch(y0B * a.W + x0B, x0B, y0B, (x0B + 1) < a.W, (y0B + 1) < a.H, u0, u1, u2, u3);
+    // the gathers are consumed HERE (an empty asm that uses the registers): otherwise the wait for them lands at the merge
+    // with the LDS path as s_waitcnt vmcnt(0) -- for every pixel, and for everything else in flight (the previous
+    // step's stores, the next step's inputs)
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
+    dnw = (v2f){t0, u0};
+    dne = (v2f){t1, u1};
+    dsw = (v2f){t2, u2};
+    dse = (v2f){t3, u3};
+  }
+  // EXACT: W2.z (the four tap rays have z = 1): ATen's mul + 3 fma in tap order
+  v2f W2z = dnw * w_nw;
+  W2z = fma2(dne, w_ne, W2z);
+  W2z = fma2(dsw, w_sw, W2z);
+  W2z = fma2(dse, w_se, W2z);
+  // --- EXACT: Q = (P1 + s - t2) @ R2T ; I = Q @ K
+  const v4f tk = ldq(cam, 3);                  // t2[0], t2[1], t2[2], K[0]
+  const v4f m0 = ldq(cam, 4), m1 = ldq(cam, 5), m2 = ldq(cam, 6);     // columns of R2T | K[4], K[6], K[7]
+  const v2f Ps0 = P0 + s0, Ps1 = P1 + s1, Ps2 = P2 + s2;
+  const v2f A0 = Ps0 - tk.x, A1 = Ps1 - tk.y, A2 = Ps2 - tk.z;
+  const v2f Q0 = (A0 * m0.x + A1 * m0.y) + A2 * m0.z;
+  const v2f Q1 = (A0 * m1.x + A1 * m1.y) + A2 * m1.z;
+  const v2f Q2 = (A0 * m2.x + A1 * m2.y) + A2 * m2.z;
+  const v2f I0 = Q0 * tk.w + Q2 * m1.w;
+  const v2f I1 = Q1 * m0.w + Q2 * m2.w;
+  const v2f den = Q2 + 1e-8f;
+  const bool behindA = Q2.x < 1e-3f, behindB = Q2.y < 1e-3f;
+  const v2f y0 = rcp2(den);
+  const v2f yden = fma2(fma2(-den, y0, (v2f){1.0f, 1.0f}), y0, y0);
+  v2f u = div_exact2(I0, den, yden), v = div_exact2(I1, den, yden);
+  u.x = behindA ? xf : u.x;
+  u.y = behindB ? X.y : u.y;
+  v.x = behindA ? yf : v.x;
+  v.y = behindB ? yf : v.y;
+  const v2f ex = (u - X) - fx, ey = (v - yf) - fy;
+
+  // --- FAST: warped world point of frame 2 (affine structure of the tap rays)
+  const v2f q0 = fma2(x0f, ki.x, ki.z), q1 = fma2(y0f, ki.y, ki.w);
+  const v2f a_nw = w_nw * dnw, a_ne = w_ne * dne, a_sw = w_sw * dsw, a_se = w_se * dse;
+  const v2f sE = a_ne + a_se, sS = a_sw + a_se, sA = (a_nw + a_ne) + sS;
+  const v2f V0 = fma2(q0, sA, ki.x * sE), V1 = fma2(q1, sA, ki.y * sS);
+  // (R_2 read through its stored transpose R_2_T -- the block checked that the two ARE transposes of each other, bit for
+  //  bit, as the data files write them (generate_sequence_midas.py:69-72): nine scalar registers less)
+  const v2f G0 = fma2(V0, m0.x, fma2(V1, m1.x, fma2(sA, m2.x, tk.x)));
+  const v2f G1 = fma2(V0, m0.y, fma2(V1, m1.y, fma2(sA, m2.y, tk.y)));
+  const v2f G2 = fma2(V0, m0.z, fma2(V1, m1.z, fma2(sA, m2.z, tk.z)));
+  const v2f f0 = G0 - Ps0, f1 = G1 - Ps1, f2 = G2 - Ps2;          // sf_by_depth - sf (FAST: one rounding regrouped)
+  // --- mask (EXACT comparisons) and per-pixel errors
+  const v2f m = {W2z.x < 100.0f ? mk1.x : 0.0f, W2z.y < 100.0f ? mk1.y : 0.0f};
+  const v2f flow_err = CRIT_L2 ? (ex * ex + ey * ey) : (abs2(ex) + abs2(ey));
+  const v2f rca = rcp2((v2f){fmaxf(Q2.x, 1e-3f), fmaxf(Q2.y, 1e-3f)});
+  const v2f rcb = rcp2((v2f){fmaxf(W2z.x, 1e-3f), fmaxf(W2z.y, 1e-3f)});
+  const v2f ediff = rca - rcb;
+  const v2f disp_err = 100.0f * abs2(ediff);
+  const v2f sf_err = (abs2(f0) + abs2(f1)) + abs2(f2);
+  // (one accumulator per sum, the two pixels added first: four registers held across the pair instead of eight)
+  {
+    const v2f e1 = m * flow_err, e2 = m * disp_err, e3 = m * sf_err;
+    acc[0] += m.x + m.y;
+    acc[1] += e1.x + e1.y;
+    acc[2] += e2.x + e2.y;
+    acc[3] += e3.x + e3.y;
+  }
+  if (!GRADS) {
+    between_phases();
+    return;
+  }
+  // ------------------------------ FAST: backward (un-normalised) ----------
+  const v2f fm = a.flow_mul * m;
+  const v2f gu = CRIT_L2 ? fm * 2.0f * ex : fm * sgn2(ex);
+  const v2f gv = CRIT_L2 ? fm * 2.0f * ey : fm * sgn2(ey);
+  const v2f guv = fma2(gu, u, gv * v);           // (the backward needs u, v only through this dot product)
+  const v2f ue = (m * 100.0f) * sgn2(ediff);
+  const v2f rca2 = {Q2.x >= 1e-3f ? rca.x * rca.x : 0.0f, Q2.y >= 1e-3f ? rca.y * rca.y : 0.0f};
+  const v2f h2 = {W2z.x >= 1e-3f ? ue.x * (rcb.x * rcb.x) : 0.0f, W2z.y >= 1e-3f ? ue.y * (rcb.y * rcb.y) : 0.0f};
+  // ---- phase boundary: what the backward needs is (gu, gv, u, v, 1/den, ue, rca2, h2, the four weights, the cells, the
+  //      ray); the scheduler may not mix the phases (it would hold both phases' values at once and spill), and the
+  //      caller requests the NEXT thread-step's inputs here, so that they fly under the backward and the scatter
+#if DVD_WARP_V5_SCHED
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  between_phases();
+#if DVD_WARP_V5_SCHED
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  // behind the camera: the projection was replaced by the pixel's own coordinates, no gradient (a zero reciprocal:
+  // u, v are finite there)
+  const v2f rden = {behindA ? 0.0f : y0.x, behindB ? 0.0f : y0.y};
+  const v2f gI0 = gu * rden, gI1 = gv * rden;
+  const v2f gI2 = -guv * rden;
+  // (the camera is read again for the backward: a second set of LDS broadcasts costs less than 32 registers held
+  //  across the whole pixel pair)
+  const v4f bk = ldq(cam, 3), b0 = ldq(cam, 4), b1 = ldq(cam, 5), b2 = ldq(cam, 6);
+  const v2f gQ0 = gI0 * bk.w, gQ1 = gI1 * b0.w;
+  v2f gQ2 = fma2(gI0, b1.w, fma2(gI1, b2.w, gI2));
+  // disparity term: 100 |1/max(Q.z,1e-3) - 1/max(W2.z,1e-3)|; W2.z reaches depth_2 (units of disp_mul, like pixel())
+  gQ2 = fma2((-ue) * a.disp_mul, rca2, gQ2);
+  const v2f gA0 = fma2(gQ0, b0.x, fma2(gQ1, b1.x, gQ2 * b2.x));
+  const v2f gA1 = fma2(gQ0, b0.y, fma2(gQ1, b1.y, gQ2 * b2.y));
+  const v2f gA2 = fma2(gQ0, b0.z, fma2(gQ1, b1.z, gQ2 * b2.z));
+  const v4f e0 = ldq(cam, 0), e1 = ldq(cam, 1), e2 = ldq(cam, 2);
+  const v2f gp0 = fma2(gA0, e0.x, fma2(gA1, e1.x, gA2 * e2.x));
+  const v2f gp1 = fma2(gA0, e0.y, fma2(gA1, e1.y, gA2 * e2.y));
+  const v2f gp2 = fma2(gA0, e0.z, fma2(gA1, e1.z, gA2 * e2.z));
+  const v2f g_d1 = fma2(gp0, r0, fma2(gp1, r1, gp2));
+  auto store_grads = [&]() { store(g_d1, gA0, gA1, gA2); };
+  // the pair's gradients leave before the scatter starts (the scatter then holds the weights, h2 and the two cells only)
+  store_grads();
+  // depth_2 taps: d/d(d2_k) = w_k * h2 (every tap ray has z = 1).  One tap PAIR at a time -- multiply, v_fract, * 2^32,
+  // two conversions, two ds_add_u64 -- with scheduling barriers in between: evaluated all at once (what the scheduler does
+  // for the instruction-level parallelism) the eight taps hold 40 registers and the pixel pair no longer fits 128.
+  // Fixed-point range: the bilinear weights are >= 0 and sum to 1, so sum_k |w_k h2| = |h2| (a SUM-like test on h2 itself;
+  // NaN fails it and takes the per-tap path, where it reaches the spill list and g_depth_2).
+  if (h2.x != 0.0f || h2.y != 0.0f) {
+    if (inside && (fabsf(h2.x) + fabsf(h2.y)) < kFixMax) {
+      unsigned long long* pA = io.accw + cellA;
+      unsigned long long* pB = io.accw + cellB;
+      auto tap = [&](v2f w, int off) {
+        const v2f t = w * h2;
+        const v2f k = (v2f){__builtin_amdgcn_fractf(t.x), __builtin_amdgcn_fractf(t.y)} * kFixScale;
+        atomicAdd(pA + off, to_fixed_fast(t.x, k.x));
+        atomicAdd(pB + off, to_fixed_fast(t.y, k.y));
+#if DVD_WARP_V5_SCHED
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      };
+      tap(w_nw, 0);
+      tap(w_ne, 1);
+      tap(w_sw, WW);
+      tap(w_se, WW + 1);
+    } else {
+#ifndef DVD_WARP_NO_SLOW
+      const v2f t_nw = w_nw * h2, t_ne = w_ne * h2, t_sw = w_sw * h2, t_se = w_se * h2;
+      if (h2.x != 0.0f)
+        io.scatter(y0A * a.W + x0A, x0A, y0A, (x0A + 1) < a.W, (y0A + 1) < a.H, t_nw.x, t_ne.x, t_sw.x, t_se.x);
+      if (h2.y != 0.0f)
+        io.scatter(y0B * a.W + x0B, x0B, y0B, (x0B + 1) < a.W, (y0B + 1) < a.H, t_nw.y, t_ne.y, t_sw.y, t_se.y);
+#endif
+    }
+  }
+}
 
 struct TileArgs {
   float* slabs;
@@ -626,7 +913,7 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-constexpr int tile_lds_bytes(int tw, int th, int r) { return (tw + 2 * r + 4) * (th + 2 * r + 1) * 12; }
+constexpr int tile_lds_bytes(int tw, int th, int r) { return (tw + 2 * r + 4) * (th + 2 * r + 1) * 12 + 32 * 4; }
 constexpr int tile_blocks_per_cu(int tw, int th, int r) { return 163840 / tile_lds_bytes(tw, th, r); }
 // Measured on MI355X: this kernel is latency bound and its time falls steeply with resident
 // waves (12 -> 16 waves/CU: 335 -> 233 us at 48x384x672), so take 4 waves/SIMD (128 VGPRs)
@@ -647,6 +934,8 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);  // [WH][WW] u64 first (8-byte aligned)
   float* win = smem + 2 * WW * WH;
+  float* camL = win + WW * WH;              // the pair's camera for the lockstep loop (kCamLdsFloats floats, 16-byte aligned)
+  static_assert((3 * WW * WH) % 4 == 0 && kCamLdsFloats == 32, "camera quads must be 16-byte aligned");
 
   const int logical = ta.tile0 + xcd_contiguous_block(blockIdx.x, gridDim.x);      // global tile index
   const int tiles = ta.ntx * ta.nty;
@@ -665,14 +954,62 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   // The 51 camera scalars are wave-uniform; left alone they all land in SGPRs and push the
   // kernel past the 102-SGPR file (hundreds of v_readlane spill reloads).  Pin the three
   // matrices used mostly by the FMA-heavy parts into VGPRs instead.
+  // (Round 5: the lockstep loop halves the uses per pixel and needs the VGPRs for two pixels' live values, so its
+  //  instantiations keep the camera in SGPRs -- a packed instruction takes one SGPR pair as an operand; the pinhole
+  //  form needs 41 of the 51 scalars.  DVD_WARP_CAM_VGPR selects matrices to pin for A/B builds.)
+  constexpr int kCamV = (PX == 2 && SHIPPED && DVD_WARP_V5) ? DVD_WARP_CAM_VGPR : 15;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    asm volatile("" : "+v"(c.R1[i]));
-    asm volatile("" : "+v"(c.R2[i]));
-    asm volatile("" : "+v"(c.K[i]));
-    asm volatile("" : "+v"(c.R2T[i]));
+    if (kCamV & 1) asm volatile("" : "+v"(c.R1[i]));
+    if (kCamV & 2) asm volatile("" : "+v"(c.R2[i]));
+    if (kCamV & 4) asm volatile("" : "+v"(c.K[i]));
+    if (kCamV & 8) asm volatile("" : "+v"(c.R2T[i]));
   }
   const float* d2b = a.d2 + (size_t)b * a.HW;
+
+  const bool wv = (a.W % PX) == 0;   // rows stay vector aligned
+  auto locate = [&](int q, int& x, int& y) {
+    const int ly = q / QW, lx = (q - ly * QW) * PX;
+    y = ty0 + ly;
+    x = tx0 + lx;
+    return (q < QW * TH) && (y < a.H) && (x < a.W);
+  };
+  // ---- lockstep loop (round 5): per-pair input pointers.  DVD_WARP_V5_EARLY = 1 requests the FIRST thread-step's inputs
+  //      before the window fill (their latency under the fill and the barrier): measured 231 us against 223 us for the
+  //      launch sequence -- the requests queue in front of the window's and the registers they hold cost more; off.
+  struct In2 {
+    v2f d1, mk, s0, s1, s2;
+    float4 fl;
+  };
+  // per-pair base pointers (wave-uniform: scalar registers) + one 32-bit byte offset per thread-step
+  const char* d1b = reinterpret_cast<const char*>(a.d1 + (size_t)b * a.HW);
+  const char* mkb = reinterpret_cast<const char*>(a.mask + (size_t)b * a.HW);
+  const char* flb = reinterpret_cast<const char*>(a.flow + 2 * (size_t)b * a.HW);
+  const char* sfb0 = reinterpret_cast<const char*>(a.sf + (size_t)b * 3 * a.HW);
+  char* gd1b = reinterpret_cast<char*>(a.g_d1 + (size_t)b * a.HW);
+  char* gsb0 = reinterpret_cast<char*>(a.g_sf + (size_t)b * 3 * a.HW);
+  const unsigned plane = (unsigned)a.HW * 4u;
+  // Branch free: a thread-step outside the tile / image reads the pair's first pixels instead (valid memory, never used),
+  // so the requests are straight-line code that the scheduling barriers can hold in place -- behind a branch the block
+  // was moved to the front of the step, and a wait for the rare global tap gathers (s_waitcnt vmcnt(0) at the merge) then
+  // also waited for the prefetch.
+  auto fetch2 = [&](int q) {
+    int x, y;
+    const bool ok = locate(q, x, y);
+    const unsigned o = ok ? (unsigned)(y * a.W + x) * 4u : 0u;
+    In2 r;
+    r.d1 = *reinterpret_cast<const v2f*>(d1b + o);
+    r.mk = *reinterpret_cast<const v2f*>(mkb + o);
+    r.fl = *reinterpret_cast<const float4*>(flb + 2u * o);
+    r.s0 = *reinterpret_cast<const v2f*>(sfb0 + o);
+    r.s1 = *reinterpret_cast<const v2f*>(sfb0 + (o + plane));
+    r.s2 = *reinterpret_cast<const v2f*>(sfb0 + (o + 2u * plane));
+    return r;
+  };
+  In2 first = {};
+  if constexpr (PX == 2 && SHIPPED && DVD_WARP_V5 && DVD_WARP_V5_EARLY) {
+    if (wv) first = fetch2(threadIdx.x);
+  }
 
   // ---- phase 0: fill the depth_2 window, clear the accumulator.  All of a thread's window loads are
   //      requested before the first one is consumed (the trip count is a compile-time constant).
@@ -713,6 +1050,14 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
       }
     }
   }
+  if constexpr (PX == 2 && SHIPPED && DVD_WARP_V5) {
+    if (threadIdx.x < kCamLdsFloats) {
+      float v = 0.0f;
+#pragma unroll
+      for (int i = 0; i < kCamLdsFloats; ++i) v = (int)threadIdx.x == i ? cam_lds_value(c, i) : v;
+      camL[threadIdx.x] = v;
+    }
+  }
   __syncthreads();
 
   TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, logical % kOvfLists, a.disp_mul, ta.ovf};
@@ -721,15 +1066,8 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   //      step i is evaluated: all waves of a block leave the barrier together, so without this every
   //      load latency of the block is exposed at the same time.  Build-time switch DVD_WARP_PREFETCH, off by
   //      default: measured 297 us with it (the 14 extra live registers spill) against 259 us without
-  const bool wv = (a.W % PX) == 0;   // rows stay vector aligned
   struct In {
     float d1[PX], mk[PX], fl[2 * PX], s0[PX], s1[PX], s2[PX];
-  };
-  auto locate = [&](int q, int& x, int& y) {
-    const int ly = q / QW, lx = (q - ly * QW) * PX;
-    y = ty0 + ly;
-    x = tx0 + lx;
-    return (q < QW * TH) && (y < a.H) && (x < a.W);
   };
   auto fetch = [&](int q, In& r) {
     int x, y;
@@ -806,20 +1144,70 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
       fetch(q + NT, cur);
   }
   };
-  if (pinhole)
-    tile_pixels(std::true_type{});
-  else
-    tile_pixels(std::false_type{});
+  // ---- the lockstep loop (round 5): shipped flag set, pinhole pair, rows of whole pixel pairs
+  auto tile_pixels2 = [&](auto crit_tag, const In2 first) {
+    constexpr bool CRIT = decltype(crit_tag)::value;
+    // (wave-uniform values computed on the vector unit: back into scalar registers, they are loop invariant)
+    const float yhw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rcp_refined(a.half_w))));
+    const float yhh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rcp_refined(a.half_h))));
+    In2 cur = DVD_WARP_V5_EARLY ? first : fetch2(threadIdx.x), nxt = cur;
+    for (int q = threadIdx.x; q < QW * TH; q += NT) {
+      int x, y;
+      if (locate(q, x, y)) {
+        const unsigned o = (unsigned)(y * a.W + x) * 4u;
+        pixel2<GRADS, CRIT>(a, camL, io, y, x, cur.d1, (v2f){cur.fl.x, cur.fl.z}, (v2f){cur.fl.y, cur.fl.w}, cur.mk, cur.s0,
+                            cur.s1, cur.s2, yhw, yhh, acc,
+                            [&]() {
+                              if (DVD_WARP_V5_PREFETCH) nxt = fetch2(q + NT);
+                            },
+                            [&](v2f gd1, v2f g0, v2f g1, v2f g2) {
+                              *reinterpret_cast<v2f*>(gd1b + o) = gd1;
+                              *reinterpret_cast<v2f*>(gsb0 + o) = g0;
+                              *reinterpret_cast<v2f*>(gsb0 + (o + plane)) = g1;
+                              *reinterpret_cast<v2f*>(gsb0 + (o + 2u * plane)) = g2;
+                            });
+      } else if (DVD_WARP_V5_PREFETCH) {
+        nxt = fetch2(q + NT);
+      }
+      if (DVD_WARP_V5_PREFETCH)
+        cur = nxt;
+      else
+        cur = fetch2(q + NT);
+    }
+  };
+  if constexpr (PX == 2 && SHIPPED && DVD_WARP_V5) {
+    // (a pinhole pair with odd-width rows takes the general instantiation: correct for every camera)
+    bool r2t = true;            // R_2 and R_2_T are each other's transposes, bit for bit (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) r2t = r2t && (c.R2[3 * i + j] == c.R2T[3 * j + i]);
+    if (pinhole && wv && r2t) {
+      if (a.crit_l2)
+        tile_pixels2(std::true_type{}, first);
+      else
+        tile_pixels2(std::false_type{}, first);
+    } else {
+#ifndef DVD_WARP_NO_GENERAL
+      tile_pixels(std::false_type{});
+#endif
+    }
+  } else {
+    if (pinhole)
+      tile_pixels(std::true_type{});
+    else
+      tile_pixels(std::false_type{});
+  }
   // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
   __syncthreads();
   if (GRADS) {
     float* slab = ta.slabs + (size_t)logical * (WW * WH);
     float* gb = a.g_d2 + (size_t)b * a.HW;
-    const float back = kFixInv * a.disp_mul;
+    const float back = a.disp_mul;
     for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
       const longlong2 lo = reinterpret_cast<const longlong2*>(accw)[2 * i];
       const longlong2 hi = reinterpret_cast<const longlong2*>(accw)[2 * i + 1];
-      const float4 v = make_float4((float)lo.x * back, (float)lo.y * back, (float)hi.x * back, (float)hi.y * back);
+      const float4 v = make_float4(from_fixed(lo.x) * back, from_fixed(lo.y) * back, from_fixed(hi.x) * back, from_fixed(hi.y) * back);
       const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
       if (ta.direct && tile_exclusive<TW, TH, R>(wx, wy)) {
         const int x = wx0 + wx, y = wy0 + wy;          // x is a multiple of 4 (R, the offset and the tile origin are)
@@ -879,6 +1267,83 @@ __global__ __launch_bounds__(256) void combine_slabs_kernel(const float* __restr
   const int x = (qid - row * qpr) * 4;
   const int b = b0 + row / H, y = row - (row / H) * H;      // this launch covers the pairs b0 ...
   combine_quad<TW, TH, R>(slabs, offs[b], g_d2, H, W, ntx, nty, b, y, x, direct);
+}
+
+// Round 5: the combine with one block per TILE.  The round-4 kernel above ran one thread per quad of every pixel: 37 % of its
+// lanes belonged to quads the tile kernel had already written (exclusive cells) and left at once, every wave first waited
+// for its pair's window offset, and a thread had at most four 16-byte loads in flight -- 35 us for 122 MB (3.5 TB/s).  Here a
+// block owns one tile of the pair's (unshifted) tile grid; for a pair whose windows are not shifted (mean flow below 4 px:
+// the common case) it enumerates ONLY the ring quads of its tile -- (R+1) + R full rows and (R+4)/4 + R/4 quads of every
+// other row, 483 of 768 for a 96 x 32 tile -- two per thread with all their slab loads requested before the first sum, and
+// knows from the quad's position which of the nine neighbouring windows cover it (same fixed order dj outer / di inner:
+// bit-identical to combine_quad).  A pair with shifted windows takes combine_quad over the block's 96 x 32 image region.
+template <int TW, int TH, int R>
+__global__ __launch_bounds__(256) void combine_tiles_kernel(const float* __restrict__ slabs, const int2* __restrict__ offs,
+                                                            float* __restrict__ g_d2, int H, int W, int ntx, int nty,
+                                                            int direct, int b0) {
+  constexpr int WW = TW + 2 * R + 4, WH = TH + 2 * R + 1;
+  constexpr int QW = TW / 4;
+  constexpr int kTop = R + 1, kBot = R, kLeft = (R + 4) / 4, kRight = R / 4;       // ring rows / ring quads of a middle row
+  constexpr int kFull = (kTop + kBot) * QW, kRing = kFull + (TH - kTop - kBot) * (kLeft + kRight);
+  static_assert(R % 4 == 0 && TW % 4 == 0 && 2 * R + 4 <= TW && 2 * R + 1 <= TH, "tile geometry");
+  const int tiles = ntx * nty;
+  const int b = b0 + blockIdx.x / tiles, t = blockIdx.x % tiles;
+  const int tj = t / ntx, ti = t - tj * ntx;
+  const int2 off = offs[b];
+  if (off.x != 0 || off.y != 0 || !direct || (W & 3) != 0) {
+    // shifted windows (or no exclusive cells): the general definition over this block's part of the image
+    for (int q = threadIdx.x; q < QW * TH; q += 256) {
+      const int hy = q / QW, hx = (q - hy * QW) * 4;
+      const int x = ti * TW + hx, y = tj * TH + hy;
+      if (x < W && y < H) combine_quad<TW, TH, R>(slabs, off, g_d2, H, W, ntx, nty, b, y, x, direct);
+    }
+    return;
+  }
+  const float* tile_slab = slabs + ((size_t)(b * nty + tj) * ntx + ti) * (WW * WH);
+  float* gb = g_d2 + (size_t)b * H * W;
+  constexpr int kPer = (kRing + 255) / 256;
+#pragma unroll
+  for (int it = 0; it < kPer; ++it) {
+    const int idx = it * 256 + threadIdx.x;
+    int hy, qx;
+    if (idx < kFull) {
+      const int r = idx / QW;
+      hy = r < kTop ? r : r + (TH - kTop - kBot);
+      qx = idx - r * QW;
+    } else {
+      const int m = idx - kFull, r = m / (kLeft + kRight), k = m - r * (kLeft + kRight);
+      hy = kTop + r;
+      qx = k < kLeft ? k : QW - (kLeft + kRight) + k;
+    }
+    const int hx = qx * 4, x = ti * TW + hx, y = tj * TH + hy;
+    if (!(idx < kRing && x < W && y < H)) continue;
+    // which neighbouring windows cover the quad (the own window always does): rows above / below, columns left / right
+    const int dj = hy < kTop ? -1 : (hy >= TH - kBot ? 1 : 0);
+    const int di = hx < R + 4 ? -1 : (hx >= TW - R ? 1 : 0);
+    const bool okj = dj != 0 && (unsigned)(tj + dj) < (unsigned)nty, oki = di != 0 && (unsigned)(ti + di) < (unsigned)ntx;
+    // window coordinates of the quad in tile (ti + a, tj + c): wx = hx + R - a TW, wy = hy + R - c TH.  A window that does
+    // not cover the quad is read at the own window's address instead and multiplied by 0: no branch around a load
+    const float* p_own = tile_slab + (hy + R) * WW + (hx + R);
+    const float* p_hor = oki ? p_own + (ptrdiff_t)di * (WW * WH) - di * TW : p_own;
+    const float* p_ver = okj ? p_own + (ptrdiff_t)dj * ntx * (WW * WH) - dj * TH * WW : p_own;
+    const float* p_dia = (oki && okj) ? p_own + (ptrdiff_t)(dj * ntx + di) * (WW * WH) - dj * TH * WW - di * TW : p_own;
+    // (ext-vector values: a select between two HIP float4 STRUCTS goes through the stack)
+    const v4f own = *reinterpret_cast<const v4f*>(p_own);
+    v4f hor = *reinterpret_cast<const v4f*>(p_hor);
+    v4f ver = *reinterpret_cast<const v4f*>(p_ver);
+    v4f dia = *reinterpret_cast<const v4f*>(p_dia);
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    hor = oki ? hor : zero;
+    ver = okj ? ver : zero;
+    dia = (oki && okj) ? dia : zero;
+    // fixed order of combine_quad: dj outer (-1, 0, 1), di inner (-1, 0, 1)
+    const bool hfirst = di < 0, vfirst = dj < 0;
+    const v4f r0a = hfirst ? dia : ver, r0b = hfirst ? ver : dia;      // the neighbouring row of tiles (dj != 0)
+    const v4f r1a = hfirst ? hor : own, r1b = hfirst ? own : hor;      // the own row of tiles
+    const v4f t0 = vfirst ? r0a : r1a, t1 = vfirst ? r0b : r1b, t2 = vfirst ? r1a : r0a, t3 = vfirst ? r1b : r0b;
+    const v4f s4 = (((zero + t0) + t1) + t2) + t3;
+    *reinterpret_cast<v4f*>(gb + y * W + x) = s4;
+  }
 }
 
 // Second stage: fixed-order sum of the per-block partials (deterministic).
@@ -982,6 +1447,7 @@ constexpr int kNumShapes = sizeof(kShapes) / sizeof(kShapes[0]);
 static int g_variant = 0;   // 0 tiled (production), 1 direct (global gathers + hardware atomics)
 static int g_tile = -1;     // -1 auto, else index into kShapes
 static int g_px = 0;        // 0 auto, 2 or 4 pixels per thread-step
+static int g_combine = 0;   // 0 per-tile combine (round 5), 1 the per-quad combine of rounds 2-4 (tests: px == 4 selects it too)
 
 // Least padded area wins; ties go to the earlier (larger) shape.
 static int choose_shape(int H, int W) {
@@ -1055,7 +1521,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.direct = ((a.W & 3) == 0 && DVD_WARP_DIRECT_INTERIOR) ? 1 : 0;
   ta.tile0 = 0;
   const int tiles = p.ntx * p.nty, nblocks = tiles * a.B;
-  const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long));
+  const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long)) + kCamLdsFloats * sizeof(float);
   hipLaunchKernelGGL(warp_prep_kernel, dim3(a.B), dim3(64), 0, stream, a.flow, a.H, a.W, offs, ta.ovf.count);
   DVD_LAUNCH_OK();
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
@@ -1073,6 +1539,16 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
     hipLaunchKernelGGL(k, dim3(nb), dim3(NT), lds, stream, a, t2);                                        \
   } while (0)
+#ifdef DVD_WARP_QUICK
+    {
+#ifndef DVD_WARP_QUICK_GRADS
+#define DVD_WARP_QUICK_GRADS true
+#endif
+      auto k = warp_loss_tiled_kernel<TW, TH, kR, NT, DVD_WARP_QUICK_GRADS, true, 2>;
+      hipLaunchKernelGGL(k, dim3(nb), dim3(NT), lds, stream, a, t2);
+      return DVD_OK;
+    }
+#else
     if (grads) {
       if (shipped)
         DVD_TILED_LAUNCH(true, true);
@@ -1084,6 +1560,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
       else
         DVD_TILED_LAUNCH(false, false);
     }
+#endif
 #undef DVD_TILED_LAUNCH
     DVD_LAUNCH_OK();
     return DVD_OK;
@@ -1091,8 +1568,12 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   auto combine_launch = [&](int pair0, int npairs, hipStream_t st) -> int {
     const int qpr = (a.W + 3) / 4;
     const int total_quads = qpr * a.H * npairs;
-    hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, st, ta.slabs,
-                       (const int2*)offs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads, ta.direct, pair0);
+    if (DVD_WARP_COMBINE_TILES && g_combine == 0)
+      hipLaunchKernelGGL((combine_tiles_kernel<TW, TH, kR>), dim3(npairs * tiles), dim3(256), 0, st, ta.slabs,
+                         (const int2*)offs, a.g_d2, a.H, a.W, p.ntx, p.nty, ta.direct, pair0);
+    else
+      hipLaunchKernelGGL((combine_slabs_kernel<TW, TH, kR>), dim3((total_quads + 255) / 256), dim3(256), 0, st, ta.slabs,
+                         (const int2*)offs, a.g_d2, a.H, a.W, p.ntx, p.nty, total_quads, ta.direct, pair0);
     DVD_LAUNCH_OK();
     return DVD_OK;
   };
@@ -1187,6 +1668,9 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
     return DVD_OK;
   }
   char* ws = static_cast<char*>(workspace);
+#ifdef DVD_WARP_QUICK      // development: compile the production instantiation only (tools/isa_stats.py ... -DDVD_WARP_QUICK)
+  return launch_tiled<96, 32, DVD_WARP_QUICK>(a, plan, ws, grads, stream);
+#else
   switch (plan.shape) {
     case 0:
       return launch_tiled<96, 32, 512>(a, plan, ws, grads, stream);
@@ -1199,6 +1683,7 @@ static int run(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth
     default:
       return launch_tiled<64, 32, 256>(a, plan, ws, grads, stream);
   }
+#endif
 }
 
 }  // namespace dvd
@@ -1211,6 +1696,7 @@ int dvd_warp_loss_select(int variant, int tile, int px) {
   dvd::g_variant = variant;
   dvd::g_tile = tile;
   dvd::g_px = px;
+  dvd::g_combine = px == 4 ? 1 : 0;      // the 4-pixel test variant also keeps the per-quad combine of rounds 2-4 covered
   return DVD_OK;
 }
 

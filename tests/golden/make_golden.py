@@ -269,6 +269,78 @@ def case_full_step(name, midas, B, H, W, gap, epoch, seed, over=None):
     print('wrote', name, {k: float(v) for k, v in log.items()})
 
 
+def case_trajectory(name, midas, B, H, W, gap, epoch, seed, steps=5, over=None):
+    """K consecutive `Model._train_on_batch` calls of the REAL reference (same construction as case_full_step) on ONE
+    batch: the logged losses of every step, the norm of every parameter after step K and a few parameter tensors.  Pins
+    more than one step: Adam's moments and bias correction across steps, the second step's forward on updated weights, and
+    the direction the loss takes on a repeated batch."""
+    import tempfile
+    import unittest.mock as mock
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    import third_party.hourglass as RH
+    import third_party.MiDaS as RM
+    import visualize.html_visualizer as HV
+    from models.scene_flow_motion_field import Model
+    from oracle import resnext
+    o = dict(helpers.FULL_STEP_OPT)
+    o.update(midas=midas, full_logdir=tempfile.mkdtemp())
+    o.update(over or {})
+    opt = SimpleNamespace(**o)
+
+    class _Loggers(object):
+        def add_logger(self, *a):
+            pass
+
+        def get_html_logger(self):
+            return None
+    real_load = torch.load
+    with mock.patch.object(HV, 'Pool', lambda n: None), \
+            mock.patch.object(torch.hub, 'load', lambda repo, entry, *a, **k: resnext.resnext101_32x8d()), \
+            mock.patch.object(RM.BaseModel, 'load', lambda self, path: None), \
+            mock.patch.object(torch, 'load', lambda path, *a, **k: RH.HourglassModel().state_dict()
+                              if 'pretrained_depth_ckpt' in str(path) else real_load(path, *a, **k)):
+        model = Model(opt, _Loggers())
+    helpers.seeded_fill_(model.net_depth, seed)
+    helpers.seeded_fill_(model.net_sceneflow, seed + 1)
+    if midas:
+        with torch.no_grad():
+            model.net_depth.scratch.output_conv[4].weight.mul_(30.0)
+            model.net_depth.scratch.output_conv[4].bias.fill_(2000.0)
+    model.to(torch.device('cpu'))
+    batch = synthetic.make_batch(B, H, W, gap=gap, seed=seed + 2)
+    out = {'B': np.array(B), 'H': np.array(H), 'W': np.array(W), 'gap': np.array(gap), 'epoch': np.array(epoch),
+           'seed': np.array(seed), 'midas': np.array(int(midas)), 'steps': np.array(steps),
+           'over_keys': np.array(sorted(over or {})), 'over_vals': np.array([float((over or {})[k]) for k in sorted(over or {})])}
+    keys = ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg')
+    series = {k: [] for k in keys}
+    for i in range(steps):
+        log = model._train_on_batch(epoch, i, helpers.loader_batch({k: (v.clone() if torch.is_tensor(v) else v)
+                                                                    for k, v in batch.items()}))
+        for k in keys:
+            series[k].append(float(log[k]))
+        print(name, 'step', i, {k: float(log[k]) for k in keys})
+    for k in keys:
+        out['series_' + k] = np.array(series[k], dtype=np.float64)
+    names, pnorm = [], []
+    for prefix, net in (('depth', model.net_depth), ('sf', model.net_sceneflow)):
+        for k, p in net.named_parameters():
+            names.append(prefix + '/' + k)
+            pnorm.append(float(p.data.double().norm()))
+    out['param_names'] = np.array(names)
+    out['param_norms_after'] = np.array(pnorm)
+    for k, p in model.net_sceneflow.named_parameters():
+        if k in ('convs.0.conv.weight', 'convs.5.conv.weight', 'convs.5.conv.bias'):
+            out['p_sf/' + k] = p.data.numpy()
+    dkeep = (['scratch.output_conv.4.weight', 'scratch.output_conv.2.weight', 'pretrained.layer4.2.bn3.weight'] if midas else
+             ['net_depth.pred_layer.weight', 'net_depth.seq.1.weight'])
+    for k, p in model.net_depth.named_parameters():
+        if k in dkeep:
+            out['p_depth/' + k] = p.data.numpy()
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name)
+
+
 def case_flow_masks(name):
     """Occlusion / out-of-bounds masks: `get_oob_mask`, `backward_flow_warp` and the mask statements of
     `generate_pair_data` (scripts/preprocess/davis/generate_flows.py:57-82,139-148) cut out of the reference's source
@@ -301,6 +373,10 @@ def main():
         case_full_step('fullstep_hourglass_b2_32x48_usecnn_gap2', midas=False, B=2, H=32, W=48, gap=2, epoch=6, seed=127,
                        over=dict(use_cnn=True))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'trajectory':          # K-step trajectories of the real reference (round 5)
+        case_trajectory('traj5_hourglass_b2_32x48', midas=False, B=2, H=32, W=48, gap=1, epoch=6, seed=131)
+        case_trajectory('traj5_midas_b1_64x96', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=137)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'midas_192x384':       # only the configs[0]-shape fixture (round 2)
         case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
         return
@@ -323,6 +399,8 @@ def main():
     case_full_step('fullstep_hourglass_b2_32x48_usecnn_gap2', midas=False, B=2, H=32, W=48, gap=2, epoch=6, seed=127,
                    over=dict(use_cnn=True))
     case_flow_masks('flow_masks')
+    case_trajectory('traj5_hourglass_b2_32x48', midas=False, B=2, H=32, W=48, gap=1, epoch=6, seed=131)
+    case_trajectory('traj5_midas_b1_64x96', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=137)
 
 
 if __name__ == '__main__':

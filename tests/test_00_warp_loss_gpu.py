@@ -14,14 +14,15 @@ from oracle import losses as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['tiled', 'tile64x32', 'px4', 'direct'], autouse=True)
+@pytest.fixture(params=['tiled', 'tile64x32', 'tile96x32x384', 'px4', 'direct'], autouse=True)
 def warp_variant(request):
     """Every case runs on the production tiled kernel (auto tile shape: the reference's rounding sequence for every
-    pixel), on the smallest tile shape (more tile seams / halo traffic), with 4 pixels per thread-step, and on the
-    global-atomics reference variant.  All of them must reproduce the oracle's masks, counts and sub-gradient signs."""
+    pixel; since round 5 the two-pixel lockstep loop for pinhole pairs with even rows), on the smallest tile shape (more
+    tile seams / halo traffic), on the 384-thread blocks of the 96 x 32 tile (three waves per SIMD), with 4 pixels per
+    thread-step (the one-pixel loop of rounds 1-4), and on the global-atomics reference variant.  All of them must reproduce the oracle's masks, counts and sub-gradient signs."""
     from dvd_hip import ops
     ops.warp_loss_select(variant='direct' if request.param == 'direct' else 'tiled',
-                         tile=3 if request.param == 'tile64x32' else -1, px=4 if request.param == 'px4' else 0)
+                         tile={'tile64x32': 3, 'tile96x32x384': 4}.get(request.param, -1), px=4 if request.param == 'px4' else 0)
     yield request.param
     ops.warp_loss_select()
 

@@ -25,12 +25,13 @@ def main():
     ap.add_argument('--fwd_only', action='store_true')
     ap.add_argument('--direct', action='store_true', help='global-atomics reference variant')
     ap.add_argument('--tile', type=int, default=-1, help='force tile shape index')
+    ap.add_argument('--px', type=int, default=0, help='pixels per thread-step (0 auto, 2, 4)')
     ap.add_argument('--flow_sigma', type=float, default=3.0)
     ap.add_argument('--smooth_flow', action='store_true', help='constant flow per pair instead of iid noise')
     ap.add_argument('--calm_border', type=int, default=0, help='zero the flow within this many pixels of the image border')
     a = ap.parse_args()
     B, H, W = a.B, a.H, a.W
-    ops.warp_loss_select(variant='direct' if a.direct else 'tiled', tile=a.tile)
+    ops.warp_loss_select(variant='direct' if a.direct else 'tiled', tile=a.tile, px=a.px)
     batch = synthetic.make_batch(B, H, W, device='cuda', with_images=False)
     batch['flow_1_2'] = batch['flow_1_2'] * (a.flow_sigma / 3.0)
     if a.smooth_flow:
