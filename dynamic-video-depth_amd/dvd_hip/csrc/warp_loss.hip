@@ -476,15 +476,15 @@ __global__ __launch_bounds__(256) void warp_loss_kernel(const WarpArgs a) {
 // Blocks are numbered so that each XCD receives a contiguous run of tiles
 // (neighbouring tiles share depth_2 halo lines in that XCD's L2).
 
-// Window-overflow records go to kOvfLists separate lists (a block appends to list `block % kOvfLists`): returned
-// atomics on ONE word saturate at ~88 per microsecond on MI355X, which made a flow field that leaves the windows
-// (iid noise of 10 px) cost 8 ms; 256 counters on different cache lines take that to tens of microseconds.
-constexpr int kOvfLists = 256;
-constexpr int kOvfStride = 16;   // unsigned per counter: one 64-byte line each
+// Window-overflow records (taps that no LDS window of their tile takes): one list PER TILE since round 5.  The tile's block
+// counts its records in LDS (wave-aggregated ds_add with return) and stores the count when it is done; the finish kernel walks
+// the lists.  No global counter is touched while the tiles run -- rounds 2-4 appended to 256 shared lists with returned global
+// atomics (one list: ~88 appends per microsecond, 8 ms for a flow field that leaves the windows; 256 lists: tens of
+// microseconds) and needed a launch in front of the tile kernel to zero the counters.
 struct Overflow {
-  unsigned* count;   // [kOvfLists * kOvfStride]
-  int2* rec;         // [kOvfLists][cap]
-  unsigned cap;      // records per list (sized so that no list can overflow)
+  unsigned* count;   // [tiles of the launch sequence]: written by each tile's block
+  int2* rec;         // [tiles][cap]
+  unsigned cap;      // records per list = every tap of every pixel of a tile: no list can overflow
 };
 
 // LDS accumulation is 64-bit fixed point (Q31.32): ds_add_u64 sustains ~6.5 lane-ops/clk/CU
@@ -512,6 +512,7 @@ struct TileIO {
   int W, wx0, wy0, pair_base, list;
   float unit;                // accumulated values are multiplied by this at the end
   Overflow ovf;
+  unsigned* lcount;          // LDS: records of this tile so far
   __device__ __forceinline__ bool inside(int x0, int y0) const {
     const int lx = x0 - wx0, ly = y0 - wy0;
     return (lx >= 0) && (lx + 1 < WW) && (ly >= 0) && (ly + 1 < WH);
@@ -540,7 +541,7 @@ struct TileIO {
     const unsigned long long m = __ballot(1);
     const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
     unsigned base = 0u;
-    if (lane == leader) base = atomicAdd(ovf.count + list * kOvfStride, (unsigned)__popcll(m));
+    if (lane == leader) base = atomicAdd(lcount, (unsigned)__popcll(m));     // ds_add_rtn_u32
     base = __shfl(base, leader, 64);
     const unsigned i = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
     if (i < ovf.cap) ovf.rec[(size_t)list * ovf.cap + i] = make_int2(pair_base + idx, __float_as_int(v * unit));
@@ -850,7 +851,7 @@ __device__ __forceinline__ void pixel2(const WarpArgs& a, const float* cam, cons
 struct TileArgs {
   float* slabs;
   Overflow ovf;
-  const int2* offs;   // per pair: window offset (multiple of 4 in x), written by warp_prep_kernel
+  int2* offs;         // per pair: window offset (multiple of 4 in x), written by the pair's first tile
   int ntx, nty;
   int direct;         // 1: window cells no neighbouring window covers go straight to g_depth_2 (needs W % 4 == 0)
   int tile0;          // global index of this launch's first tile (a launch covers a contiguous run of pairs)
@@ -913,7 +914,38 @@ __device__ __forceinline__ int xcd_contiguous_block(int bid, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-constexpr int tile_lds_bytes(int tw, int th, int r) { return (tw + 2 * r + 4) * (th + 2 * r + 1) * 12 + 32 * 4; }
+// The window offset of a pair: its mean flow, sampled on an 8 x 8 grid, rounded (x to a multiple of 4 so that window rows stay
+// 16-byte aligned).  A coherent motion of tens of pixels (camera pan, the frame gaps 2-4 of the shipped schedule) then lands
+// inside the LDS windows instead of on the overflow path; mean flows below 4 px keep the unshifted window.  Any offset is
+// correct: it only moves where the on-chip window sits.  Called by all 64 lanes of a wave; the result is wave uniform.
+__device__ __forceinline__ int2 pair_window_offset(const float* __restrict__ flow, int b, int H, int W) {
+  const int lane = threadIdx.x & 63;
+  const int gy = lane >> 3, gx = lane & 7;
+  const int y = (int)(((2 * gy + 1) * (long long)H) / 16), x = (int)(((2 * gx + 1) * (long long)W) / 16);
+  const float2 f = load_pair(flow + 2 * ((size_t)b * H * W + (size_t)y * W + x));
+  // butterfly sum over the wave (every lane ends with the total, in the same order).  The lane index is made opaque: the
+  // permute addresses would otherwise be shared with the wave_sum of the block sums at the END of the kernel, i.e. six
+  // registers alive (spilled and reloaded) across the whole tile.
+  int lid = lane;
+  asm volatile("" : "+v"(lid));
+  float sx = f.x, sy = f.y;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int src = (lid ^ o) << 2;
+    sx += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, sx)));
+    sy += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, sy)));
+  }
+  const float mx = sx * (1.0f / 64.0f), my = sy * (1.0f / 64.0f);
+  int ox = 0, oy = 0;
+  if (fabsf(mx) >= 4.0f || fabsf(my) >= 4.0f) {
+    const float cx = fminf(fmaxf(mx, -(float)W), (float)W), cy = fminf(fmaxf(my, -(float)H), (float)H);   // (NaN -> bound)
+    ox = ((int)rintf(cx * 0.25f)) * 4;
+    oy = (int)rintf(cy);
+  }
+  return make_int2(__builtin_amdgcn_readfirstlane(ox), __builtin_amdgcn_readfirstlane(oy));
+}
+
+constexpr int tile_lds_bytes(int tw, int th, int r) { return (tw + 2 * r + 4) * (th + 2 * r + 1) * 12 + 32 * 4 + 16; }
 constexpr int tile_blocks_per_cu(int tw, int th, int r) { return 163840 / tile_lds_bytes(tw, th, r); }
 // Measured on MI355X: this kernel is latency bound and its time falls steeply with resident
 // waves (12 -> 16 waves/CU: 335 -> 233 us at 48x384x672), so take 4 waves/SIMD (128 VGPRs)
@@ -935,6 +967,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);  // [WH][WW] u64 first (8-byte aligned)
   float* win = smem + 2 * WW * WH;
   float* camL = win + WW * WH;              // the pair's camera for the lockstep loop (kCamLdsFloats floats, 16-byte aligned)
+  unsigned* lcount = reinterpret_cast<unsigned*>(camL + kCamLdsFloats);    // overflow records of this tile
   static_assert((3 * WW * WH) % 4 == 0 && kCamLdsFloats == 32, "camera quads must be 16-byte aligned");
 
   const int logical = ta.tile0 + xcd_contiguous_block(blockIdx.x, gridDim.x);      // global tile index
@@ -943,10 +976,15 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   const int t = logical - b * tiles;
   const int tj = t / ta.ntx, ti = t - tj * ta.ntx;
   const int tx0 = ti * TW, ty0 = tj * TH;
-  const int2 off = ta.offs[b];
+  // window offset of the pair (round 5: computed by every wave instead of a launch in front of this kernel -- 64 samples of
+  // the flow on an 8 x 8 grid, the same shuffle tree in every wave of every tile, so all blocks of a pair agree bit for bit;
+  // the requests fly next to the scalar loads of the camera below)
+  const int2 off = pair_window_offset(a.flow, b, a.H, a.W);
+  if (t == 0 && threadIdx.x == 0) ta.offs[b] = off;                 // for the combine and finish kernels
   const int wx0 = tx0 - R + off.x, wy0 = ty0 - R + off.y;
-  Cam c;
-  load_cam(a, b, c);
+  Cam c0;
+  load_cam(a, b, c0);
+  Cam& c = c0;
   // pinhole intrinsics without skew (exact zeros / one in K^T and (K^-1)^T): block-uniform, selects pixel<.., PIN = true>
   const bool pinhole = c.Ki[1] == 0.0f && c.Ki[2] == 0.0f && c.Ki[3] == 0.0f && c.Ki[5] == 0.0f && c.Ki[8] == 1.0f &&
                        c.K[1] == 0.0f && c.K[2] == 0.0f && c.K[3] == 0.0f && c.K[5] == 0.0f && c.K[8] == 1.0f &&
@@ -1050,6 +1088,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
       }
     }
   }
+  if (threadIdx.x == 0) *lcount = 0u;
   if constexpr (PX == 2 && SHIPPED && DVD_WARP_V5) {
     if (threadIdx.x < kCamLdsFloats) {
       float v = 0.0f;
@@ -1060,7 +1099,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   }
   __syncthreads();
 
-  TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, logical % kOvfLists, a.disp_mul, ta.ovf};
+  TileIO<WW, WH> io{d2b, win, accw, a.W, wx0, wy0, b * a.HW, logical, a.disp_mul, ta.ovf, lcount};
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   // ---- phase 1: the tile's pixels, PX per thread per step.  The inputs of step i+1 are requested before
   //      step i is evaluated: all waves of a block leave the barrier together, so without this every
@@ -1100,6 +1139,22 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   };
   auto tile_pixels = [&](auto pin_tag) {
   constexpr bool PIN = decltype(pin_tag)::value;
+  // In the instantiations that have the lockstep loop this one-pixel loop is the rare path (a camera with skew, odd-width
+  // rows): it reads the camera AGAIN instead of keeping the 51 scalars of the prologue alive across the window fill -- they
+  // pushed the whole kernel over its register budget (spills in the prologue and in the flush loop of every tile).
+  Cam c;
+  if constexpr (PX == 2 && SHIPPED && DVD_WARP_V5) {
+    load_cam(a, b, c);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {                 // (as in the other instantiations: the FMA-heavy matrices in VGPRs)
+      asm volatile("" : "+v"(c.R1[i]));
+      asm volatile("" : "+v"(c.R2[i]));
+      asm volatile("" : "+v"(c.K[i]));
+      asm volatile("" : "+v"(c.R2T[i]));
+    }
+  } else {
+    c = c0;
+  }
   In cur, nxt;
   fetch(threadIdx.x, cur);
   for (int q = threadIdx.x; q < QW * TH; q += NT) {
@@ -1200,6 +1255,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
   }
   // ---- phase 2: accumulator window -> this tile's slab (coalesced), block sums
   __syncthreads();
+  if (threadIdx.x == 0) ta.ovf.count[logical] = *lcount < ta.ovf.cap ? *lcount : ta.ovf.cap;
   if (GRADS) {
     float* slab = ta.slabs + (size_t)logical * (WW * WH);
     float* gb = a.g_d2 + (size_t)b * a.HW;
@@ -1230,30 +1286,6 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
     for (int w = 0; w < NT / 64; ++w) v += red[w * 4 + threadIdx.x];
     a.partial[(size_t)logical * 4 + threadIdx.x] = v;
   }
-}
-
-// ---------------------------------------------------------------------------
-// One small launch before the tile kernel (it takes the place of the counter memset): zeroes the overflow counter
-// and chooses the window offset of every pair -- the pair's mean flow, sampled on an 8 x 8 grid, rounded (x to a
-// multiple of 4 so that window rows stay 16-byte aligned).  A coherent motion of tens of pixels (camera pan, the
-// frame gaps 2-4 of the shipped schedule) then lands inside the LDS windows instead of on the overflow path; mean
-// flows below 4 px keep the unshifted window.  Any offset is correct: it only moves where the on-chip window sits.
-__global__ __launch_bounds__(64) void warp_prep_kernel(const float* __restrict__ flow, int H, int W, int2* __restrict__ offs,
-                                                       unsigned* __restrict__ counters) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  for (int i = b * 64 + lane; i < kOvfLists * kOvfStride; i += gridDim.x * 64) counters[i] = 0u;
-  const int gy = lane >> 3, gx = lane & 7;
-  const int y = (int)(((2 * gy + 1) * (long long)H) / 16), x = (int)(((2 * gx + 1) * (long long)W) / 16);
-  const float* f = flow + 2 * ((size_t)b * H * W + (size_t)y * W + x);
-  const float mx = wave_sum(f[0]) * (1.0f / 64.0f), my = wave_sum(f[1]) * (1.0f / 64.0f);
-  if (lane != 0) return;
-  int ox = 0, oy = 0;
-  if (fabsf(mx) >= 4.0f || fabsf(my) >= 4.0f) {
-    const float cx = fminf(fmaxf(mx, -(float)W), (float)W), cy = fminf(fmaxf(my, -(float)H), (float)H);   // (NaN -> bound)
-    ox = ((int)rintf(cx * 0.25f)) * 4;
-    oy = (int)rintf(cy);
-  }
-  offs[b] = make_int2(ox, oy);
 }
 
 template <int TW, int TH, int R>
@@ -1404,11 +1436,13 @@ __global__ __launch_bounds__(1024) void warp_finish_kernel(const float* __restri
     return;
   }
   if (g_d2 == nullptr) return;
-  for (int l = blockIdx.x - 1; l < kOvfLists; l += gridDim.x - 1) {
-    unsigned m = count[l * kOvfStride];
+  // one wave per tile's list (round 5: per-tile lists, a few hundred records each at most in the benchmark's flow field)
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x - 1) * 16 + (threadIdx.x >> 6), nwaves = (gridDim.x - 1) * 16;
+  for (int l = wave; l < n; l += nwaves) {
+    unsigned m = count[l];
     if (m > cap) m = cap;
     const int2* lr = rec + (size_t)l * cap;
-    for (unsigned i = threadIdx.x; i < m; i += 1024) {
+    for (unsigned i = lane; i < m; i += 64) {
       const int2 r = lr[i];
       unsafeAtomicAdd(g_d2 + r.x, __int_as_float(r.y));
     }
@@ -1484,7 +1518,8 @@ static Plan make_plan(int B, int H, int W) {
   size_t off = p.n_partials * 4 * sizeof(float);
   off = (off + 255) & ~(size_t)255;
   p.off_count = off;
-  off += (size_t)kOvfLists * kOvfStride * sizeof(unsigned);
+  off += tiles * sizeof(unsigned);
+  off = (off + 255) & ~(size_t)255;
   p.off_offs = off;
   off += (size_t)B * sizeof(int2);
   off = (off + 255) & ~(size_t)255;
@@ -1492,14 +1527,15 @@ static Plan make_plan(int B, int H, int W) {
   off += tiles * (size_t)p.ww * p.wh * sizeof(float);
   off = (off + 255) & ~(size_t)255;
   p.off_ovf = off;
-  // per list: every tap of every pixel of the tiles that append to it -- no list can overflow
-  p.ovf_cap = ((tiles + kOvfLists - 1) / kOvfLists) * (size_t)t.tw * t.th * 4;
-  off += (size_t)kOvfLists * p.ovf_cap * sizeof(int2);
+  // per tile: every tap of every pixel -- no list can overflow
+  p.ovf_cap = (size_t)t.tw * t.th * 4;
+  off += tiles * p.ovf_cap * sizeof(int2);
   p.total = off;
   return p;
 }
 
-// Launch sequence: prep (counters + window offsets) -> tile kernel -> slab combine -> finish, on one stream.
+// Launch sequence: tile kernel -> slab combine -> finish, on one stream (round 5: the prep launch -- counters, window offsets --
+// is gone: the offsets are computed by the tiles themselves, the overflow lists are per tile with their counters in LDS).
 // Round 4 tried to take the combine (34 us at 48 x 384 x 672) off the serial tail twice; both lost and are not kept:
 //   * combine inside the tile kernel by the block that stores the LAST slab of a 3 x 3 tile neighbourhood (bit-identical
 //     results, tests green): 2.9 ms instead of 0.24 -- the release / acquire fences the hand-over needs are agent-scope, and on
@@ -1513,7 +1549,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.slabs = reinterpret_cast<float*>(ws + p.off_slabs);
   ta.ovf.count = reinterpret_cast<unsigned*>(ws + p.off_count);
   ta.ovf.rec = reinterpret_cast<int2*>(ws + p.off_ovf);
-  ta.ovf.cap = (unsigned)(p.ovf_cap > 0xffffffffULL ? 0xffffffffULL : p.ovf_cap);
+  ta.ovf.cap = (unsigned)p.ovf_cap;
   int2* offs = reinterpret_cast<int2*>(ws + p.off_offs);
   ta.offs = offs;
   ta.ntx = p.ntx;
@@ -1521,9 +1557,7 @@ static int launch_tiled(const WarpArgs& a, const Plan& p, char* ws, bool grads, 
   ta.direct = ((a.W & 3) == 0 && DVD_WARP_DIRECT_INTERIOR) ? 1 : 0;
   ta.tile0 = 0;
   const int tiles = p.ntx * p.nty, nblocks = tiles * a.B;
-  const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long)) + kCamLdsFloats * sizeof(float);
-  hipLaunchKernelGGL(warp_prep_kernel, dim3(a.B), dim3(64), 0, stream, a.flow, a.H, a.W, offs, ta.ovf.count);
-  DVD_LAUNCH_OK();
+  const size_t lds = (size_t)WW * WH * (sizeof(float) + sizeof(unsigned long long)) + kCamLdsFloats * sizeof(float) + 16;
   const bool shipped = a.midas_mask && a.disp_mode == 1 && !a.loss_on_sf;
   // 2 pixels per thread-step when that splits the tile evenly over the block and 4 does not
   constexpr bool kEven4 = ((TW / 4) * TH) % NT == 0, kEven2 = ((TW / 2) * TH) % NT == 0;
