@@ -42,6 +42,14 @@ H, W, PAIRS, GAP = 384, 672, 48, 1
 PAIRS_CFG4 = 24                  # BASELINE configs[4] (768x1344, fp16 activations): frame pairs per GPU whose depth-net state stays resident (2 x 59 GB of kept slots + 119 GB of MLP stashes); more pairs run with recomputed chunks
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 WARP_BYTES_PER_PIXEL = 52        # fused fwd+bwd, unique bytes
+MFMA_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak (2.5 PFLOP/s; the 5 PF figure is 2:1 sparsity)
+# MFMAs issued per algorithmic multiply-accumulate: fp32 storage = two-term fp16 split of both operands,
+# three partial products; fp16 activation storage = one-term activations: 2 in forward / backward-data, 1 in the weight
+# gradients; the scene-flow MLP keeps three (its weight gradient two with the fp16 stash)
+PRODUCTS_FP32 = {k: 3.0 for k in ('xconv_1x1_wide', 'xconv_wide', 'xconv_128', 'xconv_small', 'xwgrad3', 'xwgrad3g', 'xwgrad1b',
+                                   'xwgrad1s', 'xwgradk', 'mlp_fwd', 'mlp_bwd_dx', 'mlp_bwd_dw')}
+PRODUCTS_FP16 = dict(PRODUCTS_FP32, xconv_1x1_wide=2.0, xconv_wide=2.0, xconv_128=2.0, xconv_small=2.0, xwgrad3=1.0, xwgrad3g=1.0,
+                     xwgrad1b=1.0, xwgrad1s=1.0, mlp_bwd_dw=2.0)
 
 
 def make_opt(**over):
@@ -185,6 +193,45 @@ def hip_parity(first, device, act_fp16=False):
     return out
 
 
+def hip_fp32_first_step(pairs=1, gap=None):
+    """The fp32-storage HIP Model's first step on the benchmark workload at the CURRENT image size, in the shape
+    `oracle_first_step` returns: the reference of the fp16-activation parity leg where the CPU oracle does not fit the host
+    (BASELINE configs[4]: 768 x 1344 needs ~4x the 60 GB the oracle holds at 384 x 672)."""
+    from dvd_hip import synthetic
+    gap = GAP if gap is None else gap
+    device = torch.device('cuda', torch.cuda.current_device())
+    opt = make_opt(depth_chunk=1, midas=True, act_fp16=False)
+    model = build_model(opt, torch.device('cpu'), seed=0, to_device=False)
+    init = ({k: v.detach().clone() for k, v in model.net_depth.state_dict().items()},
+            {k: v.detach().clone() for k, v in model.net_sceneflow.state_dict().items()})
+    model.to(device)
+    batch = synthetic.make_batch(pairs, H, W, gap=gap, seed=1234)
+    b = {k: (v.to(device) if torch.is_tensor(v) and k != 'time_step' else v) for k, v in batch.items()}
+    t0 = time.time()
+    log = model._train_on_batch(opt.warm_sf + 1, 0, synthetic.with_loader_dim(b))
+    torch.cuda.synchronize()
+    out = {'init': init, 'batch': batch, 'log': {k: float(v) for k, v in log.items()}, 'gap': gap, 'warm': False, 'depth': 'midas',
+           'mlp_grads': {k: p.grad.detach().cpu().clone() for k, p in model.net_sceneflow.named_parameters()},
+           'depth_grad_norms': {k: float(p.grad.double().norm()) for k, p in model.net_depth.named_parameters() if p.grad is not None},
+           'seconds': time.time() - t0, 'reference': 'HIP Model with fp32 activation storage (the arithmetic the 384 x 672 parity legs '
+                                                   'check against the CPU oracle)'}
+    del model
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def host_mem_available_gb():
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                return float(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
 def cpu_baseline(first, timed_steps=3, budget_s=240.0):
     """The oracle step (a port of the reference's `_train_on_batch`, pinned to the real reference's logs by
     tests/golden/fullstep_*.npz) on the host cores: ONE frame pair of the same workload at 384x672 -- the
@@ -210,6 +257,60 @@ def cpu_baseline(first, timed_steps=3, budget_s=240.0):
                                                            ', '.join('%.1f' % t for t in times)),
             'pairs_per_s': 1.0 / med, 'first_step_loss': first['log']['loss'], 'cpu_model': _cpu_model(),
             'os_cpu_count': os.cpu_count(), 'torch_threads': threads}
+
+
+def _valu_issue(pixels_per_launch):
+    """The warp+loss tile kernel's OTHER roofline: vector-instruction issue.  Static, from the committed SQ counters of the
+    CURRENT kernel (profiles/warp_loss_sq.json, written by tools/sq_to_json.py from a rocprofv3 --pmc pass of the
+    micro-benchmark at 48 x 384 x 672): wave instructions x 64 lanes / pixels, and the time they take at 100 % issue."""
+    path = os.path.join(ROOT, 'profiles', 'warp_loss_sq.json')
+    try:
+        rec = json.load(open(path))
+        ipp = rec['valu_wave_instructions'] * 64.0 / rec['pixels']
+        return {'instr_per_pixel': round(ipp, 1), 'issue_bound_ms': round(ipp * pixels_per_launch / (256 * 64 * rec['clock_hz']) * 1e3, 4),
+                'source': 'static: profiles/warp_loss_sq.json (%s)' % rec.get('collected', '')}
+    except Exception:                      # noqa: BLE001 -- informational only
+        return None
+
+
+def _roofline_mfma(f0, f1, steps, dt, world, act_fp16):
+    """Matrix-pipe roofline of the step (the kernels that own ~85 % of it): the algorithmic work the timed steps EXECUTED per
+    kernel class -- counted by the library at launch / graph-capture time and at every graph replay (dvd_flop_counters,
+    ops.executed_flops) -- over the timed wall clock, as fp32-equivalent TFLOP/s, as issued fp16 MFMA TFLOP/s (x products per
+    multiply-accumulate of the arithmetic in use) and as a fraction of the 2.5 PFLOP/s dense peak.  Per-class kernel TIME is
+    not measurable in this process; the committed trace of the same command supplies it (profiles/mfma_roofline.json, written by
+    tools/mfma_roofline.py; provenance stated) for the three classes with the most time."""
+    prod = PRODUCTS_FP16 if act_fp16 else PRODUCTS_FP32
+    per_step = {k: (f1[k] - f0[k]) / steps for k in f1}
+    total = sum(per_step.values())
+    issued = sum(per_step[k] * prod[k] for k in per_step)
+    s_per_step = dt / steps
+    out = {'bound': 'mfma', 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'algorithmic_TFLOP_per_step': total / 1e12,
+           'algorithmic_TFLOP_per_step_by_class': {k: round(v / 1e12, 4) for k, v in per_step.items() if v},
+           'achieved_fp32_equivalent': total / s_per_step / 1e12,
+           'achieved': issued / s_per_step / 1e12, 'frac': issued / s_per_step / 1e12 / MFMA_PEAK_TFLOPS,
+           'products_per_mac': {k: prod[k] for k in per_step if per_step[k]},
+           'note': 'step-wide: all matrix-kernel work of a step over the WHOLE step time (per GPU; the other ~15 % of the step '
+                   'is memory-bound helper kernels); achieved = issued fp16 MFMA rate = sum(work x products per MAC) / time'}
+    path = os.path.join(ROOT, 'profiles', 'mfma_roofline.json')
+    try:
+        rec = json.load(open(path))
+        key = 'fp16' if act_fp16 else 'fp32'
+        top = []
+        for r in rec.get(key, {}).get('classes', [])[:3]:
+            w = per_step.get(r['class'], 0.0)
+            ms = r['ms_per_step']
+            top.append({'class': r['class'], 'kernels': r['kernels'], 'ms_per_step': ms, 'share_of_step_kernel_time': r.get('share'),
+                        'algorithmic_TFLOP_per_step': w / 1e12, 'fp32_equivalent_TFLOPs': w / (ms * 1e-3) / 1e12 if ms else None,
+                        'issued_TFLOPs': w * prod[r['class']] / (ms * 1e-3) / 1e12 if ms else None,
+                        'frac_of_peak': w * prod[r['class']] / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if ms else None})
+        out['top_kernels'] = top
+        out['top_kernels_source'] = 'static kernel times: profiles/mfma_roofline.json (%s); work: counted live in this run' % \
+            rec.get(key, {}).get('collected', '')
+    except Exception:                      # noqa: BLE001 -- informational only
+        out['top_kernels'] = None
+    return out
 
 
 def relaunch_under_torchrun(n):
@@ -249,6 +350,9 @@ def main():
                     help='2 (default): BASELINE configs[1]/[2], the headline.  4: BASELINE configs[4] on ONE GPU -- synthetic '
                          '768x1344, fp16 activations with fp32 loss accumulation, as many frame pairs as fit one MI355X '
                          '(--pairs, default %d)' % PAIRS_CFG4)
+    ap.add_argument('--cfg4_parity', choices=('auto', 'oracle', 'hip', 'none'), default='auto',
+                    help='--config 4: the parity leg at 768x1344 (one pair): against the fp32 CPU oracle if the host has the memory '
+                         '(auto / oracle), else against the fp32-storage HIP step (hip)')
     ap.add_argument('--feed', choices=('hbm', 'host'), default='hbm',
                     help="hbm (default, the contract's `value`): inputs resident in HBM before the timed region; host: every "
                          "step's batch starts in host memory and goes through the pinned double-buffered feeder "
@@ -276,6 +380,17 @@ def main():
 
     if os.environ.get('DVD_CUDNN_BENCHMARK'):
         torch.backends.cudnn.benchmark = True     # MIOpen find mode (experiments; the default run uses FAST immediate mode)
+    # DVD_RESERVE_GB=N: take N GB of the device with a raw hipMalloc BEFORE the model's memory planner runs -- a stand-in for what
+    # RCCL's communicator holds on an 8-rank run (the planner sees less free memory and keeps fewer depth-net slots); outside
+    # torch's allocator, so hbm_peak_reserved_GB below is the model's own
+    ballast = None
+    if os.environ.get('DVD_RESERVE_GB'):
+        import ctypes
+        hip = ctypes.CDLL('libamdhip64.so')
+        ballast = ctypes.c_void_p()
+        nbytes = int(float(os.environ['DVD_RESERVE_GB']) * 2 ** 30)
+        if hip.hipMalloc(ctypes.byref(ballast), ctypes.c_size_t(nbytes)) != 0:
+            raise SystemExit('DVD_RESERVE_GB: hipMalloc of %d bytes failed' % nbytes)
     opt = make_opt(global_rank=rank, depth_chunk=min(a.depth_chunk, a.pairs), depth_graphs=bool(a.depth_graphs),
                    midas=a.depth == 'midas', act_fp16=bool(a.act_fp16))
     model = build_model(opt, device, seed=0)
@@ -306,10 +421,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
         wt.on = True
+        from dvd_hip import ops as _ops
+        flops0 = _ops.executed_flops()
         t0 = time.time()
         for i in range(a.steps):
             log = one_step(a.warmup + i)
         torch.cuda.synchronize()
+        flops1 = _ops.executed_flops()
         if parallel.is_distributed():
             torch.distributed.barrier()
         dt = time.time() - t0
@@ -366,6 +484,7 @@ def main():
         'dist_backend': dist_backend, 'ranks_seen': world,
         # the collective library behind torch.distributed's 'nccl' backend on ROCm (RCCL) and the planner's head room
         'rccl_version': rccl_version, 'hbm_head_room_GB': head_room_gb,
+        'hbm_reserved_by_others_GB': float(os.environ.get('DVD_RESERVE_GB') or 0.0),      # the DVD_RESERVE_GB ballast
     }
     if warp is not None:
         # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 --pmc passes of
@@ -376,7 +495,10 @@ def main():
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                traffic = rec.get('hbm_bytes_per_launch') * warp['pixels_per_launch'] / (48.0 * H * W)
+                # (the committed counters are for ONE launch of `algorithmic_bytes_per_launch` / 52 pixels: scale by this
+                #  run's pixels per launch -- round 4 scaled by 48 * H * W after --config 4 had changed H and W)
+                pmc_pixels = rec.get('algorithmic_bytes_per_launch') / float(WARP_BYTES_PER_PIXEL)
+                traffic = rec.get('hbm_bytes_per_launch') * warp['pixels_per_launch'] / pmc_pixels
                 traffic_src = 'static: profiles/warp_loss_pmc.json (%s)' % rec.get('collected', 'rocprofv3 --pmc passes')
             except Exception:
                 traffic = None
@@ -389,13 +511,26 @@ def main():
                            # for everything that decides a mask or a tap index).  Static, from the committed SQ counters of
                            # this kernel: wave instructions x 64 lanes / pixels, and the time they take at 100 % issue
                            # (256 CUs x 64 lanes per clock at the measured 2.16 GHz)
-                           'valu_issue': {'instr_per_pixel': 371, 'issue_bound_ms': round(
-                               371.0 * warp['pixels_per_launch'] / (256 * 64 * 2.16e9) * 1e3, 4),
-                               'source': 'static: profiles/r03_warp_loss_sq_counters.txt (SQ_INSTS_VALU 7.18e7 for 48x384x672)'}}
+                           'valu_issue': _valu_issue(warp['pixels_per_launch'])}
+    out['roofline_mfma'] = _roofline_mfma(flops0, flops1, a.steps, dt, world, a.act_fp16)
     if a.act_fp16:
         st = model._gscale.tolist()
         out['loss_scale'] = {'log2_S': __import__('math').log2(st[0]) if st[0] > 0 else None, 'target_exponent': st[2],
                              'steps_skipped': st[5]}
+    if world == 1 and a.config == 4 and a.cfg4_parity != 'none' and a.depth == 'midas' and a.gap == GAP:
+        # BASELINE configs[4]'s own image size: one frame pair, the fp16-activation step against the fp32 CPU oracle where
+        # the host holds it (~4 x the 60 GB of 384 x 672; --cfg4_parity oracle forces it), else against the fp32-storage HIP
+        # step -- which one is stated in parity.reference
+        import gc
+        del model, batch
+        gc.collect()
+        torch.cuda.empty_cache()
+        use_oracle = a.cfg4_parity == 'oracle' or (a.cfg4_parity == 'auto' and not a.no_cpu_baseline and host_mem_available_gb() >= 330.0)
+        first = oracle_first_step() if use_oracle else hip_fp32_first_step()
+        out['parity'] = hip_parity(first, device, act_fp16=True)
+        out['parity']['reference'] = ('CPU oracle (fp32, ATen-CPU), %.0f s for its step' % first['seconds']) if use_oracle else \
+            first['reference']
+        out['parity']['host_mem_available_GB'] = host_mem_available_gb()
     if world == 1 and not a.no_cpu_baseline and a.depth == 'midas' and a.gap == GAP and a.config == 2:
         # the 48-pair model's graph slots hold most of the HBM: release them before the 1-pair parity model is built
         import gc

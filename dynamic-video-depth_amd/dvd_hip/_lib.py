@@ -17,7 +17,7 @@ c_float = ctypes.c_float
 c_void_p = ctypes.c_void_p
 
 DVD_OK, DVD_EINVAL, DVD_EHIP, DVD_ENOSPC = 0, -1, -2, -3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Cameras(ctypes.Structure):
@@ -56,6 +56,7 @@ SIGNATURES = {
     'dvd_abi_version': (c_int, []),
     'dvd_last_error': (ctypes.c_char_p, []),
     'dvd_device_cu_count': (c_int, []),
+    'dvd_flop_counters': (c_int, [c_void_p, c_int, c_int]),
     'dvd_unproject_fwd': (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     'dvd_unproject_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_int, c_void_p]),
@@ -142,7 +143,7 @@ SIGNATURES = {
     'dvd_gconv3x3_c8_bwd_data_t': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_bwd_weight_t': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p, c_int,
                                              c_int, c_int, c_int, c_void_p]),
-    'dvd_head1x1_fwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_head1x1_fwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_head1x1_bwd_workspace_bytes': (c_size_t, [c_int]),
     'dvd_head1x1_bwd': (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gscale_init': (c_int, [c_void_p, c_float, c_void_p]),

@@ -69,6 +69,15 @@ def _gs(i):
     return st[i:i + 1]
 
 
+def _fwd_monitor():
+    """Slot [6] of the loss-scale state: max |activation| that the fp16-output convolution epilogues and the depth head fold
+    in during the forward pass (NaN as +Inf).  dvd_gscale_end skips the step when an activation left fp16's range: its Inf
+    would otherwise reach the weight gradients (Inf x 0 = NaN) without any GRADIENT monitor seeing it.  None
+    without a state (inference with fp16 activations outside a training model)."""
+    st = GRAD_SCALE['state']
+    return None if st is None else st[6:7]
+
+
 class _BnRelu(torch.autograd.Function):
     """y = relu(bn_eval(x) (+ residual)); see csrc/bnrelu.hip."""
 
@@ -156,7 +165,9 @@ class _Head1x1(torch.autograd.Function):
         x = x.contiguous()
         N, C, H, W = x.shape
         y = torch.empty(N, 1, H, W, device=x.device, dtype=torch.float32)
-        _lib.check(_lib.load().dvd_head1x1_fwd(_p(x), int(_is16(x)), _p(weight), _p(bias), _p(y), N, C, H * W, int(bool(relu_in)),
+        # (fp16 features: the head output's max|y| goes to the forward monitor of the overflow guard, state[6])
+        _lib.check(_lib.load().dvd_head1x1_fwd(_p(x), int(_is16(x)), _p(weight), _p(bias), _p(y),
+                                               _p(_fwd_monitor()) if _is16(x) else None, N, C, H * W, int(bool(relu_in)),
                                                _stream()), 'dvd_head1x1_fwd')
         ctx.save_for_backward(x, weight)
         ctx.cfg = (bool(relu_in), bias is not None)
@@ -617,9 +628,10 @@ class _XConv(torch.autograd.Function):
         if residual is not None:
             residual = residual.contiguous()
         Cout, _, KS, _ = weight.shape
-        y_amax = None if _is16(x) else new_scalar(x.device)       # fp16 activations carry no operand scale
+        # fp16 activations carry no operand scale; their epilogue folds max|y| into the overflow guard's forward monitor
+        y_amax = None if _is16(x) else new_scalar(x.device)
         y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=bias, residual=residual, relu_in=relu_in,
-                       res_relu=res_relu, groups=groups, x_amax=x_amax, y_amax=y_amax)
+                       res_relu=res_relu, groups=groups, x_amax=x_amax, y_amax=_fwd_monitor() if _is16(x) else y_amax)
         ctx.save_for_backward(x, residual if (res_relu and not res_unmasked) else None, x_amax)
         ctx.wparam = weight          # the tensor object that carries the packed copies
         ctx.cfg = (bool(relu_in), bool(res_relu), bias is not None, residual is not None, groups, bool(res_unmasked))
@@ -771,7 +783,8 @@ class _XConvBn(torch.autograd.Function):
         Cout, _, KS, _ = weight.shape
         y_amax = None if _is16(x) else new_scalar(x.device)
         y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, KS, bias=cbias, residual=residual, relu_out=relu,
-                       groups=groups, bn=(gamma, beta, mean, var, eps), x_amax=x_amax, y_amax=y_amax)
+                       groups=groups, bn=(gamma, beta, mean, var, eps), x_amax=x_amax,
+                       y_amax=_fwd_monitor() if _is16(x) else y_amax)
         ctx.save_for_backward(x, y if relu else None, gamma, mean, var, cbias, x_amax)
         ctx.wparam = weight
         ctx.cfg = (float(eps), bool(relu), residual is not None, groups)

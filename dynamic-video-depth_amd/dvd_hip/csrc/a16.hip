@@ -17,16 +17,20 @@
 //                                               before the first step overflows; re-centred after every step)
 //       state[3] = observed max |S g| of the fp16 gradient tensors of this step (the backward-data epilogues fold it in)
 //       state[4] = skip flag of this step, state[5] = steps skipped so far
+//       state[6] = forward monitor (round 5): max |y| every fp16-OUTPUT convolution epilogue and the depth head stored / read
+//                  this step (NaN counted as +Inf); >= 65504 means an activation overflowed fp16 -> the step is skipped too
 //     dvd_gscale_end (once per step, before the optimiser): an observed maximum of 2^15.5 or more means fp16 range was
 //     exceeded somewhere -> the step's depth-net update is SKIPPED (dvd_adam_step_guarded); in either case the target moves
 //     by the whole number of octaves that puts the observed maximum at 2^13 (upwards by at most 4 per step).  Every kernel that produces a PARAMETER gradient from fp16 gradients
 //     multiplies by state[1] (`out_scale`), so the flat gradient buffers always hold true gradients.
 #include "dvd_io.h"
+#include "dvd_split.h"      // wave_amax_to
 
 namespace dvd {
 
 constexpr int kHeadMaxC = 64;
 constexpr float kGsOverflow = 46340.95f;      // 2^15.5
+constexpr float kF16Max = 65504.0f;           // largest finite _Float16: an activation at or beyond it was stored as Inf
 
 __global__ void gscale_init_kernel(float* __restrict__ st, float target) {
   if (threadIdx.x < 8) st[threadIdx.x] = threadIdx.x == 0 || threadIdx.x == 1 ? 1.0f : (threadIdx.x == 2 ? target : 0.0f);
@@ -61,8 +65,12 @@ __global__ __launch_bounds__(64) void gscale_begin_kernel(float* __restrict__ st
 __global__ void gscale_end_kernel(float* __restrict__ st) {
   if (threadIdx.x != 0) return;
   const float obs = st[3];
+  const float fwd = st[6];             // forward monitor: max |activation| the fp16-output epilogues and the depth head saw
   float target = st[2];
-  if (!(obs < kGsOverflow)) {          // fp16 range exceeded (or Inf / NaN): skip this step's update, back off
+  if (!(fwd < kF16Max)) {              // an fp16 ACTIVATION left the format's range (or was NaN): the parameter gradients
+    st[4] = 1.0f;                      // of this step are not trustworthy -- skip it; the loss scale is not at fault
+    st[5] += 1.0f;
+  } else if (!(obs < kGsOverflow)) {   // fp16 range exceeded (or Inf / NaN): skip this step's update, back off
     st[4] = 1.0f;
     st[5] += 1.0f;
     target -= (obs < 3.0e38f) ? ceilf(log2f(obs) - 13.0f) : 8.0f;
@@ -76,17 +84,19 @@ __global__ void gscale_end_kernel(float* __restrict__ st) {
   }
   st[2] = fminf(fmaxf(target, -24.0f), 14.0f);
   st[3] = 0.0f;
+  st[6] = 0.0f;
 }
 
 // y[n][p] = bias + sum_c w[c] * act(x[n][c][p]); a thread owns 4 consecutive pixels (HW % 4 == 0)
 template <class T>
 __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, int C, int HW4,
-                                                          long long total, int relu_in) {
+                                                          long long total, int relu_in, float* fmax) {
   __shared__ float sw[kHeadMaxC];
   if (threadIdx.x < C) sw[threadIdx.x] = w[threadIdx.x];
   __syncthreads();
   const float b = bias ? bias[0] : 0.0f;
+  float ym = 0.0f;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long n = i / HW4;
     const int q = (int)(i - n * HW4);
@@ -102,7 +112,9 @@ __global__ __launch_bounds__(256) void head1x1_fwd_kernel(const T* __restrict__ 
       acc.w = __builtin_fmaf(wc, v.w, acc.w);
     }
     *reinterpret_cast<float4*>(y + i * 4) = acc;
+    if (fmax) ym = amax_acc(amax_acc(amax_acc(amax_acc(ym, acc.x), acc.y), acc.z), acc.w);
   }
+  if (fmax) wave_amax_to(ym, fmax);       // forward monitor of the fp16 overflow guard: an Inf / NaN feature shows up here
 }
 
 // gx[n][c][p] = S * w[c] * gy[n][p] * [x > 0];  partial[block][c] = sum gy * act(x[c]),  partial[block][C] = sum gy
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(const T* __restrict__ 
         v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       }
       st4(gx + base + (size_t)c * HW4 * 4, o);
-      gm = fmaxf(fmaxf(gm, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+      gm = amax_acc(amax_acc(amax_acc(amax_acc(gm, o.x), o.y), o.z), o.w);
       sums[c] += __builtin_fmaf(g.x, v.x, __builtin_fmaf(g.y, v.y, __builtin_fmaf(g.z, v.z, g.w * v.w)));
     }
   }
@@ -224,14 +236,14 @@ int dvd_gscale_end(float* state, dvd_stream_t stream) {
   return DVD_OK;
 }
 
-int dvd_head1x1_fwd(const void* x, int f16, const float* w, const float* bias, float* y, int N, int C, int HW, int relu_in,
-                    dvd_stream_t stream) {
+int dvd_head1x1_fwd(const void* x, int f16, const float* w, const float* bias, float* y, float* fwd_amax, int N, int C, int HW,
+                    int relu_in, dvd_stream_t stream) {
   DVD_REQUIRE(x && w && y, "head1x1 fwd: null pointer");
   DVD_REQUIRE(N > 0 && C > 0 && C <= dvd::kHeadMaxC && HW > 0 && (HW & 3) == 0, "head1x1 fwd: bad shape N=%d C=%d HW=%d (C <= 64, HW %% 4 == 0)", N, C, HW);
   const long long total = (long long)N * (HW / 4);
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::head1x1_fwd_kernel<T>, dim3(dvd::blocks_for(total)), dim3(256), 0,
                                          static_cast<hipStream_t>(stream), static_cast<const T*>(x), w, bias, y, C, HW / 4, total,
-                                         relu_in));
+                                         relu_in, fwd_amax));
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -8,15 +8,15 @@ namespace dvd {
 // `head` leading elements bring x to a 16-byte boundary (a contiguous batch slice of odd-sized planes is only 4-byte aligned)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int head, long long n, float* __restrict__ out) {
   float m = 0.0f;
-  if (blockIdx.x == 0 && threadIdx.x < head) m = fabsf(x[threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x < head) m = amax_acc(m, x[threadIdx.x]);
   x += head;
   n -= head;
   const long long nv = n >> 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = amax_acc(amax_acc(amax_acc(amax_acc(m, v.x), v.y), v.z), v.w);       // (NaN -> +Inf: see amax_acc)
   }
-  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) m = fmaxf(m, fabsf(x[(nv << 2) + threadIdx.x]));
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) m = amax_acc(m, x[(nv << 2) + threadIdx.x]);
   wave_amax_to(m, out);
 }
 

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const T* __restrict__ g
         g.w = o.w > 0.0f ? g.w : 0.0f;
       }
       sg += (g.x + g.y) + (g.z + g.w);
-      gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(g.x), fabsf(g.y))), fmaxf(fabsf(g.z), fabsf(g.w)));
+      gmax = amax_acc(amax_acc(amax_acc(amax_acc(gmax, g.x), g.y), g.z), g.w);
       if (x) {
         const float4 v = ld4(x + base + i);
         sgx = __builtin_fmaf(g.x, v.x - mu,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_kernel(const T* __restrict__ g
       float g = ldf(gy + base + i);
       if (relu) g = ldf(y + base + i) > 0.0f ? g : 0.0f;
       sg += g;
-      gmax = fmaxf(gmax, fabsf(g));
+      gmax = amax_acc(gmax, g);
       if (x) sgx = __builtin_fmaf(g, ldf(x + base + i) - mu, sgx);
       if (gres) stf(gres + base + i, g);
       if (gx) stf(gx + base + i, g * s);

@@ -26,11 +26,27 @@ int zero_words(void* p, int n_words, hipStream_t stream) {
   return DVD_OK;
 }
 
+// Algorithmic-work accounting of the matrix kernels (round 5; bench.py's roofline_mfma): every launch of a convolution /
+// weight-gradient kernel adds its 2 * MACs to the counter of the kernel CLASS it dispatched to, on the host, at launch (or
+// graph-capture) time.  Process wide, relaxed: a measurement aid, not part of any result.
+static double g_flops[DVD_FLOP_CLASSES] = {0};
+void flops_add(int cls, double flops) {
+  if (cls >= 0 && cls < DVD_FLOP_CLASSES) g_flops[cls] += flops;
+}
+
 }  // namespace dvd
 
 extern "C" {
 
 int dvd_abi_version(void) { return DVD_ABI_VERSION; }
+
+int dvd_flop_counters(double* out, int n, int reset) {
+  DVD_REQUIRE(out && n > 0, "flop_counters: null output");
+  for (int i = 0; i < n; ++i) out[i] = i < DVD_FLOP_CLASSES ? dvd::g_flops[i] : 0.0;
+  if (reset)
+    for (int i = 0; i < DVD_FLOP_CLASSES; ++i) dvd::g_flops[i] = 0.0;
+  return DVD_OK;
+}
 
 const char* dvd_last_error(void) { return dvd::g_err; }
 

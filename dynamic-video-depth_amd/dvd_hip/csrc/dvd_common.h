@@ -11,6 +11,7 @@ namespace dvd {
 
 void set_error(const char* fmt, ...);
 int zero_words(void* p, int n_words, hipStream_t stream);   // device-side clear by a kernel (core.hip)
+void flops_add(int cls, double flops);                       // algorithmic-work accounting per kernel class (core.hip)
 
 #define DVD_REQUIRE(cond, ...)             \
   do {                                     \
@@ -60,6 +61,14 @@ __device__ __forceinline__ void rowvec_mat3_T(const float g0, const float g1, co
   o0 = g0 * M[0] + g1 * M[1] + g2 * M[2];
   o1 = g0 * M[3] + g1 * M[4] + g2 * M[5];
   o2 = g0 * M[6] + g1 * M[7] + g2 * M[8];
+}
+
+// max|.| accumulation that keeps a NaN: fmaxf (and an unsigned atomicMax of the bit pattern's magnitude order) DROP a NaN
+// operand, so every observed-maximum reduction the fp16 overflow guard and the operand scales look at records a NaN as
+// +Inf, which all later fmaxf / atomicMax steps keep (a NaN gradient used to leave the skip flag at 0).
+__device__ __forceinline__ float amax_acc(float m, float v) {
+  const float a = fabsf(v);
+  return fmaxf(m, a == a ? a : __builtin_inff());
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -750,7 +750,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
               *reinterpret_cast<float4*>(yb + o) = make_float4(v[0], v[1], v[2], v[3]);
             }
 #pragma unroll
-            for (int e = 0; e < PXL; ++e) ymax = fmaxf(ymax, fabsf(v[e]));
+            for (int e = 0; e < PXL; ++e) ymax = amax_acc(ymax, v[e]);
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
         const int co = cob + (r & 3) + 8 * (r >> 2);
         if (pok && (full || co < a.Cout)) {
           yb[o0 + ((r & 3) + 8 * (r >> 2)) * iplane] = (TY)v[r];
-          ymax = fmaxf(ymax, fabsf(v[r]));
+          ymax = amax_acc(ymax, v[r]);
         }
       }
     }
@@ -929,9 +929,14 @@ static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t 
     DVD_LAUNCH_OK();
     return DVD_OK;
   };
+  const double flops = 2.0 * a.N * (double)a.G * a.Cout * a.Cin * a.T * (double)a.H * a.W;      // (a.Cin / a.Cout: per group)
   if constexpr (TM >= 4 && !B1 && FAST && DVD_XCONV_ROLL != 0) {
-    if (a.T == 1 && FI == 1 && g_xcfg != 6) return go(xconv_kernel<TM, TN, WM, WN, kXFitOne, FAST, B1, IN16, OUT16>);
+    if (a.T == 1 && FI == 1 && g_xcfg != 6) {
+      flops_add(DVD_FLOP_XCONV_1X1_WIDE, flops);
+      return go(xconv_kernel<TM, TN, WM, WN, kXFitOne, FAST, B1, IN16, OUT16>);
+    }
   }
+  flops_add(TM >= 4 ? DVD_FLOP_XCONV_WIDE : (WM == 2 ? DVD_FLOP_XCONV_128 : DVD_FLOP_XCONV_SMALL), flops);
   switch (FI) {
     case 1: return go(xconv_kernel<TM, TN, WM, WN, 1, FAST, B1, IN16, OUT16>);
     case 2: return go(xconv_kernel<TM, TN, WM, WN, 2, FAST, B1, IN16, OUT16>);

@@ -1217,6 +1217,7 @@ static int xwgrad3_impl(const void* x, const float* x_amax, const void* gy, cons
   // whole 16-byte staging items (and 64 channels of one image within a 31-bit buffer range): the branch-free row step
   const bool fw = (!h16 || W % 2 == 0) && (long long)64 * H * W * (h16 ? 2 : 4) < (1ll << 31) && dvd::g_w3_variant != 1;
   int e;
+  dvd::flops_add(small ? DVD_FLOP_XWGRAD3G : DVD_FLOP_XWGRAD3, 2.0 * 9 * N * (double)Cout_total * Cin * (double)H * W);
   if (small) e = h16 ? go(dvd::xwgrad3g_kernel<true>) : go(dvd::xwgrad3g_kernel<false>);
   else if (h16) e = fw ? go(dvd::xwgrad3_kernel<true, true>) : go(dvd::xwgrad3_kernel<true, false>);
   else e = fw ? go(dvd::xwgrad3_kernel<false, true>) : go(dvd::xwgrad3_kernel<false, false>);
@@ -1308,6 +1309,7 @@ int dvd_xwgradk(const float* x, const float* x_amax, const float* gy, const floa
     DVD_LAUNCH_OK();
     return DVD_OK;
   };
+  dvd::flops_add(DVD_FLOP_XWGRADK, 2.0 * KS * KS * N * (double)Cout * Cin * (double)H * W);
   if (KS == 5) {
     if (int e = go(dvd::xwgradk_kernel<5, 0, 5>, 5)) return e;
   } else if (KS == 7) {
@@ -1387,6 +1389,7 @@ static int xwgrad1s_impl(const void* x, const float* x_amax, const void* gy, con
       hipLaunchKernelGGL(kern, grid, dim3(512), dvd::kWbLds, s, a);
       return DVD_OK;
     };
+    dvd::flops_add(DVD_FLOP_XWGRAD1B, 2.0 * N * (double)Cout * Cin * (double)H * W);
     // whole 16-pixel chunks, 256 channel rows of one image inside a 31-bit buffer range
     const bool fw = (H * W) % 16 == 0 && (long long)256 * H * W * (h16 ? 2 : 4) < (1ll << 31) && dvd::g_w3_variant != 1;
     int e;
@@ -1425,6 +1428,7 @@ static int xwgrad1s_impl(const void* x, const float* x_amax, const void* gy, con
   a.out_scale = out_scale;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = (size_t)2 * 2 * dvd::kW1CB * dvd::kW1Pitch;
+  dvd::flops_add(DVD_FLOP_XWGRAD1S, 2.0 * N * (double)Cout * Cin * (double)H * W);
   if (h16) {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(dvd::xwgrad1s_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -55,7 +55,13 @@ def head_room_fraction(world):
     memory, parallel.init_from_env, so its channel / staging buffers are already counted as used).  Single process: 8 % (23 GB
     of 288); data parallel: 10 % (29 GB), derated automatically -- the benchmark configuration still keeps both of its slots
     (225 GB free - 60 GB slot >= 130 GB of stashes + 29 GB)."""
-    return 0.08 if world <= 1 else 0.10
+    frac = 0.08 if world <= 1 else 0.10
+    # DVD_HEAD_ROOM_GB: an explicit head room (GB of a 288 GB device) for runs that must leave more to other tenants of the
+    # device -- the 8-rank run's RCCL buffers when the communicator is created late, or a memory-capped deployment
+    gb = os.environ.get('DVD_HEAD_ROOM_GB')
+    if gb:
+        frac = max(frac, float(gb) * 2 ** 30 / float(288 * 2 ** 30))
+    return frac
 
 
 def keep_slot_fits(est, free, total, reserve, spare, kept, budget, head_room=0.08):
@@ -155,6 +161,7 @@ class Model(NetInterface):
         self._flat_depth = self._flat_sf = None     # created by .to(device)
         self._optimizers = []
         self._depth_graphs = {}
+        self._graph_flops = {}          # id(CUDAGraph) -> algorithmic work per kernel class, counted at its capture
         self._keep_bytes = 0         # HBM held by kept-activation graph slots
         self._keep_per_px = 0.0      # measured bytes per image pixel of a captured slot
         self._pool_bytes = 0         # HBM reserved by the private pools of all captured graphs
@@ -235,6 +242,7 @@ class Model(NetInterface):
             # the capture; the step also keeps collectives out of flight while a graph is being captured
             mode = dict(capture_error_mode='thread_local')
             ops.begin_capture()
+            f0 = ops.flop_counters()       # (bench.py roofline_mfma: the graph's algorithmic work, added at every replay)
             if kind == 'f':
                 with torch.no_grad(), torch.cuda.graph(graph, **mode):
                     static_out = self._depth_forward(static_in, fid)
@@ -252,6 +260,7 @@ class Model(NetInterface):
                     self._flat_depth.absorb_grads()
                 entry = (graph, static_in, static_out, static_g)
                 self._flat_depth.grad.copy_(grad_backup)   # warm-up / capture passes used zero output gradients
+            self._graph_flops[id(graph)] = ops.flops_since(f0)
             self._pool_bytes += self._pool_size(graph.pool(), img.device)
         except Exception as e:                             # noqa: BLE001 -- capture is an optimisation only
             warnings.warn('depth-net HIP graph capture failed (%s); running eagerly' % (str(e).splitlines()[0],))
@@ -323,15 +332,19 @@ class Model(NetInterface):
             pool = torch.cuda.graph_pool_handle()
             g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             ops.begin_capture()
+            f0 = ops.flop_counters()
             with torch.cuda.graph(g_f, pool=pool, **mode):
                 with torch.enable_grad():
                     static_out = self._depth_forward(static_in, fid)
+            self._graph_flops[id(g_f)] = ops.flops_since(f0)
             static_g = torch.zeros(chunk.shape[0], 1, chunk.shape[2], chunk.shape[3], device=chunk.device)
             self._flat_depth.detach_grads()
             ops.begin_capture()         # its own generation: g_b's scalars are zero-filled by g_b's replay
+            f0 = ops.flop_counters()
             with torch.cuda.graph(g_b, pool=pool, **mode):
                 static_out.backward(static_g)
                 self._flat_depth.absorb_grads()
+            self._graph_flops[id(g_b)] = ops.flops_since(f0)
             self._flat_depth.grad.copy_(grad_backup)
             used = self._pool_size(pool, chunk.device)
             self._keep_bytes += used
@@ -393,6 +406,7 @@ class Model(NetInterface):
             if e is not None:
                 e[2].copy_(chunk)
                 e[0].replay()
+                ops.note_replay(self._graph_flops.get(id(e[0])))
                 out.append(e[3].detach().clone())
             else:
                 out.append(self._depths_nograd(chunk, fid))
@@ -412,6 +426,7 @@ class Model(NetInterface):
                 if g is not None:
                     g[1].copy_(chunk)
                     g[0].replay()
+                    ops.note_replay(self._graph_flops.get(id(g[0])))
                     out.append(g[2].clone())
                 else:
                     out.append(self._depth_forward(chunk, fid))
@@ -426,12 +441,14 @@ class Model(NetInterface):
             if kept is not None:                        # the forward of phase 1 left this chunk's graph state in its slot
                 kept[4].copy_(g_depth[b0:b0 + c])
                 kept[1].replay()
+                ops.note_replay(self._graph_flops.get(id(kept[1])))
                 continue
             g = self._capture_depth_graph('fb', chunk, fid) if self._use_graphs(chunk, fid) else None
             if g is not None:
                 g[1].copy_(chunk)
                 g[3].copy_(g_depth[b0:b0 + c])
                 g[0].replay()
+                ops.note_replay(self._graph_flops.get(id(g[0])))
                 continue
             self._flat_depth.detach_grads()          # one multi-tensor accumulation per chunk instead of ~620 adds
             with torch.enable_grad():

@@ -216,6 +216,53 @@ def warp_loss_fused(cfg, depth_1, depth_2, flow_1_2, mask_2, sf_1_2, cams, grads
     return sums, g1, g2, gs
 
 
+FLOP_CLASSES = ('xconv_1x1_wide', 'xconv_wide', 'xconv_128', 'xconv_small', 'xwgrad3', 'xwgrad3g', 'xwgrad1b', 'xwgrad1s',
+                'xwgradk', 'mlp_fwd', 'mlp_bwd_dx', 'mlp_bwd_dw')
+# kernel-name fragments (mangled names of a rocprofv3 trace) of each class: tools/mfma_roofline.py joins a trace on these
+FLOP_CLASS_KERNELS = {
+    'xconv_1x1_wide': ('xconv_kernelILi4ELi2ELi2ELi2ELi11E',),
+    'xconv_wide': ('xconv_kernelILi4ELi2ELi2ELi4E', 'xconv_kernelILi4ELi2ELi2ELi2ELi0E', 'xconv_kernelILi4ELi2ELi2ELi2ELi1E',
+                   'xconv_kernelILi4ELi2ELi2ELi2ELi2E', 'xconv_kernelILi4ELi2ELi2ELi2ELi3E'),
+    'xconv_128': ('xconv_kernelILi2ELi2ELi2ELi2E',),
+    'xconv_small': ('xconv_kernelILi1ELi2ELi1ELi4E', 'xconv_kernelILi2ELi2ELi1ELi4E'),
+    'xwgrad3': ('xwgrad3_kernel',), 'xwgrad3g': ('xwgrad3g_kernel',), 'xwgrad1b': ('xwgrad1b_kernel',),
+    'xwgrad1s': ('xwgrad1s_kernel',), 'xwgradk': ('xwgradk_kernel',),
+    'mlp_fwd': ('mlp_fwd_kernel',), 'mlp_bwd_dx': ('mlp_bwd_dx_kernel',), 'mlp_bwd_dw': ('mlp_bwd_dw_kernel',),
+}
+
+
+def flop_counters(reset=False):
+    """Algorithmic work (2 x MACs) the matrix kernels were launched with since the last reset, per kernel class
+    (include/dvd_hip.h: dvd_flop_counters).  Counted at launch / graph-capture time: read it after a step that CAPTURED (or
+    ran eagerly) everything a step launches."""
+    lib = _lib.load()
+    buf = (ctypes.c_double * len(FLOP_CLASSES))()
+    _lib.check(lib.dvd_flop_counters(ctypes.cast(buf, ctypes.c_void_p), len(FLOP_CLASSES), 1 if reset else 0), 'dvd_flop_counters')
+    return dict(zip(FLOP_CLASSES, [float(v) for v in buf]))
+
+
+# work of REPLAYED HIP graphs: a graph's launches are counted once, when it is captured (flops_since around the capture);
+# whoever replays it adds that record here, so that (flop_counters + REPLAYED) over a region is the work the region executed
+REPLAYED = {k: 0.0 for k in FLOP_CLASSES}
+
+
+def flops_since(snapshot):
+    now = flop_counters()
+    return {k: now[k] - snapshot.get(k, 0.0) for k in FLOP_CLASSES}
+
+
+def note_replay(flops):
+    if flops:
+        for k, v in flops.items():
+            REPLAYED[k] += v
+
+
+def executed_flops():
+    """Per kernel class: work launched eagerly plus work of replayed graphs, since process start (take differences)."""
+    now = flop_counters()
+    return {k: now[k] + REPLAYED[k] for k in FLOP_CLASSES}
+
+
 def warp_loss_select(variant='tiled', tile=-1, px=0):
     """Test hook: run dvd_warp_loss_fused on another variant ('direct' = global gathers + hardware atomics), tile
     shape or pixels-per-step mapping.  Process wide; call warp_loss_select() to restore the production path."""

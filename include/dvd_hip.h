@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DVD_ABI_VERSION 4
+#define DVD_ABI_VERSION 5
 
 typedef void* dvd_stream_t; /* hipStream_t */
 
@@ -47,6 +47,27 @@ int dvd_abi_version(void);
 const char* dvd_last_error(void);
 /* Static properties the host needs for sizing (CU count etc.). */
 int dvd_device_cu_count(void);
+
+/* Algorithmic work (2 x multiply-accumulates) the matrix kernels were LAUNCHED with since the last reset, per kernel class --
+ * the class is the template the dispatcher picked, so a profiler trace's per-kernel time and this table join on the kernel
+ * name (bench.py `roofline_mfma`, tools/mfma_roofline.py).  Counted on the host at launch / graph-capture time; a replayed
+ * graph does not count again.  Measurement aid with no counterpart in the reference; out[i] = class i, n <= DVD_FLOP_CLASSES. */
+enum {
+  DVD_FLOP_XCONV_1X1_WIDE = 0, /* xconv_kernel<4,2,2,2,FitOne>: 1x1, >= 256 rows, one position tile per block row       */
+  DVD_FLOP_XCONV_WIDE = 1,     /* xconv_kernel<4,2,2,{2,4},*>: >= 256 output rows per group (3x3 and larger, other 1x1)   */
+  DVD_FLOP_XCONV_128 = 2,      /* xconv_kernel<2,2,2,2,*>: 128 x 128 blocks                                                */
+  DVD_FLOP_XCONV_SMALL = 3,    /* xconv_kernel<{1,2},2,1,4,*>: <= 64 rows per group (grouped 3x3 of ResNeXt, thin layers)  */
+  DVD_FLOP_XWGRAD3 = 4,        /* xwgrad3_kernel: dense 3x3 weight gradient                                                */
+  DVD_FLOP_XWGRAD3G = 5,       /* xwgrad3g_kernel: grouped 3x3 weight gradient                                             */
+  DVD_FLOP_XWGRAD1B = 6,       /* xwgrad1b_kernel: wide 1x1 weight gradient                                                */
+  DVD_FLOP_XWGRAD1S = 7,       /* xwgrad1s_kernel: other 1x1 weight gradients                                              */
+  DVD_FLOP_XWGRADK = 8,        /* xwgradk_kernel: 5x5 / 7x7 / 11x11 weight gradients                                       */
+  DVD_FLOP_MLP_FWD = 9,        /* mlp_fwd_kernel                                                                           */
+  DVD_FLOP_MLP_DX = 10,        /* mlp_bwd_dx_kernel                                                                        */
+  DVD_FLOP_MLP_DW = 11,        /* mlp_bwd_dw_kernel                                                                        */
+  DVD_FLOP_CLASSES = 12
+};
+int dvd_flop_counters(double* out, int n, int reset);
 
 /* Camera block of a batch of frame pairs (the eight tensors the reference
  * forwards take by name: losses/scene_flow_projection.py:114,222). */
@@ -443,8 +464,10 @@ int dvd_gconv3x3_c8_bwd_weight_t(const void* x, const void* gy, float* gw, int a
 /* The depth head `ReLU -> Conv2d(C, 1, 1)` (third_party/MiDaS.py:192-194), the fp16 / fp32 boundary: y fp32 [N,1,H,W] from
  * x [N,C,H,W] (C <= 64, H * W % 4 == 0); backward: gx = S * w[c] * gy * [x > 0] (storage of x), gw [C], gb [1] fp32 from the
  * unscaled fp32 gy; gscale_state: the loss-scale state (null: S = 1).  Deterministic (fixed-order partial sums). */
-int dvd_head1x1_fwd(const void* x, int f16, const float* w, const float* bias, float* y, int N, int C, int HW, int relu_in,
-                    dvd_stream_t stream);
+/* fwd_amax (optional): max |y| of the head output is folded into it (NaN counted as +Inf) -- slot [6] of the loss-scale state,
+ * the forward monitor of the fp16 overflow guard. */
+int dvd_head1x1_fwd(const void* x, int f16, const float* w, const float* bias, float* y, float* fwd_amax, int N, int C, int HW,
+                    int relu_in, dvd_stream_t stream);
 size_t dvd_head1x1_bwd_workspace_bytes(int C);
 int dvd_head1x1_bwd(const void* x, int f16, const float* w, const float* gy, const float* gscale_state, void* gx, float* gw,
                     float* gb, void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu_in, dvd_stream_t stream);

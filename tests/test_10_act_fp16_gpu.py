@@ -408,6 +408,52 @@ def test_fp16_step_graph_replay_matches_eager():
         assert abs(logs[a][0] - logs[b][0]) <= 5e-4 * abs(logs[a][0]) and abs(logs[a][1] - logs[b][1]) <= 2e-2 * logs[a][1], logs
 
 
+@pytest.mark.parametrize('where,value', [('activation', float('inf')), ('activation', float('nan')),
+                                         ('gradient', float('nan')), ('gradient', float('inf'))])
+def test_non_finite_fp16_values_skip_the_step(where, value):
+    """the overflow guard must see NaNs and FORWARD overflows.  A non-finite value planted in an fp16
+    activation (a forward hook on a decoder convolution) or in an fp16 activation gradient (a tensor hook) must set the skip
+    flag -- every observed-maximum reduction records a NaN as +Inf (csrc/dvd_common.h amax_acc), the fp16-output convolution
+    epilogues and the depth head fold max|y| into the forward monitor (state[6]) -- and the guarded Adam step must leave the
+    depth net's parameters untouched.  A clean step on the same model right after is NOT skipped."""
+    import test_30_full_step_gpu as T30
+    import helpers
+    gd = helpers.load_golden('fullstep_midas_b1_64x96_train')
+    model, opt, batch = T30._build(gd, act_fp16=True, depth_graphs=0)
+    net = model.net_depth
+    target = net.scratch.refinenet3           # a fusion block in the middle of the decoder (called as a module), fp16 in and out
+    state = {'armed': True}
+
+    def plant(t):
+        t = t.clone()
+        t.view(-1)[t.numel() // 3] = value
+        return t
+
+    def fwd_hook(mod, inp, out):
+        if not state['armed']:
+            return None
+        assert out.dtype == torch.float16
+        if where == 'activation':
+            return plant(out)
+        out.register_hook(lambda g: plant(g) if state['armed'] else g)
+        return None
+    h = target.register_forward_hook(fwd_hook)
+    before = [p.detach().clone() for p in net.parameters()]
+    log = model._train_on_batch(int(gd['epoch']), 0, helpers.loader_batch(dict(batch)))
+    torch.cuda.synchronize()
+    st = model._gscale.tolist()
+    assert st[4] == 1.0 and st[5] == 1.0, 'the step with a non-finite %s was not skipped: state %r' % (where, st)
+    for p, b in zip(net.parameters(), before):
+        assert torch.equal(p.detach(), b), 'a skipped step changed the depth net'
+    state['armed'] = False
+    log = model._train_on_batch(int(gd['epoch']), 1, helpers.loader_batch(dict(batch)))
+    torch.cuda.synchronize()
+    st = model._gscale.tolist()
+    h.remove()
+    assert st[4] == 0.0 and st[5] == 1.0 and np.isfinite(log['loss']), st
+    assert any(not torch.equal(p.detach(), b) for p, b in zip(net.parameters(), before))
+
+
 # ---- the scene-flow MLP's fp16 stash ----------------------------------------------------------------------------------
 def test_mlp_fp16_stash_changes_only_the_weight_gradients():
     """dvd_mlp_desc.stash_f16: the hidden activations h_0 .. h_4 of the stash are stored as fp16 (networks/sceneflow_field.py:43-53
