@@ -104,8 +104,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    const float* __restrict__ sa_ptr, const float* __restrict__ g2,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
                                                    float b1, float b2, float eps, float step_size, float inv_sqrt_bc2,
-                                                   const float* __restrict__ skip) {
+                                                   const float* __restrict__ skip, int step, float lr) {
   if (skip && skip[0] != 0.0f) return;       // fp16 gradient overflow in this step (csrc/a16.hip): no update, moments untouched
+  // Steps skipped EARLIER (skip[1], the loss-scale state's count) did not touch the moments, so Adam's bias correction must
+  // not count them either: the effective step is step - skipped, like torch.amp's GradScaler, which does not advance the
+  // optimiser on a skipped step.  The host's double-precision factors are used unchanged when nothing
+  // was skipped; otherwise one thread per block redoes that arithmetic.
+  __shared__ float bc[2];
+  const int skipped = skip ? (int)skip[1] : 0;
+  if (skipped > 0) {
+    if (threadIdx.x == 0) {
+      const double se = (double)(step - skipped > 1 ? step - skipped : 1);
+      bc[0] = (float)((double)lr / (1.0 - pow((double)b1, se)));
+      bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)b2, se)));
+    }
+    __syncthreads();
+    step_size = bc[0];
+    inv_sqrt_bc2 = bc[1];
+  }
   const float s = sa * (sa_ptr ? sa_ptr[0] : 1.0f);
   const long long n4 = n >> 2;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -208,7 +224,7 @@ int dvd_adam_step_guarded(float* param, const float* grad1, float scale, const f
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, static_cast<hipStream_t>(stream), param, grad1,
-                     scale, scale_ptr, grad2, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_sqrt_bc2, skip_flag);
+                     scale, scale_ptr, grad2, exp_avg, exp_avg_sq, n, beta1, beta2, eps, step_size, inv_sqrt_bc2, skip_flag, step, lr);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -1046,7 +1046,7 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   a.out_scale = out_scale;
   const int grid = persistent_grid(a.n_tiles, DVD_MLP_FWD_OCC);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  flops_add(DVD_FLOP_MLP_FWD, 2.0 * ((double)a.g.c_in * kHidden + 4.0 * kHidden * kHidden + 3.0 * kHidden) * (double)n_pix);
+  flops_add(DVD_FLOP_MLP_FWD, 2.0 * ((double)a.g.c_in * kWidth + 4.0 * kWidth * kWidth + 3.0 * kWidth) * (double)n_pix);
   if (stash)   // per-layer maxima behind the tiles (embedding, h_0 .. h_4; the dX kernel zeroes its own half)
     if (int e = zero_words(a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, a.g.s16 != 0), kStashTail, s)) return e;
   auto go = [&](auto kern) -> int {
@@ -1098,7 +1098,7 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
   if (int e = zero_words(const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, a.g.s16 != 0) + 8, 8,
                          static_cast<hipStream_t>(stream)))
     return e;
-  flops_add(DVD_FLOP_MLP_DX, 2.0 * ((double)a.g.c_in * kHidden + 4.0 * kHidden * kHidden + 3.0 * kHidden) * (double)a.n_pix);
+  flops_add(DVD_FLOP_MLP_DX, 2.0 * ((double)a.g.c_in * kWidth + 4.0 * kWidth * kWidth + 3.0 * kWidth) * (double)a.n_pix);
   if (a.g.s16) {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
@@ -1134,7 +1134,7 @@ int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, void* gstash, lo
   r.S = a.S;
   r.c_in = a.g.c_in;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  flops_add(DVD_FLOP_MLP_DW, 2.0 * ((double)a.g.c_in * kHidden + 4.0 * kHidden * kHidden + 3.0 * kHidden) * (double)n_pix);
+  flops_add(DVD_FLOP_MLP_DW, 2.0 * ((double)a.g.c_in * kWidth + 4.0 * kWidth * kWidth + 3.0 * kWidth) * (double)n_pix);
   if (a.g.s16) {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kDwLds));

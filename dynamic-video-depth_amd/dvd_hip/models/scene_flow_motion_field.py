@@ -757,8 +757,11 @@ class Model(NetInterface):
             if self._gscale is not None:
                 # fp16 gradients: did this step stay inside fp16 range?  (device-side decision; with several ranks an
                 # overflow anywhere skips the update everywhere)
-                if parallel.is_distributed():
-                    torch.distributed.all_reduce(self._gscale[3:4], op=torch.distributed.ReduceOp.MAX)
+                if parallel.is_distributed():          # both monitors: gradients [3], forward activations [6]
+                    both = torch.stack([self._gscale[3], self._gscale[6]])
+                    torch.distributed.all_reduce(both, op=torch.distributed.ReduceOp.MAX)
+                    self._gscale[3:4].copy_(both[0:1])
+                    self._gscale[6:7].copy_(both[1:2])
                 ops.gscale_end(self._gscale)
                 skip = self._gscale[4:5]
             self._flat_depth.all_reduce_and_adam_step(getattr(opt, 'grad_buckets', 4), skip_ptr=skip)
@@ -766,7 +769,9 @@ class Model(NetInterface):
             k.all_reduce_grads()
         if h_sf is not None:
             h_sf.wait()
-        k.adam_step()
+        # (fp16 activations: a skipped step skips BOTH updates -- an activation that overflowed fp16 makes the depth map, and
+        #  with it the scene-flow network's gradient, non-finite too; round 4 guarded the depth net only)
+        k.adam_step(skip_ptr=None if (warm or self._gscale is None) else self._gscale[4:5])
 
         host = torch.cat([scalars, sums[4:5]]).tolist()          # the only host synchronisation of the step
         acc_reg = opt.acc_mul * host[8] / (3.0 * n_global * HW + 1e-6) if do_reg else 0
@@ -838,8 +843,11 @@ class Model(NetInterface):
             self._depth_backward(inp.img_2, fid2, g_d2, slot0=n_slots)
             skip = None
             if self._gscale is not None:
-                if parallel.is_distributed():
-                    torch.distributed.all_reduce(self._gscale[3:4], op=torch.distributed.ReduceOp.MAX)
+                if parallel.is_distributed():          # both monitors: gradients [3], forward activations [6]
+                    both = torch.stack([self._gscale[3], self._gscale[6]])
+                    torch.distributed.all_reduce(both, op=torch.distributed.ReduceOp.MAX)
+                    self._gscale[3:4].copy_(both[0:1])
+                    self._gscale[6:7].copy_(both[1:2])
                 ops.gscale_end(self._gscale)
                 skip = self._gscale[4:5]
             self._flat_depth.all_reduce_and_adam_step(getattr(opt, 'grad_buckets', 4), skip_ptr=skip)
@@ -847,7 +855,9 @@ class Model(NetInterface):
             k.all_reduce_grads()
         if h_sf is not None:
             h_sf.wait()
-        k.adam_step()
+        # (fp16 activations: a skipped step skips BOTH updates -- an activation that overflowed fp16 makes the depth map, and
+        #  with it the scene-flow network's gradient, non-finite too; round 4 guarded the depth net only)
+        k.adam_step(skip_ptr=None if (warm or self._gscale is None) else self._gscale[4:5])
         host = torch.cat([scalars, sums[4:5]]).tolist()
         acc_reg = opt.acc_mul * host[8] / (3.0 * n_global * HW + 1e-6) if do_reg else 0
         batch_log = {'size': opt.batch_size, 'loss': host[1] / mul, 'total_loss': host[1] / mul, 'flow_loss_1_2': host[2],

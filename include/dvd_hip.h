@@ -472,15 +472,18 @@ size_t dvd_head1x1_bwd_workspace_bytes(int C);
 int dvd_head1x1_bwd(const void* x, int f16, const float* w, const float* gy, const float* gscale_state, void* gx, float* gw,
                     float* gb, void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu_in, dvd_stream_t stream);
 /* Loss scale of the fp16 gradients, kept on the device (state: 8 floats; [0] = S, [1] = 1 / S, [2] = target exponent,
- * [3] = observed max |S g| this step, [4] = skip flag, [5] = skipped steps).  begin: S = 2^(target - ceil(log2(max|g| * max|w|)))
+ * [3] = observed max |S g| this step, [4] = skip flag, [5] = skipped steps, [6] = forward monitor: max |activation| the fp16-output
+ * convolution epilogues and the depth head folded in this step -- every maximum counts a NaN as +Inf).  begin: S = 2^(target - ceil(log2(max|g| * max|w|)))
  * from the device scalar max|g_out| and the n_w head weights; end (once per step, before the optimiser): overflow -> skip flag +
- * back-off, small observed maximum -> raise the target.  Policy and thresholds: csrc/a16.hip. */
+ * back-off, small observed maximum -> raise the target; an ACTIVATION beyond fp16's range ([6] >= 65504) -> skip flag only.  Policy and thresholds: csrc/a16.hip. */
 int dvd_gscale_init(float* state, float target_exponent, dvd_stream_t stream);
 int dvd_gscale_begin(float* state, const float* g_amax, const float* w, int n_w, dvd_stream_t stream);
 int dvd_gscale_end(float* state, dvd_stream_t stream);
 /* out[i] = scale[0] * in[i] as fp32 (n % 4 == 0): the gradient leaving the fp16 region towards the fp32 stem. */
 int dvd_cast_scale_f32(const void* in, int f16, float* out, long long n, const float* scale, dvd_stream_t stream);
-/* dvd_adam_step that does nothing when skip_flag[0] != 0 (state[4] above): the GradScaler "skipped step". */
+/* dvd_adam_step that does nothing when skip_flag[0] != 0 (state[4] above): the GradScaler "skipped step".  skip_flag points INTO
+ * the loss-scale state: skip_flag[1] (state[5], the steps skipped so far) is subtracted from `step` for Adam's bias correction,
+ * so that skipped steps do not advance the optimiser (round 5). */
 int dvd_adam_step_guarded(float* param, const float* grad1, float scale, const float* scale_ptr, const float* grad2,
                           float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2, float eps,
                           int step, const float* skip_flag, dvd_stream_t stream);

@@ -375,7 +375,13 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'trajectory':          # K-step trajectories of the real reference (round 5)
         case_trajectory('traj5_hourglass_b2_32x48', midas=False, B=2, H=32, W=48, gap=1, epoch=6, seed=131)
-        case_trajectory('traj5_midas_b1_64x96', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=137)
+        # MiDaS with the learning rates of the shipped script (experiments/davis/train_sequence.sh:31,51: lr 1e-6, MLP x 1000).
+        # With the one-step fixtures' lr = 1e-4 this 64 x 96 case is chaotic in the REFERENCE itself: two CPU runs of the real
+        # reference that differ only in torch.set_num_threads (2 vs 8) agree to 1e-5 after the second step and to 2 % after the
+        # third (loss 5.756 vs 5.641), 2.5 % after the fifth -- nothing to pin a port to; at the shipped rates the same two runs
+        # agree to 1e-6 over all five steps.
+        case_trajectory('traj5_midas_b1_64x96', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=137,
+                        over=dict(lr=1e-6, scene_lr_mul=1000.0))
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'midas_192x384':       # only the configs[0]-shape fixture (round 2)
         case_full_step('fullstep_midas_b2_192x384_train', midas=True, B=2, H=192, W=384, gap=1, epoch=6, seed=113)
@@ -400,7 +406,8 @@ def main():
                    over=dict(use_cnn=True))
     case_flow_masks('flow_masks')
     case_trajectory('traj5_hourglass_b2_32x48', midas=False, B=2, H=32, W=48, gap=1, epoch=6, seed=131)
-    case_trajectory('traj5_midas_b1_64x96', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=137)
+    case_trajectory('traj5_midas_b1_64x96', midas=True, B=1, H=64, W=96, gap=1, epoch=6, seed=137,
+                    over=dict(lr=1e-6, scene_lr_mul=1000.0))
 
 
 if __name__ == '__main__':

@@ -421,7 +421,11 @@ def test_non_finite_fp16_values_skip_the_step(where, value):
     gd = helpers.load_golden('fullstep_midas_b1_64x96_train')
     model, opt, batch = T30._build(gd, act_fp16=True, depth_graphs=0)
     net = model.net_depth
-    target = net.scratch.refinenet3           # a fusion block in the middle of the decoder (called as a module), fp16 in and out
+    # the first convolution of the output head: fp16 in and out, and its consumers (bilinear up-sampling, a convolution WITHOUT
+    # an input ReLU) pass a non-finite value on.  (Behind most other layers a NaN ACTIVATION is absorbed: the fused kernels
+    # evaluate ReLU as fmaxf(x, 0), which maps NaN to 0 in the forward, in the masks and in the weight gradients alike --
+    # nothing is poisoned and no step needs skipping; torch.relu would have propagated it.)
+    target = net.scratch.output_conv[0]
     state = {'armed': True}
 
     def plant(t):
@@ -435,7 +439,8 @@ def test_non_finite_fp16_values_skip_the_step(where, value):
         assert out.dtype == torch.float16
         if where == 'activation':
             return plant(out)
-        out.register_hook(lambda g: plant(g) if state['armed'] else g)
+        if out.requires_grad:                 # (phase 1 runs the forward without autograd; phase 3 recomputes it with)
+            out.register_hook(lambda g: plant(g) if state['armed'] else g)
         return None
     h = target.register_forward_hook(fwd_hook)
     before = [p.detach().clone() for p in net.parameters()]

@@ -4,9 +4,11 @@ of every step, and the parameters after the fifth.
 
 Every fixture / parity test before round 5 was ONE step (missing 3 / weak 2).  What K steps add: Adam's
 moments and bias correction across steps (flat.py + dvd_adam_step), replayed depth-net graphs following the weights, the
-regulariser's shared evaluations on updated weights -- and the DIRECTION of the loss: on the MiDaS fixture the reference's own
-loss goes UP at the second step (5.818 -> 7.444: a 1e-4 Adam step on a head calibrated for random weights) and comes back, the
-same as the product's; the smoke test's "loss changed" assertion is therefore all one can ask of two steps.
+regulariser's shared evaluations on updated weights -- and the DIRECTION of the loss at every step.  (On the MiDaS case at the
+one-step fixtures' lr = 1e-4 the reference's OWN loss goes up at the second step, 5.818 -> 7.444 -- a 1e-4 Adam step on a head
+calibrated for random weights -- and the product's does the same, 7.4446: the smoke test's "loss changed" assertion is all one
+can ask of two steps there.  That configuration is not a fixture: the reference does not reproduce itself on it beyond the
+second step, see CASES.)
 
 Tolerances: step 0 is the one-step bound (1e-5).  Later steps see parameters that moved by +-lr per element in the direction
 of sign(g): an element whose gradient is within rounding of 0 can move the other way, so the bound grows with the step --
@@ -31,6 +33,8 @@ def _build(gd, **over):
     from dvd_hip.models.scene_flow_motion_field import Model
     o = dict(helpers.FULL_STEP_OPT)
     o.update(midas=bool(gd['midas']), full_logdir='/tmp')
+    if 'over_keys' in gd:                     # option overrides the fixture was generated with
+        o.update({str(k): (bool(v) if isinstance(o.get(str(k)), bool) else float(v)) for k, v in zip(gd['over_keys'], gd['over_vals'])})
     o.update(over)
     opt = SimpleNamespace(**o)
     with pytest.warns(UserWarning):
@@ -65,10 +69,13 @@ def _rel(a, b):
 
 # (fixture, per-step bound on the relative difference of the logged losses, bound on acc_reg, bound on parameter norms)
 CASES = [
-    ('traj5_hourglass_b2_32x48', (1e-5, 2e-4, 5e-4, 1e-3, 2e-3), 2e-2, 1e-4),
-    # the 2 x 3-pixel deepest level of this fixture amplifies ReLU' sign flips (tests/test_30: two CPU runs of the real
-    # reference differ by 3e-4 in one step's gradients), and its second step is a 28 % excursion of the loss
-    ('traj5_midas_b1_64x96', (1e-5, 3e-2, 3e-2, 3e-2, 3e-2), 2e-1, 1e-4),
+    # measured on MI355X (profiles/r05_parity_measured.jsonl): 2.0e-7, 1.1e-7, 7.3e-7, 9.8e-7, 1.1e-5; acc_reg <= 3.6e-5
+    ('traj5_hourglass_b2_32x48', (1e-5, 1e-5, 1e-5, 2e-5, 5e-5), 2e-4, 1e-4),
+    # MiDaS at the shipped learning rates (lr 1e-6, MLP x 1000).  At the one-step fixtures' lr = 1e-4 this case is chaotic in the
+    # REFERENCE itself (two CPU runs of the real reference with 2 and 8 threads: 2 % apart after the third step, its loss
+    # jumping 5.82 -> 7.44 -> 5.6) -- see make_golden.py; at the shipped rates those two runs agree to 1e-6
+    # measured: 4.1e-7, 2.3e-6, 1.9e-5, 2.0e-5, 1.3e-4; acc_reg <= 1.6e-4
+    ('traj5_midas_b1_64x96', (1e-5, 2e-5, 1e-4, 1e-4, 5e-4), 1e-3, 1e-4),
 ]
 
 
@@ -128,8 +135,8 @@ def test_five_steps_fp16_activations_stay_near_the_fp32_reference():
     rels = [_rel(series['loss'][i], float(ref[i])) for i in range(len(ref))]
     print('fp16 trajectory: loss', series['loss'], 'reference', ref.tolist(), 'rel', rels)
     for i, r in enumerate(rels):
-        helpers.log_measured('trajectory/fp16/step%d_loss_rel' % i, r, 2e-3 if i == 0 else 1e-1)
-    assert rels[0] <= 2e-3
-    assert max(rels) <= 1e-1
+        helpers.log_measured('trajectory/fp16/step%d_loss_rel' % i, r, 2e-4 if i == 0 else 3e-3)
+    assert rels[0] <= 2e-4             # measured 1.5e-5
+    assert max(rels) <= 3e-3           # measured 5.5e-4 (third step)
     for i in range(1, len(ref)):
         assert (series['loss'][i] - series['loss'][i - 1]) * (ref[i] - ref[i - 1]) > 0, 'step %d moves the other way' % i
