@@ -45,6 +45,9 @@
 #ifndef DVD_WARP_COMBINE_TILES
 #define DVD_WARP_COMBINE_TILES 1
 #endif
+#ifndef DVD_WARP_COMBINE_MASKED
+#define DVD_WARP_COMBINE_MASKED 1
+#endif
 #ifndef DVD_WARP_V5_EARLY
 #define DVD_WARP_V5_EARLY 0
 #endif
@@ -1360,14 +1363,21 @@ __global__ __launch_bounds__(256) void combine_tiles_kernel(const float* __restr
     const float* p_ver = okj ? p_own + (ptrdiff_t)dj * ntx * (WW * WH) - dj * TH * WW : p_own;
     const float* p_dia = (oki && okj) ? p_own + (ptrdiff_t)(dj * ntx + di) * (WW * WH) - dj * TH * WW - di * TW : p_own;
     // (ext-vector values: a select between two HIP float4 STRUCTS goes through the stack)
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
     const v4f own = *reinterpret_cast<const v4f*>(p_own);
+#if DVD_WARP_COMBINE_MASKED
+    v4f hor = zero, ver = zero, dia = zero;            // lane-masked loads: only the windows that cover the quad are read
+    if (oki) hor = *reinterpret_cast<const v4f*>(p_hor);
+    if (okj) ver = *reinterpret_cast<const v4f*>(p_ver);
+    if (oki && okj) dia = *reinterpret_cast<const v4f*>(p_dia);
+#else
     v4f hor = *reinterpret_cast<const v4f*>(p_hor);
     v4f ver = *reinterpret_cast<const v4f*>(p_ver);
     v4f dia = *reinterpret_cast<const v4f*>(p_dia);
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
     hor = oki ? hor : zero;
     ver = okj ? ver : zero;
     dia = (oki && okj) ? dia : zero;
+#endif
     // fixed order of combine_quad: dj outer (-1, 0, 1), di inner (-1, 0, 1)
     const bool hfirst = di < 0, vfirst = dj < 0;
     const v4f r0a = hfirst ? dia : ver, r0b = hfirst ? ver : dia;      // the neighbouring row of tiles (dj != 0)

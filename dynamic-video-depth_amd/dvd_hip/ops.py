@@ -219,12 +219,15 @@ def warp_loss_fused(cfg, depth_1, depth_2, flow_1_2, mask_2, sf_1_2, cams, grads
 FLOP_CLASSES = ('xconv_1x1_wide', 'xconv_wide', 'xconv_128', 'xconv_small', 'xwgrad3', 'xwgrad3g', 'xwgrad1b', 'xwgrad1s',
                 'xwgradk', 'mlp_fwd', 'mlp_bwd_dx', 'mlp_bwd_dw')
 # kernel-name fragments (mangled names of a rocprofv3 trace) of each class: tools/mfma_roofline.py joins a trace on these
-FLOP_CLASS_KERNELS = {
-    'xconv_1x1_wide': ('xconv_kernelILi4ELi2ELi2ELi2ELi11E',),
+FLOP_CLASS_KERNELS = {          # mangled (rocpd database) and demangled (rocprofv3 csv) spellings
+    'xconv_1x1_wide': ('xconv_kernelILi4ELi2ELi2ELi2ELi11E', 'xconv_kernel<4, 2, 2, 2, 11,'),
     'xconv_wide': ('xconv_kernelILi4ELi2ELi2ELi4E', 'xconv_kernelILi4ELi2ELi2ELi2ELi0E', 'xconv_kernelILi4ELi2ELi2ELi2ELi1E',
-                   'xconv_kernelILi4ELi2ELi2ELi2ELi2E', 'xconv_kernelILi4ELi2ELi2ELi2ELi3E'),
-    'xconv_128': ('xconv_kernelILi2ELi2ELi2ELi2E',),
-    'xconv_small': ('xconv_kernelILi1ELi2ELi1ELi4E', 'xconv_kernelILi2ELi2ELi1ELi4E'),
+                   'xconv_kernelILi4ELi2ELi2ELi2ELi2E', 'xconv_kernelILi4ELi2ELi2ELi2ELi3E', 'xconv_kernel<4, 2, 2, 4,',
+                   'xconv_kernel<4, 2, 2, 2, 0,', 'xconv_kernel<4, 2, 2, 2, 1,', 'xconv_kernel<4, 2, 2, 2, 2,',
+                   'xconv_kernel<4, 2, 2, 2, 3,'),
+    'xconv_128': ('xconv_kernelILi2ELi2ELi2ELi2E', 'xconv_kernel<2, 2, 2, 2,'),
+    'xconv_small': ('xconv_kernelILi1ELi2ELi1ELi4E', 'xconv_kernelILi2ELi2ELi1ELi4E', 'xconv_kernel<1, 2, 1, 4,',
+                    'xconv_kernel<2, 2, 1, 4,'),
     'xwgrad3': ('xwgrad3_kernel',), 'xwgrad3g': ('xwgrad3g_kernel',), 'xwgrad1b': ('xwgrad1b_kernel',),
     'xwgrad1s': ('xwgrad1s_kernel',), 'xwgradk': ('xwgradk_kernel',),
     'mlp_fwd': ('mlp_fwd_kernel',), 'mlp_bwd_dx': ('mlp_bwd_dx_kernel',), 'mlp_bwd_dw': ('mlp_bwd_dw_kernel',),

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-step kernel time of every matrix-kernel class from TWO rocprofv3 --kernel-trace --stats runs of bench.py that differ only
-in --steps: (time_B - time_A) / (steps_B - steps_A) is the steady-state time per step, free of graph-capture / warm-up passes.
+in --steps: (calls_B - calls_A) / (steps_B - steps_A) launches per steady step (graph-capture / warm-up passes cancel) times the
+mean duration of a launch in the longer run (without its slowest launch: first launches pay a code load).
 Joins on the kernel-name fragments of dvd_hip.ops.FLOP_CLASS_KERNELS and writes profiles/mfma_roofline.json, which bench.py
 reads for `roofline_mfma.top_kernels` (the algorithmic work per class is counted live by bench.py itself).
 
@@ -17,11 +18,11 @@ sys.path.insert(0, os.path.join(ROOT, 'dynamic-video-depth_amd'))
 
 
 def load(path):
+    """name -> (calls, total ns, max ns)"""
     out = {}
     for r in csv.DictReader(open(path)):
         name = r.get('Name') or r.get('KernelName') or ''
-        tot = float(r.get('TotalDurationNs') or r.get('TotalDuration(ns)') or 0.0)
-        out[name] = out.get(name, 0.0) + tot
+        out[name] = (int(r.get('Calls') or 0), float(r.get('TotalDurationNs') or 0.0), float(r.get('MaxNs') or 0.0))
     return out
 
 
@@ -37,7 +38,14 @@ def main():
     (na, pa), (nb, pb) = a.a.split(':', 1), a.b.split(':', 1)
     na, nb = int(na), int(nb)
     ta, tb = load(pa), load(pb)
-    per = {k: (tb.get(k, 0.0) - ta.get(k, 0.0)) / float(nb - na) for k in set(ta) | set(tb)}
+    # calls per steady step from the DIFFERENCE of the two runs (graph captures, warm-up passes and set-up steps cancel); the
+    # average duration of a call from the longer run without its single slowest call -- a first launch of a kernel can take
+    # 100+ ms (code load), which as a difference of totals would swamp three steps of real time
+    per = {}
+    for k, (cb, totb, maxb) in tb.items():
+        ca = ta.get(k, (0, 0.0, 0.0))[0]
+        if cb > 1 and cb > ca:
+            per[k] = (cb - ca) / float(nb - na) * (totb - maxb) / (cb - 1)
     total = sum(v for v in per.values() if v > 0)
     classes = []
     for cls, frags in FLOP_CLASS_KERNELS.items():
