@@ -142,9 +142,9 @@ class _ToHalf(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        out = torch.empty(g.shape, device=g.device, dtype=torch.float32)
         if g.numel() % 4:
             return g.float() * _gs(1)
+        out = torch.empty(g.shape, device=g.device, dtype=torch.float32)
         _lib.check(_lib.load().dvd_cast_scale_f32(_p(g), 1, _p(out), ctypes.c_longlong(g.numel()), _p(_gs(1)), _stream()),
                    'dvd_cast_scale_f32')
         return out
@@ -361,10 +361,17 @@ def s2d_weight(w):
     return w_ext.index_select(2, _s2d_index(w.device)).reshape(Co, C * 4, 5, 5)
 
 
+def is_resnet_stem(conv, bn):
+    """The 7x7 / stride 2 / padding 3 convolution + eval-mode BatchNorm that stem_conv_bn_relu implements (any other stem
+    stays on ATen: MidasNet.forward checks this before it takes the native path -- ADVICE round 4)."""
+    return (isinstance(conv, torch.nn.Conv2d) and isinstance(bn, torch.nn.BatchNorm2d) and conv.kernel_size == (7, 7) and
+            conv.stride == (2, 2) and conv.padding == (3, 3) and conv.groups == 1 and conv.dilation == (1, 1) and
+            not bn.training and bn.track_running_stats)
+
+
 def stem_conv_bn_relu(conv, bn, x):
     """relu(bn(conv(x))) for the 7x7 / stride 2 / padding 3 stem convolution and its eval-mode BatchNorm, GPU fp32 tensors."""
-    if not (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.groups == 1 and
-            not bn.training and bn.track_running_stats):
+    if not is_resnet_stem(conv, bn):
         raise RuntimeError('stem_conv_bn_relu: not the ResNet stem (%r)' % (conv,))
     H, W = x.shape[2], x.shape[3]
     if H % 2 or W % 2:                    # the zero row / column the convolution's padding would have supplied

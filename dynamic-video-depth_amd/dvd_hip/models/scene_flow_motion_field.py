@@ -161,6 +161,7 @@ class Model(NetInterface):
         self._flat_depth = self._flat_sf = None     # created by .to(device)
         self._optimizers = []
         self._depth_graphs = {}
+        self._cnn_px_measured = 0.0     # --use_cnn: measured autograd bytes per pixel and U-Net evaluation
         self._graph_flops = {}          # id(CUDAGraph) -> algorithmic work per kernel class, counted at its capture
         self._keep_bytes = 0         # HBM held by kept-activation graph slots
         self._keep_per_px = 0.0      # measured bytes per image pixel of a captured slot
@@ -466,6 +467,15 @@ class Model(NetInterface):
         gap = torch.mean(ts2.float() - ts1.float())
         return int((gap / time_step).round().long().item()), time_step
 
+    def _cnn_bytes_per_px(self):
+        """Autograd state of ONE U-Net evaluation per pixel (--use_cnn): the measured value once a step has run; before that
+        an a-priori figure that grows with the depth of the U-Net -- 2.6 KB per pixel was measured for n_down = 3 on the
+        CPU path; the GPU path's Conv2dBlocks also keep a reflect-padded copy and a sliced .contiguous() copy of their
+        inputs, hence the factor 1.5."""
+        if self._cnn_px_measured > 0:
+            return self._cnn_px_measured
+        return 2600.0 * 1.5 * (1.0 + 0.15 * max(0, int(getattr(self.opt, 'n_down', 3)) - 3))
+
     def _pairs_per_chunk(self, B, HW, steps, with_reg):
         if self._mlp is None:            # --use_cnn: the whole batch goes through the U-Net at once
             return B
@@ -516,8 +526,8 @@ class Model(NetInterface):
             depth_2 = self._depths_nograd(inp.img_2, fid2)
         else:
             Bc0 = self._pairs_per_chunk(B, HW, steps, do_reg)
-            if self._mlp is None:        # --use_cnn: ~2.6 KB of autograd state per pixel and U-Net evaluation
-                mlp_need = B * HW * 2600 * (steps + (1 if do_reg else 0)) + 24 * B * HW * 4
+            if self._mlp is None:        # --use_cnn: autograd state of the U-Net, per pixel and evaluation (measured, below)
+                mlp_need = B * HW * self._cnn_bytes_per_px() * (steps + (1 if do_reg else 0)) + 24 * B * HW * 4
             else:
                 stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
                 mlp_need = min(B * steps * stash + Bc0 * (gstash + (stash if (do_reg and steps == 1) else 0)),
@@ -808,6 +818,15 @@ class Model(NetInterface):
         reg_coef = opt.acc_mul / (3.0 * n_global * HW + 1e-6)
         P1 = ops.unproject(depth_1, inp.R_1, inp.t_1, inp.K_inv, planar=True).requires_grad_(True)
         ts = inp.time_stamp_1
+        # the whole batch goes through the U-Net under autograd: fail early, with the numbers, instead of somewhere inside it
+        evals = steps + (1 if do_reg else 0)
+        need = B * HW * self._cnn_bytes_per_px() * evals
+        free, _total = self._free_hbm(dev)
+        if need > free:
+            raise RuntimeError('--use_cnn: the U-Net\'s autograd state for %d pairs at %dx%d (%d evaluations, %.0f B per pixel and '
+                               'evaluation) needs %.1f GB, %.1f GB are free: use fewer pairs per step or a smaller --depth_keep_gb'
+                               % (B, H, W, evals, self._cnn_bytes_per_px(), need / 2 ** 30, free / 2 ** 30))
+        mem0 = torch.cuda.memory_allocated(dev)
         with torch.enable_grad():
             sf_acc, p, t, sf0 = None, P1, ts, None
             for i in range(steps):
@@ -815,6 +834,9 @@ class Model(NetInterface):
                 sf0 = s_i if i == 0 else sf0
                 sf_acc = s_i if sf_acc is None else sf_acc + s_i
                 p, t = p + s_i, t + time_step
+        # measured footprint of an evaluation (like _keep_per_px for the depth net's slots): the planner's next decisions
+        # use it instead of the a-priori figure
+        self._cnn_px_measured = max(self._cnn_px_measured, (torch.cuda.memory_allocated(dev) - mem0) / float(B * HW * steps))
         sf_all = sf_acc.detach().contiguous()
         sf_used = ops.mul_mask(torch.empty_like(sf_all), sf_all, mseg) if mseg is not None else sf_all
         csum, g_sf = torch.empty(4, device=dev), torch.empty_like(sf_all)

@@ -82,7 +82,7 @@ def unproject_backward(g_points, planar, R, K_inv, scale=None, out=None, accumul
 # the power-of-two scale of their fp16 operand split from it on the device (csrc/dvd_split.h); the host never reads it.
 # The scalar hangs on the tensor OBJECT together with the tensor's version counter (an in-place update invalidates it)
 # and the capture context it was computed in.
-_capture_state = [0]        # capture generation: bumped by begin_capture(), i.e. once per HIP-graph capture
+_capture_state = [0, False, False]     # [capture generation, the previous _capture_gen() call was inside a capture, announced]
 
 
 def begin_capture():
@@ -92,18 +92,27 @@ def begin_capture():
     captures; back-to-back captures of two kept slots then shared a chunk: slot N+1's scalars were zeroed by slot N's
     replay, or never)."""
     _capture_state[0] += 1
+    _capture_state[2] = True
     return _capture_state[0]
 
 
 def _capture_gen():
-    """0 outside a capture; inside one, the generation begin_capture() opened.  A scalar computed eagerly must never be
-    baked into a graph (the replay would scale new data with the warm-up pass's maximum), and a scalar that lives in a
-    graph's private pool must not be used outside it."""
+    """0 outside a capture; inside one, the capture's generation.  A scalar computed eagerly must never be baked into a
+    graph (the replay would scale new data with the warm-up pass's maximum), and a scalar that lives in a graph's private
+    pool must not be used outside it.  The generation is opened by begin_capture() -- and, for a capture nobody announced
+    (tests, tools, future capture sites: ADVICE round 4), by the first call made inside a capture after a call made outside
+    one: the two mechanisms together leave only back-to-back unannounced captures with no eager call in between sharing
+    a generation."""
+    st = _capture_state
     if not torch.cuda.is_current_stream_capturing():
+        st[1] = False
         return 0
-    if _capture_state[0] == 0:          # a capture nobody announced (user code): still never generation 0
-        _capture_state[0] = 1
-    return _capture_state[0]
+    if not st[1]:                       # first call inside this capture
+        if not st[2]:
+            st[0] += 1                  # unannounced: a generation of its own all the same
+        st[2] = False
+    st[1] = True
+    return st[0]
 
 
 _scalar_pool = {}        # (device index, capture generation) -> [zeroed chunk, next free element]

@@ -72,3 +72,28 @@ def test_eager_chunks_are_reused_across_captures(fake_capture):
     st['capturing'] = False
     b = ops.new_scalar('cpu')
     assert _storage(a) == _storage(b) and a.data_ptr() != b.data_ptr()
+
+
+def test_unannounced_captures_get_generations_of_their_own(fake_capture):
+    """a `torch.cuda.graph` capture that does not call ops.begin_capture() (a test, a tool, a future capture
+    site) must not continue the previous capture's generation: the first scalar call inside a capture that follows a call
+    outside one opens a generation by itself."""
+    st = fake_capture
+    ops.begin_capture()
+    st['capturing'] = True
+    a = ops.new_scalar('cpu')
+    g1 = ops._capture_gen()
+    st['capturing'] = False
+    ops.new_scalar('cpu')                    # an eager call between the two captures
+    st['capturing'] = True                   # a capture nobody announced
+    b = ops.new_scalar('cpu')
+    g2 = ops._capture_gen()
+    st['capturing'] = False
+    assert g2 != g1 and g2 != 0
+    assert _storage(a) != _storage(b)
+    # an announced capture right after an unannounced one is not counted twice
+    ops.begin_capture()
+    st['capturing'] = True
+    g3 = ops._capture_gen()
+    st['capturing'] = False
+    assert g3 == g2 + 1
