@@ -45,6 +45,12 @@
 #ifndef DVD_WARP_COMBINE_TILES
 #define DVD_WARP_COMBINE_TILES 1
 #endif
+#ifndef DVD_WARP_KO_FILL           // knock-out builds (timing studies only; results are wrong): no window loads / no flush
+#define DVD_WARP_KO_FILL 0
+#endif
+#ifndef DVD_WARP_KO_FLUSH
+#define DVD_WARP_KO_FLUSH 0
+#endif
 #ifndef DVD_WARP_COMBINE_MASKED
 #define DVD_WARP_COMBINE_MASKED 1
 #endif
@@ -1065,7 +1071,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
       const int wy = i / (WW / 4), wx = (i - wy * (WW / 4)) * 4;
       const int iy = wy0 + wy, ixx = wx0 + wx;
       v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < kCells && iy >= 0 && iy < a.H) {
+      if (i < kCells && iy >= 0 && iy < a.H && !DVD_WARP_KO_FILL) {
         if (w4) {
           if (ixx >= 0 && ixx < a.W) v[it] = *reinterpret_cast<const float4*>(d2b + (size_t)iy * a.W + ixx);
         } else {
@@ -1263,7 +1269,7 @@ __global__ __launch_bounds__(NT, tile_waves_per_simd(TW, TH, R, NT)) void warp_l
     float* slab = ta.slabs + (size_t)logical * (WW * WH);
     float* gb = a.g_d2 + (size_t)b * a.HW;
     const float back = a.disp_mul;
-    for (int i = threadIdx.x; i < (WW * WH) / 4; i += NT) {
+    for (int i = threadIdx.x; i < (WW * WH) / 4 && !DVD_WARP_KO_FLUSH; i += NT) {
       const longlong2 lo = reinterpret_cast<const longlong2*>(accw)[2 * i];
       const longlong2 hi = reinterpret_cast<const longlong2*>(accw)[2 * i + 1];
       const float4 v = make_float4(from_fixed(lo.x) * back, from_fixed(lo.y) * back, from_fixed(hi.x) * back, from_fixed(hi.y) * back);
