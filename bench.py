@@ -2,6 +2,8 @@
 """bench.py -- headline benchmark of the MI355X dynamic-video-depth step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py --config 4 [--pairs 64]        BASELINE configs[4] on one GPU (768x1344, fp16 activations) with its parity leg
+    DVD_RESERVE_GB=24 python bench.py ...           the same with 24 GB of the device taken first (stand-in for RCCL's buffers)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With --gpus N > 1 and no torch.distributed environment the script re-launches itself under
@@ -19,6 +21,9 @@ resident in HBM before the timed region.
 Prints ONE JSON line: whole-job `value` in 48-pair iterations per second (weak scaling:
 every rank owns 48 pairs), plus
   roofline     -- the fused warp+loss op (HBM bound), timed live with events on its stream;
+  roofline_mfma -- the matrix kernels (85 % of the step): algorithmic work the timed steps executed, counted by the library per
+                  kernel class, over the step time, as a fraction of the 2.5 PFLOP/s dense fp16 MFMA peak; per-class kernel
+                  times of the three largest classes from the committed trace (provenance stated);
   cpu_baseline -- the CPU oracle (a port of the reference step) on a bounded sample;
   parity       -- the HIP Model against that oracle on the SAME frame pair and weights at the benchmark's image size
                   (losses and gradients of one step).
