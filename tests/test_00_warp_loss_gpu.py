@@ -251,3 +251,34 @@ def test_coherent_large_flow_against_oracle(mean):
     cfg = _cfg_from_opt(ops, opt, False, B, H, W)
     sums, sc, g1, g2, gs = _run_hip(ops, cfg, bg, d1.cuda(), d2.cuda(), sf.cuda())
     _compare(ref, sums, sc, g1, g2, gs)
+
+
+@pytest.mark.parametrize('case', ['skew', 'r2t_not_transpose', 'k22_not_one'])
+def test_cameras_outside_the_lockstep_loop_s_preconditions(case):
+    """The two-pixel lockstep loop (round 5) runs for pairs whose intrinsics have the pinhole form of the data files
+    (generate_frame_midas.py:135-139) and whose R_2 / R_2_T are bit-for-bit transposes (generate_sequence_midas.py:69-72); a
+    block tests both (wave-uniform) and otherwise takes the general one-pixel path in the SAME launch.  Here: intrinsics with a
+    skew term, an R_2_T that differs from R_2's transpose in the last bit of one entry, and a K whose [2][2] is not exactly 1 --
+    one pair each, next to a regular pair in the same batch; the result must be the oracle's (which uses the tensors as given)."""
+    from dvd_hip import ops, synthetic
+    B, H, W = 2, 64, 96
+    opt = L.default_opt()
+    batch = synthetic.make_batch(B, H, W, gap=1, seed=77, with_images=False)
+    if case == 'skew':
+        K = batch['K'][1].reshape(3, 3).clone()          # stored transposed: K^T = [fx 0 0; s fy 0; cx cy 1]
+        K[1, 0] = 0.7                                     # skew
+        batch['K'][1] = K.reshape(batch['K'][1].shape)
+        batch['K_inv'][1] = torch.linalg.inv(K.double()).float().reshape(batch['K_inv'][1].shape)
+    elif case == 'r2t_not_transpose':
+        r = batch['R_2_T'][0].reshape(-1)
+        r[1] = torch.nextafter(r[1], torch.tensor(2.0))
+    else:
+        k = batch['K'][0].reshape(-1)
+        k[8] = torch.nextafter(k[8], torch.tensor(2.0))
+    d1, d2 = synthetic.make_depths(B, H, W, seed=3, far_depth_frac=0.01)
+    sf = synthetic.make_scene_flow(B, H, W, seed=9)
+    ref = L.warp_loss_leaf_sf(opt, False, batch, d1, d2, sf)
+    bg = {k: (v.cuda() if k != 'time_step' else v) for k, v in batch.items()}
+    cfg = _cfg_from_opt(ops, opt, False, B, H, W)
+    sums, sc, g1, g2, gs = _run_hip(ops, cfg, bg, d1.cuda(), d2.cuda(), sf.cuda())
+    _compare(ref, sums, sc, g1, g2, gs)
