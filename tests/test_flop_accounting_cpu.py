@@ -1,0 +1,56 @@
+"""dvd_flop_counters / ops.executed_flops (ABI 5): the algorithmic-work accounting behind bench.py's `roofline_mfma`.  Host-side
+only -- the counters live in the library and are written at launch time, so without a GPU they can be read and reset, and the
+Python bookkeeping of replayed graphs can be exercised."""
+import ctypes
+import re
+import os
+
+from dvd_hip import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_classes_match_the_header_and_the_trace_join_table():
+    text = open(os.path.join(ROOT, 'include', 'dvd_hip.h')).read()
+    m = re.search(r'DVD_FLOP_CLASSES\s*=\s*(\d+)', text)
+    assert m and int(m.group(1)) == len(ops.FLOP_CLASSES)
+    enum = re.findall(r'DVD_FLOP_([A-Z0-9_]+)\s*=\s*(\d+),', text)
+    assert [int(v) for _, v in enum] == list(range(len(ops.FLOP_CLASSES)))
+    assert [n.lower() for n, _ in enum] == [c.replace('bwd_', '') for c in ops.FLOP_CLASSES]
+    assert set(ops.FLOP_CLASS_KERNELS) == set(ops.FLOP_CLASSES)
+    # every class can be found in both spellings of a kernel name (rocpd database: mangled, rocprofv3 csv: demangled)
+    demangled = 'void dvd::xconv_kernel<4, 2, 2, 2, 11, true, false, false, false>(dvd::XArgs)'
+    mangled = '_ZN3dvd12xconv_kernelILi4ELi2ELi2ELi2ELi11ELb1ELb0ELb0ELb0EEEvNS_5XArgsE.kd'
+    for name in (demangled, mangled):
+        hits = [c for c, frags in ops.FLOP_CLASS_KERNELS.items() if any(f in name for f in frags)]
+        assert hits == ['xconv_1x1_wide'], (name, hits)
+
+
+def test_counters_read_reset_and_replay_bookkeeping():
+    lib = _lib.load()
+    buf = (ctypes.c_double * len(ops.FLOP_CLASSES))()
+    assert lib.dvd_flop_counters(ctypes.cast(buf, ctypes.c_void_p), len(ops.FLOP_CLASSES), 1) == 0      # read + reset
+    assert all(v == 0.0 for v in ops.flop_counters().values())
+    assert lib.dvd_flop_counters(None, 3, 0) != 0                                                        # null output: an error code
+    before = ops.executed_flops()
+    ops.note_replay({'xconv_wide': 2.0e9, 'xwgrad3': 1.0e9})
+    ops.note_replay(None)                                                                                # an uncounted graph
+    ops.note_replay({'xconv_wide': 2.0e9})
+    after = ops.executed_flops()
+    d = {k: after[k] - before[k] for k in after}
+    assert d['xconv_wide'] == 4.0e9 and d['xwgrad3'] == 1.0e9 and sum(d.values()) == 5.0e9
+    assert ops.flops_since(ops.flop_counters()) == {k: 0.0 for k in ops.FLOP_CLASSES}
+
+
+def test_head_room_knob(monkeypatch):
+    from dvd_hip.models.scene_flow_motion_field import head_room_fraction, keep_slot_fits
+    monkeypatch.delenv('DVD_HEAD_ROOM_GB', raising=False)
+    assert head_room_fraction(1) == 0.08 and head_room_fraction(8) == 0.10
+    monkeypatch.setenv('DVD_HEAD_ROOM_GB', '48')
+    assert abs(head_room_fraction(1) - 48.0 / 288.0) < 1e-12 and head_room_fraction(8) == head_room_fraction(1)
+    monkeypatch.setenv('DVD_HEAD_ROOM_GB', '10')                 # never below the default
+    assert head_room_fraction(8) == 0.10
+    gb = 2 ** 30
+    # a 60 GB slot next to 130 GB of stashes on a 288 GB device with 225 GB free: fits at 8 %, not with 48 GB of head room
+    assert keep_slot_fits(60 * gb, 225 * gb, 288 * gb, 130 * gb, 0, 0, 150 * gb, 0.08)
+    assert not keep_slot_fits(60 * gb, 225 * gb, 288 * gb, 130 * gb, 0, 0, 150 * gb, 48.0 / 288.0)
