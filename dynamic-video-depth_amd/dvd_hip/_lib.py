@@ -17,7 +17,7 @@ c_float = ctypes.c_float
 c_void_p = ctypes.c_void_p
 
 DVD_OK, DVD_EINVAL, DVD_EHIP, DVD_ENOSPC = 0, -1, -2, -3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Cameras(ctypes.Structure):
@@ -120,6 +120,7 @@ SIGNATURES = {
     'dvd_xwgrad3_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgrad1s_workspace_bytes': (c_size_t, [c_int] * 5),
     'dvd_xwgrad_select': (c_int, [c_int]),
+    'dvd_sf_mlp_select': (c_int, [c_int]),
     'dvd_xwgradk_workspace_bytes': (c_size_t, [c_int] * 6),
     'dvd_xwgradk': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 7 + [c_void_p]),
     'dvd_xwgrad1s': (c_int, [c_void_p] * 6 + [c_size_t] + [c_int] * 6 + [c_void_p]),

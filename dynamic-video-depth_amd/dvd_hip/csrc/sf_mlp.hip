@@ -38,6 +38,8 @@
 //   Per-workgroup partial matrices go to a workspace at the end of `gstash` and are summed in fixed order by a
 //   second kernel: the weight gradients are bitwise reproducible (the first generation used float atomics).
 
+#include <stdlib.h>
+
 #include "dvd_split.h"
 
 // waves per SIMD the forward / dX kernels are compiled for: 2 = one 512-thread workgroup per CU (<= 256 VGPRs: forward 193,
@@ -47,6 +49,16 @@
 #endif
 #ifndef DVD_MLP_DX_OCC
 #define DVD_MLP_DX_OCC 2
+#endif
+// waves per workgroup the forward / dX kernels start with (dvd_sf_mlp_select changes it at run time): see mlp_fwd_kernel
+#ifndef DVD_MLP_NW
+#define DVD_MLP_NW 4
+#endif
+#ifndef DVD_MLP_KO
+#define DVD_MLP_KO 0     // knock-out builds for timing studies (wrong results): 1 = stash aliased to 64 tiles, 2 = lane-contiguous rows
+#endif
+#ifndef DVD_MLP_PHASE_DEFAULT
+#define DVD_MLP_PHASE_DEFAULT 0
 #endif
 
 namespace dvd {
@@ -207,54 +219,68 @@ constexpr size_t kDwPartial = (size_t)kWidth * kWidth + kWidth;   // floats per 
 // ---- the GEMM core of forward and dX ---------------------------------------------------------
 // acc[ct] += A (this wave's 32 rows, fragments streamed from global / L2) x B (X in LDS, column tile ct) over nk K steps.
 // Ap = fragment base of the wave's row tile + lane; Xl = LDS base of X + (lane>>5) * 1024 + (lane&31) * 16.
-__device__ __forceinline__ void load_frags(const u32x4* __restrict__ Ap, const unsigned char* Xl, int kc, u32x4 (&A)[2],
-                                           u32x4 (&B)[2][2]) {
+template <int RT>
+__device__ __forceinline__ void load_frags(const u32x4* __restrict__ Ap, int rt_stride, const unsigned char* Xl, int kc,
+                                           u32x4 (&A)[RT][2], u32x4 (&B)[2][2]) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    A[t] = Ap[(size_t)kc * 128 + t * 64];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) A[r][t] = Ap[(size_t)r * rt_stride + (size_t)kc * 128 + t * 64];
     B[0][t] = *reinterpret_cast<const u32x4*>(Xl + t * kTermStride + kc * 2048);
     B[1][t] = *reinterpret_cast<const u32x4*>(Xl + t * kTermStride + kc * 2048 + 512);
   }
 }
 
-__device__ __forceinline__ void mfma_step(const u32x4 (&A)[2], const u32x4 (&B)[2][2], f32x16 (&acc)[2]) {
-#define DVD_MLP_TERM(SA, SB)                                                                             \
-  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA]),                      \
-                                                  __builtin_bit_cast(f16x8, B[0][SB]), acc[0], 0, 0, 0); \
-  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[SA]),                      \
-                                                  __builtin_bit_cast(f16x8, B[1][SB]), acc[1], 0, 0, 0);
+template <int RT>
+__device__ __forceinline__ void mfma_step(const u32x4 (&A)[RT][2], const u32x4 (&B)[2][2], f32x16 (*acc)[2]) {
+  // per accumulator the order of the three partial products is the same for every RT (smallest first): RT = 1 and RT = 2
+  // give bit-identical sums
+#define DVD_MLP_TERM(SA, SB)                                                                                    \
+  _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                                              \
+    acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[r][SA]),                     \
+                                                       __builtin_bit_cast(f16x8, B[0][SB]), acc[r][0], 0, 0, 0); \
+    acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[r][SA]),                     \
+                                                       __builtin_bit_cast(f16x8, B[1][SB]), acc[r][1], 0, 0, 0); \
+  }
   DVD_MLP_TERM(1, 0)   // smallest partial products first
   DVD_MLP_TERM(0, 1)
   DVD_MLP_TERM(0, 0)
 #undef DVD_MLP_TERM
 }
 
-__device__ __forceinline__ void gemm_rows32(const u32x4* __restrict__ Ap, int nk, const unsigned char* Xl, f32x16 (&acc)[2]) {
+// RT row tiles of 32 output channels per wave (RT = 1: eight waves per 64-pixel tile; RT = 2: four, every B fragment feeds
+// two row tiles).  Ap = fragment base of the wave's FIRST row tile + lane, rt_stride = fragments (u32x4) per row tile.
+template <int RT>
+__device__ __forceinline__ void gemm_rows(const u32x4* __restrict__ Ap, int rt_stride, int nk, const unsigned char* Xl,
+                                          f32x16 (*acc)[2]) {
   // two fragment sets, ping-pong: the loads of step kc+1 are issued before the MFMAs of step kc.  The scheduling
   // barriers keep them there (the scheduler otherwise sinks the loads to their first use and every K step waits a
   // full L2 round trip); steps past the end re-read the last one (no conditional loads).
-  u32x4 A0[2], B0[2][2], A1[2], B1[2][2];
-  load_frags(Ap, Xl, 0, A0, B0);
+  u32x4 A0[RT][2], B0[2][2], A1[RT][2], B1[2][2];
+  load_frags<RT>(Ap, rt_stride, Xl, 0, A0, B0);
   int kc = 0;
 #pragma unroll 1
   for (; kc + 1 < nk; kc += 2) {
-    load_frags(Ap, Xl, kc + 1, A1, B1);
+    load_frags<RT>(Ap, rt_stride, Xl, kc + 1, A1, B1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_step(A0, B0, acc);
+    mfma_step<RT>(A0, B0, acc);
     __builtin_amdgcn_sched_barrier(0);
-    load_frags(Ap, Xl, kc + 2 < nk ? kc + 2 : nk - 1, A0, B0);
+    load_frags<RT>(Ap, rt_stride, Xl, kc + 2 < nk ? kc + 2 : nk - 1, A0, B0);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_step(A1, B1, acc);
+    mfma_step<RT>(A1, B1, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (kc < nk) mfma_step(A0, B0, acc);   // odd nk: set 0 already holds the last step
+  if (kc < nk) mfma_step<RT>(A0, B0, acc);   // odd nk: set 0 already holds the last step
 }
 
-__device__ __forceinline__ void zero2(f32x16 (&acc)[2]) {
+template <int RT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[RT][2]) {
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int r = 0; r < RT; ++r)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.0f;
 }
 
 // Four consecutive channels (n4 .. n4+3, the half `hh` of k-octet ko) of pixel m, times the tile's scale -> the two split
@@ -279,6 +305,12 @@ __device__ __forceinline__ float quad_swap1(float v) {     // from lane ^ 1
 __device__ __forceinline__ float quad_swap2(float v) {     // from lane ^ 2
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
 }
+__device__ __forceinline__ float row_ror4(float v) {          // from lane (L + 4) % 16 of the row of 16 lanes
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_ror8(float v) {          // from lane (L + 8) % 16
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+}
 __device__ __forceinline__ void quad_transpose4(float (&v)[4], int lane) {
   const bool odd = lane & 1, hi = lane & 2;
   const float r01 = quad_swap1(odd ? v[0] : v[1]), r23 = quad_swap1(odd ? v[2] : v[3]);
@@ -292,30 +324,49 @@ __device__ __forceinline__ void quad_transpose4(float (&v)[4], int lane) {
   v[1] = hi ? r13 : v[1];
   v[3] = hi ? v[3] : r13;
 }
-// rows = first of the four channel rows [.][kTM] the lane's values v0 .. v3 belong to, m = the lane's pixel: one 16-byte
-// (fp16 rows: 8-byte) store per lane
-__device__ __forceinline__ void store_rows4(float* rows, int m, int lane, float v0, float v1, float v2, float v3) {
-  float v[4] = {v0, v1, v2, v3};
-  quad_transpose4(v, lane);
-  *reinterpret_cast<float4*>(rows + (size_t)(lane & 3) * kTM + (m & ~3)) = make_float4(v[0], v[1], v[2], v[3]);
+// ---- layout of a layer's [256 channels][64 pixels] block in the stashes ("T4") -------------------------------------------
+// element (channel n, pixel m) sits at (n >> 2) * 256 + (m >> 2) * 16 + (n & 3) * 4 + (m & 3): blocks of 4 channels, inside a
+// block 16 pixel quads, inside a quad the 4 channels' runs of 4 pixels.  Why: the accumulator layout gives a lane one pixel
+// of four consecutive channels; a quad transpose (two DPP exchanges) turns that into 4 consecutive pixels of ONE channel per
+// lane, and v_permlane32_swap between the registers of the two 32-pixel column tiles puts all 64 pixels of channels
+// 8q .. 8q+3 into one register set and those of 8q+4 .. 8q+7 into the other -- lane L = 4 (pixel quad) + (channel & 3).  With
+// T4 that IS address order: one store instruction writes 1 KB (fp16: 512 B) contiguous, lane after lane.  (Rounds 2-4 stored
+// [channel][64 pixels] rows: 8 separate 128-byte pieces per instruction, lanes 256 bytes apart -- measured with wrong-layout
+// builds: forward 10.4 -> 9.4 ms, dX 11.2 -> 9.4 ms per 16-pair launch for the same bytes.)  The weight-gradient kernel reads
+// 16-pixel chunks: 256 contiguous bytes per 4-channel block.  The embedding rows stay [channel][64 pixels].
+__host__ __device__ inline size_t t4_off(int n, int m) { return (size_t)(n >> 2) * 256 + (m >> 2) * 16 + (n & 3) * 4 + (m & 3); }
+
+// x[e] / y[e] = channels n8 + 4 hh + e (e = 0..3; n8 a multiple of 8, hh = lane >> 5) of the pixels (lane & 31) / 32 + (lane & 31)
+// -- an accumulator register quad of the two column tiles.  blk = the layer block + t4_off(n8, 0).
+__device__ __forceinline__ void t4_exchange(float (&a)[4], float (&b)[4], int lane) {
+  quad_transpose4(a, lane);
+  quad_transpose4(b, lane);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[k]), __float_as_uint(b[k]), false, false);
+    a[k] = __uint_as_float(r[0]);
+    b[k] = __uint_as_float(r[1]);
+  }
 }
-__device__ __forceinline__ void store_rows4(_Float16* rows, int m, int lane, float v0, float v1, float v2, float v3) {
-  float v[4] = {v0, v1, v2, v3};
-  quad_transpose4(v, lane);
-  const f16x2 a = {(_Float16)v[0], (_Float16)v[1]}, b = {(_Float16)v[2], (_Float16)v[3]};
-  *reinterpret_cast<u32x2*>(rows + (size_t)(lane & 3) * kTM + (m & ~3)) = (u32x2){__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+__device__ __forceinline__ void store_t4(float* blk, int lane, const float (&x)[4], const float (&y)[4]) {
+  float a[4] = {x[0], x[1], x[2], x[3]}, b[4] = {y[0], y[1], y[2], y[3]};
+  t4_exchange(a, b, lane);
+#if DVD_MLP_KO & 16   // timing study: non-temporal stash stores
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((f4v){a[0], a[1], a[2], a[3]}, reinterpret_cast<f4v*>(blk + 4 * lane));
+  __builtin_nontemporal_store((f4v){b[0], b[1], b[2], b[3]}, reinterpret_cast<f4v*>(blk + 256 + 4 * lane));
+#else
+  *reinterpret_cast<float4*>(blk + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
+  *reinterpret_cast<float4*>(blk + 256 + 4 * lane) = make_float4(b[0], b[1], b[2], b[3]);
+#endif
 }
-// the reverse: the lane's pixel m of the four channel rows, from one 16-byte (8-byte) load per lane
-__device__ __forceinline__ void load_rows4(const float* rows, int m, int lane, float (&v)[4]) {
-  const float4 t = *reinterpret_cast<const float4*>(rows + (size_t)(lane & 3) * kTM + (m & ~3));
-  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  quad_transpose4(v, lane);
-}
-__device__ __forceinline__ void load_rows4(const _Float16* rows, int m, int lane, float (&v)[4]) {
-  const u32x2 t = *reinterpret_cast<const u32x2*>(rows + (size_t)(lane & 3) * kTM + (m & ~3));
-  const f16x2 a = __builtin_bit_cast(f16x2, (unsigned)t[0]), b = __builtin_bit_cast(f16x2, (unsigned)t[1]);
-  v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)b[0]; v[3] = (float)b[1];
-  quad_transpose4(v, lane);
+__device__ __forceinline__ void store_t4(_Float16* blk, int lane, const float (&x)[4], const float (&y)[4]) {
+  float a[4] = {x[0], x[1], x[2], x[3]}, b[4] = {y[0], y[1], y[2], y[3]};
+  t4_exchange(a, b, lane);
+  const f16x2 a0 = {(_Float16)a[0], (_Float16)a[1]}, a1 = {(_Float16)a[2], (_Float16)a[3]};
+  const f16x2 b0 = {(_Float16)b[0], (_Float16)b[1]}, b1 = {(_Float16)b[2], (_Float16)b[3]};
+  *reinterpret_cast<u32x2*>(blk + 4 * lane) = (u32x2){__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1)};
+  *reinterpret_cast<u32x2*>(blk + 256 + 4 * lane) = (u32x2){__builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1)};
 }
 
 // max over the wave's lanes, in every lane
@@ -336,6 +387,37 @@ __device__ __forceinline__ void fold_amax(float* dst, float m) {      // (read f
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, kSlope * v); }
 
+// ---- start-up phase of a workgroup ---------------------------------------------------------------------------------
+// Every workgroup runs the same sequence (GEMM of a layer, then the epilogue with its 64 KB burst of stash stores), they all
+// start together and nothing makes them drift: left alone, the two workgroups of a CU sit in their epilogues at the same
+// time (matrix pipe idle), and all 512 of them send their bursts to HBM at the same time.  The kernels therefore start
+// the SECOND workgroup that arrives on a CU (arrival order: an atomic counter per CU, keyed by XCC / SE / SH / CU id) a fixed
+// number of 1024-clock sleeps late, plus a small per-workgroup spread.  A performance heuristic only: the results do not
+// depend on it.  `phase` = mode | delay << 4 | spread << 12; mode 0 = off, 1 = slot from blockIdx parity, 2 = from
+// blockIdx / 256, 3 = arrival order on the CU.
+__device__ unsigned g_cu_arrivals[4096];
+
+__device__ __forceinline__ void phase_delay(int phase, float* flag) {
+  if (!phase) return;
+  const int mode = phase & 15, d2 = (phase >> 4) & 255, sp = (phase >> 12) & 255;
+  int slot;
+  if (mode == 1) slot = blockIdx.x & 1;
+  else if (mode == 2) slot = (blockIdx.x >> 8) & 1;
+  else {
+    if (threadIdx.x == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+      const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));    // XCC_ID [3:0]
+      const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
+      *reinterpret_cast<int*>(flag) = (int)(atomicAdd(&g_cu_arrivals[key], 1u) & 1u);
+    }
+    __syncthreads();
+    slot = *reinterpret_cast<const int*>(flag);
+    __syncthreads();
+  }
+  const int n = slot * d2 + (int)((blockIdx.x * 2654435761u) >> 29) * sp;
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 // ==========================================================================================
 // forward
 struct FwdArgs {
@@ -351,19 +433,19 @@ struct FwdArgs {
   PackLayout L;
   Geometry g;
   long long n_pix;
-  int pix_per_img, n_tiles;
+  int pix_per_img, n_tiles, phase;
   float t_offset, out_scale;
 };
 
-// LDS: X | psm [4][64] | w5 [3][256] + bias5 [4] | red [8][3][64] | tmx [8]
-constexpr size_t kFwdLds = (size_t)kXBytes + 4 * kTM * 4 + (3 * kWidth + 4) * 4 + 8 * 3 * kTM * 4 + 8 * 4;
+// LDS: X (at the end of a tile: red [8 row tiles][3][64]) | psm [4][64] | w5 [3][256] + bias5 [4] | tmx [8] | bias [5][256]
+constexpr size_t kFwdLds = (size_t)kXBytes + 4 * kTM * 4 + (3 * kWidth + 4) * 4 + 8 * 4 + kHidden * kWidth * 4;
 
 // Input embedding of one tile: split into X, fp32 to the stash.  psm = [4][64] floats: x, y, z, t of the pixels.
 // `sx` = the tile's operand scale (pow2_scale of the largest |input| of the tile; sin / cos are bounded by 1).
-template <bool STASH>
+template <bool STASH, int NW>
 __device__ __forceinline__ void build_embedding(const Geometry& g, const float* __restrict__ fx, const float* __restrict__ ft,
                                                 const float* psm, unsigned char* X, float* st_emb, float sx) {
-  const int m = threadIdx.x & 63, part = threadIdx.x >> 6;   // 8 parts
+  const int m = threadIdx.x & 63, part = threadIdx.x >> 6;   // NW parts
   auto put = [&](int ch, float v) {
     unsigned h, l;
     split_pair_f16(v * sx, 0.0f, h, l);
@@ -382,7 +464,7 @@ __device__ __forceinline__ void build_embedding(const Geometry& g, const float* 
   }
   const int nt = g.n_freq_t, nx = g.n_freq_xyz;
   const int items = nt + 3 * nx;
-  for (int e = part; e < items; e += 8) {
+  for (int e = part; e < items; e += NW) {
     float arg;
     int ch_cos, ch_sin;
     if (e < nt) {
@@ -402,19 +484,29 @@ __device__ __forceinline__ void build_embedding(const Geometry& g, const float* 
   }
 }
 
-template <bool STASH, bool S16>
-__global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const FwdArgs a) {
+// NW = waves per workgroup: 8 (one 512-thread workgroup per CU, wave w = row tile w) or 4 (two 256-thread workgroups per CU,
+// wave w = row tiles 2w and 2w + 1).  Both compute every value with the same operations in the same order: bit-identical
+// outputs, stash and maxima (tests/test_02_sf_mlp_gpu.py).
+template <bool STASH, bool S16, int NW>
+__global__ __launch_bounds__(64 * NW, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const FwdArgs a) {
+  constexpr int RT = 8 / NW, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* X = smem;
   float* psm = reinterpret_cast<float*>(smem + kXBytes);   // [4][64]
   float* w5 = psm + 4 * kTM;                               // [3][256] + bias5[4]
-  float* red = w5 + 3 * kWidth + 4;                        // [8 waves][3][64]
-  float* tmx = red + 8 * 3 * kTM;                          // [8 waves]: maxima of the values a layer's epilogue produced
+  float* tmx = w5 + 3 * kWidth + 4;                        // [8] (NW used): maxima of the values a layer's epilogue produced
+  float* bl = tmx + 8;                                     // [5][256]: biases of the hidden layers
+  float* red = reinterpret_cast<float*>(smem);             // [8 row tiles][3][64]: the output layer's partial sums, in X's place
+                                                           // (written after the last layer's GEMM has read X, summed before
+                                                           // the next tile's first barrier)
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const float* pf = static_cast<const float*>(a.packed);
   const u32x4* P4 = static_cast<const u32x4*>(a.packed);
-  for (int i = tid; i < 3 * kWidth + 4; i += kNT) w5[i] = pf[i < 3 * kWidth ? a.L.w5 + i : a.L.bias[5] + (i - 3 * kWidth)];
+  for (int i = tid; i < 3 * kWidth + 4; i += NT) w5[i] = pf[i < 3 * kWidth ? a.L.w5 + i : a.L.bias[5] + (i - 3 * kWidth)];
+  phase_delay(a.phase, psm);
+  if (tid < 8) tmx[tid] = 0.0f;
+  for (int i = tid; i < kHidden * kWidth; i += NT) bl[i] = pf[a.L.bias[i / kWidth] + (i % kWidth)];
   const unsigned char* Xl = X + hh * 1024 + j * 16;
   float* tail = STASH ? a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;   // per-layer maxima
 
@@ -435,40 +527,42 @@ __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const Fwd
       psm[c * kTM + lane] = v;
     }
     __syncthreads();
+#if DVD_MLP_KO & 1   // timing study: every tile's stash in one slot per XCD (L2 resident)
+    float* st = STASH ? a.stash + (size_t)(blockIdx.x & 7) * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;
+#else
     float* st = STASH ? a.stash + (size_t)tile * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;
+#endif
     // operand scale of the embedding: the largest input magnitude of the tile (every wave sees all 64 pixels in its lanes)
     const float emax = wave_max_all(fmaxf(fmaxf(fabsf(psm[lane]), fabsf(psm[kTM + lane])),
                                           fmaxf(fmaxf(fabsf(psm[2 * kTM + lane]), fabsf(psm[3 * kTM + lane])), 1.0f)));
     float sx = pow2_scale(emax);                       // scale of what X currently holds (uniform over the workgroup)
     if (STASH && tid == 0) fold_amax(tail + 0, emax);
-    build_embedding<STASH>(a.g, a.freqs_xyz, a.freqs_t, psm, X, st, sx);
+    build_embedding<STASH, NW>(a.g, a.freqs_xyz, a.freqs_t, psm, X, st, sx);
     __syncthreads();
 
 #pragma unroll 1
     for (int l = 0; l < kHidden; ++l) {
-      f32x16 acc[2];
-      zero2(acc);
+      f32x16 acc[RT][2];
+      zero_acc<RT>(acc);
       const int nk = a.L.nk[l];
-      const float* bias = pf + a.L.bias[l];
-      float4 bvq[4];   // requested before the GEMM: an L2 round trip each if loaded where they are used
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bvq[q] = *reinterpret_cast<const float4*>(bias + 32 * w + 8 * q + 4 * hh);
-      gemm_rows32(P4 + a.L.fwd[l] + (size_t)w * nk * 128 + lane, nk, Xl, acc);
+      gemm_rows<RT>(P4 + a.L.fwd[l] + (size_t)(RT * w) * nk * 128 + lane, nk * 128, nk, Xl, acc);
       // activations in place of the accumulators (exact unscaling: a power of two), their maximum over the wave -> LDS
       const float unscale = 1.0f / (sx * pow2_scale(pf[a.L.wamax + l]));
       float vmax = 0.0f;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 bv = bvq[q];
-          acc[ct][4 * q + 0] = lrelu(__builtin_fmaf(acc[ct][4 * q + 0], unscale, bv.x));
-          acc[ct][4 * q + 1] = lrelu(__builtin_fmaf(acc[ct][4 * q + 1], unscale, bv.y));
-          acc[ct][4 * q + 2] = lrelu(__builtin_fmaf(acc[ct][4 * q + 2], unscale, bv.z));
-          acc[ct][4 * q + 3] = lrelu(__builtin_fmaf(acc[ct][4 * q + 3], unscale, bv.w));
-          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(acc[ct][4 * q + 0]), fabsf(acc[ct][4 * q + 1]))),
-                       fmaxf(fabsf(acc[ct][4 * q + 2]), fabsf(acc[ct][4 * q + 3])));
-        }
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 bv = *reinterpret_cast<const float4*>(bl + l * kWidth + 32 * (RT * w + r) + 8 * q + 4 * hh);
+            acc[r][ct][4 * q + 0] = lrelu(__builtin_fmaf(acc[r][ct][4 * q + 0], unscale, bv.x));
+            acc[r][ct][4 * q + 1] = lrelu(__builtin_fmaf(acc[r][ct][4 * q + 1], unscale, bv.y));
+            acc[r][ct][4 * q + 2] = lrelu(__builtin_fmaf(acc[r][ct][4 * q + 2], unscale, bv.z));
+            acc[r][ct][4 * q + 3] = lrelu(__builtin_fmaf(acc[r][ct][4 * q + 3], unscale, bv.w));
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(acc[r][ct][4 * q + 0]), fabsf(acc[r][ct][4 * q + 1]))),
+                         fmaxf(fabsf(acc[r][ct][4 * q + 2]), fabsf(acc[r][ct][4 * q + 3])));
+          }
       vmax = wave_max_all(vmax);
       if (lane == 0) tmx[w] = vmax;
       __syncthreads();  // every wave has finished reading this layer's input; the waves' maxima are visible
@@ -476,44 +570,57 @@ __global__ __launch_bounds__(kNT, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const Fwd
       sx = pow2_scale(hmax);                           // scale of the next layer's input
       if (STASH && tid == 0) fold_amax(tail + 1 + l, hmax);
       float* sh = STASH ? st + stash_h_off(a.g.c_in16, l, S16) : nullptr;
-      unsigned sw = 0;
-      float po[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int r = 0; r < RT; ++r) {
+        const int rt = RT * w + r;                     // the row tile: output channels [32 rt, 32 rt + 32)
+        unsigned sw = 0;
+        float po[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n4 = 32 * w + 8 * q + 4 * hh;  // first of 4 consecutive output channels
-          const float v0 = acc[ct][4 * q + 0], v1 = acc[ct][4 * q + 1], v2 = acc[ct][4 * q + 2], v3 = acc[ct][4 * q + 3];
-          const int m = 32 * ct + j;
-          if (l < kHidden - 1) store_split4(X, 4 * w + q, m, hh, sx, v0, v1, v2, v3);   // the next layer's input
-          if (STASH) {
-            if constexpr (S16) store_rows4(reinterpret_cast<_Float16*>(sh) + (size_t)n4 * kTM, m, lane, v0, v1, v2, v3);
-            else store_rows4(sh + (size_t)n4 * kTM, m, lane, v0, v1, v2, v3);
-            const int b0 = 16 * ct + 4 * q;
-            sw |= (v0 > 0.f ? 1u : 0u) << b0 | (v1 > 0.f ? 1u : 0u) << (b0 + 1) | (v2 > 0.f ? 1u : 0u) << (b0 + 2) |
-                  (v3 > 0.f ? 1u : 0u) << (b0 + 3);
-          }
-          if (l == kHidden - 1) {   // 256 -> 3 output layer: this lane's share of the dot products
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float4 ww = *reinterpret_cast<const float4*>(w5 + c * kWidth + n4);
-              po[c][ct] = __builtin_fmaf(v0, ww.x, __builtin_fmaf(v1, ww.y, __builtin_fmaf(v2, ww.z, __builtin_fmaf(v3, ww.w, po[c][ct]))));
-            }
-          }
-        }
-      if (STASH) reinterpret_cast<unsigned*>(st + stash_sign_off(a.g.c_in16, l, S16))[tid] = sw;
-      if (l == kHidden - 1) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
+          const int n4 = 32 * rt + 8 * q + 4 * hh;  // first of 4 consecutive output channels
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) {
-            const float v = po[c][ct] + __shfl_xor(po[c][ct], 32, 64);
-            if (hh == 0) red[(w * 3 + c) * kTM + 32 * ct + j] = v;
+            const float v0 = acc[r][ct][4 * q + 0], v1 = acc[r][ct][4 * q + 1], v2 = acc[r][ct][4 * q + 2], v3 = acc[r][ct][4 * q + 3];
+            const int m = 32 * ct + j;
+            if (l < kHidden - 1) store_split4(X, 4 * rt + q, m, hh, sx, v0, v1, v2, v3);   // the next layer's input
+            if (STASH) {
+              const int b0 = 16 * ct + 4 * q;
+              sw |= (v0 > 0.f ? 1u : 0u) << b0 | (v1 > 0.f ? 1u : 0u) << (b0 + 1) | (v2 > 0.f ? 1u : 0u) << (b0 + 2) |
+                    (v3 > 0.f ? 1u : 0u) << (b0 + 3);
+            }
+            if (l == kHidden - 1) {   // 256 -> 3 output layer: this lane's share of the dot products
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const float4 ww = *reinterpret_cast<const float4*>(w5 + c * kWidth + n4);
+                po[c][ct] = __builtin_fmaf(v0, ww.x, __builtin_fmaf(v1, ww.y, __builtin_fmaf(v2, ww.z, __builtin_fmaf(v3, ww.w, po[c][ct]))));
+              }
+            }
           }
+          if (STASH) {
+            const float x[4] = {acc[r][0][4 * q + 0], acc[r][0][4 * q + 1], acc[r][0][4 * q + 2], acc[r][0][4 * q + 3]};
+            const float y[4] = {acc[r][1][4 * q + 0], acc[r][1][4 * q + 1], acc[r][1][4 * q + 2], acc[r][1][4 * q + 3]};
+            if constexpr (S16) store_t4(reinterpret_cast<_Float16*>(sh) + t4_off(32 * rt + 8 * q, 0), lane, x, y);
+            else store_t4(sh + t4_off(32 * rt + 8 * q, 0), lane, x, y);
+          }
+        }
+#if DVD_MLP_KO & 8   // timing study: wait for the stash stores right here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        // one sign word per (row tile, lane): word 64 rt + lane, the same layout for every NW
+        if (STASH) reinterpret_cast<unsigned*>(st + stash_sign_off(a.g.c_in16, l, S16))[64 * rt + lane] = sw;
+        if (l == kHidden - 1) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              const float v = po[c][ct] + __shfl_xor(po[c][ct], 32, 64);
+              if (hh == 0) red[(rt * 3 + c) * kTM + 32 * ct + j] = v;
+            }
+        }
       }
       __syncthreads();
     }
-    if (tid < 3 * kTM) {  // thread (c, m): sum the 8 waves' shares in fixed order
+    if (tid < 3 * kTM) {  // thread (c, m): sum the 8 row tiles' shares in fixed order
       const int c = tid >> 6;
       float s = 0.0f;
 #pragma unroll
@@ -548,38 +655,48 @@ struct BwdArgs {
   PackLayout L;
   Geometry g;
   long long n_pix;
-  int pix_per_img, n_tiles;
+  int pix_per_img, n_tiles, phase;
   float out_scale, gscale;
 };
 
-// LDS: X (gradient tile, split; at the end fp32 g_in [<= 256][64]) | gz5 [4][64] | w5 [3][256] | tmx [8]
-constexpr size_t kBwdLds = (size_t)kXBytes + 4 * kTM * 4 + 3 * kWidth * 4 + 8 * 4;
+// LDS: X (gradient tile, split; at the end fp32 g_in [<= 256][64]) | gz5 [4][64] | w5 [3][256] | tmx [8] | dw5s [3][256]
+constexpr size_t kBwdLds = (size_t)kXBytes + 4 * kTM * 4 + 3 * kWidth * 4 + 8 * 4 + 3 * kWidth * 4;
 
-template <bool S16>
-__global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const BwdArgs a) {
+// NW as in the forward.  The input gradient and the gradient stash are bit-identical for NW = 4 and 8 (the last layer's
+// parameter gradients are float atomics over workgroups in both).
+template <bool S16, int NW>
+__global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const BwdArgs a) {
+  constexpr int RT = 8 / NW, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* X = smem;
   float* Xf = reinterpret_cast<float*>(smem);
   float* gz5 = reinterpret_cast<float*>(smem + kXBytes);   // [4][64]: g of the 3 outputs (already * out_scale)
   float* w5 = gz5 + 4 * kTM;                               // [3][256]
-  float* tmx = w5 + 3 * kWidth;                            // [8 waves]
+  float* tmx = w5 + 3 * kWidth;                            // [8] (NW used)
+  float* dw5s = tmx + 8;                                   // [3][256]: this workgroup's share of dW5
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const float* pf = static_cast<const float*>(a.packed);
   const u32x4* P4 = static_cast<const u32x4*>(a.packed);
-  for (int i = tid; i < 3 * kWidth; i += kNT) w5[i] = pf[a.L.w5 + i];
+  phase_delay(a.phase, gz5);
+  for (int i = tid; i < 3 * kWidth; i += NT) w5[i] = pf[a.L.w5 + i];
+  if (tid < 8) tmx[tid] = 0.0f;
   // per-layer maxima of the pre-activation gradients over all tiles (for the weight-gradient kernel): stash tail [8 + l]
   float* gtail = const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, S16) + 8;
   const float s1 = a.gscale * (a.scale_ptr ? a.scale_ptr[0] : 1.0f);
   const unsigned char* Xl = X + hh * 1024 + j * 16;
   float sx = 1.0f;                                         // operand scale of what X currently holds
-  // last layer's parameter gradients, accumulated over this workgroup's tiles: dw5[c][i] belongs to channel
-  // 32 w + 8 (i >> 2) + 4 hh + (i & 3) (summed over this lane's pixels; over the 32 lanes j at the end)
-  float dw5[3][16];
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dw5[c][i] = 0.0f;
+  // Last layer's parameter gradients dW5[c][n] = sum_m g_z5[c][m] h4[n][m], accumulated over this workgroup's tiles in LDS
+  // (dw5s).  Wave w owns the channels [kCW w, kCW w + kCW) and reads their h4 blocks (T4 layout: contiguous) 16 bytes per
+  // lane and load.  fp32 stash: load i is the block of channels kCW w + 4 i .. + 3, lane L holds pixel quad L >> 2 of channel
+  // L & 3; fp16: load i covers two blocks, lane L holds pixel quad (L & 31) >> 1 of the channels 2 (L & 1), + 1 of block L >> 5.
+  // The lanes of a channel are summed by DPP exchanges inside each row of 16 lanes, the rows' sums meet in LDS atomics.
+  // (Until round 5 this was done in the accumulator mapping -- a pixel per lane, 48 accumulator registers per row tile that
+  // lived across the whole kernel.)
+  constexpr int kCW = kWidth / NW;                         // channels per wave
+  constexpr int kNL = kCW / (S16 ? 8 : 4);                 // 16-byte loads per lane and tile
+  const int pq = S16 ? (lane & 31) >> 1 : lane >> 2;       // the lane's pixel quad
+  for (int i = tid; i < 3 * kWidth; i += NT) dw5s[i] = 0.0f;
   float db5 = 0.0f;
   const size_t spt = stash_floats_per_tile(a.g.c_in16, S16), gpt = gstash_floats_per_tile();
 
@@ -603,14 +720,73 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
       db5 += v;
     }
     __syncthreads();
-    {  // layer 5 (256 -> 3): g_z4 = (W5^T g_z5) * LeakyReLU'(h4); dW5 += g_z5 h4^T -- in the epilogue mapping
-      const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4, S16))[tid];
+    {  // dW5 += g_z5 h4^T
       const float* h4 = st + stash_h_off(a.g.c_in16, 4, S16);
+      const unsigned char* hb = reinterpret_cast<const unsigned char*>(h4) + (size_t)kCW * w * kTM * (S16 ? 2 : 4) + lane * 16;
+      float g5[3][4];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(gz5 + c * kTM + 4 * pq);
+        g5[c][0] = t.x; g5[c][1] = t.y; g5[c][2] = t.z; g5[c][3] = t.w;
+      }
+      constexpr int kBatch = 4;                            // loads in flight (4 x 4 registers)
+#pragma unroll
+      for (int i0 = 0; i0 < kNL; i0 += kBatch) {
+        u32x4 raw[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) raw[i] = *reinterpret_cast<const u32x4*>(hb + (i0 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i) {
+          if constexpr (S16) {
+            // two channels of the lane's pixel quad
+            float hv[2][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f16x2 pr = __builtin_bit_cast(f16x2, (unsigned)raw[i][k]);
+              hv[k >> 1][2 * (k & 1)] = (float)pr[0];
+              hv[k >> 1][2 * (k & 1) + 1] = (float)pr[1];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                float v = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v = __builtin_fmaf(g5[c][k], hv[u][k], v);
+                v += quad_swap2(v);                        // lanes L ^ 2, then L + 8, L + 4 (row rotations): the 8 pixel quads
+                v += row_ror8(v);                          // of this row of 16 lanes
+                v += row_ror4(v);
+                if ((lane & 14) == 0)                      // lanes 0 / 1 of each row; the block's two rows meet in the atomic
+                  unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 8 * (i0 + i) + 4 * (lane >> 5) + 2 * (lane & 1) + u, v);
+              }
+          } else {
+            float hv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hv[k] = __uint_as_float(raw[i][k]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              float v = 0.0f;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) v = __builtin_fmaf(g5[c][k], hv[k], v);
+              v += row_ror8(v);                            // lanes L + 8, L + 4 (row rotations): the 4 pixel quads of this row
+              v += row_ror4(v);
+              if ((lane & 12) == 0)                        // lanes 0 .. 3 of each row; the four rows meet in the atomic
+                unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 4 * (i0 + i) + (lane & 3), v);
+            }
+          }
+        }
+      }
+    }
+    {  // layer 5 (256 -> 3): g_z4 = (W5^T g_z5) * LeakyReLU'(h4) -- in the epilogue mapping
+      unsigned sw[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+        sw[r] = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4, S16))[64 * (RT * w + r) + lane];
       float* g4 = gs + (size_t)4 * kWidth * kTM;
       // g_z4 of (pixel m, channels n4 .. n4 + 3): three FMAs and the slope per value -- evaluated twice (first for the
-      // tile maximum, the stash and dW5, then for the split store) rather than kept in 32 registers across the barrier
-      auto gz4 = [&](int ct, int q, float (&v)[4]) {
-        const int m = 32 * ct + j, n4 = 32 * w + 8 * q + 4 * hh;
+      // tile maximum and the stash, then for the split store) rather than kept in 32 registers per row tile across the barrier
+      auto gz4 = [&](int r, int ct, int q, float (&v)[4]) {
+        const int m = 32 * ct + j, n4 = 32 * (RT * w + r) + 8 * q + 4 * hh;
         const float ga = gz5[m], gb = gz5[kTM + m], gc = gz5[2 * kTM + m];
         const float4 wa = *reinterpret_cast<const float4*>(w5 + n4);
         const float4 wb = *reinterpret_cast<const float4*>(w5 + kWidth + n4);
@@ -618,33 +794,22 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
         const float war[4] = {wa.x, wa.y, wa.z, wa.w}, wbr[4] = {wb.x, wb.y, wb.z, wb.w}, wcr[4] = {wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool pos = (sw >> (16 * ct + 4 * q + e)) & 1u;
+          const bool pos = (sw[r] >> (16 * ct + 4 * q + e)) & 1u;
           v[e] = (ga * war[e] + gb * wbr[e] + gc * wcr[e]) * (pos ? 1.0f : kSlope);
         }
       };
       float vmax = 0.0f;
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
 #pragma unroll 1
-      for (int ct = 0; ct < 2; ++ct) {
-        const int m = 32 * ct + j;
-        const float ga = gz5[m], gb = gz5[kTM + m], gc = gz5[2 * kTM + m];
-#pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n4 = 32 * w + 8 * q + 4 * hh;
-          float v[4], hq[4];
-          gz4(ct, q, v);
-          if constexpr (S16) load_rows4(reinterpret_cast<const _Float16*>(h4) + (size_t)n4 * kTM, m, lane, hq);
-          else load_rows4(h4 + (size_t)n4 * kTM, m, lane, hq);
-          store_rows4(g4 + (size_t)n4 * kTM, m, lane, v[0], v[1], v[2], v[3]);
+          float v0[4], v1[4];
+          gz4(r, 0, q, v0);
+          gz4(r, 1, q, v1);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float hv = hq[e];
-            vmax = fmaxf(vmax, fabsf(v[e]));
-            dw5[0][4 * q + e] = __builtin_fmaf(ga, hv, dw5[0][4 * q + e]);
-            dw5[1][4 * q + e] = __builtin_fmaf(gb, hv, dw5[1][4 * q + e]);
-            dw5[2][4 * q + e] = __builtin_fmaf(gc, hv, dw5[2][4 * q + e]);
-          }
+          for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+          store_t4(g4 + t4_off(32 * (RT * w + r) + 8 * q, 0), lane, v0, v1);
         }
-      }
       // the tile's operand scale: the waves' maxima through LDS (X is idle here: the previous tile is done with it)
       vmax = wave_max_all(vmax);
       if (lane == 0) tmx[w] = vmax;
@@ -652,33 +817,40 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
       const float gmax = tile_max(tmx);
       sx = pow2_scale(gmax);
       if (tid == 0) fold_amax(gtail + 4, gmax);
-#pragma unroll 1
-      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-          gz4(ct, q, v);
-          store_split4(X, 4 * w + q, 32 * ct + j, hh, sx, v[0], v[1], v[2], v[3]);
-        }
+      for (int r = 0; r < RT; ++r)
+#pragma unroll 1
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v[4];
+            gz4(r, ct, q, v);
+            store_split4(X, 4 * (RT * w + r) + q, 32 * ct + j, hh, sx, v[0], v[1], v[2], v[3]);
+          }
     }
     __syncthreads();
     // layers 4..1: g_z_{l-1} = (W_l^T g_z_l) * LeakyReLU'(h_{l-1})
 #pragma unroll 1
     for (int l = 4; l >= 1; --l) {
-      f32x16 acc[2];
-      zero2(acc);
-      const unsigned sw = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, l - 1, S16))[tid];
-      gemm_rows32(P4 + a.L.bwd[l] + (size_t)w * 16 * 128 + lane, 16, Xl, acc);
+      f32x16 acc[RT][2];
+      zero_acc<RT>(acc);
+      unsigned sw[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+        sw[r] = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, l - 1, S16))[64 * (RT * w + r) + lane];
+      gemm_rows<RT>(P4 + a.L.bwd[l] + (size_t)(RT * w) * 16 * 128 + lane, 16 * 128, 16, Xl, acc);
       const float unscale = 1.0f / (sx * pow2_scale(pf[a.L.wamax + l]));
       float vmax = 0.0f;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool pos = (sw >> (16 * ct + r)) & 1u;
-          acc[ct][r] *= unscale * (pos ? 1.0f : kSlope);
-          vmax = fmaxf(vmax, fabsf(acc[ct][r]));
-        }
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const bool pos = (sw[r] >> (16 * ct + e)) & 1u;
+            acc[r][ct][e] *= unscale * (pos ? 1.0f : kSlope);
+            vmax = fmaxf(vmax, fabsf(acc[r][ct][e]));
+          }
       vmax = wave_max_all(vmax);
       if (lane == 0) tmx[w] = vmax;
       __syncthreads();  // every wave has finished reading g_z_l; the waves' maxima are visible
@@ -687,29 +859,38 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
       if (tid == 0) fold_amax(gtail + (l - 1), gmax);
       float* gl = gs + (size_t)(l - 1) * kWidth * kTM;
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n4 = 32 * w + 8 * q + 4 * hh, m = 32 * ct + j;
-          store_rows4(gl + (size_t)n4 * kTM, m, lane, acc[ct][4 * q + 0], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]);
-          store_split4(X, 4 * w + q, m, hh, sx, acc[ct][4 * q + 0], acc[ct][4 * q + 1], acc[ct][4 * q + 2], acc[ct][4 * q + 3]);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            store_split4(X, 4 * (RT * w + r) + q, 32 * ct + j, hh, sx, acc[r][ct][4 * q + 0], acc[r][ct][4 * q + 1], acc[r][ct][4 * q + 2], acc[r][ct][4 * q + 3]);
+          const float x[4] = {acc[r][0][4 * q + 0], acc[r][0][4 * q + 1], acc[r][0][4 * q + 2], acc[r][0][4 * q + 3]};
+          const float y[4] = {acc[r][1][4 * q + 0], acc[r][1][4 * q + 1], acc[r][1][4 * q + 2], acc[r][1][4 * q + 3]};
+          store_t4(gl + t4_off(32 * (RT * w + r) + 8 * q, 0), lane, x, y);
         }
       __syncthreads();
     }
-    // layer 0: g_in = W_0^T g_z0  (c_in <= 256 rows = rt0 <= 8 row tiles, wave w takes tile w), as fp32 [channel][64]
+    // layer 0: g_in = W_0^T g_z0  (c_in <= 256 rows = rt0 <= 8 row tiles; wave w takes the tiles RT w .. RT w + RT - 1 that
+    // exist), as fp32 [channel][64]
     {
-      f32x16 acc[2];
-      zero2(acc);
-      if (w < a.g.rt0) gemm_rows32(P4 + a.L.bwd[0] + (size_t)w * 16 * 128 + lane, 16, Xl, acc);
+      f32x16 acc[RT][2];
+      zero_acc<RT>(acc);
+      const int nv = a.g.rt0 - RT * w;                       // this wave's row tiles that exist (wave uniform)
+      const u32x4* Ap = P4 + a.L.bwd[0] + (size_t)(RT * w) * 16 * 128 + lane;
+      if (nv >= RT) gemm_rows<RT>(Ap, 16 * 128, 16, Xl, acc);
+      else if (RT > 1 && nv == 1) gemm_rows<1>(Ap, 16 * 128, 16, Xl, acc);
       const float unscale = 1.0f / (sx * pow2_scale(pf[a.L.wamax + 0]));
       __syncthreads();  // all waves finished reading g_z0
-      if (w < a.g.rt0) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+      for (int r = 0; r < RT; ++r)
+        if (r < nv) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            Xf[(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3)) * kTM + 32 * ct + j] = acc[ct][r] * unscale;
-      }
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              Xf[(32 * (RT * w + r) + 8 * (e >> 2) + 4 * hh + (e & 3)) * kTM + 32 * ct + j] = acc[r][ct][e] * unscale;
+        }
       __syncthreads();
     }
     // embedding backward -> g_p[c][m]:  thread (c, m), waves 0..2
@@ -734,18 +915,8 @@ __global__ __launch_bounds__(kNT, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(const B
     }
   }
   // flush the last layer's parameter gradients
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v = dw5[c][i];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      if (j == 0) unsafeAtomicAdd(a.gW5 + c * kWidth + 32 * w + 8 * (i >> 2) + 4 * hh + (i & 3), v);
-    }
+  __syncthreads();
+  for (int i = tid; i < 3 * kWidth; i += NT) unsafeAtomicAdd(a.gW5 + i, dw5s[i]);
   {
     const float v = wave_sum(db5);
     if (lane == 0 && w < 3) unsafeAtomicAdd(a.gb5 + w, v);
@@ -792,41 +963,49 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.0f;
-  float rs[2] = {0.f, 0.f};                        // row sums of G (bias gradient): rows (tid >> 2) and 128 + (tid >> 2)
+  float rs[2] = {0.f, 0.f};                        // row sums of G (bias gradient): rows row_of(0), row_of(1) of this thread's pixel quad
   // per-launch operand scales from the maxima the forward / dX kernels left behind the stash's tiles
   const float* tail = a.stash + (size_t)a.n_tiles * spt;
   const float scg = pow2_scale(tail[8 + layer]);                                  // G_layer
   const float sch = H16 ? 1.0f : pow2_scale(tail[layer]);                         // H = embedding (0) or h_{layer-1}
 
-  // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread; q = i * 512 + tid, row = q >> 2, quad = q & 3.
+  // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread (i = 0, 1: G rows 0 .. 255; i = 2, 3: H rows).  Operands in
+  // the T4 layout (G, h_l): 16 consecutive threads read the 256 contiguous bytes one 4-channel block holds of this 16-pixel
+  // chunk (fp16: 128) -- thread t = channel t & 3, pixel quad (t >> 2) & 3 of block t >> 4; the embedding (layer 0's H) is
+  // [channel][64 pixels] rows: four consecutive threads read a row's 64 bytes.
   // Two register sets: the chunk loaded during step `it` is split and stored during step it + 1 and consumed by the
   // MFMAs of step it + 2, so no wave ever waits for HBM.
   float4 sg0[4], sg1[4];
+  auto row_of = [&](int i) { return (FULL || i < 2) ? i * 128 + 4 * (tid >> 4) + (tid & 3) : i * 128 + (tid >> 2); };
+  auto quad_of = [&](int i) { return (FULL || i < 2) ? (tid >> 2) & 3 : tid & 3; };
   auto stage_load = [&](int it, float4 (&sg)[4]) {
     const int tile = t0 + (it >> 2), chunk = it & 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = i * 128 + (tid >> 2), quad = tid & 3;
+      const int row = row_of(i), quad = quad_of(i);
       const bool isH = i >= 2;
       const int r = row & 255;
-      const bool valid = FULL || !isH || r < hrows;
       if (H16 && isH) {      // four fp16 values = 8 bytes, carried in the first two lanes of the float4 as raw bits
-        const _Float16* src = reinterpret_cast<const _Float16*>(a.stash + (size_t)tile * spt + hoff) + (size_t)r * kTM;
-        const float2 raw = *reinterpret_cast<const float2*>(src + chunk * 16 + quad * 4);
+        const _Float16* src = reinterpret_cast<const _Float16*>(a.stash + (size_t)tile * spt + hoff);
+        const float2 raw = *reinterpret_cast<const float2*>(src + t4_off(r, chunk * 16 + quad * 4));
         sg[i] = make_float4(raw.x, raw.y, 0.f, 0.f);
         continue;
       }
-      const float* src = isH ? a.stash + (size_t)tile * spt + hoff + (size_t)(valid ? r : 0) * kTM
-                             : a.gstash + (size_t)tile * gpt + goff + (size_t)r * kTM;
-      const float4 v = *reinterpret_cast<const float4*>(src + chunk * 16 + quad * 4);
-      sg[i] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (isH && !FULL) {    // the embedding
+        const bool valid = r < hrows;
+        const float4 v = *reinterpret_cast<const float4*>(a.stash + (size_t)tile * spt + (size_t)(valid ? r : 0) * kTM + chunk * 16 + quad * 4);
+        sg[i] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
+      const float* src = isH ? a.stash + (size_t)tile * spt + hoff : a.gstash + (size_t)tile * gpt + goff;
+      sg[i] = *reinterpret_cast<const float4*>(src + t4_off(r, chunk * 16 + quad * 4));
     }
   };
   auto stage_store = [&](int buf, const float4 (&sg)[4], bool count) {
     unsigned char* base = smem + buf * kDwBuf;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = i * 128 + (tid >> 2), quad = tid & 3;
+      const int row = row_of(i), quad = quad_of(i);
       if (i < 2) rs[i] += count ? (sg[i].x + sg[i].y) + (sg[i].z + sg[i].w) : 0.0f;
       if (H16 && i >= 2) {
         unsigned char* dst16 = base + 2 * kDwTerm + (row & 255) * kDwPitch + quad * 8;
@@ -902,11 +1081,11 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
         dst[(size_t)n * kWidth + k] = acc[rr][c][r] * unscale;
       }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i) {   // G rows: thread = (row row_of(i), pixel quad (tid >> 2) & 3)
     float v = rs[i];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    if ((tid & 3) == 0) dst[(size_t)kWidth * kWidth + i * 128 + (tid >> 2)] = v;
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if (((tid >> 2) & 3) == 0) dst[(size_t)kWidth * kWidth + row_of(i)] = v;
   }
 }
 
@@ -960,16 +1139,37 @@ static int check_desc(const dvd_mlp_desc* d) {
 
 static int dw_slices(int n_tiles) { return n_tiles < kDwSlices ? n_tiles : kDwSlices; }
 
-static int persistent_grid(int n_tiles, int occ) {
+// waves per workgroup of the forward / dX kernels: 4 = two 256-thread workgroups per CU (default), 8 = one of 512 threads
+// (rounds 2-4).  dvd_sf_mlp_select.
+static int g_mlp_nw = DVD_MLP_NW;
+
+// start-up phase of the workgroups (phase_delay): DVD_MLP_PHASE overrides the default (timing studies)
+static int mlp_phase(int nw) {
+  static const int env = [] {
+    const char* e = getenv("DVD_MLP_PHASE");
+    return e ? atoi(e) : -1;
+  }();
+  if (env >= 0) return env;
+  return nw == 4 ? DVD_MLP_PHASE_DEFAULT : 0;
+}
+
+static int persistent_grid(int n_tiles, int occ, int nw) {
   int cus = dvd_device_cu_count();
   if (cus <= 0) cus = 256;
-  const int wgs = cus * (occ / 2);               // 512-thread workgroups resident at once
+  const int wgs = cus * (occ / 2) * (8 / nw);    // workgroups resident at once (8 waves per CU at occ = 2)
   return n_tiles < wgs ? n_tiles : wgs;
 }
 
 }  // namespace dvd
 
 extern "C" {
+
+int dvd_sf_mlp_select(int waves_per_workgroup) {
+  DVD_REQUIRE(waves_per_workgroup == 0 || waves_per_workgroup == 4 || waves_per_workgroup == 8,
+              "sf_mlp_select: waves per workgroup must be 4 or 8 (0 = default), got %d", waves_per_workgroup);
+  dvd::g_mlp_nw = waves_per_workgroup ? waves_per_workgroup : DVD_MLP_NW;
+  return DVD_OK;
+}
 
 int dvd_sf_mlp_in_channels(const dvd_mlp_desc* d) { return d ? dvd::make_geometry(d).c_in : -1; }
 
@@ -1044,23 +1244,23 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   a.n_tiles = (int)((n_pix + kTM - 1) / kTM);
   a.t_offset = t_offset;
   a.out_scale = out_scale;
-  const int grid = persistent_grid(a.n_tiles, DVD_MLP_FWD_OCC);
+  const int nw = g_mlp_nw;
+  a.phase = mlp_phase(nw);
+  const int grid = persistent_grid(a.n_tiles, DVD_MLP_FWD_OCC, nw);
   hipStream_t s = static_cast<hipStream_t>(stream);
   flops_add(DVD_FLOP_MLP_FWD, 2.0 * ((double)a.g.c_in * kWidth + 4.0 * kWidth * kWidth + 3.0 * kWidth) * (double)n_pix);
   if (stash)   // per-layer maxima behind the tiles (embedding, h_0 .. h_4; the dX kernel zeroes its own half)
     if (int e = zero_words(a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, a.g.s16 != 0), kStashTail, s)) return e;
   auto go = [&](auto kern) -> int {
     DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), kFwdLds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), kFwdLds, s, a);
     return DVD_OK;
   };
-  if (stash && a.g.s16) {
-    if (int e = go(mlp_fwd_kernel<true, true>)) return e;
-  } else if (stash) {
-    if (int e = go(mlp_fwd_kernel<true, false>)) return e;
-  } else {
-    if (int e = go(mlp_fwd_kernel<false, false>)) return e;
-  }
+  int e;
+  if (stash && a.g.s16) e = nw == 4 ? go(mlp_fwd_kernel<true, true, 4>) : go(mlp_fwd_kernel<true, true, 8>);
+  else if (stash) e = nw == 4 ? go(mlp_fwd_kernel<true, false, 4>) : go(mlp_fwd_kernel<true, false, 8>);
+  else e = nw == 4 ? go(mlp_fwd_kernel<false, false, 4>) : go(mlp_fwd_kernel<false, false, 8>);
+  if (e) return e;
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -1093,21 +1293,23 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
   a.n_tiles = (int)((n_pix + kTM - 1) / kTM);
   a.out_scale = out_scale;
   a.gscale = gscale;
-  const int grid = persistent_grid(a.n_tiles, DVD_MLP_DX_OCC);
+  const int nw = g_mlp_nw;
+  a.phase = mlp_phase(nw);
+  const int grid = persistent_grid(a.n_tiles, DVD_MLP_DX_OCC, nw);
   // maxima of G_0 .. G_4 over all tiles, folded in by the kernel: floats [8, 16) behind the stash's tiles
   if (int e = zero_words(const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, a.g.s16 != 0) + 8, 8,
                          static_cast<hipStream_t>(stream)))
     return e;
   flops_add(DVD_FLOP_MLP_DX, 2.0 * ((double)a.g.c_in * kWidth + 4.0 * kWidth * kWidth + 3.0 * kWidth) * (double)a.n_pix);
-  if (a.g.s16) {
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
-    hipLaunchKernelGGL(mlp_bwd_dx_kernel<true>, dim3(grid), dim3(kNT), kBwdLds, static_cast<hipStream_t>(stream), a);
-  } else {
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_dx_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
-    hipLaunchKernelGGL(mlp_bwd_dx_kernel<false>, dim3(grid), dim3(kNT), kBwdLds, static_cast<hipStream_t>(stream), a);
-  }
+  auto go = [&](auto kern) -> int {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), kBwdLds, static_cast<hipStream_t>(stream), a);
+    return DVD_OK;
+  };
+  int e;
+  if (a.g.s16) e = nw == 4 ? go(mlp_bwd_dx_kernel<true, 4>) : go(mlp_bwd_dx_kernel<true, 8>);
+  else e = nw == 4 ? go(mlp_bwd_dx_kernel<false, 4>) : go(mlp_bwd_dx_kernel<false, 8>);
+  if (e) return e;
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DVD_ABI_VERSION 5
+#define DVD_ABI_VERSION 6
 
 typedef void* dvd_stream_t; /* hipStream_t */
 
@@ -175,6 +175,10 @@ typedef struct dvd_mlp_desc {
                            * term, 2 MFMAs per product).  Losses and the input gradient do not depend on it. */
 } dvd_mlp_desc;
 
+/* Test / A-B hook (process wide, ABI 6): waves per workgroup of the forward / dX kernels.  4 (default) = two 256-thread
+ * workgroups per CU, each wave two 32-channel row tiles; 8 = one 512-thread workgroup per CU (rounds 2-4).  Outputs, stashes
+ * and input gradients are BIT-identical between the two (same products, same order); 0 = back to the default. */
+int dvd_sf_mlp_select(int waves_per_workgroup);
 int dvd_sf_mlp_in_channels(const dvd_mlp_desc* d);             /* 132 for the shipped config */
 size_t dvd_sf_mlp_packed_bytes(const dvd_mlp_desc* d);
 size_t dvd_sf_mlp_stash_bytes(const dvd_mlp_desc* d, long long n_pix);

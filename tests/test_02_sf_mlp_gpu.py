@@ -124,3 +124,49 @@ def test_unsupported_configuration_is_refused():
     from dvd_hip.networks.sceneflow_field import SceneFlowFieldNet
     with pytest.raises(NotImplementedError):
         SceneFlowFieldNet(net_width=128, n_layers=4, N_freq_xyz=16, N_freq_t=16)
+
+
+@pytest.mark.parametrize('stash_f16', [False, True])
+@pytest.mark.parametrize('B,H,W', [(2, 24, 40), (3, 17, 23), (4, 96, 168)])
+def test_workgroup_shapes_give_the_same_bits(B, H, W, stash_f16):
+    """dvd_sf_mlp_select: two 4-wave workgroups per CU (the default since round 5) against one of 8 waves (rounds 2-4).  Who
+    computes a 32-channel row tile changes, the products and their order do not: outputs, both stashes (activations, sign
+    words, per-layer maxima) and the input gradient are bit-identical; the weight gradients are computed from identical
+    stashes by the same kernel.  dW5 / db5 are float atomics over workgroups in both shapes: equal to rounding only."""
+    from dvd_hip import _lib, ops
+    lib = _lib.load()
+    sd = M.init_params(seed=11)
+    g = torch.Generator().manual_seed(5)
+    p = (3.0 * torch.randn(B, 3, H, W, generator=g)).cuda()
+    ts = torch.rand(B, 1, H, W, generator=g).cuda()
+    gout = torch.randn(B, 3, H, W, generator=g).cuda()
+    n_pix = B * H * W
+    res = {}
+    try:
+        for nw in (8, 4):
+            _lib.check(lib.dvd_sf_mlp_select(nw), 'dvd_sf_mlp_select')
+            k = ops.SceneFlowMLPKernels('cuda', 16, 16, True, stash_f16=stash_f16)
+            k.pack([sd['convs.%d.conv.weight' % i].cuda() for i in range(6)], [sd['convs.%d.conv.bias' % i].cuda() for i in range(6)])
+            st, gst = k.new_stash(n_pix).zero_(), k.new_gstash(n_pix).zero_()
+            sf, sf2, gp = torch.empty_like(p), torch.empty_like(p), torch.empty_like(p)
+            k.forward(p, ts, 0.25, 0.01, sf_out=sf, stash=st)
+            k.forward(p, ts, 0.25, 0.01, sf_out=sf2)                 # the instantiation without a stash
+            gW5, gb5 = torch.zeros(3, 256, device='cuda'), torch.zeros(3, device='cuda')
+            k.backward_dx(st, 0.01, gout, gp, gst, gW5, gb5, (B, H, W))
+            n_g = ((n_pix + 63) // 64) * 5 * 256 * 64      # the gradient tiles (the dW partials behind them are scratch)
+            gW = [torch.zeros(256, k.c_in if i == 0 else 256, device='cuda') for i in range(5)]
+            gb = [torch.zeros(256, device='cuda') for _ in range(5)]
+            k.backward_dw(st, gst, n_pix, gW, gb)
+            torch.cuda.synchronize()
+            res[nw] = dict(sf=sf.cpu(), sf2=sf2.cpu(), st=st.cpu(), gst=gst[:n_g].cpu(), gp=gp.cpu(), gW5=gW5.cpu(), gb5=gb5.cpu(),
+                           gW=[x.cpu() for x in gW], gb=[x.cpu() for x in gb])
+    finally:
+        _lib.check(lib.dvd_sf_mlp_select(0), 'dvd_sf_mlp_select')
+    a, b = res[8], res[4]
+    for key in ('sf', 'sf2', 'st', 'gst', 'gp'):
+        assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), key
+    for x, y in zip(a['gW'] + a['gb'], b['gW'] + b['gb']):
+        assert torch.equal(x, y)
+    assert torch.equal(a['sf'], a['sf2'])
+    for key in ('gW5', 'gb5'):
+        np.testing.assert_allclose(b[key].numpy(), a[key].numpy(), rtol=0, atol=2e-5 * float(a[key].abs().max()))
