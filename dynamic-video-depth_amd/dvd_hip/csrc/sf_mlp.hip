@@ -19,18 +19,21 @@
 //
 // 593 408 FLOP per pixel forward, the same again for dX and for dW.
 //
-// Forward and dX: a 512-thread workgroup (8 waves, two per SIMD, one workgroup per CU) owns a tile of 64 pixels.
+// Forward and dX: a workgroup owns a tile of 64 pixels.  Round 5: 256 threads = 4 waves, two workgroups per CU (rounds 2-4:
+// one of 8 waves; dvd_sf_mlp_select switches, the results are bit-identical).
 //   * Activations live in LDS already split: X[term][k-octet][pixel] cells of 8 fp16 (64 KB).  A lane's B fragment
 //     of one K step (16 channels) is one ds_read_b128 per term; 32 consecutive pixels = 32 consecutive cells.
 //   * Weights never touch LDS: dvd_sf_mlp_pack writes them split and in fragment order (both orientations,
 //     2.3 MB, resident in each XCD's 4 MB L2); a lane's A fragment is one 16-byte global load per term.
-//   * Wave w computes output channels [32w, 32w+32) for all 64 pixels (1x2 tiles of 32x32), layer after layer in
-//     place: 6 MFMAs per K step against 2 global + 4 LDS fragment loads.
-//   * The epilogue (bias, LeakyReLU, split, LDS write) also streams the fp32 activation to the stash as
-//     [channel][64 pixels] rows -- the K-contiguous operand layout of the dW GEMM -- and one SIGN BIT per unit:
-//     the dX chain needs LeakyReLU' only, so it reads 4 bytes per lane and layer instead of the activations.
+//   * Wave w computes output channels [64w, 64w+64) for all 64 pixels (2x2 tiles of 32x32), layer after layer in
+//     place: 12 MFMAs per K step against 4 global + 4 LDS fragment loads (8 waves: 6 against 2 + 4 -- every B fragment
+//     now feeds two row tiles, half the LDS reads per MFMA).
+//   * The epilogue (bias from LDS, LeakyReLU, split, LDS write) also streams the fp32 activation to the stash in the T8
+//     layout below -- pixel runs per channel, the K-contiguous operand layout of the dW GEMM -- and one SIGN BIT per unit:
+//     the dX chain needs LeakyReLU' only, so it reads 4 bytes per lane, row tile and layer instead of the activations.
 //   * The 256 -> 3 output layer is folded into the last epilogue (per-lane partial dot products of the fp32
-//     values, reduced over the waves through LDS in fixed order).
+//     values, reduced over the row tiles through LDS in fixed order); its weight gradient in the dX kernel is a
+//     [3 x 64] x [64 x 256] product per tile, read from the h4 blocks 16 bytes per lane and accumulated in LDS.
 // dW: dW_l = G_l H_{l-1}^T contracts over PIXELS.  A 512-thread workgroup owns the whole 256 x 256 matrix of one
 //   layer for a run of tiles (each operand is read from HBM exactly once): per 16-pixel chunk 512 channel rows are
 //   loaded as fp32, split and written to a double-buffered LDS stage while the MFMAs of the previous chunk run
@@ -38,12 +41,10 @@
 //   Per-workgroup partial matrices go to a workspace at the end of `gstash` and are summed in fixed order by a
 //   second kernel: the weight gradients are bitwise reproducible (the first generation used float atomics).
 
-#include <stdlib.h>
-
 #include "dvd_split.h"
 
-// waves per SIMD the forward / dX kernels are compiled for: 2 = one 512-thread workgroup per CU (<= 256 VGPRs: forward 193,
-// dX 256), 4 = two per CU (the 75 KB of LDS allow it, <= 128 VGPRs do not yet: 46 / 216 spilled registers)
+// waves per SIMD the forward / dX kernels are compiled for: 2 = <= 256 VGPRs (forward 212, dX 225 with four waves per
+// workgroup).  4 (<= 128 VGPRs) with 8-wave workgroups, two per CU: 7 / 25 spilled registers and no faster (round 5)
 #ifndef DVD_MLP_FWD_OCC
 #define DVD_MLP_FWD_OCC 2
 #endif
@@ -53,12 +54,6 @@
 // waves per workgroup the forward / dX kernels start with (dvd_sf_mlp_select changes it at run time): see mlp_fwd_kernel
 #ifndef DVD_MLP_NW
 #define DVD_MLP_NW 4
-#endif
-#ifndef DVD_MLP_KO
-#define DVD_MLP_KO 0     // knock-out builds for timing studies (wrong results): 1 = stash aliased to 64 tiles, 2 = lane-contiguous rows
-#endif
-#ifndef DVD_MLP_PHASE_DEFAULT
-#define DVD_MLP_PHASE_DEFAULT 0
 #endif
 
 namespace dvd {
@@ -295,78 +290,64 @@ __device__ __forceinline__ void store_split4(unsigned char* X, int ko, int m, in
   *reinterpret_cast<u32x2*>(dst + kTermStride) = (u32x2){l0, l1};
 }
 
-// 4 x 4 transpose inside every quad of lanes (two DPP exchanges): on return lane p of a quad holds in v[i] what lane i held
-// in v[p].  The accumulator layout gives a lane ONE pixel of four consecutive channels; the stashes are [channel][64 pixels]
-// rows, so storing (or loading) them register by register costs four dword instructions per lane where the transposed quad
-// needs one 16-byte instruction -- the dX kernel spent 20 % of its time issuing gstash stores, the forward 25 % on the stash.
+// DPP exchanges inside a quad of lanes
 __device__ __forceinline__ float quad_swap1(float v) {     // from lane ^ 1
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float quad_swap2(float v) {     // from lane ^ 2
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float row_ror4(float v) {          // from lane (L + 4) % 16 of the row of 16 lanes
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row_ror8(float v) {          // from lane (L + 8) % 16
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
-}
-__device__ __forceinline__ void quad_transpose4(float (&v)[4], int lane) {
-  const bool odd = lane & 1, hi = lane & 2;
-  const float r01 = quad_swap1(odd ? v[0] : v[1]), r23 = quad_swap1(odd ? v[2] : v[3]);
-  v[0] = odd ? r01 : v[0];
-  v[1] = odd ? v[1] : r01;
-  v[2] = odd ? r23 : v[2];
-  v[3] = odd ? v[3] : r23;
-  const float r02 = quad_swap2(hi ? v[0] : v[2]), r13 = quad_swap2(hi ? v[1] : v[3]);
-  v[0] = hi ? r02 : v[0];
-  v[2] = hi ? v[2] : r02;
-  v[1] = hi ? r13 : v[1];
-  v[3] = hi ? v[3] : r13;
-}
-// ---- layout of a layer's [256 channels][64 pixels] block in the stashes ("T4") -------------------------------------------
-// element (channel n, pixel m) sits at (n >> 2) * 256 + (m >> 2) * 16 + (n & 3) * 4 + (m & 3): blocks of 4 channels, inside a
-// block 16 pixel quads, inside a quad the 4 channels' runs of 4 pixels.  Why: the accumulator layout gives a lane one pixel
-// of four consecutive channels; a quad transpose (two DPP exchanges) turns that into 4 consecutive pixels of ONE channel per
-// lane, and v_permlane32_swap between the registers of the two 32-pixel column tiles puts all 64 pixels of channels
-// 8q .. 8q+3 into one register set and those of 8q+4 .. 8q+7 into the other -- lane L = 4 (pixel quad) + (channel & 3).  With
-// T4 that IS address order: one store instruction writes 1 KB (fp16: 512 B) contiguous, lane after lane.  (Rounds 2-4 stored
-// [channel][64 pixels] rows: 8 separate 128-byte pieces per instruction, lanes 256 bytes apart -- measured with wrong-layout
-// builds: forward 10.4 -> 9.4 ms, dX 11.2 -> 9.4 ms per 16-pair launch for the same bytes.)  The weight-gradient kernel reads
-// 16-pixel chunks: 256 contiguous bytes per 4-channel block.  The embedding rows stay [channel][64 pixels].
-__host__ __device__ inline size_t t4_off(int n, int m) { return (size_t)(n >> 2) * 256 + (m >> 2) * 16 + (n & 3) * 4 + (m & 3); }
+// ---- layout of a layer's [256 channels][64 pixels] block in the stashes ("T8") -------------------------------------------
+// Blocks of 8 channels; inside a block four chunks of 16 pixel POSITIONS; inside a chunk the 8 channels' runs of 16 positions:
+//     element (channel n, pixel m) at (n >> 3) * 512 + (pos >> 4) * 128 + (n & 7) * 16 + (pos & 15),  pos = (m & 15) * 4 + (m >> 4).
+// Why: the accumulator layout gives a lane ONE pixel (column lane & 31 of the column tile ct) of four consecutive channels,
+// the weight-gradient GEMM contracts over pixels and wants runs of pixels per channel.  One v_permlane16_swap between the
+// registers of channels 2 e1 and 2 e1 + 1 moves pixel bit 4 from the lane index into the register index (and channel bit 0
+// the other way): with the two column tiles a lane then holds the pixels jl, jl + 16, jl + 32, jl + 48 (jl = lane & 15) of ONE
+// channel -- the positions 4 jl .. 4 jl + 3 -- in four registers = one 16-byte store (fp16: 8), 4 exchanges per 32 values.
+// (Rounds 3-4 transposed 4 x 4 blocks inside each quad of lanes with DPP moves and selects: 36 instructions per 32 values,
+// a third of all vector instructions of the forward's epilogue.)  Which pixels share a run does not matter to the
+// contraction as long as both operands agree: the gradient stash, the activation stash AND the embedding rows
+// ([channel][64 positions]) use the same pixel -> position map.  The weight-gradient kernel reads 16-position chunks: 512
+// contiguous bytes per 8-channel block.
+__host__ __device__ inline int t8_pos(int m) { return (m & 15) * 4 + (m >> 4); }
+__host__ __device__ inline size_t t8_off(int n, int pos) { return (size_t)(n >> 3) * 512 + (pos >> 4) * 128 + (n & 7) * 16 + (pos & 15); }
 
 // x[e] / y[e] = channels n8 + 4 hh + e (e = 0..3; n8 a multiple of 8, hh = lane >> 5) of the pixels (lane & 31) / 32 + (lane & 31)
-// -- an accumulator register quad of the two column tiles.  blk = the layer block + t4_off(n8, 0).
-__device__ __forceinline__ void t4_exchange(float (&a)[4], float (&b)[4], int lane) {
-  quad_transpose4(a, lane);
-  quad_transpose4(b, lane);
+// -- an accumulator register quad of the two column tiles.  blk = the layer block + t8_off(n8, 0).  On return o[e1][k] =
+// channel n8 + 4 hh + 2 e1 + ((lane >> 4) & 1), pixel (lane & 15) + 16 k.
+__device__ __forceinline__ void t8_exchange(const float (&x)[4], const float (&y)[4], float (&o)[2][4]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[k]), __float_as_uint(b[k]), false, false);
-    a[k] = __uint_as_float(r[0]);
-    b[k] = __uint_as_float(r[1]);
+  for (int e1 = 0; e1 < 2; ++e1) {
+    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[2 * e1]), __float_as_uint(x[2 * e1 + 1]), false, false);
+    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(y[2 * e1]), __float_as_uint(y[2 * e1 + 1]), false, false);
+    o[e1][0] = __uint_as_float(s0[0]);
+    o[e1][1] = __uint_as_float(s0[1]);
+    o[e1][2] = __uint_as_float(s1[0]);
+    o[e1][3] = __uint_as_float(s1[1]);
   }
 }
-__device__ __forceinline__ void store_t4(float* blk, int lane, const float (&x)[4], const float (&y)[4]) {
-  float a[4] = {x[0], x[1], x[2], x[3]}, b[4] = {y[0], y[1], y[2], y[3]};
-  t4_exchange(a, b, lane);
-#if DVD_MLP_KO & 16   // timing study: non-temporal stash stores
-  typedef float f4v __attribute__((ext_vector_type(4)));
-  __builtin_nontemporal_store((f4v){a[0], a[1], a[2], a[3]}, reinterpret_cast<f4v*>(blk + 4 * lane));
-  __builtin_nontemporal_store((f4v){b[0], b[1], b[2], b[3]}, reinterpret_cast<f4v*>(blk + 256 + 4 * lane));
-#else
-  *reinterpret_cast<float4*>(blk + 4 * lane) = make_float4(a[0], a[1], a[2], a[3]);
-  *reinterpret_cast<float4*>(blk + 256 + 4 * lane) = make_float4(b[0], b[1], b[2], b[3]);
-#endif
+// the lane's element offset inside an 8-channel block for e1 = 0 (e1 = 1: + 32)
+__device__ __forceinline__ int t8_lane_off(int lane) {
+  const int jl = lane & 15;
+  return (jl >> 2) * 128 + (4 * (lane >> 5) + ((lane >> 4) & 1)) * 16 + (jl & 3) * 4;
 }
-__device__ __forceinline__ void store_t4(_Float16* blk, int lane, const float (&x)[4], const float (&y)[4]) {
-  float a[4] = {x[0], x[1], x[2], x[3]}, b[4] = {y[0], y[1], y[2], y[3]};
-  t4_exchange(a, b, lane);
-  const f16x2 a0 = {(_Float16)a[0], (_Float16)a[1]}, a1 = {(_Float16)a[2], (_Float16)a[3]};
-  const f16x2 b0 = {(_Float16)b[0], (_Float16)b[1]}, b1 = {(_Float16)b[2], (_Float16)b[3]};
-  *reinterpret_cast<u32x2*>(blk + 4 * lane) = (u32x2){__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1)};
-  *reinterpret_cast<u32x2*>(blk + 256 + 4 * lane) = (u32x2){__builtin_bit_cast(unsigned, b0), __builtin_bit_cast(unsigned, b1)};
+__device__ __forceinline__ void store_t8(float* blk, int lane, const float (&x)[4], const float (&y)[4]) {
+  float o[2][4];
+  t8_exchange(x, y, o);
+  float* dst = blk + t8_lane_off(lane);
+  *reinterpret_cast<float4*>(dst) = make_float4(o[0][0], o[0][1], o[0][2], o[0][3]);
+  *reinterpret_cast<float4*>(dst + 32) = make_float4(o[1][0], o[1][1], o[1][2], o[1][3]);
+}
+__device__ __forceinline__ void store_t8(_Float16* blk, int lane, const float (&x)[4], const float (&y)[4]) {
+  float o[2][4];
+  t8_exchange(x, y, o);
+  _Float16* dst = blk + t8_lane_off(lane);
+#pragma unroll
+  for (int e1 = 0; e1 < 2; ++e1) {
+    const f16x2 a0 = {(_Float16)o[e1][0], (_Float16)o[e1][1]}, a1 = {(_Float16)o[e1][2], (_Float16)o[e1][3]};
+    *reinterpret_cast<u32x2*>(dst + 32 * e1) = (u32x2){__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1)};
+  }
 }
 
 // max over the wave's lanes, in every lane
@@ -387,37 +368,6 @@ __device__ __forceinline__ void fold_amax(float* dst, float m) {      // (read f
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, kSlope * v); }
 
-// ---- start-up phase of a workgroup ---------------------------------------------------------------------------------
-// Every workgroup runs the same sequence (GEMM of a layer, then the epilogue with its 64 KB burst of stash stores), they all
-// start together and nothing makes them drift: left alone, the two workgroups of a CU sit in their epilogues at the same
-// time (matrix pipe idle), and all 512 of them send their bursts to HBM at the same time.  The kernels therefore start
-// the SECOND workgroup that arrives on a CU (arrival order: an atomic counter per CU, keyed by XCC / SE / SH / CU id) a fixed
-// number of 1024-clock sleeps late, plus a small per-workgroup spread.  A performance heuristic only: the results do not
-// depend on it.  `phase` = mode | delay << 4 | spread << 12; mode 0 = off, 1 = slot from blockIdx parity, 2 = from
-// blockIdx / 256, 3 = arrival order on the CU.
-__device__ unsigned g_cu_arrivals[4096];
-
-__device__ __forceinline__ void phase_delay(int phase, float* flag) {
-  if (!phase) return;
-  const int mode = phase & 15, d2 = (phase >> 4) & 255, sp = (phase >> 12) & 255;
-  int slot;
-  if (mode == 1) slot = blockIdx.x & 1;
-  else if (mode == 2) slot = (blockIdx.x >> 8) & 1;
-  else {
-    if (threadIdx.x == 0) {
-      const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-      const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));    // XCC_ID [3:0]
-      const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
-      *reinterpret_cast<int*>(flag) = (int)(atomicAdd(&g_cu_arrivals[key], 1u) & 1u);
-    }
-    __syncthreads();
-    slot = *reinterpret_cast<const int*>(flag);
-    __syncthreads();
-  }
-  const int n = slot * d2 + (int)((blockIdx.x * 2654435761u) >> 29) * sp;
-  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-}
-
 // ==========================================================================================
 // forward
 struct FwdArgs {
@@ -433,7 +383,7 @@ struct FwdArgs {
   PackLayout L;
   Geometry g;
   long long n_pix;
-  int pix_per_img, n_tiles, phase;
+  int pix_per_img, n_tiles;
   float t_offset, out_scale;
 };
 
@@ -452,7 +402,7 @@ __device__ __forceinline__ void build_embedding(const Geometry& g, const float* 
     unsigned char* dst = X + ((ch >> 3) * kTM + m) * 16 + (ch & 7) * 2;
     *reinterpret_cast<unsigned short*>(dst) = (unsigned short)h;
     *reinterpret_cast<unsigned short*>(dst + kTermStride) = (unsigned short)l;
-    if (STASH) st_emb[(size_t)ch * kTM + m] = v;
+    if (STASH) st_emb[(size_t)ch * kTM + t8_pos(m)] = v;      // rows of 64 pixel POSITIONS, like the T8 blocks
   };
   const float x0 = psm[m], x1 = psm[kTM + m], x2 = psm[2 * kTM + m], tt = psm[3 * kTM + m];
   if (part == 0) {
@@ -504,7 +454,6 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const
   const float* pf = static_cast<const float*>(a.packed);
   const u32x4* P4 = static_cast<const u32x4*>(a.packed);
   for (int i = tid; i < 3 * kWidth + 4; i += NT) w5[i] = pf[i < 3 * kWidth ? a.L.w5 + i : a.L.bias[5] + (i - 3 * kWidth)];
-  phase_delay(a.phase, psm);
   if (tid < 8) tmx[tid] = 0.0f;
   for (int i = tid; i < kHidden * kWidth; i += NT) bl[i] = pf[a.L.bias[i / kWidth] + (i % kWidth)];
   const unsigned char* Xl = X + hh * 1024 + j * 16;
@@ -527,11 +476,7 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const
       psm[c * kTM + lane] = v;
     }
     __syncthreads();
-#if DVD_MLP_KO & 1   // timing study: every tile's stash in one slot per XCD (L2 resident)
-    float* st = STASH ? a.stash + (size_t)(blockIdx.x & 7) * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;
-#else
     float* st = STASH ? a.stash + (size_t)tile * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;
-#endif
     // operand scale of the embedding: the largest input magnitude of the tile (every wave sees all 64 pixels in its lanes)
     const float emax = wave_max_all(fmaxf(fmaxf(fabsf(psm[lane]), fabsf(psm[kTM + lane])),
                                           fmaxf(fmaxf(fabsf(psm[2 * kTM + lane]), fabsf(psm[3 * kTM + lane])), 1.0f)));
@@ -599,13 +544,10 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const
           if (STASH) {
             const float x[4] = {acc[r][0][4 * q + 0], acc[r][0][4 * q + 1], acc[r][0][4 * q + 2], acc[r][0][4 * q + 3]};
             const float y[4] = {acc[r][1][4 * q + 0], acc[r][1][4 * q + 1], acc[r][1][4 * q + 2], acc[r][1][4 * q + 3]};
-            if constexpr (S16) store_t4(reinterpret_cast<_Float16*>(sh) + t4_off(32 * rt + 8 * q, 0), lane, x, y);
-            else store_t4(sh + t4_off(32 * rt + 8 * q, 0), lane, x, y);
+            if constexpr (S16) store_t8(reinterpret_cast<_Float16*>(sh) + t8_off(32 * rt + 8 * q, 0), lane, x, y);
+            else store_t8(sh + t8_off(32 * rt + 8 * q, 0), lane, x, y);
           }
         }
-#if DVD_MLP_KO & 8   // timing study: wait for the stash stores right here
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         // one sign word per (row tile, lane): word 64 rt + lane, the same layout for every NW
         if (STASH) reinterpret_cast<unsigned*>(st + stash_sign_off(a.g.c_in16, l, S16))[64 * rt + lane] = sw;
         if (l == kHidden - 1) {
@@ -655,12 +597,12 @@ struct BwdArgs {
   PackLayout L;
   Geometry g;
   long long n_pix;
-  int pix_per_img, n_tiles, phase;
+  int pix_per_img, n_tiles;
   float out_scale, gscale;
 };
 
-// LDS: X (gradient tile, split; at the end fp32 g_in [<= 256][64]) | gz5 [4][64] | w5 [3][256] | tmx [8] | dw5s [3][256]
-constexpr size_t kBwdLds = (size_t)kXBytes + 4 * kTM * 4 + 3 * kWidth * 4 + 8 * 4 + 3 * kWidth * 4;
+// LDS: X (gradient tile, split; at the end fp32 g_in [<= 256][64]) | gz5 [4][64] | gz5p [4][64] | w5 [3][256] | tmx [8] | dw5s [3][256]
+constexpr size_t kBwdLds = (size_t)kXBytes + 2 * 4 * kTM * 4 + 3 * kWidth * 4 + 8 * 4 + 3 * kWidth * 4;
 
 // NW as in the forward.  The input gradient and the gradient stash are bit-identical for NW = 4 and 8 (the last layer's
 // parameter gradients are float atomics over workgroups in both).
@@ -671,14 +613,14 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
   unsigned char* X = smem;
   float* Xf = reinterpret_cast<float*>(smem);
   float* gz5 = reinterpret_cast<float*>(smem + kXBytes);   // [4][64]: g of the 3 outputs (already * out_scale)
-  float* w5 = gz5 + 4 * kTM;                               // [3][256]
+  float* gz5p = gz5 + 4 * kTM;                             // [4][64]: the same in pixel-POSITION order (t8_pos), for dW5
+  float* w5 = gz5p + 4 * kTM;                              // [3][256]
   float* tmx = w5 + 3 * kWidth;                            // [8] (NW used)
   float* dw5s = tmx + 8;                                   // [3][256]: this workgroup's share of dW5
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const float* pf = static_cast<const float*>(a.packed);
   const u32x4* P4 = static_cast<const u32x4*>(a.packed);
-  phase_delay(a.phase, gz5);
   for (int i = tid; i < 3 * kWidth; i += NT) w5[i] = pf[a.L.w5 + i];
   if (tid < 8) tmx[tid] = 0.0f;
   // per-layer maxima of the pre-activation gradients over all tiles (for the weight-gradient kernel): stash tail [8 + l]
@@ -687,15 +629,13 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
   const unsigned char* Xl = X + hh * 1024 + j * 16;
   float sx = 1.0f;                                         // operand scale of what X currently holds
   // Last layer's parameter gradients dW5[c][n] = sum_m g_z5[c][m] h4[n][m], accumulated over this workgroup's tiles in LDS
-  // (dw5s).  Wave w owns the channels [kCW w, kCW w + kCW) and reads their h4 blocks (T4 layout: contiguous) 16 bytes per
-  // lane and load.  fp32 stash: load i is the block of channels kCW w + 4 i .. + 3, lane L holds pixel quad L >> 2 of channel
-  // L & 3; fp16: load i covers two blocks, lane L holds pixel quad (L & 31) >> 1 of the channels 2 (L & 1), + 1 of block L >> 5.
-  // The lanes of a channel are summed by DPP exchanges inside each row of 16 lanes, the rows' sums meet in LDS atomics.
-  // (Until round 5 this was done in the accumulator mapping -- a pixel per lane, 48 accumulator registers per row tile that
-  // lived across the whole kernel.)
+  // (dw5s).  Wave w owns the channels [kCW w, kCW w + kCW) and reads their h4 blocks (T8 layout: contiguous) 16 bytes per
+  // lane and load: one channel, 4 (fp16: 8) consecutive pixel positions -- the same positions of g_z5 are one (two)
+  // ds_read_b128 from gz5p.  The lanes of a channel are summed by DPP exchanges inside the quad, the rest meets in LDS
+  // atomics.  (Until round 5 this was done in the accumulator mapping -- a pixel per lane, 48 accumulator registers per
+  // row tile that lived across the whole kernel.)
   constexpr int kCW = kWidth / NW;                         // channels per wave
   constexpr int kNL = kCW / (S16 ? 8 : 4);                 // 16-byte loads per lane and tile
-  const int pq = S16 ? (lane & 31) >> 1 : lane >> 2;       // the lane's pixel quad
   for (int i = tid; i < 3 * kWidth; i += NT) dw5s[i] = 0.0f;
   float db5 = 0.0f;
   const size_t spt = stash_floats_per_tile(a.g.c_in16, S16), gpt = gstash_floats_per_tile();
@@ -717,18 +657,13 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
         v *= a.out_scale;
       }
       gz5[c * kTM + lane] = v;
+      gz5p[c * kTM + t8_pos(lane)] = v;
       db5 += v;
     }
     __syncthreads();
     {  // dW5 += g_z5 h4^T
       const float* h4 = st + stash_h_off(a.g.c_in16, 4, S16);
       const unsigned char* hb = reinterpret_cast<const unsigned char*>(h4) + (size_t)kCW * w * kTM * (S16 ? 2 : 4) + lane * 16;
-      float g5[3][4];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float4 t = *reinterpret_cast<const float4*>(gz5 + c * kTM + 4 * pq);
-        g5[c][0] = t.x; g5[c][1] = t.y; g5[c][2] = t.z; g5[c][3] = t.w;
-      }
       constexpr int kBatch = 4;                            // loads in flight (4 x 4 registers)
 #pragma unroll
       for (int i0 = 0; i0 < kNL; i0 += kBatch) {
@@ -738,40 +673,38 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
           if constexpr (S16) {
-            // two channels of the lane's pixel quad
-            float hv[2][4];
+            // load i = the 8-channel block i of this wave: lane L holds channel (L >> 1) & 7, positions 16 (L >> 4) + 8 (L & 1) ..
+            float hv[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const f16x2 pr = __builtin_bit_cast(f16x2, (unsigned)raw[i][k]);
-              hv[k >> 1][2 * (k & 1)] = (float)pr[0];
-              hv[k >> 1][2 * (k & 1) + 1] = (float)pr[1];
+              hv[2 * k] = (float)pr[0];
+              hv[2 * k + 1] = (float)pr[1];
             }
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-              for (int u = 0; u < 2; ++u) {
-                float v = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v = __builtin_fmaf(g5[c][k], hv[u][k], v);
-                v += quad_swap2(v);                        // lanes L ^ 2, then L + 8, L + 4 (row rotations): the 8 pixel quads
-                v += row_ror8(v);                          // of this row of 16 lanes
-                v += row_ror4(v);
-                if ((lane & 14) == 0)                      // lanes 0 / 1 of each row; the block's two rows meet in the atomic
-                  unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 8 * (i0 + i) + 4 * (lane >> 5) + 2 * (lane & 1) + u, v);
-              }
-          } else {
-            float hv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) hv[k] = __uint_as_float(raw[i][k]);
+            const int p0 = 16 * (lane >> 4) + 8 * (lane & 1);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-              float v = 0.0f;
+              const float4 ga = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0), gb = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0 + 4);
+              float v = ga.x * hv[0];
+              v = __builtin_fmaf(ga.y, hv[1], v); v = __builtin_fmaf(ga.z, hv[2], v); v = __builtin_fmaf(ga.w, hv[3], v);
+              v = __builtin_fmaf(gb.x, hv[4], v); v = __builtin_fmaf(gb.y, hv[5], v); v = __builtin_fmaf(gb.z, hv[6], v); v = __builtin_fmaf(gb.w, hv[7], v);
+              v += quad_swap1(v);                          // the other half of the chunk; the four chunks meet in the atomic
+              if ((lane & 1) == 0) unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 8 * (i0 + i) + ((lane >> 1) & 7), v);
+            }
+          } else {
+            // loads 2 b, 2 b + 1 = the 8-channel block b of this wave: lane L holds channel (L >> 2) & 7, positions
+            // 16 (2 (i & 1) + (L >> 5)) + 4 (L & 3) ..
+            const int p0 = 16 * (2 * ((i0 + i) & 1) + (lane >> 5)) + 4 * (lane & 3);
 #pragma unroll
-              for (int k = 0; k < 4; ++k) v = __builtin_fmaf(g5[c][k], hv[k], v);
-              v += row_ror8(v);                            // lanes L + 8, L + 4 (row rotations): the 4 pixel quads of this row
-              v += row_ror4(v);
-              if ((lane & 12) == 0)                        // lanes 0 .. 3 of each row; the four rows meet in the atomic
-                unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 4 * (i0 + i) + (lane & 3), v);
+            for (int c = 0; c < 3; ++c) {
+              const float4 ga = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0);
+              float v = ga.x * __uint_as_float(raw[i][0]);
+              v = __builtin_fmaf(ga.y, __uint_as_float(raw[i][1]), v);
+              v = __builtin_fmaf(ga.z, __uint_as_float(raw[i][2]), v);
+              v = __builtin_fmaf(ga.w, __uint_as_float(raw[i][3]), v);
+              v += quad_swap1(v);                          // the 16 positions of the chunk; the four chunks meet in the atomic
+              v += quad_swap2(v);
+              if ((lane & 3) == 0) unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 8 * ((i0 + i) >> 1) + ((lane >> 2) & 7), v);
             }
           }
         }
@@ -808,7 +741,7 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
           gz4(r, 1, q, v1);
 #pragma unroll
           for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
-          store_t4(g4 + t4_off(32 * (RT * w + r) + 8 * q, 0), lane, v0, v1);
+          store_t8(g4 + t8_off(32 * (RT * w + r) + 8 * q, 0), lane, v0, v1);
         }
       // the tile's operand scale: the waves' maxima through LDS (X is idle here: the previous tile is done with it)
       vmax = wave_max_all(vmax);
@@ -867,7 +800,7 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
             store_split4(X, 4 * (RT * w + r) + q, 32 * ct + j, hh, sx, acc[r][ct][4 * q + 0], acc[r][ct][4 * q + 1], acc[r][ct][4 * q + 2], acc[r][ct][4 * q + 3]);
           const float x[4] = {acc[r][0][4 * q + 0], acc[r][0][4 * q + 1], acc[r][0][4 * q + 2], acc[r][0][4 * q + 3]};
           const float y[4] = {acc[r][1][4 * q + 0], acc[r][1][4 * q + 1], acc[r][1][4 * q + 2], acc[r][1][4 * q + 3]};
-          store_t4(gl + t4_off(32 * (RT * w + r) + 8 * q, 0), lane, x, y);
+          store_t8(gl + t8_off(32 * (RT * w + r) + 8 * q, 0), lane, x, y);
         }
       __syncthreads();
     }
@@ -898,7 +831,7 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
       const int c = tid >> 6;
       const int nx = a.g.n_freq_xyz, xb = a.g.xyz_base;
       auto gin = [&](int ch) { return Xf[ch * kTM + lane]; };
-      auto emb = [&](int ch) { return st[(size_t)ch * kTM + lane]; };
+      auto emb = [&](int ch) { return st[(size_t)ch * kTM + t8_pos(lane)]; };
       float gx = gin(xb + c);
       for (int i = 0; i < nx; ++i) {
         const int cc = xb + 3 + 3 * i + c, cs = xb + 3 + 3 * nx + 3 * i + c;
@@ -969,15 +902,15 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
   const float scg = pow2_scale(tail[8 + layer]);                                  // G_layer
   const float sch = H16 ? 1.0f : pow2_scale(tail[layer]);                         // H = embedding (0) or h_{layer-1}
 
-  // staging: 512 rows x 4 quads of 4 pixels -> 4 float4 per thread (i = 0, 1: G rows 0 .. 255; i = 2, 3: H rows).  Operands in
-  // the T4 layout (G, h_l): 16 consecutive threads read the 256 contiguous bytes one 4-channel block holds of this 16-pixel
-  // chunk (fp16: 128) -- thread t = channel t & 3, pixel quad (t >> 2) & 3 of block t >> 4; the embedding (layer 0's H) is
-  // [channel][64 pixels] rows: four consecutive threads read a row's 64 bytes.
+  // staging: 512 rows x 4 quads of 4 pixel positions -> 4 float4 per thread; q = i * 512 + tid, row = q >> 2, quad = q & 3
+  // (i = 0, 1: G rows 0 .. 255; i = 2, 3: H rows).  Operands in the T8 layout (G, h_l): 32 consecutive threads read the 512
+  // contiguous bytes one 8-channel block holds of this 16-position chunk (fp16: 256); the embedding (layer 0's H) is
+  // [channel][64 positions] rows: four consecutive threads read a row's 64 bytes.
   // Two register sets: the chunk loaded during step `it` is split and stored during step it + 1 and consumed by the
   // MFMAs of step it + 2, so no wave ever waits for HBM.
   float4 sg0[4], sg1[4];
-  auto row_of = [&](int i) { return (FULL || i < 2) ? i * 128 + 4 * (tid >> 4) + (tid & 3) : i * 128 + (tid >> 2); };
-  auto quad_of = [&](int i) { return (FULL || i < 2) ? (tid >> 2) & 3 : tid & 3; };
+  auto row_of = [&](int i) { return i * 128 + (tid >> 2); };
+  auto quad_of = [&](int) { return tid & 3; };
   auto stage_load = [&](int it, float4 (&sg)[4]) {
     const int tile = t0 + (it >> 2), chunk = it & 3;
 #pragma unroll
@@ -987,7 +920,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
       const int r = row & 255;
       if (H16 && isH) {      // four fp16 values = 8 bytes, carried in the first two lanes of the float4 as raw bits
         const _Float16* src = reinterpret_cast<const _Float16*>(a.stash + (size_t)tile * spt + hoff);
-        const float2 raw = *reinterpret_cast<const float2*>(src + t4_off(r, chunk * 16 + quad * 4));
+        const float2 raw = *reinterpret_cast<const float2*>(src + t8_off(r, chunk * 16 + quad * 4));
         sg[i] = make_float4(raw.x, raw.y, 0.f, 0.f);
         continue;
       }
@@ -998,7 +931,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
         continue;
       }
       const float* src = isH ? a.stash + (size_t)tile * spt + hoff : a.gstash + (size_t)tile * gpt + goff;
-      sg[i] = *reinterpret_cast<const float4*>(src + t4_off(r, chunk * 16 + quad * 4));
+      sg[i] = *reinterpret_cast<const float4*>(src + t8_off(r, chunk * 16 + quad * 4));
     }
   };
   auto stage_store = [&](int buf, const float4 (&sg)[4], bool count) {
@@ -1081,11 +1014,11 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, unsigned char* smem) {
         dst[(size_t)n * kWidth + k] = acc[rr][c][r] * unscale;
       }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {   // G rows: thread = (row row_of(i), pixel quad (tid >> 2) & 3)
+  for (int i = 0; i < 2; ++i) {   // G rows: thread = (row row_of(i), quad tid & 3)
     float v = rs[i];
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    if (((tid >> 2) & 3) == 0) dst[(size_t)kWidth * kWidth + row_of(i)] = v;
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    if ((tid & 3) == 0) dst[(size_t)kWidth * kWidth + row_of(i)] = v;
   }
 }
 
@@ -1142,16 +1075,6 @@ static int dw_slices(int n_tiles) { return n_tiles < kDwSlices ? n_tiles : kDwSl
 // waves per workgroup of the forward / dX kernels: 4 = two 256-thread workgroups per CU (default), 8 = one of 512 threads
 // (rounds 2-4).  dvd_sf_mlp_select.
 static int g_mlp_nw = DVD_MLP_NW;
-
-// start-up phase of the workgroups (phase_delay): DVD_MLP_PHASE overrides the default (timing studies)
-static int mlp_phase(int nw) {
-  static const int env = [] {
-    const char* e = getenv("DVD_MLP_PHASE");
-    return e ? atoi(e) : -1;
-  }();
-  if (env >= 0) return env;
-  return nw == 4 ? DVD_MLP_PHASE_DEFAULT : 0;
-}
 
 static int persistent_grid(int n_tiles, int occ, int nw) {
   int cus = dvd_device_cu_count();
@@ -1245,7 +1168,6 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   a.t_offset = t_offset;
   a.out_scale = out_scale;
   const int nw = g_mlp_nw;
-  a.phase = mlp_phase(nw);
   const int grid = persistent_grid(a.n_tiles, DVD_MLP_FWD_OCC, nw);
   hipStream_t s = static_cast<hipStream_t>(stream);
   flops_add(DVD_FLOP_MLP_FWD, 2.0 * ((double)a.g.c_in * kWidth + 4.0 * kWidth * kWidth + 3.0 * kWidth) * (double)n_pix);
@@ -1294,7 +1216,6 @@ int dvd_sf_mlp_bwd_dx(const dvd_mlp_desc* d, const void* packed, const void* sta
   a.out_scale = out_scale;
   a.gscale = gscale;
   const int nw = g_mlp_nw;
-  a.phase = mlp_phase(nw);
   const int grid = persistent_grid(a.n_tiles, DVD_MLP_DX_OCC, nw);
   // maxima of G_0 .. G_4 over all tiles, folded in by the kernel: floats [8, 16) behind the stash's tiles
   if (int e = zero_words(const_cast<float*>(a.stash) + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, a.g.s16 != 0) + 8, 8,
