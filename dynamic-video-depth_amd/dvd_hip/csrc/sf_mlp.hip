@@ -459,13 +459,12 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const
   const unsigned char* Xl = X + hh * 1024 + j * 16;
   float* tail = STASH ? a.stash + (size_t)a.n_tiles * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;   // per-layer maxima
 
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const long long n0 = (long long)tile * kTM;
-    __syncthreads();  // previous tile's readers are done with X / psm / red
-    if (tid < 4 * kTM) {  // pixel inputs: thread (c = tid >> 6, m = lane)
+  // pixel inputs of a tile: thread (c = tid >> 6, m = lane), requested one tile ahead (an HBM round trip per tile otherwise)
+  auto pixel_input = [&](int tile) {
+    float v = 0.0f;
+    if (tid < 4 * kTM && tile < a.n_tiles) {
       const int c = tid >> 6;
-      const long long n = n0 + lane;
-      float v = 0.0f;
+      const long long n = (long long)tile * kTM + lane;
       if (n < a.n_pix) {
         const long long b = n / a.pix_per_img, hw = n - b * a.pix_per_img;
         if (c < 3)
@@ -473,8 +472,16 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const
         else
           v = a.t ? a.t[n] + a.t_offset : 0.0f;
       }
-      psm[c * kTM + lane] = v;
     }
+    return v;
+  };
+  float v_in = pixel_input(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long long n0 = (long long)tile * kTM;
+    __syncthreads();  // previous tile's readers are done with X / psm / red
+    if (tid < 4 * kTM) psm[(tid >> 6) * kTM + lane] = v_in;
+    v_in = pixel_input(tile + gridDim.x);
     __syncthreads();
     float* st = STASH ? a.stash + (size_t)tile * stash_floats_per_tile(a.g.c_in16, S16) : nullptr;
     // operand scale of the embedding: the largest input magnitude of the tile (every wave sees all 64 pixels in its lanes)
@@ -640,81 +647,48 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
   float db5 = 0.0f;
   const size_t spt = stash_floats_per_tile(a.g.c_in16, S16), gpt = gstash_floats_per_tile();
 
-  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-    const long long n0 = (long long)tile * kTM;
-    const float* st = a.stash + (size_t)tile * spt;
-    float* gs = a.gstash + (size_t)tile * gpt;
-    __syncthreads();
-    if (tid < 4 * kTM) {  // g_z5[c][m]
+  // g_z5[c][m] of a tile: thread (c = tid >> 6, m = lane), requested one tile ahead (an HBM round trip per tile otherwise)
+  auto out_grad = [&](int tile) {
+    float v = 0.0f;
+    if (tid < 3 * kTM && tile < a.n_tiles) {
       const int c = tid >> 6;
-      const long long n = n0 + lane;
-      float v = 0.0f;
-      if (c < 3 && n < a.n_pix) {
+      const long long n = (long long)tile * kTM + lane;
+      if (n < a.n_pix) {
         const long long b = n / a.pix_per_img, hw = n - b * a.pix_per_img;
         const size_t o = (size_t)((b * 3 + c) * a.pix_per_img + hw);
         v = s1 * a.g_out1[o];
         if (a.g_out2) v += a.g_out2[o];
         v *= a.out_scale;
       }
-      gz5[c * kTM + lane] = v;
-      gz5p[c * kTM + t8_pos(lane)] = v;
-      db5 += v;
     }
+    return v;
+  };
+  float v_in = out_grad(blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const long long n0 = (long long)tile * kTM;
+    const float* st = a.stash + (size_t)tile * spt;
+    float* gs = a.gstash + (size_t)tile * gpt;
     __syncthreads();
-    {  // dW5 += g_z5 h4^T
-      const float* h4 = st + stash_h_off(a.g.c_in16, 4, S16);
-      const unsigned char* hb = reinterpret_cast<const unsigned char*>(h4) + (size_t)kCW * w * kTM * (S16 ? 2 : 4) + lane * 16;
-      constexpr int kBatch = 4;                            // loads in flight (4 x 4 registers)
+    // this tile's h4 blocks (for dW5) and the sign words of layer 5: requested here, consumed after the g_z4 passes below
+    const unsigned char* hb = reinterpret_cast<const unsigned char*>(st + stash_h_off(a.g.c_in16, 4, S16)) +
+                              (size_t)kCW * w * kTM * (S16 ? 2 : 4) + lane * 16;
+    u32x4 raw[kNL];
 #pragma unroll
-      for (int i0 = 0; i0 < kNL; i0 += kBatch) {
-        u32x4 raw[kBatch];
+    for (int i = 0; i < kNL; ++i) raw[i] = *reinterpret_cast<const u32x4*>(hb + i * 1024);
+    unsigned sw5[RT];
 #pragma unroll
-        for (int i = 0; i < kBatch; ++i) raw[i] = *reinterpret_cast<const u32x4*>(hb + (i0 + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-          if constexpr (S16) {
-            // load i = the 8-channel block i of this wave: lane L holds channel (L >> 1) & 7, positions 16 (L >> 4) + 8 (L & 1) ..
-            float hv[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const f16x2 pr = __builtin_bit_cast(f16x2, (unsigned)raw[i][k]);
-              hv[2 * k] = (float)pr[0];
-              hv[2 * k + 1] = (float)pr[1];
-            }
-            const int p0 = 16 * (lane >> 4) + 8 * (lane & 1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float4 ga = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0), gb = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0 + 4);
-              float v = ga.x * hv[0];
-              v = __builtin_fmaf(ga.y, hv[1], v); v = __builtin_fmaf(ga.z, hv[2], v); v = __builtin_fmaf(ga.w, hv[3], v);
-              v = __builtin_fmaf(gb.x, hv[4], v); v = __builtin_fmaf(gb.y, hv[5], v); v = __builtin_fmaf(gb.z, hv[6], v); v = __builtin_fmaf(gb.w, hv[7], v);
-              v += quad_swap1(v);                          // the other half of the chunk; the four chunks meet in the atomic
-              if ((lane & 1) == 0) unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 8 * (i0 + i) + ((lane >> 1) & 7), v);
-            }
-          } else {
-            // loads 2 b, 2 b + 1 = the 8-channel block b of this wave: lane L holds channel (L >> 2) & 7, positions
-            // 16 (2 (i & 1) + (L >> 5)) + 4 (L & 3) ..
-            const int p0 = 16 * (2 * ((i0 + i) & 1) + (lane >> 5)) + 4 * (lane & 3);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const float4 ga = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0);
-              float v = ga.x * __uint_as_float(raw[i][0]);
-              v = __builtin_fmaf(ga.y, __uint_as_float(raw[i][1]), v);
-              v = __builtin_fmaf(ga.z, __uint_as_float(raw[i][2]), v);
-              v = __builtin_fmaf(ga.w, __uint_as_float(raw[i][3]), v);
-              v += quad_swap1(v);                          // the 16 positions of the chunk; the four chunks meet in the atomic
-              v += quad_swap2(v);
-              if ((lane & 3) == 0) unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 8 * ((i0 + i) >> 1) + ((lane >> 2) & 7), v);
-            }
-          }
-        }
-      }
+    for (int r = 0; r < RT; ++r)
+      sw5[r] = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4, S16))[64 * (RT * w + r) + lane];
+    if (tid < 4 * kTM) {
+      const int c = tid >> 6;
+      gz5[c * kTM + lane] = v_in;
+      gz5p[c * kTM + t8_pos(lane)] = v_in;
+      db5 += v_in;
     }
+    v_in = out_grad(tile + gridDim.x);
+    __syncthreads();
     {  // layer 5 (256 -> 3): g_z4 = (W5^T g_z5) * LeakyReLU'(h4) -- in the epilogue mapping
-      unsigned sw[RT];
-#pragma unroll
-      for (int r = 0; r < RT; ++r)
-        sw[r] = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4, S16))[64 * (RT * w + r) + lane];
       float* g4 = gs + (size_t)4 * kWidth * kTM;
       // g_z4 of (pixel m, channels n4 .. n4 + 3): three FMAs and the slope per value -- evaluated twice (first for the
       // tile maximum and the stash, then for the split store) rather than kept in 32 registers per row tile across the barrier
@@ -727,7 +701,7 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
         const float war[4] = {wa.x, wa.y, wa.z, wa.w}, wbr[4] = {wb.x, wb.y, wb.z, wb.w}, wcr[4] = {wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool pos = (sw[r] >> (16 * ct + 4 * q + e)) & 1u;
+          const bool pos = (sw5[r] >> (16 * ct + 4 * q + e)) & 1u;
           v[e] = (ga * war[e] + gb * wbr[e] + gc * wcr[e]) * (pos ? 1.0f : kSlope);
         }
       };
@@ -760,6 +734,46 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
             gz4(r, ct, q, v);
             store_split4(X, 4 * (RT * w + r) + q, 32 * ct + j, hh, sx, v[0], v[1], v[2], v[3]);
           }
+    }
+    {  // dW5 += g_z5 h4^T  (raw = the h4 blocks requested at the top of the tile)
+#pragma unroll
+      for (int i = 0; i < kNL; ++i) {
+        if constexpr (S16) {
+          // load i = the 8-channel block i of this wave: lane L holds channel (L >> 1) & 7, positions 16 (L >> 4) + 8 (L & 1) ..
+          float hv[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const f16x2 pr = __builtin_bit_cast(f16x2, (unsigned)raw[i][k]);
+            hv[2 * k] = (float)pr[0];
+            hv[2 * k + 1] = (float)pr[1];
+          }
+          const int p0 = 16 * (lane >> 4) + 8 * (lane & 1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float4 ga = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0), gb = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0 + 4);
+            float v = ga.x * hv[0];
+            v = __builtin_fmaf(ga.y, hv[1], v); v = __builtin_fmaf(ga.z, hv[2], v); v = __builtin_fmaf(ga.w, hv[3], v);
+            v = __builtin_fmaf(gb.x, hv[4], v); v = __builtin_fmaf(gb.y, hv[5], v); v = __builtin_fmaf(gb.z, hv[6], v); v = __builtin_fmaf(gb.w, hv[7], v);
+            v += quad_swap1(v);                          // the other half of the chunk; the four chunks meet in the atomic
+            if ((lane & 1) == 0) unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 8 * i + ((lane >> 1) & 7), v);
+          }
+        } else {
+          // loads 2 b, 2 b + 1 = the 8-channel block b of this wave: lane L holds channel (L >> 2) & 7, positions
+          // 16 (2 (i & 1) + (L >> 5)) + 4 (L & 3) ..
+          const int p0 = 16 * (2 * (i & 1) + (lane >> 5)) + 4 * (lane & 3);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float4 ga = *reinterpret_cast<const float4*>(gz5p + c * kTM + p0);
+            float v = ga.x * __uint_as_float(raw[i][0]);
+            v = __builtin_fmaf(ga.y, __uint_as_float(raw[i][1]), v);
+            v = __builtin_fmaf(ga.z, __uint_as_float(raw[i][2]), v);
+            v = __builtin_fmaf(ga.w, __uint_as_float(raw[i][3]), v);
+            v += quad_swap1(v);                          // the 16 positions of the chunk; the four chunks meet in the atomic
+            v += quad_swap2(v);
+            if ((lane & 3) == 0) unsafeAtomicAdd(dw5s + c * kWidth + kCW * w + 8 * (i >> 1) + ((lane >> 2) & 7), v);
+          }
+        }
+      }
     }
     __syncthreads();
     // layers 4..1: g_z_{l-1} = (W_l^T g_z_l) * LeakyReLU'(h_{l-1})
