@@ -670,16 +670,20 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
     const float* st = a.stash + (size_t)tile * spt;
     float* gs = a.gstash + (size_t)tile * gpt;
     __syncthreads();
-    // this tile's h4 blocks (for dW5) and the sign words of layer 5: requested here, consumed after the g_z4 passes below
+    // this tile's h4 blocks (for dW5) and its sign words: requested here, consumed after the g_z4 passes below / in the layers
     const unsigned char* hb = reinterpret_cast<const unsigned char*>(st + stash_h_off(a.g.c_in16, 4, S16)) +
                               (size_t)kCW * w * kTM * (S16 ? 2 : 4) + lane * 16;
     u32x4 raw[kNL];
 #pragma unroll
     for (int i = 0; i < kNL; ++i) raw[i] = *reinterpret_cast<const u32x4*>(hb + i * 1024);
-    unsigned sw5[RT];
+    // (the sign words of ALL five layers: requested inside the layer loop they would sit in front of that layer's first weight
+    //  fragments in the one in-order memory counter -- an HBM round trip before every GEMM)
+    unsigned swl[kHidden][RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r)
-      sw5[r] = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, 4, S16))[64 * (RT * w + r) + lane];
+    for (int l = 0; l < kHidden; ++l)
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+        swl[l][r] = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, l, S16))[64 * (RT * w + r) + lane];
     if (tid < 4 * kTM) {
       const int c = tid >> 6;
       gz5[c * kTM + lane] = v_in;
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
         const float war[4] = {wa.x, wa.y, wa.z, wa.w}, wbr[4] = {wb.x, wb.y, wb.z, wb.w}, wcr[4] = {wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bool pos = (sw5[r] >> (16 * ct + 4 * q + e)) & 1u;
+          const bool pos = (swl[4][r] >> (16 * ct + 4 * q + e)) & 1u;
           v[e] = (ga * war[e] + gb * wbr[e] + gc * wcr[e]) * (pos ? 1.0f : kSlope);
         }
       };
@@ -781,12 +785,11 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_DX_OCC) void mlp_bwd_dx_kernel(con
     for (int l = 4; l >= 1; --l) {
       f32x16 acc[RT][2];
       zero_acc<RT>(acc);
-      unsigned sw[RT];
-#pragma unroll
-      for (int r = 0; r < RT; ++r)
-        sw[r] = reinterpret_cast<const unsigned*>(st + stash_sign_off(a.g.c_in16, l - 1, S16))[64 * (RT * w + r) + lane];
       gemm_rows<RT>(P4 + a.L.bwd[l] + (size_t)(RT * w) * 16 * 128 + lane, 16 * 128, 16, Xl, acc);
       const float unscale = 1.0f / (sx * pow2_scale(pf[a.L.wamax + l]));
+      unsigned sw[RT];                                   // sign words of h_{l-1} (register selects: l is a run-time value)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) sw[r] = l == 4 ? swl[3][r] : (l == 3 ? swl[2][r] : (l == 2 ? swl[1][r] : swl[0][r]));
       float vmax = 0.0f;
 #pragma unroll
       for (int r = 0; r < RT; ++r)

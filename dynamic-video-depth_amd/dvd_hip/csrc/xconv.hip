@@ -43,7 +43,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of it stay in registers
 
-// Packed weights: a 256-byte header (float 0: max|A| over the whole tensor, written by xconv_wamax_kernel) followed by
+// Packed weights: a 256-byte header (float 0: max|A| over the whole tensor, written by xconv_pack_kernel from the partial maxima
+// xconv_wamax*_kernel leaves in floats 4 .. 63) followed by
 // frag[(((mt * nkc + kc) * T + tap) * 2 + term) * 64 + lane] : 8 fp16 of A * pow2_scale(max|A|)
 //   forward:    A[m][k] = w[co = m][ci = k][tap]
 //   transposed: A[m][k] = w[co = k][ci = m][T - 1 - tap]      (backward-data: roles swapped, taps flipped)
@@ -64,7 +65,27 @@ __device__ __forceinline__ float xconv_weight(const float* __restrict__ w, int c
   return val;
 }
 
-// max |w[co][...]| * |bn scale[co]| over all weights -> header (zeroed before).  grid.y = output channel (row), so the
+// Block maximum -> header float [kXPartial0 + blockIdx.x].  No atomics and nothing to clear: every block of the launch writes
+// its slot, the pack kernel that follows takes the maximum of the slots (round 5; rounds 2-4 cleared header[0] with a launch of
+// its own and let every wave race an atomic max into it: 503 clearing launches per step and, with many waves, ~88 serialised
+// atomics per microsecond).
+constexpr int kXPartial0 = 4, kXPartials = 60;      // floats 4 .. 63 of the 256-byte header
+template <int NWAVES>
+__device__ __forceinline__ void block_partial_max(float m, float* header) {
+  __shared__ float wm[NWAVES];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, kWave));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float r = wm[0];
+#pragma unroll
+    for (int i = 1; i < NWAVES; ++i) r = fmaxf(r, wm[i]);
+    header[kXPartial0 + blockIdx.x] = r;
+  }
+}
+
+// max |w[co][...]| * |bn scale[co]| over all weights -> the header's partial slots.  grid.y = output channel (row), so the
 // BatchNorm scale is a per-block constant and the loop is a plain strided read (a flat index with a 64-bit division per
 // element ran 45 us per call, 20 ms per step).
 __global__ __launch_bounds__(256) void xconv_wamax_kernel(const float* __restrict__ w, float* __restrict__ header, int rows,
@@ -78,39 +99,48 @@ __global__ __launch_bounds__(256) void xconv_wamax_kernel(const float* __restric
     if (sc_var) m *= fabsf((sc_gamma ? sc_gamma[row] : 1.0f) / sqrtf(sc_var[row] + sc_eps));
     mall = fmaxf(mall, m);
   }
-  wave_amax_to(mall, header);
+  block_partial_max<4>(mall, header);
 }
 
 // The same for rows of whole float4s at 16-byte aligned addresses (every layer but the stem's 27-element rows, and weights
-// that sit at an odd offset of a flat parameter buffer): one WAVE per (row, chunk of 1024 floats), four 16-byte loads per lane
-// in flight.  The row-per-block loop above reads 4 bytes per lane and instruction from at most 128 blocks: 14.7 us per call on
-// average over the 486 weight tensors a step packs (7.2 ms per step = 98 GB/s); this one is launch bound.
-__global__ __launch_bounds__(256) void xconv_wamax4_kernel(const float* __restrict__ w, float* __restrict__ header, int rows,
+// that sit at an odd offset of a flat parameter buffer): a WAVE per (row, chunk of 1024 floats) unit, four 16-byte loads per lane
+// in flight, at most 60 blocks of 16 waves walking the units.  (The row-per-block loop above reads 4 bytes per lane and instruction: 14.7 us
+// per call on average over the 486 weight tensors a step packs = 98 GB/s.  A first version of this kernel with one wave per unit
+// and an atomic per wave was SLOWER, 17.7 us: 2 048 waves finishing together on one header word; with one atomic per block 7.4.)
+constexpr int kWamaxWaves = 16;      // 1024-thread blocks: the number of blocks is bounded by the header's partial slots
+__global__ __launch_bounds__(64 * kWamaxWaves) void xconv_wamax4_kernel(const float* __restrict__ w, float* __restrict__ header, int rows,
                                                            int row_len, int cpr, const float* __restrict__ sc_gamma,
                                                            const float* __restrict__ sc_var, float sc_eps) {
-  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  float m = 0.0f;
-  if (unit < rows * cpr) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, units = rows * cpr, n4 = row_len >> 2;
+  float mall = 0.0f;
+  for (int unit = blockIdx.x * kWamaxWaves + wave; unit < units; unit += gridDim.x * kWamaxWaves) {
     const int row = unit / cpr, ch = unit - row * cpr;
     const float4* p = reinterpret_cast<const float4*>(w + (size_t)row * row_len);
-    const int n4 = row_len >> 2;
     float4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = ch * 256 + k * 64 + lane;
       v[k] = i < n4 ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float m = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
     if (sc_var) m *= fabsf((sc_gamma ? sc_gamma[row] : 1.0f) / sqrtf(sc_var[row] + sc_eps));
+    mall = fmaxf(mall, m);
   }
-  wave_amax_to(m, header);
+  block_partial_max<kWamaxWaves>(mall, header);
 }
 
 __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
                                                          int Cin, int T, int transposed, int mtiles, int nkc, int G,
                                                          const float* __restrict__ sc_gamma, const float* __restrict__ sc_var,
-                                                         float sc_eps) {
+                                                         float sc_eps, int npart) {
+  // max|A| from the partial maxima the wamax launch left in the header (one load per lane, wave maximum); block 0 publishes it
+  // in header[0] for the convolution kernels
+  float amax = (int)(threadIdx.x & 63) < npart ? reinterpret_cast<const float*>(packed)[kXPartial0 + (threadIdx.x & 63)] : 0.0f;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, kWave));
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(packed)[0] = amax;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long total = (long long)G * mtiles * nkc * T * 64;
   if (idx >= total) return;
@@ -135,7 +165,7 @@ __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict
     }
     v[e] = val;
   }
-  const float sw = pow2_scale(reinterpret_cast<const float*>(packed)[0]);
+  const float sw = pow2_scale(amax);
   uint4 h, l;
   split8_f16(v, sw, h, l);
   packed[kXHeader + (f * 2 + 0) * 64 + lane] = h;
@@ -1000,24 +1030,26 @@ static int xconv_pack_impl(const float* w, void* packed, int Cout, int Cin, int 
   const int M = transposed ? ci : co, K = transposed ? co : ci;
   const int mtiles = dvd::xconv_mtiles(M), nkc = (K + 15) / 16, T = KS * KS;
   const long long total = (long long)groups * mtiles * nkc * T * 64;
-  // header: max |A| (BatchNorm scale included) -> the power-of-two operand scale of this packing
-  if (int e = dvd::zero_words(packed, dvd::kXHeader * 4, static_cast<hipStream_t>(stream))) return e;
+  // max |A| (BatchNorm scale included) -> the power-of-two operand scale of this packing: per-block partial maxima into the
+  // header, reduced by the pack kernel
   const int row_len = ci * T;
+  int npart;
   if (row_len % 4 == 0 && reinterpret_cast<uintptr_t>(w) % 16 == 0) {
     const int cpr = (row_len + 1023) / 1024;
-    const long long units = (long long)Cout * cpr;
-    hipLaunchKernelGGL(dvd::xconv_wamax4_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+    const long long nb = ((long long)Cout * cpr + dvd::kWamaxWaves - 1) / dvd::kWamaxWaves;
+    npart = (int)(nb < dvd::kXPartials ? nb : dvd::kXPartials);
+    hipLaunchKernelGGL(dvd::xconv_wamax4_kernel, dim3((unsigned)npart), dim3(64 * dvd::kWamaxWaves), 0, static_cast<hipStream_t>(stream), w,
                        static_cast<float*>(packed), Cout, row_len, cpr, gamma, var, eps);
     DVD_LAUNCH_OK();
   } else {
-    const int nb = Cout < 128 ? Cout : 128;      // few blocks: every wave ends with an atomic on the one header word
-    hipLaunchKernelGGL(dvd::xconv_wamax_kernel, dim3((unsigned)nb), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+    npart = Cout < dvd::kXPartials ? Cout : dvd::kXPartials;
+    hipLaunchKernelGGL(dvd::xconv_wamax_kernel, dim3((unsigned)npart), dim3(256), 0, static_cast<hipStream_t>(stream), w,
                        static_cast<float*>(packed), Cout, row_len, gamma, var, eps);
     DVD_LAUNCH_OK();
   }
   hipLaunchKernelGGL(dvd::xconv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), w, static_cast<uint4*>(packed), co, ci, T, transposed ? 1 : 0,
-                     mtiles, nkc, groups, gamma, var, eps);
+                     mtiles, nkc, groups, gamma, var, eps, npart);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
