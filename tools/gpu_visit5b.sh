@@ -1,5 +1,7 @@
-# round-5 evidence of the final binary (after the MLP restructuring): everything under gpurun_out/r05f/
-export TAG=r05f
+#!/bin/bash
+# Round 5, second half: the evidence visit after the MLP restructuring (profiles/README.md, visit r05f): tests, the bench lines
+# of every schedule, the per-class traces, the MLP counters and micro-benchmarks.  Everything under gpurun_out/$TAG/.
+export TAG=${TAG:-r05f}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 STAGES="tests bench" bash tools/gpu_visit.sh
 run() { name=$1; shift; timeout 900 python bench.py --no_cpu_baseline "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; tail -1 $OUT/bench_$name.json | cut -c1-160; }

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Scene-flow MLP A/B: the kernel tests (incl. the 4-wave / 8-wave bit-identity test) and the micro-benchmark in both workgroup
+# shapes and both stash precisions (MLP_NW, MLP_STASH_F16: tools/microbench_mlp.py).  Output under gpurun_out/r05m/.
 mkdir -p gpurun_out/r05m
 timeout 900 python -m pytest tests/test_02_sf_mlp_gpu.py tests/test_10_act_fp16_gpu.py -x -q -k "mlp or sf or stash or workgroup or golden or oracle or euler" 2>&1 | tail -15 > gpurun_out/r05m/test02b.txt
 cat gpurun_out/r05m/test02b.txt
