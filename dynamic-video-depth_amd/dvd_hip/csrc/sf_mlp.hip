@@ -356,7 +356,8 @@ __device__ __forceinline__ float wave_max_all(float m) {
   for (int off = 1; off < kWave; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
   return m;
 }
-// tile maximum from the eight waves' maxima (LDS, written before the barrier the caller has just passed)
+// tile maximum from the waves' maxima (eight LDS slots, the unused ones of a 4-wave workgroup stay 0; written before the
+// barrier the caller has just passed)
 __device__ __forceinline__ float tile_max(const float* tmx) {
   const float4 a = *reinterpret_cast<const float4*>(tmx), b = *reinterpret_cast<const float4*>(tmx + 4);
   return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
