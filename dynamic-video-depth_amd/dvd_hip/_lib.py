@@ -17,7 +17,7 @@ c_float = ctypes.c_float
 c_void_p = ctypes.c_void_p
 
 DVD_OK, DVD_EINVAL, DVD_EHIP, DVD_ENOSPC = 0, -1, -2, -3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Cameras(ctypes.Structure):
@@ -148,6 +148,7 @@ SIGNATURES = {
     'dvd_head1x1_bwd_workspace_bytes': (c_size_t, [c_int]),
     'dvd_head1x1_bwd': (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gscale_init': (c_int, [c_void_p, c_float, c_void_p]),
+    'dvd_gscale_step_begin': (c_int, [c_void_p, c_void_p]),
     'dvd_gscale_begin': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'dvd_gscale_end': (c_int, [c_void_p, c_void_p]),
     'dvd_cast_scale_f32': (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_void_p, c_void_p]),

@@ -45,14 +45,14 @@ for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
 # Activations between the encoder stem and the depth head may be torch.float16 tensors: the same autograd Functions then call the
 # "_h" / "_t" entry points (csrc/xconv.hip IN16 / OUT16, csrc/xwgrad3.hip H16, the templated helper kernels).  fp16 gradients
 # carry the step's loss scale S (csrc/a16.hip); every PARAMETER gradient is multiplied by 1 / S where it is produced, so the
-# flat gradient buffers hold true fp32 gradients.  The loss-scale state (8 floats on the device) belongs to the model that is
+# flat gradient buffers hold true fp32 gradients.  The loss-scale state (16 floats on the device) belongs to the model that is
 # stepping; it is registered here because the backward Functions need its address.
 ACT_DTYPES = (torch.float32, torch.float16)
 GRAD_SCALE = {'state': None}
 
 
 def set_grad_scale_state(state):
-    """state: the 8-float device tensor of dvd_gscale_* (or None).  Its address is baked into captured HIP graphs, so a model
+    """state: the 16-float device tensor of dvd_gscale_* (or None).  Its address is baked into captured HIP graphs, so a model
     allocates it once and keeps it for its lifetime."""
     GRAD_SCALE['state'] = state
 

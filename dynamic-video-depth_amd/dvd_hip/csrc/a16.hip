@@ -18,7 +18,15 @@
 //       state[3] = observed max |S g| of the fp16 gradient tensors of this step (the backward-data epilogues fold it in)
 //       state[4] = skip flag of this step, state[5] = steps skipped so far
 //       state[6] = forward monitor (round 5): max |y| every fp16-OUTPUT convolution epilogue and the depth head stored / read
-//                  this step (NaN counted as +Inf); >= 65504 means an activation overflowed fp16 -> the step is skipped too
+//                  this step (NaN counted as +Inf); >= 65504 means an activation overflowed fp16 -> the step is skipped too.
+//                  Every fp16 forward folds into it -- warm-up epochs, validation, inference included -- so a TRAINING step
+//                  starts by clearing it (dvd_gscale_step_begin, round 6: a stale overflow from a pass that never reaches
+//                  dvd_gscale_end used to skip the next real step)
+//       state[8] = this step was skipped because an ACTIVATION overflowed, state[9] = steps skipped for that reason so far:
+//                  the (flag, count) pair the scene-flow network's guarded Adam step reads -- its fp32 gradients are valid
+//                  when only the loss scale of the depth net's fp16 GRADIENTS overflowed (state[4] covers both reasons);
+//       state[10] = consecutive steps skipped for an activation overflow (no back-off can cure that one: the host reads it
+//                  with the step's loss scalars and warns / raises);  state[7], [11..15] unused (16 floats in all)
 //     dvd_gscale_end (once per step, before the optimiser): an observed maximum of 2^15.5 or more means fp16 range was
 //     exceeded somewhere -> the step's depth-net update is SKIPPED (dvd_adam_step_guarded); in either case the target moves
 //     by the whole number of octaves that puts the observed maximum at 2^13 (upwards by at most 4 per step).  Every kernel that produces a PARAMETER gradient from fp16 gradients
@@ -33,7 +41,12 @@ constexpr float kGsOverflow = 46340.95f;      // 2^15.5
 constexpr float kF16Max = 65504.0f;           // largest finite _Float16: an activation at or beyond it was stored as Inf
 
 __global__ void gscale_init_kernel(float* __restrict__ st, float target) {
-  if (threadIdx.x < 8) st[threadIdx.x] = threadIdx.x == 0 || threadIdx.x == 1 ? 1.0f : (threadIdx.x == 2 ? target : 0.0f);
+  if (threadIdx.x < 16) st[threadIdx.x] = threadIdx.x == 0 || threadIdx.x == 1 ? 1.0f : (threadIdx.x == 2 ? target : 0.0f);
+}
+
+// First launch of a training step: the forward monitor only means something for the forward passes of THIS step.
+__global__ void gscale_step_begin_kernel(float* __restrict__ st) {
+  if (threadIdx.x == 0) st[6] = 0.0f;
 }
 
 // S = 2^(target - ceil(log2(max|g| * max|w|))); 1 when the gradient is zero / not finite (nothing to scale, or nothing to save)
@@ -70,12 +83,19 @@ __global__ void gscale_end_kernel(float* __restrict__ st) {
   if (!(fwd < kF16Max)) {              // an fp16 ACTIVATION left the format's range (or was NaN): the parameter gradients
     st[4] = 1.0f;                      // of this step are not trustworthy -- skip it; the loss scale is not at fault
     st[5] += 1.0f;
+    st[8] = 1.0f;                      // ... and the scene-flow network's gradient (through the depth map) is not either
+    st[9] += 1.0f;
+    st[10] += 1.0f;
   } else if (!(obs < kGsOverflow)) {   // fp16 range exceeded (or Inf / NaN): skip this step's update, back off
     st[4] = 1.0f;
     st[5] += 1.0f;
+    st[8] = 0.0f;                      // the depth maps were finite: the scene-flow network's fp32 gradients stand
+    st[10] = 0.0f;
     target -= (obs < 3.0e38f) ? ceilf(log2f(obs) - 13.0f) : 8.0f;
   } else {
     st[4] = 0.0f;
+    st[8] = 0.0f;
+    st[10] = 0.0f;
     if (obs > 0.0f) {
       float d = rintf(13.0f - log2f(obs));     // (whole octaves; within half an octave of 2^13 nothing moves)
       d = d > 4.0f ? 4.0f : d;                 // rise by at most 4 octaves per step
@@ -218,6 +238,13 @@ extern "C" {
 int dvd_gscale_init(float* state, float target_exponent, dvd_stream_t stream) {
   DVD_REQUIRE(state, "gscale_init: null pointer");
   hipLaunchKernelGGL(dvd::gscale_init_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state, target_exponent);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_gscale_step_begin(float* state, dvd_stream_t stream) {
+  DVD_REQUIRE(state, "gscale_step_begin: null pointer");
+  hipLaunchKernelGGL(dvd::gscale_step_begin_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -34,6 +34,14 @@ class FlatNet(object):
             p.data = seg
             p.grad = self.grad[o:o + p.numel()].view_as(p)
         self.step_count = 0
+        # 1-element device view of "steps whose update was skipped so far" (the loss-scale state's count that the guarded
+        # Adam kernel subtracts from `step`, csrc/elementwise.hip) or None.  step_count advances on every call, skipped or
+        # not -- the host never learns of a skip inside the step -- so the EFFECTIVE step, the one torch.optim.Adam /
+        # GradScaler mean and a checkpoint must carry, is step_count - skipped.
+        self.skip_count = None
+
+    def _skipped(self):
+        return int(self.skip_count.item()) if self.skip_count is not None else 0
 
     def view(self, buf, p_index):
         p, o = self.params[p_index], self.offsets[p_index]
@@ -104,10 +112,11 @@ class FlatNet(object):
     # param group -- so checkpoints written by either implementation resume in the other.
     def state_dict(self):
         state = {}
-        if self.step_count > 0:
+        eff = self.step_count - self._skipped()      # skipped steps did not advance the optimiser
+        if eff > 0:
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 n = p.numel()
-                state[i] = {'step': torch.tensor(float(self.step_count)),
+                state[i] = {'step': torch.tensor(float(eff)),
                             'exp_avg': self.exp_avg[o:o + n].view_as(p).clone(),
                             'exp_avg_sq': self.exp_avg_sq[o:o + n].view_as(p).clone()}
         group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
@@ -120,7 +129,7 @@ class FlatNet(object):
         run's lr / betas / eps (optimizer_load_state_dict(keep_training_params=True), netinterface.py:565-574).
         Parameters without state (never stepped) keep zero moments."""
         if 'state' not in sd:                      # round-1 flat layout
-            self.step_count = int(sd['step'])
+            self.step_count = int(sd['step']) + self._skipped()
             self.exp_avg.copy_(sd['exp_avg'])
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
             return
@@ -146,4 +155,5 @@ class FlatNet(object):
         if len(steps) > 1:
             raise ValueError('per-parameter Adam step counts differ (%s): the fused optimiser keeps one count per '
                              'network' % sorted(steps))
-        self.step_count = steps.pop() if steps else 0
+        # (the kernel subtracts this process's skip count: add it, so that the effective step continues from the checkpoint's)
+        self.step_count = (steps.pop() if steps else 0) + self._skipped()

@@ -49,19 +49,39 @@ from .netinterface import NetInterface
 CAM_KEYS = ops.CAM_KEYS
 
 
-def head_room_fraction(world):
+def head_room_fraction(world, total_bytes=None):
     """Fraction of the device the memory planner leaves untouched: allocator fragmentation, and -- with several ranks --
     whatever RCCL's collectives allocate while the step runs (its communicator is created BEFORE the planner reads the free
     memory, parallel.init_from_env, so its channel / staging buffers are already counted as used).  Single process: 8 % (23 GB
     of 288); data parallel: 10 % (29 GB), derated automatically -- the benchmark configuration still keeps both of its slots
     (225 GB free - 60 GB slot >= 130 GB of stashes + 29 GB)."""
     frac = 0.08 if world <= 1 else 0.10
-    # DVD_HEAD_ROOM_GB: an explicit head room (GB of a 288 GB device) for runs that must leave more to other tenants of the
-    # device -- the 8-rank run's RCCL buffers when the communicator is created late, or a memory-capped deployment
-    gb = os.environ.get('DVD_HEAD_ROOM_GB')
+    # DVD_HEAD_ROOM_GB: an explicit head room in GB for runs that must leave more to other tenants of the device -- the 8-rank
+    # run's RCCL buffers when the communicator is created late, or a memory-capped deployment.  Absolute: it is divided by the
+    # device's REAL size (keep_slot_fits multiplies the fraction by that same total), not by a hard-coded 288 GB.
+    gb = _HEAD_ROOM_GB
     if gb:
-        frac = max(frac, float(gb) * 2 ** 30 / float(288 * 2 ** 30))
+        if total_bytes is None:
+            total_bytes = torch.cuda.mem_get_info()[1] if torch.cuda.is_available() else 288 * 2 ** 30
+        frac = max(frac, min(0.9, gb * 2 ** 30 / float(total_bytes)))
     return frac
+
+
+def _head_room_gb_from_env():
+    """DVD_HEAD_ROOM_GB, validated once at import: a malformed value must not surface in the middle of step planning."""
+    raw = os.environ.get('DVD_HEAD_ROOM_GB')
+    if not raw:
+        return 0.0
+    try:
+        gb = float(raw)
+    except ValueError:
+        raise ValueError('DVD_HEAD_ROOM_GB=%r is not a number of gigabytes' % raw)
+    if not (0.0 <= gb < 1e5):
+        raise ValueError('DVD_HEAD_ROOM_GB=%r: expected a non-negative number of gigabytes' % raw)
+    return gb
+
+
+_HEAD_ROOM_GB = _head_room_gb_from_env()
 
 
 def keep_slot_fits(est, free, total, reserve, spare, kept, budget, head_room=0.08):
@@ -112,6 +132,9 @@ class Model(NetInterface):
                             help='BASELINE configs[4]: store the depth net\'s activations (and their gradients) as fp16 in HBM -- '
                                  'fp32 parameters, fp32 accumulation, fp32 loss sums; gradients carry a power-of-two loss scale kept on '
                                  'the device (csrc/a16.hip); a step whose fp16 gradients overflow skips its depth-net update.  MiDaS only')
+        parser.add_argument('--max_act_overflow_skips', type=int, default=25,
+                            help='--act_fp16: consecutive steps skipped because an fp16 ACTIVATION overflowed after which the run '
+                                 'stops with an error (a warning from the third on): the loss scale cannot cure that')
         parser.add_argument('--mlp_stash_fp16', action='store_true',
                             help='store the hidden activations of the scene-flow MLP stash as fp16 (3.2 instead of 5.7 KB per pixel and '
                                  'Euler step; the MLP weight gradients then see fp16-rounded activations, losses and input gradients '
@@ -184,11 +207,15 @@ class Model(NetInterface):
         self._mlp = None if self.opt.use_cnn else self.net_sceneflow.kernels(
             self.device, stash_f16=bool(getattr(self.opt, 'mlp_stash_fp16', False) or getattr(self.opt, 'act_fp16', False)))
         self._gscale = None
+        self._steps_skipped = 0
         if getattr(self.opt, 'act_fp16', False):
             if not self.opt.midas:
                 raise NotImplementedError('--act_fp16 covers the MiDaS depth net (BASELINE configs[4])')
             self.net_depth.act_dtype = torch.float16
             self._gscale = ops.gscale_new(self.device)       # lives as long as the model: captured graphs hold its address
+            # what each network's guarded Adam step subtracts from its step number (checkpoints carry the effective step)
+            self._flat_depth.skip_count = self._gscale[5:6]
+            self._flat_sf.skip_count = self._gscale[9:10]
         if self._pending_optimizer_state is not None:      # checkpoint restored before .to() (train.py:256,279)
             self._apply_optimizer_state(self._pending_optimizer_state)
             self._pending_optimizer_state = None
@@ -305,9 +332,9 @@ class Model(NetInterface):
         if os.environ.get('DVD_KEEP_DEBUG'):
             print('keep slot %d: est %.1f GB, free %.1f, reserve %.1f + %.1f + spare %.1f, kept so far %.1f, pools %.1f' % (
                 slot, est / 2 ** 30, free / 2 ** 30, reserve_bytes / 2 ** 30,
-                head_room_fraction(parallel.world_size()) * total / 2 ** 30, spare / 2 ** 30,
+                head_room_fraction(parallel.world_size(), total) * total / 2 ** 30, spare / 2 ** 30,
                 self._keep_bytes / 2 ** 30, self._pool_bytes / 2 ** 30), file=sys.stderr, flush=True)
-        hr = head_room_fraction(parallel.world_size())
+        hr = head_room_fraction(parallel.world_size(), total)
         if not keep_slot_fits(est, free, total, reserve_bytes, spare, self._keep_bytes, budget, hr):
             self._depth_graphs[key] = None
             self._keep_denied[key] = self._step_no
@@ -384,7 +411,7 @@ class Model(NetInterface):
             print('after phase 1: free %.1f GB, phase 2 needs %.1f, pools %.1f' % (free / 2 ** 30, need_bytes / 2 ** 30,
                                                                                self._pool_bytes / 2 ** 30), file=sys.stderr, flush=True)
         kept = [k for k, v in self._depth_graphs.items() if k[0] == 'keep' and v is not None]
-        while kept and free < need_bytes + 0.5 * head_room_fraction(parallel.world_size()) * total:
+        while kept and free < need_bytes + 0.5 * head_room_fraction(parallel.world_size(), total) * total:
             key = kept.pop()
             self._keep_bytes -= self._depth_graphs[key][5]
             self._pool_bytes -= self._depth_graphs[key][5]
@@ -497,6 +524,10 @@ class Model(NetInterface):
         opt = self.opt
         self._step_no += 1
         conv.set_grad_scale_state(self._gscale)      # the loss-scale state of THIS model's fp16 gradients (None: fp32 storage)
+        if self._gscale is not None:
+            # the forward monitor counts for THIS step's forward passes only: warm-up epochs, validation and inference fold
+            # into it too and never reach dvd_gscale_end -- a stale overflow of theirs skipped the next real step
+            ops.gscale_step_begin(self._gscale)
         self.warm = warm = epoch <= opt.warm_sf
         self.net_depth.eval()                        # BN statistics are never updated (:157,168 / hourglass.py:200-208)
         for p in self.net_depth.parameters():
@@ -779,16 +810,20 @@ class Model(NetInterface):
             k.all_reduce_grads()
         if h_sf is not None:
             h_sf.wait()
-        # (fp16 activations: a skipped step skips BOTH updates -- an activation that overflowed fp16 makes the depth map, and
-        #  with it the scene-flow network's gradient, non-finite too; round 4 guarded the depth net only)
-        k.adam_step(skip_ptr=None if (warm or self._gscale is None) else self._gscale[4:5])
+        # (fp16 activations: an ACTIVATION that overflowed fp16 makes the depth map, and with it the scene-flow network's
+        #  gradient, non-finite: that step skips BOTH updates.  A mere loss-scale overflow of the depth net's fp16 GRADIENTS
+        #  leaves the depth maps finite and the scene-flow network's fp32 gradients valid: its update goes through -- the
+        #  (flag, count) pair [8], [9] of the loss-scale state counts activation overflows only)
+        k.adam_step(skip_ptr=None if (warm or self._gscale is None) else self._gscale[8:10])
 
-        host = torch.cat([scalars, sums[4:5]]).tolist()          # the only host synchronisation of the step
+        host = self._step_scalars_to_host(scalars, sums, warm)    # the only host synchronisation of the step
         acc_reg = opt.acc_mul * host[8] / (3.0 * n_global * HW + 1e-6) if do_reg else 0
         # --weight_steps scales the gradient only: the logged loss is the unweighted one (`**loss_data`
         # overwrites 'loss' at :226)
         batch_log = {'size': opt.batch_size, 'loss': host[1] / mul, 'total_loss': host[1] / mul, 'flow_loss_1_2': host[2],
                      'disp_loss_1_2': host[3], 'sf_loss': host[4], 'acc_reg': acc_reg}
+        if self._gscale is not None:
+            batch_log['steps_skipped'] = self._steps_skipped
         self._last = {'depth_1': depth_1, 'depth_2': depth_2, 'mask_sum': host[5], 'sf_all': sf_all, 'mseg': mseg}
         self._export_train_visuals(epoch, batch_ind, batch)
         return batch_log
@@ -823,9 +858,13 @@ class Model(NetInterface):
         need = B * HW * self._cnn_bytes_per_px() * evals
         free, _total = self._free_hbm(dev)
         if need > free:
-            raise RuntimeError('--use_cnn: the U-Net\'s autograd state for %d pairs at %dx%d (%d evaluations, %.0f B per pixel and '
-                               'evaluation) needs %.1f GB, %.1f GB are free: use fewer pairs per step or a smaller --depth_keep_gb'
-                               % (B, H, W, evals, self._cnn_bytes_per_px(), need / 2 ** 30, free / 2 ** 30))
+            msg = ('--use_cnn: the U-Net\'s autograd state for %d pairs at %dx%d (%d evaluations, %.0f B per pixel and '
+                   'evaluation) needs %.1f GB, %.1f GB are free: use fewer pairs per step or a smaller --depth_keep_gb'
+                   % (B, H, W, evals, self._cnn_bytes_per_px(), need / 2 ** 30, free / 2 ** 30))
+            if self._cnn_px_measured > 0:        # a measured footprint: fail early, with the numbers
+                raise RuntimeError(msg)
+            import warnings                       # an a-priori estimate must not reject a configuration that may well run
+            warnings.warn(msg + ' (a-priori estimate: nothing has been measured yet, trying anyway)')
         mem0 = torch.cuda.memory_allocated(dev)
         with torch.enable_grad():
             sf_acc, p, t, sf0 = None, P1, ts, None
@@ -877,16 +916,42 @@ class Model(NetInterface):
             k.all_reduce_grads()
         if h_sf is not None:
             h_sf.wait()
-        # (fp16 activations: a skipped step skips BOTH updates -- an activation that overflowed fp16 makes the depth map, and
-        #  with it the scene-flow network's gradient, non-finite too; round 4 guarded the depth net only)
-        k.adam_step(skip_ptr=None if (warm or self._gscale is None) else self._gscale[4:5])
-        host = torch.cat([scalars, sums[4:5]]).tolist()
+        # (fp16 activations: an ACTIVATION that overflowed fp16 makes the depth map, and with it the scene-flow network's
+        #  gradient, non-finite: that step skips BOTH updates.  A mere loss-scale overflow of the depth net's fp16 GRADIENTS
+        #  leaves the depth maps finite and the scene-flow network's fp32 gradients valid: its update goes through -- the
+        #  (flag, count) pair [8], [9] of the loss-scale state counts activation overflows only)
+        k.adam_step(skip_ptr=None if (warm or self._gscale is None) else self._gscale[8:10])
+        host = self._step_scalars_to_host(scalars, sums, warm)    # the only host synchronisation of the step
         acc_reg = opt.acc_mul * host[8] / (3.0 * n_global * HW + 1e-6) if do_reg else 0
         batch_log = {'size': opt.batch_size, 'loss': host[1] / mul, 'total_loss': host[1] / mul, 'flow_loss_1_2': host[2],
                      'disp_loss_1_2': host[3], 'sf_loss': host[4], 'acc_reg': acc_reg}
+        if self._gscale is not None:
+            batch_log['steps_skipped'] = self._steps_skipped
         self._last = {'depth_1': depth_1, 'depth_2': depth_2, 'mask_sum': host[5], 'sf_all': sf_all, 'mseg': mseg}
         self._export_train_visuals(epoch, batch_ind, batch)
         return batch_log
+
+    def _step_scalars_to_host(self, scalars, sums, warm):
+        """The step's ONE device -> host copy: the loss scalars, the regulariser sum and -- with fp16 activation storage --
+        the loss-scale state's skip counters, so that a run whose updates are being skipped says so (batch_log
+        'steps_skipped') instead of logging a loss that never moves.  An fp16 ACTIVATION overflow has no
+        back-off (the loss scale is not at fault): a warning from the third consecutive skipped step on, an error after
+        --max_act_overflow_skips (default 25) of them."""
+        if self._gscale is None:
+            return torch.cat([scalars, sums[4:5]]).tolist()
+        host = torch.cat([scalars, sums[4:5], self._gscale[4:6], self._gscale[8:11]]).tolist()
+        self._steps_skipped = int(host[10])
+        run = 0 if warm else int(host[13])
+        if run >= 3:
+            import warnings
+            limit = int(getattr(self.opt, 'max_act_overflow_skips', 25))
+            msg = ('fp16 activation storage: an activation of the depth network left fp16\'s range in %d consecutive steps; '
+                   'every one of them was skipped (%d skipped steps in all).  The loss scale cannot cure this: lower the '
+                   'learning rate or run without --act_fp16' % (run, self._steps_skipped))
+            if run >= limit:
+                raise RuntimeError(msg)
+            warnings.warn(msg)
+        return host
 
     # -- the reference's `pred` dict and its export (scene_flow_motion_field.py:201-225, video_base.py:105-126) ----
     def _export_train_visuals(self, epoch, batch_ind, batch):

@@ -107,10 +107,11 @@ def _capture_gen():
     if not torch.cuda.is_current_stream_capturing():
         st[1] = False
         return 0
-    if not st[1]:                       # first call inside this capture
-        if not st[2]:
-            st[0] += 1                  # unannounced: a generation of its own all the same
-        st[2] = False
+    if not st[1] and not st[2]:         # first call inside a capture nobody announced: a generation of its own all the same
+        st[0] += 1
+    # the announcement is consumed by EVERY in-capture call (two announced captures back to back, with no eager
+    # call in between, left it set -- the next unannounced capture then shared the second one's generation and pool chunk)
+    st[2] = False
     st[1] = True
     return st[0]
 
@@ -511,10 +512,15 @@ def adam_step(param, grad1, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps=1e-
 
 
 def gscale_new(device, target_exponent=4.0):
-    """The loss-scale state of the fp16 gradients (8 floats on the device; layout: include/dvd_hip.h, policy: csrc/a16.hip)."""
-    st = torch.empty(8, device=device, dtype=torch.float32)
+    """The loss-scale state of the fp16 gradients (16 floats on the device; layout: include/dvd_hip.h, policy: csrc/a16.hip)."""
+    st = torch.empty(16, device=device, dtype=torch.float32)
     _lib.check(_lib.load().dvd_gscale_init(_p(st), float(target_exponent), _stream()), 'dvd_gscale_init')
     return st
+
+
+def gscale_step_begin(state):
+    """First launch of a training step: clears the forward monitor (validation / warm-up / inference passes fold into it too)."""
+    _lib.check(_lib.load().dvd_gscale_step_begin(_p(state), _stream()), 'dvd_gscale_step_begin')
 
 
 def gscale_end(state):

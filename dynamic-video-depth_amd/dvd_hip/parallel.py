@@ -20,8 +20,24 @@ import torch
 import torch.distributed as dist
 
 
+# A ONE-rank process group normally takes the single-GPU short cuts below (no collective at all).  With this switch -- the
+# DVD_FORCE_DIST=1 environment variable or force_distributed(True) -- a one-rank group runs every collective of the N-rank
+# step for real (plan agreement, loss-sum all-reduce, asynchronous MLP-gradient all-reduce under the depth-net backward, the
+# bucketed gradient all-reduce pipelined with Adam): on a 1-GPU box that is what executes the RCCL calls of this package,
+# stream semantics of `work.wait()` and interaction with captured HIP graphs included (tests/test_33_rccl_one_rank_gpu.py,
+# bench.py's `rccl_one_rank` record).  The arithmetic is unchanged: a sum over one rank is the identity.
+_FORCE = [os.environ.get('DVD_FORCE_DIST', '0') not in ('', '0')]
+
+
+def force_distributed(flag=True):
+    """Run the collectives of the data-parallel step even in a one-rank group.  Returns the previous setting."""
+    old = _FORCE[0]
+    _FORCE[0] = bool(flag)
+    return old
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE[0])
 
 
 def world_size():
@@ -30,6 +46,45 @@ def world_size():
 
 def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def rccl_info():
+    """Version of the collective library behind the 'nccl' backend (RCCL on ROCm), for bench lines and test logs."""
+    try:
+        v = torch.cuda.nccl.version()
+        return '.'.join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:          # noqa: BLE001 -- informational only
+        return 'unknown (%s)' % type(e).__name__
+
+
+def init_one_rank(backend='nccl', port=None):
+    """A ONE-rank process group on this process's current GPU + force_distributed(): every RCCL call of the N-rank step
+    executes on the box at hand.  Returns {'backend', 'rccl_version', 'comm_hbm_bytes'} -- the HBM the communicator took at
+    its first collective, measured with hipMemGetInfo around it (what head_room_fraction has to cover per rank)."""
+    if dist.is_initialized():
+        raise RuntimeError('init_one_rank: a process group exists already')
+    import socket
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    dev = torch.device('cuda', torch.cuda.current_device())
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    dist.init_process_group(backend=backend, init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    warm = torch.zeros(1, device=dev)
+    dist.all_reduce(warm)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(dev)[0]
+    force_distributed(True)
+    return {'backend': backend, 'rccl_version': rccl_info() if backend == 'nccl' else None,
+            'comm_hbm_bytes': int(max(0, free0 - free1))}
+
+
+def shutdown():
+    force_distributed(False)
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def init_from_env(backend=None):

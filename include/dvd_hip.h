@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DVD_ABI_VERSION 6
+#define DVD_ABI_VERSION 7
 
 typedef void* dvd_stream_t; /* hipStream_t */
 
@@ -475,12 +475,17 @@ int dvd_head1x1_fwd(const void* x, int f16, const float* w, const float* bias, f
 size_t dvd_head1x1_bwd_workspace_bytes(int C);
 int dvd_head1x1_bwd(const void* x, int f16, const float* w, const float* gy, const float* gscale_state, void* gx, float* gw,
                     float* gb, void* workspace, size_t workspace_bytes, int N, int C, int HW, int relu_in, dvd_stream_t stream);
-/* Loss scale of the fp16 gradients, kept on the device (state: 8 floats; [0] = S, [1] = 1 / S, [2] = target exponent,
+/* Loss scale of the fp16 gradients, kept on the device (state: 16 floats since ABI 7; [0] = S, [1] = 1 / S, [2] = target exponent,
  * [3] = observed max |S g| this step, [4] = skip flag, [5] = skipped steps, [6] = forward monitor: max |activation| the fp16-output
  * convolution epilogues and the depth head folded in this step -- every maximum counts a NaN as +Inf).  begin: S = 2^(target - ceil(log2(max|g| * max|w|)))
  * from the device scalar max|g_out| and the n_w head weights; end (once per step, before the optimiser): overflow -> skip flag +
- * back-off, small observed maximum -> raise the target; an ACTIVATION beyond fp16's range ([6] >= 65504) -> skip flag only.  Policy and thresholds: csrc/a16.hip. */
+ * back-off, small observed maximum -> raise the target; an ACTIVATION beyond fp16's range ([6] >= 65504) -> skip flag only.  Policy and thresholds: csrc/a16.hip.
+ * ABI 7: [8] = this step was skipped for an activation overflow, [9] = steps skipped for that reason so far (the (flag, count) pair
+ * for dvd_adam_step_guarded of a network whose fp32 gradients survive a mere loss-scale overflow), [10] = consecutive such skips;
+ * step_begin (first launch of every TRAINING step) clears the forward monitor [6], which every fp16 forward -- validation and
+ * inference included -- folds into. */
 int dvd_gscale_init(float* state, float target_exponent, dvd_stream_t stream);
+int dvd_gscale_step_begin(float* state, dvd_stream_t stream);
 int dvd_gscale_begin(float* state, const float* g_amax, const float* w, int n_w, dvd_stream_t stream);
 int dvd_gscale_end(float* state, dvd_stream_t stream);
 /* out[i] = scale[0] * in[i] as fp32 (n % 4 == 0): the gradient leaving the fp16 region towards the fp32 stem. */

@@ -272,7 +272,7 @@ def test_head_boundary_forward_backward_and_scale():
 def test_loss_scale_policy_transitions_and_guarded_adam():
     from dvd_hip import ops
     st = ops.gscale_new(torch.device('cuda'))
-    assert st.tolist() == [1.0, 1.0, 4.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+    assert st.tolist() == [1.0, 1.0, 4.0] + [0.0] * 13      # 16 floats since ABI 7
     p = torch.ones(8, device='cuda')
     g, m, v = torch.ones(8, device='cuda'), torch.zeros(8, device='cuda'), torch.zeros(8, device='cuda')
     st[3] = 10000.0                                  # 2^13.3: centred, nothing changes, no skip
@@ -301,6 +301,50 @@ def test_loss_scale_policy_transitions_and_guarded_adam():
     st[3] = 8192.0
     ops.gscale_end(st)
     assert st[2:6].tolist() == [-6.0, 0.0, 0.0, 2.0]
+    # --- forward monitor.  An activation beyond fp16's range skips the step for BOTH networks -- [4] and the
+    # activation-only pair [8], [9] -- without touching the target; consecutive such skips are counted in [10]
+    st[3], st[6] = 8192.0, 70000.0
+    ops.gscale_end(st)
+    assert st[2:7].tolist() == [-6.0, 0.0, 1.0, 3.0, 0.0] and st[8:11].tolist() == [1.0, 1.0, 1.0]
+    st[3], st[6] = 8192.0, float('nan')
+    ops.gscale_end(st)
+    assert st[4:6].tolist() == [1.0, 4.0] and st[8:11].tolist() == [1.0, 2.0, 2.0]
+    # a mere loss-scale overflow skips the depth net's update only: the activation pair stays clear and its run ends
+    st[3] = 2.0 ** 20
+    ops.gscale_end(st)
+    assert st[4:6].tolist() == [1.0, 5.0] and st[8:11].tolist() == [0.0, 2.0, 0.0]
+    before = (p.clone(), m.clone(), v.clone())
+    ops.adam_step(p, g, m, v, 3, 0.1, 0.5, 0.9, skip_ptr=st[4:5])          # depth net: skipped
+    assert torch.equal(p, before[0]) and torch.equal(m, before[1])
+    ops.adam_step(p, g, m, v, 3, 0.1, 0.5, 0.9, skip_ptr=st[8:10])         # scene-flow net: not skipped
+    assert not torch.equal(p, before[0])
+    # a stale overflow left behind by a pass that never reaches dvd_gscale_end (validation, warm-up, inference) is cleared by
+    # the training step's first launch and does not skip that step
+    st[6] = float('inf')
+    ops.gscale_step_begin(st)
+    assert float(st[6]) == 0.0
+    st[3] = 8192.0
+    ops.gscale_end(st)
+    assert st[4:6].tolist() == [0.0, 5.0] and st[8:11].tolist() == [0.0, 2.0, 0.0]
+
+
+def test_checkpoints_carry_the_effective_adam_step():
+    """FlatNet.step_count advances on skipped steps too (the host never learns of a skip inside the step); the guarded Adam
+    kernel subtracts the device-side skip count.  A checkpoint must carry step - skipped, the meaning torch.optim.Adam /
+    GradScaler give it, and a resume must continue from there."""
+    from dvd_hip import flat
+    net = torch.nn.Linear(4, 4).cuda()
+    fn = flat.FlatNet(net, 1e-3, (0.5, 0.9))
+    skipped = torch.tensor([3.0], device='cuda')
+    fn.skip_count = skipped
+    fn.step_count = 10
+    sd = fn.state_dict()
+    assert float(sd['state'][0]['step']) == 7.0
+    fn2 = flat.FlatNet(torch.nn.Linear(4, 4).cuda(), 1e-3, (0.5, 0.9))
+    fn2.skip_count = torch.tensor([2.0], device='cuda')          # a process that has skipped two steps of its own
+    fn2.load_state_dict(sd)
+    assert fn2.step_count - fn2._skipped() == 7
+    assert float(fn2.state_dict()['state'][0]['step']) == 7.0
 
 
 # ---- the network ------------------------------------------------------------------------------------------------------
@@ -448,6 +492,10 @@ def test_non_finite_fp16_values_skip_the_step(where, value):
     torch.cuda.synchronize()
     st = model._gscale.tolist()
     assert st[4] == 1.0 and st[5] == 1.0, 'the step with a non-finite %s was not skipped: state %r' % (where, st)
+    # an activation overflow also invalidates the scene-flow network's gradient (flag [8]); a non-finite fp16 GRADIENT of the
+    # depth net does not: the depth maps were finite, that network's fp32 update goes through
+    assert st[8] == (1.0 if where == 'activation' else 0.0) and st[9] == st[8], st
+    assert log['steps_skipped'] == 1
     for p, b in zip(net.parameters(), before):
         assert torch.equal(p.detach(), b), 'a skipped step changed the depth net'
     state['armed'] = False
@@ -457,6 +505,13 @@ def test_non_finite_fp16_values_skip_the_step(where, value):
     h.remove()
     assert st[4] == 0.0 and st[5] == 1.0 and np.isfinite(log['loss']), st
     assert any(not torch.equal(p.detach(), b) for p, b in zip(net.parameters(), before))
+    # a stale forward monitor -- what a validation pass, a warm-up epoch or an inference call with an overflowing activation
+    # leaves behind, none of them reaches dvd_gscale_end -- must not skip the NEXT training step
+    model._gscale[6] = float('inf')
+    log = model._train_on_batch(int(gd['epoch']), 2, helpers.loader_batch(dict(batch)))
+    torch.cuda.synchronize()
+    st = model._gscale.tolist()
+    assert st[4] == 0.0 and st[5] == 1.0 and st[10] == 0.0 and log['steps_skipped'] == 1, st
 
 
 # ---- the scene-flow MLP's fp16 stash ----------------------------------------------------------------------------------

@@ -1,0 +1,86 @@
+"""The data-parallel step's collectives on RCCL, on the box at hand: a ONE-rank `nccl` process group with
+parallel.force_distributed() runs the plan agreement, the loss-sum all-reduces, the asynchronous MLP-gradient all-reduce under
+the replayed depth-net backward graphs and FlatNet.all_reduce_and_adam_step's buckets for real (the
+reference's side is the no-op DistributedDataParallel wrap at train.py:285-292).  Every multi-rank test of rounds 1-5 ran on
+gloo; with nccl `work.wait()` is a stream dependency instead of a host block and the collectives sit next to graph captures.
+A sum over one rank is the identity, so the step must be BIT-identical to the non-distributed step -- logs, both networks'
+gradients, both networks' parameters after Adam -- over several steps (the first captures the graphs, the later ones replay
+them with collectives in flight).  Runs in a child process: a process group is process-wide state."""
+import json
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg')
+
+
+def _steps(name, forced, over, n_steps, q):
+    try:
+        import test_30_full_step_gpu as T30
+        from dvd_hip import parallel
+        info = None
+        if forced:
+            info = parallel.init_one_rank('nccl')
+            assert parallel.is_distributed() and parallel.world_size() == 1
+        gd = helpers.load_golden(name)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model, opt, batch = T30._build(gd, **over)
+        logs = []
+        for i in range(n_steps):
+            logs.append(model._train_on_batch(int(gd['epoch']), i, helpers.loader_batch(dict(batch))))
+        torch.cuda.synchronize()
+        live = sorted(k[0] for k, v in model._depth_graphs.items() if v is not None)
+        out = {'logs': [{k: float(l[k]) for k in KEYS} for l in logs], 'live': live, 'info': info,
+               'sf': model._flat_sf.flat.cpu().numpy(), 'depth': model._flat_depth.flat.cpu().numpy(),
+               'g_sf': model._flat_sf.grad.cpu().numpy(), 'g_depth': model._flat_depth.grad.cpu().numpy(),
+               'gscale': None if model._gscale is None else model._gscale.tolist()}
+        if forced:
+            parallel.shutdown()
+        q.put(out)
+    except BaseException as e:      # noqa: BLE001 -- hand the failure to the parent instead of a silent exit code
+        import traceback
+        q.put({'error': '%s\n%s' % (e, traceback.format_exc())})
+
+
+def _run(name, forced, over, n_steps=3):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_steps, args=(name, forced, over, n_steps, q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(60)
+    assert 'error' not in out, out.get('error')
+    return out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('name,over', [
+    ('fullstep_midas_b1_64x96_train', dict(depth_graphs=1, depth_chunk=1, lr=1e-3)),              # kept slots: graph replays
+    ('fullstep_midas_b1_64x96_train', dict(depth_graphs=1, depth_chunk=1, lr=1e-3, act_fp16=True)),   # + monitors' MAX all-reduce
+    ('fullstep_hourglass_b2_32x48_train', dict(depth_graphs=1, depth_chunk=1, depth_keep_gb=0.0)),   # recompute graphs, 2 pairs
+])
+def test_one_rank_rccl_step_is_bit_identical_to_the_single_process_step(name, over):
+    ref = _run(name, False, over)
+    got = _run(name, True, over)
+    info = got['info']
+    print('RCCL one-rank group:', json.dumps(info), 'graphs live:', got['live'])
+    assert info['backend'] == 'nccl' and info['rccl_version']
+    assert got['live'] == ref['live'] and got['live'], 'the forced-distributed run must replay the same graphs'
+    for i, (a, b) in enumerate(zip(ref['logs'], got['logs'])):
+        assert a == b, 'step %d logs differ: %r vs %r' % (i, a, b)
+    for k in ('g_sf', 'g_depth', 'sf', 'depth'):
+        assert np.array_equal(ref[k], got[k]), '%s differs between the RCCL one-rank step and the single-process step' % k
+    assert ref['gscale'] == got['gscale']
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir):          # measured communicator footprint, for DESIGN.md section 6 (replaces the 24 GB ballast guess)
+        with open(os.path.join(out_dir, 'rccl_one_rank.jsonl'), 'a') as f:
+            f.write(json.dumps({'case': name, 'over': {k: v for k, v in over.items()}, **info}) + '\n')
