@@ -24,6 +24,7 @@ SOURCES = [
     ('core.hip', []),
     ('unproject.hip', ['-ffp-contract=off']),
     ('warp_loss.hip', ['-ffp-contract=off']),
+    ('warp_strip.hip', ['-ffp-contract=off']),
     ('sf_mlp.hip', []),
     ('elementwise.hip', ['-ffp-contract=off']),
     ('gconv.hip', []),

@@ -127,10 +127,15 @@ typedef struct dvd_warp_cfg {
 } dvd_warp_cfg;
 
 size_t dvd_warp_loss_workspace_bytes(int B, int H, int W);
-/* Test hook (process wide; not an environment switch): variant 0 = tiled LDS kernel (production), 1 = reference
- * variant with global gathers + hardware atomics; tile = -1 (auto) or an index of the tile-shape table;
- * px = 0 (auto), 2 or 4 pixels per thread-step.  Every combination computes the same function. */
+/* Test hook (process wide; not an environment switch): variant 0 = production -- since ABI 7 the strip kernel
+ * (csrc/warp_strip.hip) for a backward call with the shipped flag set and W % 4 == 0 at tile = -1, px = 0, the tiled LDS
+ * kernel otherwise; 1 = reference variant with global gathers + hardware atomics; 2 = the tiled LDS kernel of rounds 2-5
+ * whatever the call; tile = -1 (auto) or an index of the tile-shape table; px = 0 (auto), 2 or 4 pixels per thread-step.
+ * Every combination computes the same function. */
 int dvd_warp_loss_select(int variant, int tile, int px);
+/* Test hook (ABI 7): image rows per unit of the strip kernel -- 0 = chosen from the shape and the device's block slots, else
+ * a multiple of 16, >= 32 (more, shorter units: more seams between units).  dvd_warp_loss_workspace_bytes follows it. */
+int dvd_warp_loss_strip_rows(int rows);
 int dvd_warp_loss_fused(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth_2,
                         const float* flow_1_2, const float* mask_2, const float* sf_1_2,
                         const dvd_cameras* cams, void* workspace, size_t workspace_bytes,

@@ -14,16 +14,20 @@ from oracle import losses as L
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=['tiled', 'tile64x32', 'tile96x32x384', 'px4', 'direct'], autouse=True)
+@pytest.fixture(params=['strips', 'strips32', 'tiles', 'tile64x32', 'tile96x32x384', 'px4', 'direct'], autouse=True)
 def warp_variant(request):
-    """Every case runs on the production tiled kernel (auto tile shape: the reference's rounding sequence for every
-    pixel; since round 5 the two-pixel lockstep loop for pinhole pairs with even rows), on the smallest tile shape (more
-    tile seams / halo traffic), on the 384-thread blocks of the 96 x 32 tile (three waves per SIMD), with 4 pixels per
-    thread-step (the one-pixel loop of rounds 1-4), and on the global-atomics reference variant.  All of them must reproduce the oracle's masks, counts and sub-gradient signs."""
+    """Every case runs on the production path -- since round 6 the strip kernel (csrc/warp_strip.hip: 96-column strips walked in
+    16-row steps, LDS rings, LDS-direct window loads) for the shipped flag set and rows of whole quads, the tile kernel
+    otherwise -- on strips cut into 32-row units (the shortest: most seams between units, every step a first or last step),
+    on the tile kernel of rounds 2-5 (auto tile shape; the smallest tile shape; the 384-thread blocks of the 96 x 32 tile;
+    4 pixels per thread-step = the one-pixel loop of rounds 1-4 with the per-quad combine), and on the global-atomics
+    reference variant.  All of them must reproduce the oracle's masks, counts and sub-gradient signs."""
     from dvd_hip import ops
-    ops.warp_loss_select(variant='direct' if request.param == 'direct' else 'tiled',
-                         tile={'tile64x32': 3, 'tile96x32x384': 4}.get(request.param, -1), px=4 if request.param == 'px4' else 0)
-    yield request.param
+    v = request.param
+    ops.warp_loss_select(variant={'direct': 'direct', 'strips': 'tiled', 'strips32': 'tiled'}.get(v, 'tiles'),
+                         tile={'tile64x32': 3, 'tile96x32x384': 4}.get(v, -1), px=4 if v == 'px4' else 0,
+                         strip_rows=32 if v == 'strips32' else 0)
+    yield v
     ops.warp_loss_select()
 
 

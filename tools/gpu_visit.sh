@@ -13,6 +13,11 @@
 #   msq     SQ counters of the scene-flow MLP kernels
 #   micro   micro-benchmarks: warp+loss, scene-flow MLP, convolutions in both activation storages
 #   a16     only the fp16-activation kernel tests
+#   mfma    rocprofv3 --kernel-trace --stats of bench.py at TWO step counts (fp32 and fp16 activations) -> tools/mfma_roofline.py
+#           -> mfma_roofline.json (per-step kernel time of every matrix-kernel class)
+#   ranks   8-GPU readiness on one GPU: DVD_RESERVE_GB ballast lines (gap 1 / gap 2 / hourglass), 8 ranks over gloo,
+#           one rank over RCCL with the collectives forced (bench.py --rccl_one_rank)
+#   wtrace  per-kernel durations of the warp+loss launch sequence (tools/warp_trace.sh)
 set -u
 OUT=gpurun_out/${TAG:-visit}; mkdir -p $OUT
 STAGES=${STAGES:-"tests bench extras trace pmc sq micro"}
@@ -118,5 +123,27 @@ for f in sys.argv[1:]:
         r = json.loads(l)
         print('  ', r['shape'], ' '.join('%s=%.3g' % (k, v) for k, v in r.items() if k.endswith('_tfs')))
 PY
+fi
+if has mfma; then
+  for mode in fp32 fp16; do
+    arg=$([ $mode = fp16 ] && echo --act_fp16)
+    for n in 2 5; do
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/tr_${mode}_$n -o b -- \
+          python $ROOT/bench.py --steps $n --warmup 1 --no_cpu_baseline --no_extras $arg > $ROOT/$OUT/tr_${mode}_$n.log 2>&1 )
+      f=$(find $OUT/tr_${mode}_$n -name '*kernel_stats.csv' | head -1); cp $f $OUT/kernel_stats_${mode}_$n.csv; rm -rf $OUT/tr_${mode}_$n
+    done
+    python tools/mfma_roofline.py --a 2:$OUT/kernel_stats_${mode}_2.csv --b 5:$OUT/kernel_stats_${mode}_5.csv --mode $mode \
+        --collected "rocprofv3 --kernel-trace --stats of bench.py --steps 2 / --steps 5, ${TAG:-visit}" --out $OUT/mfma_roofline.json | tee $OUT/mfma_$mode.txt
+  done
+fi
+if has ranks; then
+  runr() { name=$1; shift; timeout 1500 env "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; tail -1 $OUT/bench_$name.json | cut -c1-200; }
+  runr reserve24 DVD_RESERVE_GB=24 python bench.py --no_cpu_baseline --no_extras
+  runr reserve24_gap2 DVD_RESERVE_GB=24 python bench.py --no_cpu_baseline --no_extras --gap 2
+  runr reserve24_hourglass DVD_RESERVE_GB=24 python bench.py --no_cpu_baseline --no_extras --depth hourglass
+  runr gloo8 DVD_DIST_BACKEND=gloo python bench.py --gpus 8 --pairs 2 --no_cpu_baseline --steps 2
+fi
+if has wtrace; then
+  bash tools/warp_trace.sh ${TAG:-visit}/wtrace | tail -5
 fi
 du -sh $OUT
