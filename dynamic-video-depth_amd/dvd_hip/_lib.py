@@ -62,7 +62,7 @@ SIGNATURES = {
                                   c_int, c_void_p]),
     'dvd_warp_loss_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'dvd_warp_loss_select': (c_int, [c_int, c_int, c_int]),
-    'dvd_warp_loss_strip_rows': (c_int, [c_int]),
+    'dvd_warp_loss_strip_select': (c_int, [c_int, c_int]),
     'dvd_warp_loss_fused': (c_int, [ctypes.POINTER(WarpCfg)] + [c_void_p] * 5 + [ctypes.POINTER(Cameras),
                                                                                c_void_p, c_size_t] +
                             [c_void_p] * 4 + [c_void_p]),

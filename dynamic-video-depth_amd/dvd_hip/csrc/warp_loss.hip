@@ -902,9 +902,9 @@ int dvd_warp_loss_select(int variant, int tile, int px) {
   return DVD_OK;
 }
 
-int dvd_warp_loss_strip_rows(int rows) {
-  DVD_REQUIRE(rows == 0 || (rows >= 32 && rows % 16 == 0), "warp_loss_strip_rows: %d (0 = automatic, else a multiple of 16, >= 32)", rows);
-  dvd::strip_rows_override(rows);
+int dvd_warp_loss_strip_select(int rows, int shape) {
+  DVD_REQUIRE(dvd::strip_select(rows, shape) == 0,
+              "warp_loss_strip_select: rows %d shape %d (rows: 0 = automatic, else a multiple of the shape's step height, at least two steps)", rows, shape);
   return DVD_OK;
 }
 

@@ -652,6 +652,22 @@ typedef __attribute__((address_space(3))) const volatile v4f* lds_quad_ptr;     
 __device__ __forceinline__ v4f ldq(const float* cam, int i) {
   return ((lds_quad_ptr)cam)[i];                    // volatile: a read per phase, not one hoisted set
 }
+// The same eight quads held in VECTOR registers for a whole unit of the strip kernel (round 6: its 768-thread blocks have 168
+// registers per lane, 40 more than the tile kernel's budget): no camera read, and no lgkmcnt wait for one, inside a thread-step
+// (the LDS form issues 15 ds_read_b128 per thread-step).  Vector, not scalar, registers for the reason given above.
+struct CamRegs {
+  v4f q[8];
+};
+__device__ __forceinline__ v4f ldq(const CamRegs& cam, int i) { return cam.q[i]; }
+__device__ __forceinline__ CamRegs cam_regs_from_lds(const float* cam) {
+  CamRegs r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r.q[i] = ((lds_quad_ptr)cam)[i];
+    asm volatile("" : "+v"(r.q[i]));                // opaque: stays in VGPRs, is not re-derived as a scalar
+  }
+  return r;
+}
 __device__ __forceinline__ float cam_lds_value(const Cam& c, int i) {
   const int q = i >> 2, k = i & 3;
   if (q < 3) return k < 3 ? c.R1[3 * k + q] : c.t1[q];
@@ -662,8 +678,8 @@ __device__ __forceinline__ float cam_lds_value(const Cam& c, int i) {
 
 // `IO`: TileIO (a tile's window, warp_loss.hip) or RingIO (a strip's ring of window rows, warp_strip.hip) -- kWW = cells per
 // window row, win / accw, cells2() = are both pixels' tap quads on chip, and where; fetch / scatter for the taps that are not.
-template <bool GRADS, bool CRIT_L2, class IO, class MID, class ST>
-__device__ __forceinline__ void pixel2(const WarpArgs& a, const float* cam, const IO& io, int y, int x, v2f d1,
+template <bool GRADS, bool CRIT_L2, class CAMT, class IO, class MID, class ST>
+__device__ __forceinline__ void pixel2(const WarpArgs& a, const CAMT& cam, const IO& io, int y, int x, v2f d1,
                                        v2f fx, v2f fy, v2f mk, v2f s0, v2f s1, v2f s2, float yhw, float yhh, float acc[4],
                                        MID&& between_phases, ST&& store) {
   const float xf = (float)x, yf = (float)y;
@@ -889,11 +905,11 @@ __device__ __forceinline__ int2 pair_window_offset(const float* __restrict__ flo
 
 // ---- the strip generation (csrc/warp_strip.hip), called from dvd::run in csrc/warp_loss.hip
 struct StripPlan {
-  int ntx, nseg, SH;
+  int shape, ntx, nseg, SH;
   size_t n_units, off_count, off_offs, off_slabs, slab_stride, off_ovf, ovf_cap, total;
 };
 StripPlan make_strip_plan(int B, int H, int W);
-void strip_rows_override(int rows);
+int strip_select(int rows, int shape);      // test hook; non-zero = rejected
 int launch_strips(const WarpArgs& a, const StripPlan& p, char* ws, hipStream_t stream);
 int launch_warp_finish(const float* partial, int n, float* sums, const unsigned* count, const int2* rec, unsigned cap,
                        float* g_d2, hipStream_t stream);

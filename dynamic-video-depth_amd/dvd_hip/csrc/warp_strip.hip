@@ -36,8 +36,26 @@
 
 #include "warp_pixel.h"
 
-#ifndef DVD_STRIP_PREFETCH
-#define DVD_STRIP_PREFETCH 0        // 1: the second thread-step's inputs requested between the phases of the first
+#ifndef DVD_STRIP_UNROLL
+#define DVD_STRIP_UNROLL 0          // 1: the two thread-steps of a step as two code copies (precise waits, but loop invariants spill)
+#endif
+#ifndef DVD_STRIP_END_WAIT
+#define DVD_STRIP_END_WAIT -1       // >= 0: vmcnt of the step's closing wait for A/B builds (default: what the walk guarantees)
+#endif
+#ifndef DVD_STRIP_CAM_REGS
+#define DVD_STRIP_CAM_REGS 1        // 1: shapes with a 168-register budget keep the pair's camera in vector registers (0: LDS broadcasts)
+#endif
+#ifndef DVD_STRIP_PERSISTENT
+#define DVD_STRIP_PERSISTENT 0
+#endif
+#ifndef DVD_STRIP_PF_EARLY
+#define DVD_STRIP_PF_EARLY 1        // 1: the next thread-step's inputs are requested at the START of a thread-step (0: between its phases)
+#endif
+#ifndef DVD_STRIP_KO_BARRIER
+#define DVD_STRIP_KO_BARRIER 0
+#endif
+#ifndef DVD_STRIP_KO_PIXEL
+#define DVD_STRIP_KO_PIXEL 0
 #endif
 #ifndef DVD_STRIP_KO_FLUSH          // knock-out builds (timing studies only; results are wrong)
 #define DVD_STRIP_KO_FLUSH 0
@@ -48,17 +66,22 @@
 
 namespace dvd {
 
-template <int TW, int TH, int R>
+// R: halo of the window in x (R columns to the left, R + 4 to the right: rows of whole quads); RY: halo in y (RY rows above,
+// RY + 1 below).  RY may exceed R where the LDS has room: every row of a step sits RY rows from the window's edge at the
+// step's first / last row, so with RY = 8 about one pixel pair per 96 x 32 step of the benchmark's sigma = 3 px flow field
+// leaves the window -- one wave of the block then runs the global-gather path while eleven wait at the step's barrier (14 us of
+// the kernel, profiles/r06_warp_strip_experiments.txt); RY = 12 is 4 sigma.
+template <int TW, int TH, int R, int RY>
 struct StripGeo {
   static constexpr int WW = TW + 2 * R + 4;      // cells per window row (multiple of 4: rows are 16-byte aligned)
-  static constexpr int WH = TH + 2 * R + 1;      // window rows one step touches
-  static constexpr int C = 2 * TH + 2 * R + 1;   // ring rows
+  static constexpr int WH = TH + 2 * RY + 1;     // window rows one step touches
+  static constexpr int C = 2 * TH + 2 * RY + 1;  // ring rows
   static constexpr int QR = WW / 4;              // 16-byte quads per window row
-  static_assert(R % 4 == 0 && TW % 4 == 0 && TH >= 2 * R, "strip geometry");
+  static_assert(R % 4 == 0 && TW % 4 == 0 && 2 * RY + 1 <= 2 * TH, "strip geometry (a unit is at least two steps: only adjacent units overlap)");
 };
 
-constexpr int strip_lds_bytes(int tw, int th, int r, int nt) {
-  return (tw + 2 * r + 4) * (2 * th + 2 * r + 2) * 12 + kCamLdsFloats * 4 + 16 + (nt / 64) * 16;
+constexpr int strip_lds_bytes(int tw, int th, int r, int ry, int nt) {
+  return (tw + 2 * r + 4) * (2 * th + 2 * ry + 2) * 12 + kCamLdsFloats * 4 + 16 + (nt / 64) * 16;
 }
 
 // IO policy of a strip (the interface pixel() / pixel2() expect, like TileIO): the on-chip window of the CURRENT step is
@@ -148,39 +171,50 @@ struct StripArgs {
   int2* offs;         // per pair: window offset, written by the pair's first unit (for the combine and finish kernels)
   int ntx, nseg, SH;  // strips per image row, units per strip column, rows per unit (multiple of TH, >= 2 TH)
   int direct;         // 1: window cells no neighbouring unit covers go straight to g_depth_2
-  unsigned slab_stride;   // floats per unit slab = WW * (SH + 2R + 1)
+  unsigned slab_stride;   // floats per unit slab = WW * (SH + 2RY + 1)
+  int n_units;
 };
 
-// Window cell (wx, r) of a unit is covered by that unit ALONE when wx in [2R + 4, TW) and r in [2R + 1, SH): tile_exclusive
+// Window cell (wx, r) of a unit is covered by that unit ALONE when wx in [2R + 4, TW) and r in [2RY + 1, SH): tile_exclusive
 // with the unit's height.  The strip kernel and both combine forms use this one predicate.
-template <int TW, int R>
+template <int TW, int R, int RY>
 __device__ __forceinline__ bool unit_exclusive(int wx, int r, int SH) {
-  return wx >= 2 * R + 4 && wx < TW && r >= 2 * R + 1 && r < SH;
+  return wx >= 2 * R + 4 && wx < TW && r >= 2 * RY + 1 && r < SH;
 }
 
 // 16 bytes global -> LDS without a register in between (LDS-DMA).  lds_byte: wave-uniform LDS byte address; lane l's 16 bytes
 // land at lds_byte + 16 l (lanes switched off by EXEC write nothing).  M0 is compiler-reserved: saved, set and restored in
 // the statement that uses it (cdna_hip_programming.md, inline-asm section).  Not counted by the compiler's s_waitcnt
 // bookkeeping: the caller waits vmcnt(0) before the barrier that publishes the rows.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte) {
+__device__ __forceinline__ void glds16(const float* base, unsigned byte_off, unsigned lds_byte) {
+  // (scalar base + one 32-bit lane offset: a 64-bit lane address costs a register pair that the walk's loop spilled)
   unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_byte)
+      : "v"(byte_off), "s"(lds_byte), "s"(base)
       : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-template <int TW, int TH, int R, int NT>
-__global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kernel(const WarpArgs a, const StripArgs sa) {
-  using G = StripGeo<TW, TH, R>;
+// FULL: the image is whole strips wide and whole steps high (W % TW == 0, H % TH == 0: 384 x 672, 768 x 1344, 192 x 384) -- no
+// thread-step lies outside the image, so the lockstep walk is straight-line code: its gradient stores are unconditional, and
+// the compiler can count them when it places the wait for the next thread-step's inputs (behind CONDITIONAL stores that wait
+// is s_waitcnt vmcnt(0): the in-order counter cannot tell whether the newest operations are the loads or stores behind them).
+// BPC: blocks per CU the shape is meant for (register budget = 512 / (BPC * NT / 256) VGPRs).  A block's waves must spread EVENLY
+// over the CU's four SIMDs (NT a multiple of 256): the first strip shape, 384-thread blocks at two per CU, measured 40 % of the
+// expected wave residency -- the six waves of a block land 2, 2, 1, 1 on the SIMDs, the second block of a CU only fits next to
+// the first when its doubled SIMDs are the other two, and the dispatcher does not arrange that (profiles/r06_warp_strip_experiments.txt).
+template <int TW, int TH, int R, int RY, int NT, int BPC, bool FULL>
+__global__ __launch_bounds__(NT, (BPC * NT + 255) / 256) void warp_loss_strip_kernel(const WarpArgs a, const StripArgs sa) {
+  using G = StripGeo<TW, TH, R, RY>;
   constexpr int WW = G::WW, WH = G::WH, C = G::C, QR = G::QR;
   constexpr int QW = TW / 2;                     // pixel pairs per row of the strip
   constexpr int NW = NT / 64;
   static_assert((QW * TH) % NT == 0, "a step's pixel pairs must split evenly over the block");
+  constexpr int NTS = (QW * TH) / NT;            // thread-steps per step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned long long* accw = reinterpret_cast<unsigned long long*>(smem);   // [C + 1][WW] u64
   float* win = smem + 2 * WW * (C + 1);                                      // [C + 1][WW]
@@ -189,7 +223,25 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
   float* red = camL + kCamLdsFloats + 4;                                     // [NW][4] block sums
   static_assert((3 * WW * (C + 1)) % 4 == 0, "camera quads must be 16-byte aligned");
 
+  // ---- DVD_STRIP_PERSISTENT = 1 (an experiment, off: measured 207 us against 171 us -- the outer loop's live values push the
+  //      walk's loop invariants to scratch): persistent blocks (one or two per CU), a block evaluates several units.  Units are numbered so
+  //      that each XCD (block b runs on XCD b % 8: speed only, never correctness) owns a contiguous run of them -- the blocks
+  //      of an XCD take the run's units round robin, so the units in flight on an XCD at any time are neighbours (adjacent
+  //      strips of the same pair share their halo columns of depth_2 in that XCD's L2).  What a unit's start costs in a grid of
+  //      one block per unit -- block launch, clearing 76 KB of accumulator ring -- is paid once per block: every accumulator
+  //      cell a unit touched has been flushed AND cleared when the unit ends.
+  for (int i = threadIdx.x; i < (C + 1) * WW / 2; i += NT) reinterpret_cast<uint4*>(accw)[i] = make_uint4(0u, 0u, 0u, 0u);
+#if DVD_STRIP_PERSISTENT
+  const int xcd = blockIdx.x & 7, in_xcd = blockIdx.x >> 3, per_xcd = ((int)gridDim.x - xcd + 7) >> 3;
+  const int run_q = sa.n_units >> 3, run_r = sa.n_units & 7;
+  const int run_lo = xcd < run_r ? xcd * (run_q + 1) : run_r * (run_q + 1) + (xcd - run_r) * run_q;
+  const int run_n = run_q + (xcd < run_r ? 1 : 0);
+  for (int run_i = in_xcd; run_i < run_n; run_i += per_xcd) {
+  const int logical = run_lo + run_i;
+#else
+  {
   const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+#endif
   const int upp = sa.ntx * sa.nseg;              // units per pair
   const int b = logical / upp;
   const int t = logical - b * upp;
@@ -199,7 +251,7 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int2 off = pair_window_offset(a.flow, b, a.H, a.W);
   if (t == 0 && threadIdx.x == 0) sa.offs[b] = off;
-  const int wx0 = tx0 - R + off.x, wy_top = uy0 - R + off.y;
+  const int wx0 = tx0 - R + off.x, wy_top = uy0 - RY + off.y;
   const float* d2b = a.d2 + (size_t)b * a.HW;
   Cam c;
   load_cam(a, b, c);
@@ -217,7 +269,7 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
   //      of 4.  Consecutive rows are consecutive in the ring except at its end, so the rows are requested as (at most) two
   //      runs, each a sequence of 1 KB wave-instructions whose 64 lanes write 64 consecutive quads.
   const unsigned win_b = lds_addr(win);
-  auto fill_run = [&](int r0, int s0, int nrows) {          // window rows r0.., ring slots s0.. (no wrap inside)
+  auto fill_run = [&](int lane, int r0, int s0, int nrows) {          // window rows r0.., ring slots s0.. (no wrap inside)
     const int quads = nrows * QR;
     for (int q0 = wave * 64; q0 < quads; q0 += NW * 64) {
       const int q = q0 + lane;
@@ -226,30 +278,33 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
       const unsigned dst = win_b + (unsigned)(s0 * WW + q0 * 4) * 4u;        // wave-uniform
       if (q < quads) {
         if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && !DVD_STRIP_KO_FILL)
-          glds16(d2b + (size_t)y * a.W + x, __builtin_amdgcn_readfirstlane(dst));
+          glds16(d2b, (unsigned)(y * a.W + x) * 4u, __builtin_amdgcn_readfirstlane(dst));
         else
           *reinterpret_cast<float4*>(win + s0 * WW + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
   // the row that lands in ring slot 0 is kept a second time as the ghost row C (one wave's 29 quads)
-  auto fill_ghost = [&](int rg) {
+  auto fill_ghost = [&](int lane, int rg) {
     const int q = lane;
     const int y = wy_top + rg, x = wx0 + q * 4;
     const unsigned dst = win_b + (unsigned)(C * WW) * 4u;
     if (q < QR) {
       if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W && !DVD_STRIP_KO_FILL)
-        glds16(d2b + (size_t)y * a.W + x, __builtin_amdgcn_readfirstlane(dst));
+        glds16(d2b, (unsigned)(y * a.W + x) * 4u, __builtin_amdgcn_readfirstlane(dst));
       else
         *reinterpret_cast<float4*>(win + C * WW + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto fill = [&](int r0, int n) {
+  // (`tid`: the thread index behind an empty asm -- opaque, so that the index arithmetic below is redone per step instead of
+  //  hoisted out of the walk's loop, where it was spilled to scratch and reloaded behind s_waitcnt vmcnt(0))
+  auto fill = [&](int tid, int r0, int n) {
+    const int ln = tid & 63;
     const int s0 = r0 % C;
     const int nA = n < C - s0 ? n : C - s0;
-    fill_run(r0, s0, nA);
-    if (n > nA) fill_run(r0 + nA, 0, n - nA);
-    if ((s0 == 0 || n > nA) && wave == NW - 1) fill_ghost(s0 == 0 ? r0 : r0 + nA);
+    fill_run(ln, r0, s0, nA);
+    if (n > nA) fill_run(ln, r0 + nA, 0, n - nA);
+    if ((s0 == 0 || n > nA) && wave == NW - 1) fill_ghost(ln, s0 == 0 ? r0 : r0 + nA);
   };
 
   // ---- accumulator rows [r0, r0 + n) of the window: convert, store (exclusive cells -> g_depth_2, the others -> the unit's
@@ -257,39 +312,46 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
   float* slab = sa.slabs + (size_t)logical * sa.slab_stride;
   float* gb = a.g_d2 + (size_t)b * a.HW;
   const float back = a.disp_mul;
-  auto flush = [&](int r0, int n) {
-    const int s0 = r0 % C;
-    for (int i = threadIdx.x; i < n * QR && !DVD_STRIP_KO_FLUSH; i += NT) {
-      const int j = i / QR, wx = (i - j * QR) * 4;
-      int s = s0 + j;
-      s = s >= C ? s - C : s;
-      longlong2* cp = reinterpret_cast<longlong2*>(accw + s * WW + wx);
-      longlong2 lo = cp[0], hi = cp[1];
-      cp[0] = make_longlong2(0, 0);
-      cp[1] = make_longlong2(0, 0);
-      if (s == 0) {                                   // + what was scattered through the ghost row
-        longlong2* gp = reinterpret_cast<longlong2*>(accw + C * WW + wx);
-        const longlong2 glo = gp[0], ghi = gp[1];
-        gp[0] = make_longlong2(0, 0);
-        gp[1] = make_longlong2(0, 0);
-        lo.x += glo.x;
-        lo.y += glo.y;
-        hi.x += ghi.x;
-        hi.y += ghi.y;
-      }
-      const float4 v = make_float4(from_fixed(lo.x) * back, from_fixed(lo.y) * back, from_fixed(hi.x) * back, from_fixed(hi.y) * back);
-      const int r = r0 + j;
-      if (sa.direct && unit_exclusive<TW, R>(wx, r, sa.SH)) {
-        const int x = wx0 + wx, y = wy_top + r;
-        if ((unsigned)x < (unsigned)a.W && (unsigned)y < (unsigned)a.H) *reinterpret_cast<float4*>(gb + (size_t)y * a.W + x) = v;
-      } else {
-        *reinterpret_cast<float4*>(slab + r * WW + wx) = v;
-      }
+  auto flush_quad = [&](int i, int r0, int s0) {
+    const int j = i / QR, wx = (i - j * QR) * 4;
+    int s = s0 + j;
+    s = s >= C ? s - C : s;
+    longlong2* cp = reinterpret_cast<longlong2*>(accw + s * WW + wx);
+    longlong2 lo = cp[0], hi = cp[1];
+    cp[0] = make_longlong2(0, 0);
+    cp[1] = make_longlong2(0, 0);
+    if (s == 0) {                                   // + what was scattered through the ghost row
+      longlong2* gp = reinterpret_cast<longlong2*>(accw + C * WW + wx);
+      const longlong2 glo = gp[0], ghi = gp[1];
+      gp[0] = make_longlong2(0, 0);
+      gp[1] = make_longlong2(0, 0);
+      lo.x += glo.x;
+      lo.y += glo.y;
+      hi.x += ghi.x;
+      hi.y += ghi.y;
     }
+    const float4 v = make_float4(from_fixed(lo.x) * back, from_fixed(lo.y) * back, from_fixed(hi.x) * back, from_fixed(hi.y) * back);
+    const int r = r0 + j;
+    const int x = wx0 + wx, y = wy_top + r;
+    // ONE unconditional store (an exclusive cell outside the image goes to its slab cell, which nobody reads): a store
+    // count the compiler can see, see FULL above
+    const bool to_image = sa.direct && unit_exclusive<TW, R, RY>(wx, r, sa.SH) && (unsigned)x < (unsigned)a.W && (unsigned)y < (unsigned)a.H;
+    float* dst = to_image ? gb + (size_t)y * a.W + x : slab + r * WW + wx;
+    if (!DVD_STRIP_KO_FLUSH) *reinterpret_cast<float4*>(dst) = v;
+  };
+  auto flush = [&](int r0, int n) {                  // any number of rows (the unit's last window)
+    const int s0 = r0 % C;
+    for (int i = threadIdx.x; i < n * QR; i += NT) flush_quad(i, r0, s0);
+  };
+  static_assert(TH * QR <= 2 * NT, "a step's TH rows are at most two quads per thread");
+  auto flush_step = [&](int tid, int r0) {           // TH rows: one quad per thread (+ one more for the first threads)
+    const int s0 = r0 % C;
+    if (TH * QR >= NT || tid < TH * QR) flush_quad(tid, r0, s0);
+    if (TH * QR > NT && tid + NT < TH * QR) flush_quad(tid + NT, r0, s0);
   };
 
-  // ---- prologue: clear the accumulator ring, camera to LDS, first window
-  for (int i = threadIdx.x; i < (C + 1) * WW / 2; i += NT) reinterpret_cast<uint4*>(accw)[i] = make_uint4(0u, 0u, 0u, 0u);
+  // ---- the unit's prologue: camera to LDS, first window (the accumulator ring is all zero: cleared before the first unit,
+  //      by the flushes since)
   if (threadIdx.x == 0) *lcount = 0u;
   if (threadIdx.x < kCamLdsFloats) {
     float v = 0.0f;
@@ -297,7 +359,7 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
     for (int i = 0; i < kCamLdsFloats; ++i) v = (int)threadIdx.x == i ? cam_lds_value(c, i) : v;
     camL[threadIdx.x] = v;
   }
-  fill(0, WH);
+  fill(threadIdx.x, 0, WH);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -338,34 +400,6 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
   const float yhw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rcp_refined(a.half_w))));
   const float yhh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rcp_refined(a.half_h))));
 
-  // ---- the two-pixel lockstep loop over one step's rows (pinhole pair, R_2_T = R_2^T: what the data files hold)
-  auto step_pixels2 = [&](auto crit_tag, int y0) {
-    constexpr bool CRIT = decltype(crit_tag)::value;
-    In2 cur = fetch2(threadIdx.x, y0), nxt = cur;
-#pragma unroll
-    for (int it = 0; it < (QW * TH) / NT; ++it) {
-      const int q = threadIdx.x + it * NT;
-      int x, y;
-      const bool more = it + 1 < (QW * TH) / NT;
-      if (locate(q, y0, x, y)) {
-        const unsigned o = (unsigned)(y * a.W + x) * 4u;
-        pixel2<true, CRIT>(a, camL, io, y, x, cur.d1, (v2f){cur.fl.x, cur.fl.z}, (v2f){cur.fl.y, cur.fl.w}, cur.mk, cur.s0,
-                           cur.s1, cur.s2, yhw, yhh, acc,
-                           [&]() {
-                             if (DVD_STRIP_PREFETCH && more) nxt = fetch2(q + NT, y0);
-                           },
-                           [&](v2f gd1, v2f g0, v2f g1, v2f g2) {
-                             *reinterpret_cast<v2f*>(gd1b + o) = gd1;
-                             *reinterpret_cast<v2f*>(gsb0 + o) = g0;
-                             *reinterpret_cast<v2f*>(gsb0 + (o + plane)) = g1;
-                             *reinterpret_cast<v2f*>(gsb0 + (o + 2u * plane)) = g2;
-                           });
-      } else if (DVD_STRIP_PREFETCH && more) {
-        nxt = fetch2(q + NT, y0);
-      }
-      if (more) cur = DVD_STRIP_PREFETCH ? nxt : fetch2(q + NT, y0);
-    }
-  };
   // ---- the general one-pixel path (a camera with skew, an R_2_T that is not R_2's transpose): rare, correct for every camera
   auto step_pixels1 = [&](int y0) {
     Cam cc;
@@ -401,28 +435,114 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
     }
   };
 
-  // ---- the walk: one barrier per step
-  int sk = 0;
-  for (int k = 0; k < nsteps; ++k) {
-    if (k + 1 < nsteps) fill((k + 1) * TH + 2 * R + 1, TH);        // N_{k+1}: lands under this step's arithmetic
-    io.wyk = wy_top + k * TH;
-    io.sk = sk;
-    const int y0 = uy0 + k * TH;
-    if (y0 < a.H) {                                                 // (a unit that reaches below the image: nothing to evaluate)
-      if (lockstep) {
-        if (a.crit_l2)
-          step_pixels2(std::true_type{}, y0);
-        else
-          step_pixels2(std::false_type{}, y0);
-      } else {
-        step_pixels1(y0);
+  // ---- the walk: one barrier per step.  Lockstep path (pinhole pair, R_2_T = R_2^T: what the data files hold): a software
+  //      pipeline over the unit's thread-steps (two per step) -- the inputs of thread-step i + 1 are requested between the
+  //      forward and the backward phase of thread-step i (by a thread whose own pixel pair lies outside the image: on the
+  //      spot), ACROSS the step's barrier too, so no input latency is exposed.  That is why a step does not end in
+  //      s_waitcnt vmcnt(0): what must have landed before the barrier are this wave's LDS-direct loads, issued FIRST in the
+  //      step; behind them every wave issues the six input loads of the next thread-step (whatever its pixels are) and, in a FULL
+  //      image, that thread-step's four gradient stores; the counter retires in order, so vmcnt(10) (vmcnt(6) without
+  //      FULL) covers the LDS-direct loads and leaves exactly those newest requests in flight.  The barrier is the raw instruction
+  //      behind an explicit lgkmcnt(0) (the step's LDS adds / clears / zero fills); __syncthreads() would add the vmcnt(0) of
+  //      its workgroup-scope fence.
+  // kEndWait: vector-memory instructions every wave is GUARANTEED to issue behind the step's LDS-direct loads -- the six input
+  // loads of the next thread-step, and with FULL the four gradient stores of the thread-step they sit in.
+  constexpr int kEndWait = DVD_STRIP_END_WAIT >= 0 ? DVD_STRIP_END_WAIT : (FULL ? 10 : 6);
+  auto walk2 = [&](auto crit_tag) {
+    constexpr bool CRIT = decltype(crit_tag)::value;
+    // the camera of the lockstep loop: vector registers where the shape's budget has room for its 32 values (three waves per
+    // SIMD), LDS broadcasts otherwise
+    constexpr bool kCamRegs = DVD_STRIP_CAM_REGS && (BPC * NT) / 256 <= 3;
+    typename std::conditional<kCamRegs, CamRegs, const float*>::type camv;
+    if constexpr (kCamRegs)
+      camv = cam_regs_from_lds(camL);
+    else
+      camv = camL;
+    In2 cur = fetch2(threadIdx.x, uy0);
+    // (consumed here: with these loads still pending at the loop's entry -- issued in another order than the loop's own, no
+    //  store behind them -- the compiler's merged state makes the wait for a thread-step's inputs s_waitcnt vmcnt(0), which
+    //  then also waits for the previous thread-step's gradient stores and the flush's stores, in EVERY thread-step)
+    asm volatile("" : "+v"(cur.d1), "+v"(cur.mk), "+v"(cur.s0), "+v"(cur.s1), "+v"(cur.s2), "+v"(cur.fl.x), "+v"(cur.fl.y),
+                 "+v"(cur.fl.z), "+v"(cur.fl.w));
+    int sk = 0;
+#pragma unroll 1
+    for (int k = 0; k < nsteps; ++k) {
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      if (k >= 1) flush_step(tid, (k - 1) * TH);                    // F_{k-1}: disjoint from what this step touches
+      // N_{k+1}, the rows the NEXT step adds.  With one thread-step per step they are requested here, behind the flush's
+      // stores (in front of them, the first counted wait of the step -- vmcnt(n) for the thread-step's inputs, n from the
+      // compiler's count, which does not include the LDS-direct loads -- had to see them land: one exposed HBM latency per
+      // step, 31 us of the kernel); with more thread-steps behind the first one, so that they land under the second.
+      if (NTS == 1 && k + 1 < nsteps) fill(tid, (k + 1) * TH + 2 * RY + 1, TH);
+      io.wyk = wy_top + k * TH;
+      io.sk = sk;
+      const int y0 = uy0 + k * TH;
+#pragma unroll DVD_STRIP_UNROLL ? NTS : 1
+      for (int ts = 0; ts < NTS; ++ts) {
+        const int q = threadIdx.x + ts * NT;
+        const bool last = ts == NTS - 1;
+        const int qn = last ? (int)threadIdx.x : q + NT, yn = last ? y0 + TH : y0;
+        In2 nxt;
+        int x, y;
+        const bool ok = locate(q, y0, x, y);
+        // The next thread-step's inputs are requested FIRST: a whole thread-step (~2 us) for them to arrive.  Requested between
+        // the phases (round 5's place for them) they had the backward phase only, and with twelve waves per CU the kernel
+        // ran at the rate its memory latency allowed -- its time moved one for one with the bytes of a knocked-out stream
+        // (profiles/r06_warp_strip_experiments.txt).  The scheduling barrier keeps the requests from sinking towards their use.
+        constexpr bool kEarly = DVD_STRIP_PF_EARLY && kCamRegs;
+        if (kEarly) {
+          nxt = fetch2(qn, yn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((FULL || ok) && !DVD_STRIP_KO_PIXEL) {
+          const unsigned o = (unsigned)(y * a.W + x) * 4u;
+          pixel2<true, CRIT>(a, camv, io, y, x, cur.d1, (v2f){cur.fl.x, cur.fl.z}, (v2f){cur.fl.y, cur.fl.w}, cur.mk, cur.s0,
+                             cur.s1, cur.s2, yhw, yhh, acc,
+                             [&]() {
+                               if (!kEarly) nxt = fetch2(qn, yn);
+                             },
+                             [&](v2f gd1, v2f g0, v2f g1, v2f g2) {
+                               *reinterpret_cast<v2f*>(gd1b + o) = gd1;
+                               *reinterpret_cast<v2f*>(gsb0 + o) = g0;
+                               *reinterpret_cast<v2f*>(gsb0 + (o + plane)) = g1;
+                               *reinterpret_cast<v2f*>(gsb0 + (o + 2u * plane)) = g2;
+                             });
+        } else if (!kEarly) {
+          nxt = fetch2(qn, yn);
+        }
+        cur = nxt;
+        if (NTS > 1 && ts == 0 && k + 1 < nsteps) fill(tid, (k + 1) * TH + 2 * RY + 1, TH);
       }
+      sk += TH;
+      sk = sk >= C ? sk - C : sk;
+      if (DVD_STRIP_KO_BARRIER)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kEndWait) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kEndWait) : "memory");
     }
-    if (k >= 1) flush((k - 1) * TH, TH);                            // F_{k-1}: disjoint from what this step touches
-    sk += TH;
-    sk = sk >= C ? sk - C : sk;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's LDS-direct loads have landed
-    __syncthreads();
+  };
+  // ---- the general walk (a camera with skew, an R_2_T that is not R_2's transpose: rare): no pipeline, everything waited for
+  auto walk1 = [&]() {
+    int sk = 0;
+    for (int k = 0; k < nsteps; ++k) {
+      if (k + 1 < nsteps) fill(threadIdx.x, (k + 1) * TH + 2 * RY + 1, TH);
+      if (k >= 1) flush_step(threadIdx.x, (k - 1) * TH);
+      io.wyk = wy_top + k * TH;
+      io.sk = sk;
+      if (uy0 + k * TH < a.H) step_pixels1(uy0 + k * TH);
+      sk += TH;
+      sk = sk >= C ? sk - C : sk;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+  if (lockstep) {
+    if (a.crit_l2)
+      walk2(std::true_type{});
+    else
+      walk2(std::false_type{});
+  } else {
+    walk1();
   }
   flush((nsteps - 1) * TH, WH);                                     // what the last step left in the ring
   if (threadIdx.x == 0) sa.ovf.count[logical] = *lcount < sa.ovf.cap ? *lcount : sa.ovf.cap;
@@ -437,24 +557,25 @@ __global__ __launch_bounds__(NT, (2 * NT + 255) / 256) void warp_loss_strip_kern
     for (int w = 0; w < NW; ++w) v += red[w * 4 + threadIdx.x];
     a.partial[(size_t)logical * 4 + threadIdx.x] = v;
   }
+  }      // next unit of this block (everything of this one that lives in LDS was read before the barrier above)
 }
 
 // g_depth_2[b, y, x .. x+3] = sum over the units whose window covers the quad, fixed order (dj outer, di inner): combine_quad
 // of warp_loss.hip with the unit height as a run-time value.  Used for pairs whose windows are shifted.
-template <int TW, int R>
+template <int TW, int R, int RY>
 __device__ __forceinline__ void combine_quad_units(const float* __restrict__ slabs, unsigned slab_stride, int2 off,
                                                    float* __restrict__ g_d2, int H, int W, int ntx, int nseg, int SH, int b,
                                                    int y, int x, int direct) {
   constexpr int WW = TW + 2 * R + 4;
-  const int WHu = SH + 2 * R + 1;
+  const int WHu = SH + 2 * RY + 1;
   const int xs = x - off.x, ys = y - off.y;          // coordinates in the pair's shifted unit grid
   const int ti = xs >= 0 ? xs / TW : -((TW - 1 - xs) / TW), tj = ys >= 0 ? ys / SH : -((SH - 1 - ys) / SH);
-  if (direct && ti >= 0 && ti < ntx && tj >= 0 && tj < nseg && unit_exclusive<TW, R>(xs - ti * TW + R, ys - tj * SH + R, SH)) return;
+  if (direct && ti >= 0 && ti < ntx && tj >= 0 && tj < nseg && unit_exclusive<TW, R, RY>(xs - ti * TW + R, ys - tj * SH + RY, SH)) return;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int dj = -1; dj <= 1; ++dj) {
     const int j = tj + dj;
-    const int wy = ys - (j * SH - R);
+    const int wy = ys - (j * SH - RY);
     if (j < 0 || j >= nseg || wy < 0 || wy >= WHu) continue;
 #pragma unroll
     for (int di = -1; di <= 1; ++di) {
@@ -471,17 +592,17 @@ __device__ __forceinline__ void combine_quad_units(const float* __restrict__ sla
   *reinterpret_cast<float4*>(g_d2 + ((size_t)b * H + y) * W + x) = s;
 }
 
-// One block per unit: sums the slabs over the RING quads of the unit's home region (its 96 x SH pixels): R + 1 rows at the top,
-// R at the bottom, (R + 4) / 4 + R / 4 quads of every other row -- 31 % of the quads at SH = 128; everything else was written
+// One block per unit: sums the slabs over the RING quads of the unit's home region (its 96 x SH pixels): RY + 1 rows at the top,
+// RY at the bottom, (R + 4) / 4 + R / 4 quads of every other row -- 31 % of the quads at SH = 128; everything else was written
 // by the strip kernel itself.  Which of the nine neighbouring windows cover a quad follows from its position; fixed order
 // dj outer / di inner like combine_quad_units (bit-identical to it).  Pairs with shifted windows take combine_quad_units.
-template <int TW, int R>
+template <int TW, int R, int RY>
 __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restrict__ slabs, unsigned slab_stride,
                                                             const int2* __restrict__ offs, float* __restrict__ g_d2, int H, int W,
                                                             int ntx, int nseg, int SH, int direct) {
   constexpr int WW = TW + 2 * R + 4;
   constexpr int QW = TW / 4;
-  constexpr int kTop = R + 1, kBot = R, kLeft = (R + 4) / 4, kRight = R / 4;
+  constexpr int kTop = RY + 1, kBot = RY, kLeft = (R + 4) / 4, kRight = R / 4;
   const int upp = ntx * nseg;
   const int logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
   const int b = logical / upp, t = logical - b * upp;
@@ -491,7 +612,7 @@ __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restr
     for (int q = threadIdx.x; q < QW * SH; q += 256) {
       const int hy = q / QW, hx = (q - hy * QW) * 4;
       const int x = ti * TW + hx, y = sj * SH + hy;
-      if (x < W && y < H) combine_quad_units<TW, R>(slabs, slab_stride, off, g_d2, H, W, ntx, nseg, SH, b, y, x, direct);
+      if (x < W && y < H) combine_quad_units<TW, R, RY>(slabs, slab_stride, off, g_d2, H, W, ntx, nseg, SH, b, y, x, direct);
     }
     return;
   }
@@ -515,7 +636,7 @@ __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restr
     const int dj = hy < kTop ? -1 : (hy >= SH - kBot ? 1 : 0);
     const int di = hx < R + 4 ? -1 : (hx >= TW - R ? 1 : 0);
     const bool okj = dj != 0 && (unsigned)(sj + dj) < (unsigned)nseg, oki = di != 0 && (unsigned)(ti + di) < (unsigned)ntx;
-    const float* p_own = unit_slab + (hy + R) * WW + (hx + R);
+    const float* p_own = unit_slab + (hy + RY) * WW + (hx + R);
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
     const v4f own = *reinterpret_cast<const v4f*>(p_own);
     v4f hor = zero, ver = zero, dia = zero;            // lane-masked loads: only the windows that cover the quad are read
@@ -532,35 +653,55 @@ __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restr
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
-constexpr int kSTW = 96, kSTH = 16, kSR = 8, kSNT = 384;
+constexpr int kSR = 8;
+struct StripShape {
+  int tw, th, ry, nt, bpc;
+};
+// 0: 96 x 32 steps, 12 rows of vertical halo, 768 threads, one block per CU (12 waves, three per SIMD, 168 VGPRs, 125 KB of
+//    LDS) -- production;  3: the same with 8 rows of vertical halo (114 KB);
+// 1: 64 x 16 steps, 512 threads, two blocks per CU (16 waves, four per SIMD, 128 VGPRs, 2 x 50 KB): one thread-step per barrier;
+// 2: 96 x 16 steps, 384 threads, two blocks per CU -- the first strip shape, kept for the record of what uneven SIMD
+//    placement costs (see BPC above).
+static const StripShape kStripShapes[] = {{96, 32, 12, 768, 1}, {64, 16, 8, 512, 2}, {96, 16, 8, 384, 2}, {96, 32, 8, 768, 1}};
+constexpr int kNumStripShapes = sizeof(kStripShapes) / sizeof(kStripShapes[0]);
 static int g_strip_rows = 0;      // test hook: rows per unit (0 = chosen from the shape and the device's block slots)
+static int g_strip_shape = 0;     // test hook: index into kStripShapes
 
-void strip_rows_override(int rows) { g_strip_rows = rows; }
+int strip_select(int rows, int shape) {
+  if (shape < 0 || shape >= kNumStripShapes) return 1;
+  if (rows != 0 && (rows < 2 * kStripShapes[shape].th || rows % kStripShapes[shape].th != 0)) return 1;
+  g_strip_rows = rows;
+  g_strip_shape = shape;
+  return 0;
+}
 
-static int block_slots() {
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0, cus = 256;
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
       hipDeviceProp_t p;
       if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
     }
-    slots = 2 * cus;              // two 384-thread blocks per CU (LDS)
   }
-  return slots;
+  return cus;
 }
 
-// Rows per unit: whole rounds of the device's block slots (1008 units on 512 slots at 48 x 384 x 672 with SH = 128) weighed
+// Rows per unit: whole rounds of the device's block slots (1008 units on 256 slots at 48 x 384 x 672 with SH = 128) weighed
 // against the share of rows that are ring rows (2R + 1 of every SH).
 StripPlan make_strip_plan(int B, int H, int W) {
   StripPlan p;
+  const StripShape& sh0 = kStripShapes[g_strip_shape];
+  const int kSTW = sh0.tw, kSTH = sh0.th;
+  p.shape = g_strip_shape;
   p.ntx = (W + kSTW - 1) / kSTW;
   int best_sh = 2 * kSTH;
   if (g_strip_rows >= 2 * kSTH) {
     best_sh = (g_strip_rows / kSTH) * kSTH;
   } else {
     double best = -1.0;
-    const int slots = block_slots();
+    const int slots = sh0.bpc * device_cus();
     for (int nseg = 1; nseg <= 64; ++nseg) {
       int sh = ((H + nseg - 1) / nseg + kSTH - 1) / kSTH * kSTH;
       if (sh < 2 * kSTH) sh = 2 * kSTH;
@@ -568,7 +709,7 @@ StripPlan make_strip_plan(int B, int H, int W) {
       const long long units = (long long)B * p.ntx * segs;
       const long long rounds = (units + slots - 1) / slots;
       const double fill = (double)units / (double)(rounds * slots);
-      const double useful = (double)H / (double)(segs * (sh + 2 * kSR + 1));
+      const double useful = (double)H / (double)(segs * (sh + 2 * sh0.ry + 1));
       const double score = fill * useful;
       if (score > best + 1e-9) {
         best = score;
@@ -580,7 +721,7 @@ StripPlan make_strip_plan(int B, int H, int W) {
   p.SH = best_sh;
   p.nseg = (H + p.SH - 1) / p.SH;
   const int ww = kSTW + 2 * kSR + 4;
-  p.slab_stride = (size_t)ww * (p.SH + 2 * kSR + 1);
+  p.slab_stride = (size_t)ww * (p.SH + 2 * sh0.ry + 1);
   p.n_units = (size_t)B * p.ntx * p.nseg;
   size_t off = p.n_units * 4 * sizeof(float);
   off = (off + 255) & ~(size_t)255;
@@ -601,6 +742,26 @@ StripPlan make_strip_plan(int B, int H, int W) {
 }
 
 // strip kernel -> unit combine -> finish (partial sums + overflow records: warp_finish_kernel of warp_loss.hip), one stream.
+template <int TW, int TH, int RY, int NT, int BPC>
+static int launch_strips_shape(const WarpArgs& a, const StripPlan& p, StripArgs& sa, hipStream_t stream) {
+  constexpr int lds = strip_lds_bytes(TW, TH, kSR, RY, NT);
+  const bool full = (a.W % TW) == 0 && (a.H % TH) == 0;
+  auto k = full ? warp_loss_strip_kernel<TW, TH, kSR, RY, NT, BPC, true> : warp_loss_strip_kernel<TW, TH, kSR, RY, NT, BPC, false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[full]) {
+    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set[full] = true;
+  }
+  const int units = (int)p.n_units;
+  const int slots = DVD_STRIP_PERSISTENT ? BPC * device_cus() : units;
+  hipLaunchKernelGGL(k, dim3(units < slots ? units : slots), dim3(NT), lds, stream, a, sa);
+  DVD_LAUNCH_OK();
+  hipLaunchKernelGGL((combine_units_kernel<TW, kSR, RY>), dim3(units), dim3(256), 0, stream, sa.slabs, sa.slab_stride,
+                     (const int2*)sa.offs, a.g_d2, a.H, a.W, p.ntx, p.nseg, p.SH, sa.direct);
+  DVD_LAUNCH_OK();
+  return launch_warp_finish(a.partial, units, a.sums, sa.ovf.count, sa.ovf.rec, sa.ovf.cap, a.g_d2, stream);
+}
+
 int launch_strips(const WarpArgs& a, const StripPlan& p, char* ws, hipStream_t stream) {
   StripArgs sa;
   sa.slabs = reinterpret_cast<float*>(ws + p.off_slabs);
@@ -613,21 +774,18 @@ int launch_strips(const WarpArgs& a, const StripPlan& p, char* ws, hipStream_t s
   sa.SH = p.SH;
   sa.direct = 1;
   sa.slab_stride = (unsigned)p.slab_stride;
+  sa.n_units = (int)p.n_units;
   DVD_REQUIRE(p.n_units * p.slab_stride < (1ull << 32), "warp_loss: slab workspace too large for 32-bit unit strides");
-  constexpr int lds = strip_lds_bytes(kSTW, kSTH, kSR, kSNT);
-  auto k = warp_loss_strip_kernel<kSTW, kSTH, kSR, kSNT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    DVD_HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
+  switch (p.shape) {
+    case 0:
+      return launch_strips_shape<96, 32, 12, 768, 1>(a, p, sa, stream);
+    case 1:
+      return launch_strips_shape<64, 16, 8, 512, 2>(a, p, sa, stream);
+    case 2:
+      return launch_strips_shape<96, 16, 8, 384, 2>(a, p, sa, stream);
+    default:
+      return launch_strips_shape<96, 32, 8, 768, 1>(a, p, sa, stream);
   }
-  const int units = (int)p.n_units;
-  hipLaunchKernelGGL(k, dim3(units), dim3(kSNT), lds, stream, a, sa);
-  DVD_LAUNCH_OK();
-  hipLaunchKernelGGL((combine_units_kernel<kSTW, kSR>), dim3(units), dim3(256), 0, stream, sa.slabs, sa.slab_stride,
-                     (const int2*)sa.offs, a.g_d2, a.H, a.W, p.ntx, p.nseg, p.SH, sa.direct);
-  DVD_LAUNCH_OK();
-  return launch_warp_finish(a.partial, units, a.sums, sa.ovf.count, sa.ovf.rec, sa.ovf.cap, a.g_d2, stream);
 }
 
 }  // namespace dvd

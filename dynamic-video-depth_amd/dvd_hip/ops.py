@@ -276,14 +276,14 @@ def executed_flops():
     return {k: now[k] + REPLAYED[k] for k in FLOP_CLASSES}
 
 
-def warp_loss_select(variant='tiled', tile=-1, px=0, strip_rows=0):
+def warp_loss_select(variant='tiled', tile=-1, px=0, strip_rows=0, strip_shape=0):
     """Test hook: run dvd_warp_loss_fused on another variant -- 'tiled' = production (the strip kernel where it applies, at
     tile = -1 and px = 0), 'direct' = global gathers + hardware atomics, 'tiles' = the tile kernel of rounds 2-5 whatever the
-    call -- tile shape, pixels-per-step mapping or rows per strip unit.  Process wide; call warp_loss_select() to restore
+    call -- tile shape, pixels-per-step mapping, rows per strip unit or strip shape (csrc/warp_strip.hip kStripShapes).  Process wide; call warp_loss_select() to restore
     the production path."""
     lib = _lib.load()
     _lib.check(lib.dvd_warp_loss_select({'tiled': 0, 'direct': 1, 'tiles': 2}[variant], int(tile), int(px)), 'dvd_warp_loss_select')
-    _lib.check(lib.dvd_warp_loss_strip_rows(int(strip_rows)), 'dvd_warp_loss_strip_rows')
+    _lib.check(lib.dvd_warp_loss_strip_select(int(strip_rows), int(strip_shape)), 'dvd_warp_loss_strip_select')
 
 
 def loss_finalize(cfg, sums, out=None):

@@ -133,9 +133,12 @@ size_t dvd_warp_loss_workspace_bytes(int B, int H, int W);
  * whatever the call; tile = -1 (auto) or an index of the tile-shape table; px = 0 (auto), 2 or 4 pixels per thread-step.
  * Every combination computes the same function. */
 int dvd_warp_loss_select(int variant, int tile, int px);
-/* Test hook (ABI 7): image rows per unit of the strip kernel -- 0 = chosen from the shape and the device's block slots, else
- * a multiple of 16, >= 32 (more, shorter units: more seams between units).  dvd_warp_loss_workspace_bytes follows it. */
-int dvd_warp_loss_strip_rows(int rows);
+/* Test hook (ABI 7): rows = image rows per unit of the strip kernel -- 0 = chosen from the shape and the device's block slots,
+ * else a multiple of the shape's step height, at least two steps (more, shorter units: more seams between units); shape = 0
+ * (production: 96-column strips in 32-row steps, 12 rows of vertical halo, 768-thread blocks), 1 (64 x 16, 512 threads),
+ * 2 (96 x 16, 384 threads), 3 (as 0 with 8 rows of vertical halo).
+ * dvd_warp_loss_workspace_bytes follows both. */
+int dvd_warp_loss_strip_select(int rows, int shape);
 int dvd_warp_loss_fused(const dvd_warp_cfg* cfg, const float* depth_1, const float* depth_2,
                         const float* flow_1_2, const float* mask_2, const float* sf_1_2,
                         const dvd_cameras* cams, void* workspace, size_t workspace_bytes,

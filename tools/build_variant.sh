@@ -13,7 +13,7 @@ OUT=$PKG/lib/variants
 mkdir -p $OUT/obj_$NAME
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/include -I$PKG/csrc"
 EXTRA=""
-case $UNIT in warp_loss|unproject|elementwise|surfaces|upsample|consistency) EXTRA="-ffp-contract=off";; esac
+case $UNIT in warp_loss|warp_strip|unproject|elementwise|surfaces|upsample|consistency) EXTRA="-ffp-contract=off";; esac
 SRC=${SRC:-$PKG/csrc/$UNIT.hip}          # SRC=<file>: another revision of the unit (git show <rev>:<path> > file)
 hipcc $COMMON $EXTRA "$@" -c $SRC -o $OUT/obj_$NAME/$UNIT.o
 OBJS=""

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--direct', action='store_true', help='global-atomics reference variant')
     ap.add_argument('--tiles', action='store_true', help='the tile kernel of rounds 2-5 instead of the strip kernel')
     ap.add_argument('--strip_rows', type=int, default=0, help='rows per unit of the strip kernel (0 = automatic)')
+    ap.add_argument('--strip_shape', type=int, default=0, help='strip shape index (csrc/warp_strip.hip kStripShapes)')
     ap.add_argument('--tile', type=int, default=-1, help='force tile shape index')
     ap.add_argument('--px', type=int, default=0, help='pixels per thread-step (0 auto, 2, 4)')
     ap.add_argument('--flow_sigma', type=float, default=3.0)
@@ -34,7 +35,7 @@ def main():
     a = ap.parse_args()
     B, H, W = a.B, a.H, a.W
     ops.warp_loss_select(variant='direct' if a.direct else ('tiles' if a.tiles else 'tiled'), tile=a.tile, px=a.px,
-                         strip_rows=a.strip_rows)
+                         strip_rows=a.strip_rows, strip_shape=a.strip_shape)
     batch = synthetic.make_batch(B, H, W, device='cuda', with_images=False)
     batch['flow_1_2'] = batch['flow_1_2'] * (a.flow_sigma / 3.0)
     if a.smooth_flow:
@@ -66,7 +67,7 @@ def main():
     print(json.dumps({'kernel': 'warp_loss_fused' if grads else 'warp_loss_fwd', 'B': B, 'H': H, 'W': W,
                       'ms_per_call_incl_memset_and_reduce': ms, 'algorithmic_bytes': bytes_alg,
                       'GBps': bytes_alg / ms / 1e6, 'frac_of_8TBps': bytes_alg / ms / 1e6 / 8000.0,
-                      'smooth_flow': a.smooth_flow, 'direct': a.direct, 'tiles': a.tiles, 'strip_rows': a.strip_rows, 'tile': a.tile,
+                      'smooth_flow': a.smooth_flow, 'direct': a.direct, 'tiles': a.tiles, 'strip_rows': a.strip_rows, 'strip_shape': a.strip_shape, 'tile': a.tile,
                       'flow_sigma': a.flow_sigma}))
 
 

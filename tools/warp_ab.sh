@@ -16,7 +16,7 @@ run() { lib=$1; tile=$2; echo "== lib=$(basename ${lib:-product}) tile=$tile" >>
 sq() { lib=$1; tile=$2; name=$(basename ${lib:-product} .so)_t$tile
        ( cd /tmp && env ${lib:+DVD_HIP_LIB=$lib} timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE \
            --output-format csv -d $ROOT/$OUT/sq_$name -o pmc -- python $ROOT/tools/microbench_warp.py --iters 3 --tile $tile --px ${PX:-0} > $ROOT/$OUT/sq_$name.log 2>&1 )
-       python tools/pmc_summary.py "$OUT/sq_$name/" 2>&1 | grep -E "warp_loss_tiled|combine" > $OUT/sq_$name.txt; rm -rf $OUT/sq_$name; }
+       python tools/pmc_summary.py "$OUT/sq_$name/" 2>&1 | grep -E "warp_loss_tiled|warp_loss_strip|combine" > $OUT/sq_$name.txt; rm -rf $OUT/sq_$name; }
 for t in $TILES; do run "" $t; [ -n "${SQ:-}" ] && sq "" $t; done
 for f in $V/libdvd_hip_*.so; do
   [ -f $f ] || continue
@@ -31,4 +31,4 @@ for l in open('$OUT/ab.log'):
         d=json.loads(l); print('%-50s %.1f us  %.0f GB/s  frac %.3f' % (name[3:], d['ms_per_call_incl_memset_and_reduce']*1e3, d['GBps'], d['frac_of_8TBps']))
 PY
 cat $OUT/ab.txt
-for f in $OUT/sq_*.txt; do [ -f $f ] && { echo $f; cut -c30-200 $f | grep -E "INSTS_VALU|WAVE_CYCLES|GRBM|ACTIVE_INST_VALU" | grep tiled; }; done
+for f in $OUT/sq_*.txt; do [ -f $f ] && { echo $f; cut -c30-200 $f | grep -E "INSTS_VALU|WAVE_CYCLES|GRBM|ACTIVE_INST_VALU|WAIT" | grep -E "tiled|strip"; }; done

@@ -10,6 +10,6 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   ( cd /tmp && env $LIBV timeout 300 rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/sq$i -o pmc -- \
       python $ROOT/tools/microbench_warp.py --iters 3 > $ROOT/$OUT/sq$i.log 2>&1 )
 done
-python tools/pmc_summary.py "$OUT/sq*/" 2>&1 | grep -E "warp_loss_tiled|combine" > $OUT/sq_summary.txt
+python tools/pmc_summary.py "$OUT/sq*/" 2>&1 | grep -E "warp_loss_tiled|warp_loss_strip|combine" > $OUT/sq_summary.txt
 rm -rf $OUT/sq*/
 cat $OUT/sq_summary.txt
