@@ -272,8 +272,10 @@ def _valu_issue(pixels_per_launch):
     try:
         rec = json.load(open(path))
         ipp = rec['valu_wave_instructions'] * 64.0 / rec['pixels']
+        from dvd_hip import build as _build
         return {'instr_per_pixel': round(ipp, 1), 'issue_bound_ms': round(ipp * pixels_per_launch / (256 * 64 * rec['clock_hz']) * 1e3, 4),
-                'source': 'static: profiles/warp_loss_sq.json (%s)' % rec.get('collected', '')}
+                'kernel': rec.get('kernel'), 'source': 'static: profiles/warp_loss_sq.json (%s)' % rec.get('collected', ''),
+                'profile_is_of_this_binary': _profile_is_current(rec, _build.WARP_UNITS)}
     except Exception:                      # noqa: BLE001 -- informational only
         return None
 
@@ -286,7 +288,7 @@ def _roofline_mfma(f0, f1, steps, dt, world, act_fp16):
     not measurable in this process; the committed trace of the same command supplies it (profiles/mfma_roofline.json, written by
     tools/mfma_roofline.py; provenance stated) for the three classes with the most time."""
     prod = PRODUCTS_FP16 if act_fp16 else PRODUCTS_FP32
-    per_step = {k: (f1[k] - f0[k]) / steps for k in f1}
+    per_step = {k: (f1[k] - f0[k]) / steps for k in f1 if k in prod}
     total = sum(per_step.values())
     issued = sum(per_step[k] * prod[k] for k in per_step)
     s_per_step = dt / steps
@@ -313,9 +315,72 @@ def _roofline_mfma(f0, f1, steps, dt, world, act_fp16):
         out['top_kernels'] = top
         out['top_kernels_source'] = 'static kernel times: profiles/mfma_roofline.json (%s); work: counted live in this run' % \
             rec.get(key, {}).get('collected', '')
+        out['profile_is_of_this_binary'] = _profile_is_current(rec.get(key, {}), None)
     except Exception:                      # noqa: BLE001 -- informational only
         out['top_kernels'] = None
     return out
+
+
+def _profile_is_current(rec, units):
+    """Was a committed profile that this line joins collected from the kernels this process runs?  The tools that write
+    profiles/*.json on the GPU box stamp them with dvd_hip.build.source_digest (sources + flags of the translation units
+    concerned); True / False, or None for a profile from before the stamp existed."""
+    try:
+        from dvd_hip import build
+        want = rec.get('source_digest')
+        return None if not want else bool(want == build.source_digest(units))
+    except Exception:                      # noqa: BLE001 -- informational only
+        return None
+
+
+def _roofline_helpers(f0, f1, steps, act_fp16):
+    """The memory-bound helper kernels of a step (BatchNorm+ReLU, up-sampling, max|.| scalars, weight packing, pooling, the
+    stage-1 grouped convolution on the vector unit, element-wise passes, Adam, un-projection): algorithmic bytes per step per
+    class, counted live by the library (dvd_byte_counters: every operand read once, every result written once), over the
+    class's kernel time per step from the committed trace (profiles/mfma_roofline.json `helpers`, written by
+    tools/mfma_roofline.py from the same two traces as the matrix classes; static, provenance and digest stated) = GB/s against
+    the 8 TB/s HBM peak.  `other_ms_per_step` is what neither a matrix nor a helper class claims (ATen / runtime kernels)."""
+    from dvd_hip import ops
+    per_step = {k: (f1[k] - f0[k]) / steps for k in ops.BYTE_CLASSES}
+    out = {'unit': 'GB/s', 'peak': HBM_PEAK_GBPS, 'algorithmic_MB_per_step': {k: round(v / 1e6, 2) for k, v in per_step.items() if v}}
+    try:
+        rec = json.load(open(os.path.join(ROOT, 'profiles', 'mfma_roofline.json'))).get('fp16' if act_fp16 else 'fp32', {})
+        rows, tot = [], 0.0
+        for r in rec.get('helpers', []):
+            b, ms = per_step.get(r['class'], 0.0), r['ms_per_step']
+            tot += ms
+            rows.append({'class': r['class'], 'ms_per_step': ms, 'launches_per_step': r.get('launches_per_step'),
+                         'algorithmic_MB_per_step': b / 1e6, 'GBps': b / (ms * 1e-3) / 1e9 if ms else None,
+                         'frac': b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms else None})
+        out['classes'] = rows
+        out['helper_ms_per_step'] = tot
+        out['other_ms_per_step'] = rec.get('other_ms_per_step')
+        out['other_kernels'] = rec.get('other_kernels')
+        out['source'] = 'static kernel times: profiles/mfma_roofline.json (%s); bytes: counted live in this run' % rec.get('collected', '')
+        out['profile_is_of_this_binary'] = _profile_is_current(rec, None)
+    except Exception:                      # noqa: BLE001 -- informational only
+        out['classes'] = None
+    return out
+
+
+def _sub_bench(args, timeout_s, keep):
+    """One more bench line from a child process of this script (its own model, its own process group): the keys in `keep` of
+    its JSON line, or {'error': ...} -- a failing extra never takes the headline line with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + args + ['--no_extras', '--no_cpu_baseline']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        line = [l for l in r.stdout.split('\n') if l.startswith('{')]
+        if r.returncode != 0 or not line:
+            return {'error': 'exit %d: %s' % (r.returncode, (r.stderr or '')[-300:]), 'command': ' '.join(cmd[1:])}
+        rec = json.loads(line[-1])
+        out = {k: rec.get(k) for k in keep if k in rec}
+        out['command'] = 'python ' + ' '.join(os.path.basename(c) if c.endswith('bench.py') else c for c in cmd[1:])
+        return out
+    except subprocess.TimeoutExpired:
+        return {'error': 'timeout after %d s' % timeout_s, 'command': ' '.join(cmd[1:])}
+    except Exception as e:                 # noqa: BLE001 -- informational only
+        return {'error': repr(e)}
 
 
 def relaunch_under_torchrun(n):
@@ -362,6 +427,14 @@ def main():
                     help="hbm (default, the contract's `value`): inputs resident in HBM before the timed region; host: every "
                          "step's batch starts in host memory and goes through the pinned double-buffered feeder "
                          "(dvd_hip.datasets.davis_sequence.DeviceFeeder), so the PCIe copy is inside the timed region")
+    ap.add_argument('--no_extras', action='store_true',
+                    help='only the headline measurement: without the configs4 and rccl_one_rank sub-records the default N = 1 run '
+                         'adds from child processes of this script')
+    ap.add_argument('--rccl_one_rank', action='store_true',
+                    help='N = 1 with a ONE-rank nccl (= RCCL) process group and the collectives of the N-rank step forced '
+                         '(dvd_hip.parallel.init_one_rank): plan agreement, loss-sum all-reduces, MLP-gradient all-reduce under the '
+                         'depth-net backward, bucketed depth-net gradient all-reduce pipelined with Adam -- the RCCL calls of the '
+                         'data-parallel step on a 1-GPU box (the arithmetic is unchanged: a sum over one rank)')
     a = ap.parse_args()
     global H, W
     if a.config == 4:
@@ -377,6 +450,12 @@ def main():
     # the driver's multi-GPU runs use the default, nccl = RCCL over xGMI, one rank per GPU
     local = parallel.init_from_env(backend=os.environ.get('DVD_DIST_BACKEND'))
     local = local % max(torch.cuda.device_count(), 1)
+    rccl_one = None
+    if a.rccl_one_rank:
+        if a.gpus != 1 or parallel.is_distributed():
+            raise SystemExit('--rccl_one_rank is a 1-GPU, 1-process run')
+        torch.cuda.set_device(local)
+        rccl_one = parallel.init_one_rank('nccl')
     world, rank = parallel.world_size(), parallel.rank()
     if a.gpus != world:
         raise SystemExit('--gpus %d but the torch.distributed world has %d ranks' % (a.gpus, world))
@@ -495,7 +574,7 @@ def main():
         # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 --pmc passes of
         # the same launch at 48 x 384 x 672: tools/gpu_visit.sh, stage pmc -> tools/pmc_to_json.py); the committed summary of the
         # CURRENT kernel is read here and its provenance is stated next to the number
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_cur = None, None, None
         pmc = os.path.join(ROOT, 'profiles', 'warp_loss_pmc.json')
         if os.path.exists(pmc):
             try:
@@ -505,11 +584,14 @@ def main():
                 pmc_pixels = rec.get('algorithmic_bytes_per_launch') / float(WARP_BYTES_PER_PIXEL)
                 traffic = rec.get('hbm_bytes_per_launch') * warp['pixels_per_launch'] / pmc_pixels
                 traffic_src = 'static: profiles/warp_loss_pmc.json (%s)' % rec.get('collected', 'rocprofv3 --pmc passes')
+                from dvd_hip import build as _build
+                traffic_cur = _profile_is_current(rec, _build.WARP_UNITS)
             except Exception:
                 traffic = None
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'dvd_warp_loss_fused (tiled warp/loss kernel + slab combine + reductions)',
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'dvd_warp_loss_fused (strip kernel + unit combine + reductions; round 6)',
                            'achieved': warp['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                            'frac': warp['GBps'] / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                           'profile_is_of_this_binary': traffic_cur,
                            'algorithmic_bytes_per_launch': warp['pixels_per_launch'] * WARP_BYTES_PER_PIXEL,
                            'avg_launch_ms': warp['avg_ms'], 'launches_timed': warp['launches'],
                            # the kernel's OTHER roofline: it is VALU-issue bound (the reference's exact fp32 rounding sequence
@@ -518,6 +600,9 @@ def main():
                            # (256 CUs x 64 lanes per clock at the measured 2.16 GHz)
                            'valu_issue': _valu_issue(warp['pixels_per_launch'])}
     out['roofline_mfma'] = _roofline_mfma(flops0, flops1, a.steps, dt, world, a.act_fp16)
+    out['roofline_helpers'] = _roofline_helpers(flops0, flops1, a.steps, a.act_fp16)
+    if rccl_one is not None:
+        out['rccl_one_rank'] = dict(rccl_one, comm_hbm_GB=rccl_one['comm_hbm_bytes'] / 2 ** 30, collectives_forced=True)
     if a.act_fp16:
         st = model._gscale.tolist()
         out['loss_scale'] = {'log2_S': __import__('math').log2(st[0]) if st[0] > 0 else None, 'target_exponent': st[2],
@@ -545,6 +630,24 @@ def main():
         first = oracle_first_step()
         out['parity'] = hip_parity(first, device, act_fp16=a.act_fp16)      # (fp16 activations: against the SAME fp32 oracle)
         out['cpu_baseline'] = cpu_baseline(first, timed_steps=max(1, a.cpu_steps))
+    if world == 1 and not a.no_extras and a.config == 2 and not a.act_fp16 and a.depth == 'midas' and a.gap == GAP \
+            and a.feed == 'hbm' and not a.rccl_one_rank and a.pairs == PAIRS:
+        # Two more lines of the SAME script, from child processes, inside the headline line (so that the driver's BENCH record
+        # carries them): BASELINE configs[4] at its own 64 pairs per GPU, and the headline configuration with the data-parallel
+        # step's collectives running on RCCL in a one-rank group.  Neither touches `value`.
+        import gc
+        try:
+            del model, batch
+        except NameError:                  # (already released by the parity / cpu_baseline leg)
+            pass
+        gc.collect()
+        torch.cuda.empty_cache()
+        keep = ('value', 'unit', 'ms_per_step', 'steps', 'pairs_per_s', 'dtype', 'config', 'roofline', 'roofline_mfma',
+                'hbm_peak_reserved_GB', 'last_loss', 'loss_scale', 'rccl_one_rank', 'rccl_version', 'dist_backend')
+        out['configs4'] = _sub_bench(['--config', '4', '--pairs', '64', '--steps', '2', '--cfg4_parity', 'none'], 900, keep)
+        out['rccl_one_rank'] = _sub_bench(['--rccl_one_rank', '--steps', '3'], 600, keep)
+        if isinstance(out['rccl_one_rank'], dict) and 'last_loss' in out['rccl_one_rank']:
+            out['rccl_one_rank']['last_loss_equals_headline'] = bool(out['rccl_one_rank']['last_loss'] == out['last_loss'])
     print(json.dumps(out))
 
 

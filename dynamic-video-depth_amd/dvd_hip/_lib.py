@@ -57,6 +57,7 @@ SIGNATURES = {
     'dvd_last_error': (ctypes.c_char_p, []),
     'dvd_device_cu_count': (c_int, []),
     'dvd_flop_counters': (c_int, [c_void_p, c_int, c_int]),
+    'dvd_byte_counters': (c_int, [c_void_p, c_int, c_int]),
     'dvd_unproject_fwd': (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     'dvd_unproject_bwd': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_int, c_void_p]),

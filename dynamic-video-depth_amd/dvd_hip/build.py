@@ -64,6 +64,24 @@ def _digest(paths, flags):
     return h.hexdigest()
 
 
+def source_digest(units=None):
+    """sha256 (16 hex digits) over the sources a set of translation units is built from -- the .hip files named in `units`
+    (None: every unit of the library), every header of csrc/ and the C ABI header, and their flags.  A profile that bench.py
+    joins into its line (profiles/warp_loss_pmc.json, warp_loss_sq.json, mfma_roofline.json) is stamped with it by the tool that
+    writes it on the GPU box; bench.py recomputes it and says whether the profile is of the kernels it is running."""
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')]
+    headers.append(os.path.join(INCLUDE, 'dvd_hip.h'))
+    h = hashlib.sha256()
+    for src, extra in SOURCES:
+        if units is not None and src not in units:
+            continue
+        h.update(_digest([os.path.join(CSRC, src)] + headers, COMMON + extra).encode())
+    return h.hexdigest()[:16]
+
+
+WARP_UNITS = ('warp_loss.hip', 'warp_strip.hip')      # the fused warp+loss launch sequence
+
+
 def build_library(force=False, verbose=False):
     """Compile every HIP translation unit and link the shared library.
     Returns the library path.  Re-uses objects whose sources did not change."""

@@ -268,6 +268,7 @@ int dvd_head1x1_fwd(const void* x, int f16, const float* w, const float* bias, f
   DVD_REQUIRE(x && w && y, "head1x1 fwd: null pointer");
   DVD_REQUIRE(N > 0 && C > 0 && C <= dvd::kHeadMaxC && HW > 0 && (HW & 3) == 0, "head1x1 fwd: bad shape N=%d C=%d HW=%d (C <= 64, HW %% 4 == 0)", N, C, HW);
   const long long total = (long long)N * (HW / 4);
+  dvd::bytes_add(DVD_BYTES_ELEMENTWISE, (double)N * HW * ((f16 ? 2.0 : 4.0) * C + 4.0));
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::head1x1_fwd_kernel<T>, dim3(dvd::blocks_for(total)), dim3(256), 0,
                                          static_cast<hipStream_t>(stream), static_cast<const T*>(x), w, bias, y, C, HW / 4, total,
                                          relu_in, fwd_amax));
@@ -286,6 +287,7 @@ int dvd_head1x1_bwd(const void* x, int f16, const float* w, const float* gy, con
     return DVD_ENOSPC;
   }
   const long long total = (long long)N * (HW / 4);
+  dvd::bytes_add(DVD_BYTES_ELEMENTWISE, (double)N * HW * ((f16 ? 2.0 : 4.0) * 2 * C + 4.0));
   const int blocks = dvd::blocks_for(total);
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* gmax = gscale_state ? const_cast<float*>(gscale_state) + 3 : nullptr;
@@ -307,6 +309,7 @@ int dvd_head1x1_bwd(const void* x, int f16, const float* w, const float* gy, con
 
 int dvd_cast_scale_f32(const void* in, int f16, float* out, long long n, const float* scale, dvd_stream_t stream) {
   DVD_REQUIRE(in && out && n > 0 && (n & 3) == 0, "cast_scale: bad arguments (n %% 4 == 0)");
+  dvd::bytes_add(DVD_BYTES_ELEMENTWISE, (double)n * ((f16 ? 2.0 : 4.0) + 4.0));
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::cast_scale_kernel<T>, dim3(dvd::blocks_for(n >> 2)), dim3(256), 0,
                                          static_cast<hipStream_t>(stream), static_cast<const T*>(in), out, n >> 2, scale));
   DVD_LAUNCH_OK();

@@ -28,6 +28,7 @@ extern "C" {
 int dvd_amax(const float* x, long long n, float* out, dvd_stream_t stream) {
   DVD_REQUIRE(x && out && n > 0, "amax: bad arguments");
   DVD_REQUIRE(((uintptr_t)x & 3) == 0, "amax: tensor must be 4-byte aligned");
+  dvd::bytes_add(DVD_BYTES_AMAX, 4.0 * (double)n);
   long long head = (long long)(((16 - ((uintptr_t)x & 15)) & 15) >> 2);
   if (head > n) head = n;
   const long long nv = (n - head + 3) / 4;

@@ -220,6 +220,7 @@ int dvd_bnrelu_fwd_t(const void* x, const void* residual, const float* gamma, co
   const int chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
   const long long blocks = (long long)N * C * chunks;
   DVD_REQUIRE(blocks < (1LL << 31), "bnrelu fwd: grid too large");
+  dvd::bytes_add(DVD_BYTES_BNRELU_FWD, (double)N * C * HW * (f16 ? 2 : 4) * (residual ? 3 : 2));
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::bnrelu_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
                                          static_cast<hipStream_t>(stream), static_cast<const T*>(x), static_cast<const T*>(residual),
                                          gamma, beta, mean, var, eps, static_cast<T*>(y), C, HW, chunks, relu));
@@ -252,6 +253,7 @@ int dvd_bnrelu_bwd_t(const void* gy, const void* y, const void* x, const float* 
     dvd::set_error("bnrelu bwd: workspace too small");
     return DVD_ENOSPC;
   }
+  dvd::bytes_add(DVD_BYTES_BNRELU_BWD, (double)N * C * HW * (f16 ? 2 : 4) * (1 + (y ? 1 : 0) + (x ? 1 : 0) + (gx ? 1 : 0) + (g_residual ? 1 : 0)));
   const int chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
   // small planes: several images of a channel per block (as many as make ~4 096 elements, while >= 1 024 blocks remain)
   int npb = 1;

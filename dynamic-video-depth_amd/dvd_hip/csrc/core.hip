@@ -34,9 +34,22 @@ void flops_add(int cls, double flops) {
   if (cls >= 0 && cls < DVD_FLOP_CLASSES) g_flops[cls] += flops;
 }
 
+static double g_bytes[DVD_BYTES_CLASSES] = {0};
+void bytes_add(int cls, double bytes) {
+  if (cls >= 0 && cls < DVD_BYTES_CLASSES) g_bytes[cls] += bytes;
+}
+
 }  // namespace dvd
 
 extern "C" {
+
+int dvd_byte_counters(double* out, int n, int reset) {
+  DVD_REQUIRE(out && n > 0, "byte_counters: null output");
+  for (int i = 0; i < n; ++i) out[i] = i < DVD_BYTES_CLASSES ? dvd::g_bytes[i] : 0.0;
+  if (reset)
+    for (int i = 0; i < DVD_BYTES_CLASSES; ++i) dvd::g_bytes[i] = 0.0;
+  return DVD_OK;
+}
 
 int dvd_abi_version(void) { return DVD_ABI_VERSION; }
 

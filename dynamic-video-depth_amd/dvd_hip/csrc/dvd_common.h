@@ -11,7 +11,8 @@ namespace dvd {
 
 void set_error(const char* fmt, ...);
 int zero_words(void* p, int n_words, hipStream_t stream);   // device-side clear by a kernel (core.hip)
-void flops_add(int cls, double flops);                       // algorithmic-work accounting per kernel class (core.hip)
+void flops_add(int cls, double flops);
+void bytes_add(int cls, double bytes);                       // algorithmic bytes of the memory-bound helper kernels per class (core.hip)                       // algorithmic-work accounting per kernel class (core.hip)
 
 #define DVD_REQUIRE(cond, ...)             \
   do {                                     \

@@ -170,6 +170,7 @@ extern "C" {
 int dvd_mul_mask(float* out, const float* a, const float* mask, int B, int C, long long HW, dvd_stream_t stream) {
   DVD_REQUIRE(out && a && mask && B > 0 && C > 0 && HW > 0, "mul_mask: bad arguments");
   const long long n = (long long)B * C * HW;
+  dvd::bytes_add(DVD_BYTES_ELEMENTWISE, 8.0 * (double)n + 4.0 * (double)B * HW);
   hipLaunchKernelGGL(dvd::mul_mask_kernel, dim3(dvd::grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), out,
                      a, mask, C, HW, n);
   DVD_LAUNCH_OK();
@@ -181,6 +182,7 @@ int dvd_scale_add(float* out, const float* a, float scale, const float* scale_pt
   using namespace dvd;
   DVD_REQUIRE(out && a && n > 0, "scale_add: null pointer / size");
   DVD_REQUIRE(al16(out) && al16(a) && al16(b), "scale_add: pointers must be 16-byte aligned");
+  bytes_add(DVD_BYTES_ELEMENTWISE, 4.0 * (double)n * (b ? 3 : 2));
   hipLaunchKernelGGL(scale_add_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, static_cast<hipStream_t>(stream), out, a,
                      scale, scale_ptr, b, n);
   DVD_LAUNCH_OK();
@@ -194,6 +196,7 @@ int dvd_acc_reg(const float* sf0, const float* sf1, float coef, float* g_sf1, vo
   using namespace dvd;
   DVD_REQUIRE(sf0 && sf1 && g_sf1 && workspace && abs_sum && n > 0, "acc_reg: null pointer / size");
   DVD_REQUIRE(al16(sf0) && al16(sf1) && al16(g_sf1), "acc_reg: pointers must be 16-byte aligned");
+  bytes_add(DVD_BYTES_ELEMENTWISE, 12.0 * (double)n);
   const int grid = grid_for(n >> 2);
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(acc_reg_kernel, dim3(grid), dim3(256), 0, s, sf0, sf1, coef, g_sf1,
@@ -219,6 +222,7 @@ int dvd_adam_step_guarded(float* param, const float* grad1, float scale, const f
   DVD_REQUIRE(param && grad1 && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_step: bad argument");
   DVD_REQUIRE(al16(param) && al16(grad1) && al16(grad2) && al16(exp_avg) && al16(exp_avg_sq),
               "adam_step: pointers must be 16-byte aligned");
+  bytes_add(DVD_BYTES_ADAM, 4.0 * (double)n * (grad2 ? 8 : 7));
   // bias corrections in double, like torch's python-scalar arithmetic
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);

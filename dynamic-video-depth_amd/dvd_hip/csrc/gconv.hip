@@ -262,6 +262,7 @@ int dvd_gconv3x3_c8_bwd_weight(const float* x, const float* gy, float* gw, int a
 int dvd_gconv3x3_c8_fwd_t(const void* x, const float* w, void* y, int f16, int N, int C, int H, int W, dvd_stream_t stream) {
   if (int e = dvd::check_shape(N, C, H, W)) return e;
   DVD_REQUIRE(x && w && y, "gconv fwd: null pointer");
+  dvd::bytes_add(DVD_BYTES_GCONV, 2.0 * N * C * (double)H * W * (f16 ? 2 : 4));
   const int tx = (W + dvd::kFT_W - 1) / dvd::kFT_W, ty = (H + dvd::kFT_H - 1) / dvd::kFT_H;
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL((dvd::gconv3x3_c8_kernel<false, T>), dim3(tx * ty, C / dvd::kCPG, N), dim3(256), 0,
                                          static_cast<hipStream_t>(stream), static_cast<const T*>(x), w, static_cast<T*>(y), C, H, W,
@@ -274,6 +275,7 @@ int dvd_gconv3x3_c8_bwd_data_t(const void* gy, const float* w, void* gx, int f16
                                dvd_stream_t stream) {
   if (int e = dvd::check_shape(N, C, H, W)) return e;
   DVD_REQUIRE(gy && w && gx, "gconv bwd_data: null pointer");
+  dvd::bytes_add(DVD_BYTES_GCONV, 2.0 * N * C * (double)H * W * (f16 ? 2 : 4));
   const int tx = (W + dvd::kFT_W - 1) / dvd::kFT_W, ty = (H + dvd::kFT_H - 1) / dvd::kFT_H;
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL((dvd::gconv3x3_c8_kernel<true, T>), dim3(tx * ty, C / dvd::kCPG, N), dim3(256), 0,
                                          static_cast<hipStream_t>(stream), static_cast<const T*>(gy), w, static_cast<T*>(gx), C, H,
@@ -293,6 +295,7 @@ int dvd_gconv3x3_c8_bwd_weight_t(const void* x, const void* gy, float* gw, int a
                                  dvd_stream_t stream) {
   if (int e = dvd::check_shape(N, C, H, W)) return e;
   DVD_REQUIRE(x && gy && gw && workspace, "gconv bwd_weight: null pointer");
+  dvd::bytes_add(DVD_BYTES_GCONV, 2.0 * N * C * (double)H * W * (f16 ? 2 : 4));
   const size_t need = dvd_gconv3x3_c8_wgrad_workspace_bytes(N, C, H, W);
   if (workspace_bytes < need) {
     dvd::set_error("gconv bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);

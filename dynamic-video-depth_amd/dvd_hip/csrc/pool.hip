@@ -92,6 +92,7 @@ int dvd_maxpool3s2_fwd(const float* x, void* y, int y_f16, unsigned char* index,
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long total = planes * Ho * Wo;
   DVD_REQUIRE((total + 255) / 256 < (1LL << 31), "maxpool fwd: too large");
+  dvd::bytes_add(DVD_BYTES_POOL, (double)planes * (4.0 * H * W + (double)Ho * Wo * ((y_f16 ? 2 : 4) + 1)));
   DVD_DISPATCH_T(y_f16, hipLaunchKernelGGL(dvd::maxpool3s2_fwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                                            static_cast<hipStream_t>(stream), x, static_cast<T*>(y), index, H, W, Ho, Wo, total));
   DVD_LAUNCH_OK();
@@ -104,6 +105,7 @@ int dvd_maxpool3s2_bwd(const void* gy, int gy_f16, const unsigned char* index, f
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long total = planes * H * W;
   DVD_REQUIRE((total + 255) / 256 < (1LL << 31), "maxpool bwd: too large");
+  dvd::bytes_add(DVD_BYTES_POOL, (double)planes * (4.0 * H * W + (double)Ho * Wo * ((gy_f16 ? 2 : 4) + 1)));
   DVD_DISPATCH_T(gy_f16, hipLaunchKernelGGL(dvd::maxpool3s2_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                                             static_cast<hipStream_t>(stream), static_cast<const T*>(gy), index, gx, H, W, Ho, Wo,
                                             total, out_scale));

@@ -146,6 +146,7 @@ int dvd_unproject_fwd(const float* depth, const float* R, const float* t, const 
   using namespace dvd;
   DVD_REQUIRE(depth && R && t && K_inv && points, "unproject_fwd: null pointer");
   DVD_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0, "unproject_fwd: bad shape B=%d H=%d W=%d", B, H, W);
+  bytes_add(DVD_BYTES_GEOMETRY, 16.0 * (double)B * H * W);
   const int HW = H * W;
   const bool v4 = (W % 4 == 0) && aligned16(depth) && aligned16(points);
   const int px = v4 ? 4 : 1;
@@ -169,6 +170,7 @@ int dvd_unproject_bwd(const float* g_points, int planar, const float* R, const f
   using namespace dvd;
   DVD_REQUIRE(g_points && R && K_inv && g_depth, "unproject_bwd: null pointer");
   DVD_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0, "unproject_bwd: bad shape B=%d H=%d W=%d", B, H, W);
+  bytes_add(DVD_BYTES_GEOMETRY, (accumulate ? 20.0 : 16.0) * (double)B * H * W);
   const int HW = H * W;
   const bool v4 = (W % 4 == 0) && aligned16(g_points) && aligned16(g_depth);
   const int px = v4 ? 4 : 1;

@@ -302,6 +302,7 @@ int dvd_upsample_bilinear_fwd_t(const void* x, void* y, int f16, long long plane
                                 int align_corners, dvd_stream_t stream) {
   DVD_REQUIRE(x && y, "upsample fwd: null pointer");
   DVD_REQUIRE(planes > 0 && H_in > 0 && W_in > 0 && H_out > 0 && W_out > 0, "upsample fwd: bad shape");
+  dvd::bytes_add(DVD_BYTES_UPSAMPLE_FWD, (double)planes * ((double)H_in * W_in + (double)H_out * W_out) * (f16 ? 2 : 4));
   const dvd::Axis ay = dvd::make_axis(H_in, H_out, align_corners), ax = dvd::make_axis(W_in, W_out, align_corners);
   const long long rows = planes * H_out;
   DVD_REQUIRE(rows < (1LL << 32) - 4, "upsample fwd: too many rows");
@@ -324,6 +325,7 @@ int dvd_upsample_bilinear_bwd_t(const void* gy, void* gx, int f16, long long pla
                                 int align_corners, dvd_stream_t stream) {
   DVD_REQUIRE(gy && gx, "upsample bwd: null pointer");
   DVD_REQUIRE(planes > 0 && H_in > 0 && W_in > 0 && H_out > 0 && W_out > 0, "upsample bwd: bad shape");
+  dvd::bytes_add(DVD_BYTES_UPSAMPLE_BWD, (double)planes * ((double)H_in * W_in + (double)H_out * W_out) * (f16 ? 2 : 4));
   const dvd::Axis ay = dvd::make_axis(H_in, H_out, align_corners), ax = dvd::make_axis(W_in, W_out, align_corners);
   const long long rows = planes * H_in;
   DVD_REQUIRE(rows < (1LL << 32) - 4, "upsample bwd: too many rows");

@@ -620,7 +620,18 @@ __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restr
   float* gb = g_d2 + (size_t)b * H * W;
   const int kFull = (kTop + kBot) * QW, kRing = kFull + (SH - kTop - kBot) * (kLeft + kRight);
   const ptrdiff_t row_of_units = (ptrdiff_t)ntx * slab_stride;
-  for (int idx = threadIdx.x; idx < kRing; idx += 256) {
+  // (two quads per pass: the loads of both are requested before either is summed -- the kernel is a chain of dependent
+  //  round trips otherwise)
+  struct Quad {
+    v4f own, hor, ver, dia;
+    float* dst;
+    int di, dj;
+  };
+  auto request = [&](int idx, Quad& q) {
+    q.dst = nullptr;
+    q.own = q.hor = q.ver = q.dia = (v4f){0.f, 0.f, 0.f, 0.f};
+    q.di = q.dj = 0;
+    if (idx >= kRing) return;
     int hy, qx;
     if (idx < kFull) {
       const int r = idx / QW;
@@ -632,23 +643,35 @@ __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restr
       qx = k < kLeft ? k : QW - (kLeft + kRight) + k;
     }
     const int hx = qx * 4, x = ti * TW + hx, y = sj * SH + hy;
-    if (!(x < W && y < H)) continue;
+    if (!(x < W && y < H)) return;
     const int dj = hy < kTop ? -1 : (hy >= SH - kBot ? 1 : 0);
     const int di = hx < R + 4 ? -1 : (hx >= TW - R ? 1 : 0);
     const bool okj = dj != 0 && (unsigned)(sj + dj) < (unsigned)nseg, oki = di != 0 && (unsigned)(ti + di) < (unsigned)ntx;
     const float* p_own = unit_slab + (hy + RY) * WW + (hx + R);
+    q.own = *reinterpret_cast<const v4f*>(p_own);
+    // lane-masked loads: only the windows that cover the quad are read
+    if (oki) q.hor = *reinterpret_cast<const v4f*>(p_own + (ptrdiff_t)di * slab_stride - di * TW);
+    if (okj) q.ver = *reinterpret_cast<const v4f*>(p_own + dj * row_of_units - dj * SH * WW);
+    if (oki && okj) q.dia = *reinterpret_cast<const v4f*>(p_own + dj * row_of_units + (ptrdiff_t)di * slab_stride - dj * SH * WW - di * TW);
+    q.di = di;
+    q.dj = dj;
+    q.dst = gb + (size_t)y * W + x;
+  };
+  auto finish = [&](const Quad& q) {
+    if (q.dst == nullptr) return;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    const v4f own = *reinterpret_cast<const v4f*>(p_own);
-    v4f hor = zero, ver = zero, dia = zero;            // lane-masked loads: only the windows that cover the quad are read
-    if (oki) hor = *reinterpret_cast<const v4f*>(p_own + (ptrdiff_t)di * slab_stride - di * TW);
-    if (okj) ver = *reinterpret_cast<const v4f*>(p_own + dj * row_of_units - dj * SH * WW);
-    if (oki && okj) dia = *reinterpret_cast<const v4f*>(p_own + dj * row_of_units + (ptrdiff_t)di * slab_stride - dj * SH * WW - di * TW);
-    const bool hfirst = di < 0, vfirst = dj < 0;
-    const v4f r0a = hfirst ? dia : ver, r0b = hfirst ? ver : dia;      // the neighbouring row of units (dj != 0)
-    const v4f r1a = hfirst ? hor : own, r1b = hfirst ? own : hor;      // the own row of units
+    const bool hfirst = q.di < 0, vfirst = q.dj < 0;
+    const v4f r0a = hfirst ? q.dia : q.ver, r0b = hfirst ? q.ver : q.dia;      // the neighbouring row of units (dj != 0)
+    const v4f r1a = hfirst ? q.hor : q.own, r1b = hfirst ? q.own : q.hor;      // the own row of units
     const v4f t0 = vfirst ? r0a : r1a, t1 = vfirst ? r0b : r1b, t2 = vfirst ? r1a : r0a, t3 = vfirst ? r1b : r0b;
-    const v4f s4 = (((zero + t0) + t1) + t2) + t3;
-    *reinterpret_cast<v4f*>(gb + (size_t)y * W + x) = s4;
+    *reinterpret_cast<v4f*>(q.dst) = (((zero + t0) + t1) + t2) + t3;
+  };
+  for (int idx = threadIdx.x; idx < kRing; idx += 512) {
+    Quad qa, qb;
+    request(idx, qa);
+    request(idx + 256, qb);
+    finish(qa);
+    finish(qb);
   }
 }
 

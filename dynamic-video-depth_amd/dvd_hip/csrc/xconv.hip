@@ -1030,6 +1030,8 @@ static int xconv_pack_impl(const float* w, void* packed, int Cout, int Cin, int 
   const int M = transposed ? ci : co, K = transposed ? co : ci;
   const int mtiles = dvd::xconv_mtiles(M), nkc = (K + 15) / 16, T = KS * KS;
   const long long total = (long long)groups * mtiles * nkc * T * 64;
+  // (bytes: the fp32 weights read twice -- maximum, then packing -- and the packed fragments written: 16 bytes per lane)
+  dvd::bytes_add(DVD_BYTES_PACK, 8.0 * (double)Cout * ci * T + 16.0 * (double)total);
   // max |A| (BatchNorm scale included) -> the power-of-two operand scale of this packing: per-block partial maxima into the
   // header, reduced by the pack kernel
   const int row_len = ci * T;

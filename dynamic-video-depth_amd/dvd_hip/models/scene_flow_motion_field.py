@@ -59,7 +59,7 @@ def head_room_fraction(world, total_bytes=None):
     # DVD_HEAD_ROOM_GB: an explicit head room in GB for runs that must leave more to other tenants of the device -- the 8-rank
     # run's RCCL buffers when the communicator is created late, or a memory-capped deployment.  Absolute: it is divided by the
     # device's REAL size (keep_slot_fits multiplies the fraction by that same total), not by a hard-coded 288 GB.
-    gb = _HEAD_ROOM_GB
+    gb = _head_room_gb_from_env()
     if gb:
         if total_bytes is None:
             total_bytes = torch.cuda.mem_get_info()[1] if torch.cuda.is_available() else 288 * 2 ** 30
@@ -68,7 +68,8 @@ def head_room_fraction(world, total_bytes=None):
 
 
 def _head_room_gb_from_env():
-    """DVD_HEAD_ROOM_GB, validated once at import: a malformed value must not surface in the middle of step planning."""
+    """DVD_HEAD_ROOM_GB, validated (also once at import: a malformed value must not first surface in the middle of step
+    planning)."""
     raw = os.environ.get('DVD_HEAD_ROOM_GB')
     if not raw:
         return 0.0
@@ -81,7 +82,7 @@ def _head_room_gb_from_env():
     return gb
 
 
-_HEAD_ROOM_GB = _head_room_gb_from_env()
+_head_room_gb_from_env()        # validate at import
 
 
 def keep_slot_fits(est, free, total, reserve, spare, kept, budget, head_room=0.08):

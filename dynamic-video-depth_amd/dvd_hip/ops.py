@@ -244,24 +244,45 @@ FLOP_CLASS_KERNELS = {          # mangled (rocpd database) and demangled (rocpro
 }
 
 
+# Memory-bound helper kernels (round 6; bench.py's roofline_helpers): algorithmic BYTES per class, counted by the library the
+# same way (include/dvd_hip.h: dvd_byte_counters), and the kernel-name fragments tools/mfma_roofline.py joins a trace on.
+# They travel through the same snapshot / replay bookkeeping as the matrix classes, under their own keys.
+BYTE_CLASSES = ('bnrelu_fwd', 'bnrelu_bwd', 'upsample_fwd', 'upsample_bwd', 'amax', 'pack', 'pool', 'gconv_c8', 'elementwise',
+                'adam', 'geometry')
+BYTE_CLASS_KERNELS = {
+    'bnrelu_fwd': ('bnrelu_fwd_kernel',), 'bnrelu_bwd': ('bnrelu_bwd', 'bn_mask', 'bnrelu_sum'),
+    'upsample_fwd': ('upsample_bilinear_fwd',), 'upsample_bwd': ('upsample_bilinear_bwd', 'upsample_bwd'),
+    'amax': ('amax_kernel',), 'pack': ('xconv_wamax', 'xconv_pack_kernel'), 'pool': ('maxpool3s2',),
+    'gconv_c8': ('gconv3x3_c8',), 'elementwise': ('mul_mask_kernel', 'scale_add_kernel', 'acc_reg_kernel', 'sum_partials_kernel',
+                                                  'head1x1_', 'cast_scale_kernel'),
+    'adam': ('adam_kernel',), 'geometry': ('unproject_',),
+}
+ALL_CLASSES = FLOP_CLASSES + BYTE_CLASSES
+
+
 def flop_counters(reset=False):
     """Algorithmic work (2 x MACs) the matrix kernels were launched with since the last reset, per kernel class
-    (include/dvd_hip.h: dvd_flop_counters).  Counted at launch / graph-capture time: read it after a step that CAPTURED (or
-    ran eagerly) everything a step launches."""
+    (include/dvd_hip.h: dvd_flop_counters) -- and, under the BYTE_CLASSES keys, the algorithmic bytes of the helper kernels
+    (dvd_byte_counters).  Counted at launch / graph-capture time: read it after a step that CAPTURED (or ran eagerly)
+    everything a step launches."""
     lib = _lib.load()
     buf = (ctypes.c_double * len(FLOP_CLASSES))()
     _lib.check(lib.dvd_flop_counters(ctypes.cast(buf, ctypes.c_void_p), len(FLOP_CLASSES), 1 if reset else 0), 'dvd_flop_counters')
-    return dict(zip(FLOP_CLASSES, [float(v) for v in buf]))
+    out = dict(zip(FLOP_CLASSES, [float(v) for v in buf]))
+    bbuf = (ctypes.c_double * len(BYTE_CLASSES))()
+    _lib.check(lib.dvd_byte_counters(ctypes.cast(bbuf, ctypes.c_void_p), len(BYTE_CLASSES), 1 if reset else 0), 'dvd_byte_counters')
+    out.update(zip(BYTE_CLASSES, [float(v) for v in bbuf]))
+    return out
 
 
 # work of REPLAYED HIP graphs: a graph's launches are counted once, when it is captured (flops_since around the capture);
 # whoever replays it adds that record here, so that (flop_counters + REPLAYED) over a region is the work the region executed
-REPLAYED = {k: 0.0 for k in FLOP_CLASSES}
+REPLAYED = {k: 0.0 for k in ALL_CLASSES}
 
 
 def flops_since(snapshot):
     now = flop_counters()
-    return {k: now[k] - snapshot.get(k, 0.0) for k in FLOP_CLASSES}
+    return {k: now[k] - snapshot.get(k, 0.0) for k in ALL_CLASSES}
 
 
 def note_replay(flops):
@@ -273,7 +294,7 @@ def note_replay(flops):
 def executed_flops():
     """Per kernel class: work launched eagerly plus work of replayed graphs, since process start (take differences)."""
     now = flop_counters()
-    return {k: now[k] + REPLAYED[k] for k in FLOP_CLASSES}
+    return {k: now[k] + REPLAYED[k] for k in ALL_CLASSES}
 
 
 def warp_loss_select(variant='tiled', tile=-1, px=0, strip_rows=0, strip_shape=0):

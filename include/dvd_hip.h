@@ -68,6 +68,23 @@ enum {
   DVD_FLOP_CLASSES = 12
 };
 int dvd_flop_counters(double* out, int n, int reset);
+/* The same accounting for the memory-bound helper kernels of a step (ABI 7; bench.py's roofline_helpers): every launch adds the
+ * bytes it must move -- each operand tensor read once, each result written once -- to its class.  out[i] = class i. */
+enum {
+  DVD_BYTES_BNRELU_FWD = 0, /* bnrelu_fwd_kernel: x (+ residual) in, y out                                                       */
+  DVD_BYTES_BNRELU_BWD = 1, /* bnrelu_bwd kernels: gy, y / x in, gx (+ g_residual) out, per-channel sums                          */
+  DVD_BYTES_UPSAMPLE_FWD = 2,
+  DVD_BYTES_UPSAMPLE_BWD = 3,
+  DVD_BYTES_AMAX = 4,       /* amax_kernel: one read of the tensor                                                                */
+  DVD_BYTES_PACK = 5,       /* weight maximum + fragment packing of the convolution weights                                       */
+  DVD_BYTES_POOL = 6,       /* max-pool of the stem, forward and backward                                                         */
+  DVD_BYTES_GCONV = 7,      /* grouped 3x3 with 8 channels per group on the vector unit (ResNeXt stage 1), all three passes       */
+  DVD_BYTES_ELEMENTWISE = 8,/* scale_add, mul_mask, acc_reg, cast_scale, depth head                                               */
+  DVD_BYTES_ADAM = 9,       /* the fused Adam step: param, grad, two moments in, param and moments out                            */
+  DVD_BYTES_GEOMETRY = 10,  /* unproject forward / backward                                                                       */
+  DVD_BYTES_CLASSES = 11
+};
+int dvd_byte_counters(double* out, int n, int reset);
 
 /* Camera block of a batch of frame pairs (the eight tensors the reference
  * forwards take by name: losses/scene_flow_projection.py:114,222). */

@@ -78,24 +78,22 @@ def test_fp16_activation_step_matches_the_fp32_oracle_at_384x672():
     assert par['mlp_grad_worst_of_max'] < 2e-2
 
 
-def test_fp16_activation_step_at_768x1344_matches_the_fp32_storage_step():
-    """BASELINE configs[4]'s OWN image size (768 x 1344, one frame pair).  The reference here is the fp32-storage HIP step, not
-    the CPU oracle: the oracle holds ~60 GB of autograd state per pair at 384 x 672, four times that at this size, and takes
-    minutes per step -- `python bench.py --config 4` runs that comparison when the host has the memory (its `parity.reference`
-    says which it used).  The fp32-storage step is what the 384 x 672 cases above pin to the oracle (6e-8 / 3e-5).  Same bounds
-    as the fp16 mode's 384 x 672 case against the oracle."""
+def _cfg4_size_parity(reference):
+    """One frame pair at BASELINE configs[4]'s own image size (768 x 1344): the fp16-activation HIP step against `reference`
+    ('oracle': the fp32 CPU oracle, ~240 GB of host memory and a few minutes of CPU; 'hip': the fp32-storage HIP step)."""
     import bench
     old = bench.H, bench.W
     bench.H, bench.W = 768, 1344
     try:
-        first = bench.hip_fp32_first_step()
+        first = bench.oracle_first_step() if reference == 'oracle' else bench.hip_fp32_first_step()
         par = bench.hip_parity(first, torch.device('cuda', 0), act_fp16=True)
     finally:
         bench.H, bench.W = old
-    print('fp16-activation parity at 768x1344 (vs fp32 storage):', json.dumps(par))
+    par['reference'] = 'CPU oracle (fp32, ATen-CPU), %.0f s for its step' % first['seconds'] if reference == 'oracle' else first['reference']
+    print('fp16-activation parity at 768x1344 (vs %s):' % reference, json.dumps(par))
     if os.environ.get('DVD_PARITY_LOG'):
         with open(os.environ['DVD_PARITY_LOG'], 'a') as f:
-            f.write(json.dumps({'test': 'configs4_size_fp16_activations_vs_fp32_storage', **par}) + '\n')
+            f.write(json.dumps({'test': 'configs4_size_fp16_activations_vs_' + reference, **par}) + '\n')
     assert '768x1344' in par['sample']
     assert not par['step_skipped']
     assert par['rel'] < 2e-3
@@ -104,3 +102,23 @@ def test_fp16_activation_step_at_768x1344_matches_the_fp32_storage_step():
     assert par['acc_reg_rel'] < 2e-3
     assert par['depth_grad_norm_worst_rel'] < 5e-2, par['depth_grad_norm_worst_param']
     assert par['mlp_grad_worst_of_max'] < 2e-2
+
+
+@pytest.mark.timeout(1500)
+def test_fp16_activation_step_at_768x1344_matches_the_cpu_oracle():
+    """BASELINE configs[4]'s OWN image size against the ORACLE (the driver-run evidence at this shape was the
+    path compared with itself).  The oracle holds ~60 GB of autograd state per pair at 384 x 672, four times that here: the
+    test runs where the host has >= 330 GB available (the GPU boxes report 2.9 TB) and skips elsewhere -- the HIP-vs-HIP case
+    below always runs.  Same bounds as the fp16 mode's 384 x 672 case against the oracle (measured in round 5 by bench.py
+    --config 4: loss 9.7e-7, worst gradient norm 7.1e-4, MLP gradients 1.2e-3 of max)."""
+    import bench
+    avail = bench.host_mem_available_gb()
+    if avail < 330.0:
+        pytest.skip('the CPU oracle at 768 x 1344 needs ~240 GB of host memory, %.0f GB are available' % avail)
+    _cfg4_size_parity('oracle')
+
+
+def test_fp16_activation_step_at_768x1344_matches_the_fp32_storage_step():
+    """The fall-back that runs on every box: the reference is the fp32-storage HIP step -- what the 384 x 672 cases above pin
+    to the oracle (6e-8 / 3e-5).  Same bounds."""
+    _cfg4_size_parity('hip')

@@ -12,6 +12,14 @@ import re
 import sys
 
 
+def _source_digest():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'dynamic-video-depth_amd'))
+    from dvd_hip import build
+    return build.source_digest(build.WARP_UNITS)
+
+
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else 'profiles/r01_warp_loss_pmc_summary.txt'
     dst = sys.argv[2] if len(sys.argv) > 2 else 'profiles/warp_loss_pmc.json'
@@ -32,7 +40,8 @@ def main():
     out = {'workload': '48 pairs x 384 x 672 (one dvd_warp_loss_fused launch sequence)',
            'hbm_bytes_per_launch': total, 'algorithmic_bytes_per_launch': 48 * 384 * 672 * 52,
            'corrections': 'FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), KiB -> bytes', 'kernels': kernels,
-           'source': src, 'collected': sys.argv[3] if len(sys.argv) > 3 else 'rocprofv3 --pmc passes'}
+           'source': src, 'collected': sys.argv[3] if len(sys.argv) > 3 else 'rocprofv3 --pmc passes',
+           'source_digest': _source_digest()}
     json.dump(out, open(dst, 'w'), indent=1)
     print(json.dumps({k: out[k] for k in ('hbm_bytes_per_launch', 'algorithmic_bytes_per_launch')}))
 

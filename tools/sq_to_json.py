@@ -10,11 +10,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _source_digest():
+    sys.path.insert(0, os.path.join(ROOT, 'dynamic-video-depth_amd'))
+    from dvd_hip import build
+    return build.source_digest(build.WARP_UNITS)
+
+
 def main():
     src, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else '')
     vals, us = {}, None
-    for line in open(src):
-        if 'warp_loss_tiled_kernel' not in line:
+    lines = open(src).read().split('\n')
+    # the production kernel of the launch sequence: the strip kernel (round 6) where it ran, else the tile kernel
+    kernel = 'warp_loss_strip_kernel' if any('warp_loss_strip_kernel' in l for l in lines) else 'warp_loss_tiled_kernel'
+    for line in lines:
+        if kernel not in line:
             continue
         m = re.search(r'(\w+)\s+([0-9.e+]+)\s+\(n=\d+, ([0-9.]+) us\)', line)
         if m:
@@ -25,7 +34,7 @@ def main():
            'wait_any_quad': vals.get('SQ_WAIT_ANY'), 'tile_kernel_us_under_counters': us,
            # effective clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time
            'clock_hz': vals['GRBM_GUI_ACTIVE'] / 8.0 / (us * 1e-6) if 'GRBM_GUI_ACTIVE' in vals else 2.1e9,
-           'source': src, 'collected': tag}
+           'kernel': kernel, 'source': src, 'collected': tag, 'source_digest': _source_digest()}
     json.dump(out, open(os.path.join(ROOT, 'profiles', 'warp_loss_sq.json'), 'w'), indent=1)
     print(json.dumps(out))
 
