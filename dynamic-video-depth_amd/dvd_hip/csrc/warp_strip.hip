@@ -45,6 +45,9 @@
 #ifndef DVD_STRIP_CAM_REGS
 #define DVD_STRIP_CAM_REGS 1        // 1: shapes with a 168-register budget keep the pair's camera in vector registers (0: LDS broadcasts)
 #endif
+#ifndef DVD_STRIP_COMBINE2
+#define DVD_STRIP_COMBINE2 0        // 1: the unit combine requests two quads' slabs before it sums either (measured: 21 us against 16-18)
+#endif
 #ifndef DVD_STRIP_PERSISTENT
 #define DVD_STRIP_PERSISTENT 0
 #endif
@@ -620,8 +623,7 @@ __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restr
   float* gb = g_d2 + (size_t)b * H * W;
   const int kFull = (kTop + kBot) * QW, kRing = kFull + (SH - kTop - kBot) * (kLeft + kRight);
   const ptrdiff_t row_of_units = (ptrdiff_t)ntx * slab_stride;
-  // (two quads per pass: the loads of both are requested before either is summed -- the kernel is a chain of dependent
-  //  round trips otherwise)
+  // (DVD_STRIP_COMBINE2: two quads per pass, the loads of both requested before either is summed -- no gain, off)
   struct Quad {
     v4f own, hor, ver, dia;
     float* dst;
@@ -666,6 +668,7 @@ __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restr
     const v4f t0 = vfirst ? r0a : r1a, t1 = vfirst ? r0b : r1b, t2 = vfirst ? r1a : r0a, t3 = vfirst ? r1b : r0b;
     *reinterpret_cast<v4f*>(q.dst) = (((zero + t0) + t1) + t2) + t3;
   };
+#if DVD_STRIP_COMBINE2
   for (int idx = threadIdx.x; idx < kRing; idx += 512) {
     Quad qa, qb;
     request(idx, qa);
@@ -673,6 +676,13 @@ __global__ __launch_bounds__(256) void combine_units_kernel(const float* __restr
     finish(qa);
     finish(qb);
   }
+#else
+  for (int idx = threadIdx.x; idx < kRing; idx += 256) {
+    Quad qa;
+    request(idx, qa);
+    finish(qa);
+  }
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
