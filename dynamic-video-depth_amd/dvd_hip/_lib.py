@@ -39,7 +39,7 @@ class Surfaces(ctypes.Structure):
 
 class MlpDesc(ctypes.Structure):
     _fields_ = [('n_freq_xyz', c_int), ('n_freq_t', c_int), ('time_dependent', c_int), ('freqs_xyz', c_void_p),
-                ('freqs_t', c_void_p), ('stash_f16', c_int)]
+                ('freqs_t', c_void_p), ('stash_f16', c_int), ('fwd_monitor', c_void_p)]
 
 
 c_longlong = ctypes.c_longlong

@@ -422,6 +422,7 @@ struct FwdArgs {
   float* p_next;
   float* acc;
   float* stash;
+  float* monitor;     // fp16 stash: max |h| of the hidden activations is folded in here too (the step's overflow guard), or null
   PackLayout L;
   Geometry g;
   long long n_pix;
@@ -562,7 +563,12 @@ __global__ __launch_bounds__(64 * NW, DVD_MLP_FWD_OCC) void mlp_fwd_kernel(const
       __syncthreads();  // every wave has finished reading this layer's input; the waves' maxima are visible
       const float hmax = tile_max(tmx);
       sx = pow2_scale(hmax);                           // scale of the next layer's input
-      if (STASH && tid == 0) fold_amax(tail + 1 + l, hmax);
+      if (STASH && tid == 0) {
+        fold_amax(tail + 1 + l, hmax);
+        // (an fp16 stash stores h as _Float16: beyond 65504 it holds Inf and the weight gradients contracted against it are
+        //  not finite -- the step's forward monitor must see it, csrc/a16.hip state[6]; NaN counts as +Inf)
+        if (S16 && a.monitor) fold_amax(a.monitor, hmax == hmax ? hmax : __builtin_inff());
+      }
       float* sh = STASH ? st + stash_h_off(a.g.c_in16, l, S16) : nullptr;
 #pragma unroll
       for (int r = 0; r < RT; ++r) {
@@ -1246,6 +1252,7 @@ int dvd_sf_mlp_fwd(const dvd_mlp_desc* d, const void* packed, const float* p, co
   a.p_next = p_next;
   a.acc = acc;
   a.stash = static_cast<float*>(stash);
+  a.monitor = (stash && d->stash_f16) ? d->fwd_monitor : nullptr;
   a.n_pix = n_pix;
   a.pix_per_img = pix_per_img;
   a.n_tiles = (int)((n_pix + kTM - 1) / kTM);

@@ -217,6 +217,10 @@ class Model(NetInterface):
             # what each network's guarded Adam step subtracts from its step number (checkpoints carry the effective step)
             self._flat_depth.skip_count = self._gscale[5:6]
             self._flat_sf.skip_count = self._gscale[9:10]
+            if self._mlp is not None:
+                # the scene-flow MLP's fp16 stash shares the forward monitor: a hidden activation beyond fp16's range (stored
+                # as Inf, contracted into the weight gradients) skips the step like a depth-net activation does
+                self._mlp.set_forward_monitor(self._gscale[6:7])
         if self._pending_optimizer_state is not None:      # checkpoint restored before .to() (train.py:256,279)
             self._apply_optimizer_state(self._pending_optimizer_state)
             self._pending_optimizer_state = None

@@ -414,11 +414,19 @@ class SceneFlowMLPKernels(object):
         self.stash_f16 = bool(stash_f16)
         self.desc = _lib.MlpDesc(self.n_freq_xyz, self.n_freq_t, int(self.time_dependent),
                                  self.fx.data_ptr() if self.fx is not None else 0,
-                                 self.ft.data_ptr() if self.ft is not None else 0, int(self.stash_f16))
+                                 self.ft.data_ptr() if self.ft is not None else 0, int(self.stash_f16), 0)
+        self._monitor = None
         lib = _lib.load()
         self.c_in = lib.dvd_sf_mlp_in_channels(ctypes.byref(self.desc))
         self.packed = torch.empty(lib.dvd_sf_mlp_packed_bytes(ctypes.byref(self.desc)) // 4, device=self.device,
                                   dtype=torch.float32)
+
+    def set_forward_monitor(self, monitor):
+        """fp16 stash: the 1-element device tensor (slot [6] of a model's loss-scale state) that every stashing forward folds
+        max |hidden activation| into -- an activation beyond fp16's range would be stashed as Inf and poison the weight
+        gradients; the step's overflow guard (csrc/a16.hip dvd_gscale_end) then skips the step.  None: no guard."""
+        self._monitor = monitor                      # (kept alive: the descriptor holds its address)
+        self.desc.fwd_monitor = monitor.data_ptr() if monitor is not None else 0
 
     # -- sizes
     def stash_floats(self, n_pix):

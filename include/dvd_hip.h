@@ -198,6 +198,9 @@ typedef struct dvd_mlp_desc {
   int stash_f16;          /* ABI 4: 1 = the five hidden activations of the stash are stored as _Float16 (3.2 KB per pixel instead of
                            * 5.7): the weight-gradient kernel then contracts fp32 gradients (two terms) against fp16 activations (one
                            * term, 2 MFMAs per product).  Losses and the input gradient do not depend on it. */
+  float* fwd_monitor;     /* ABI 7, with stash_f16: a device float (slot [6] of the loss-scale state, dvd_gscale_*) that every
+                           * stashing forward folds max |hidden activation| into (NaN counted as +Inf) -- an activation beyond
+                           * fp16's range is stored as Inf and poisons the weight gradients: the step's guard skips it.  Or null. */
 } dvd_mlp_desc;
 
 /* Test / A-B hook (process wide, ABI 6): waves per workgroup of the forward / dX kernels.  4 (default) = two 256-thread

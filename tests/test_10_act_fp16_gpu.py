@@ -514,6 +514,38 @@ def test_non_finite_fp16_values_skip_the_step(where, value):
     assert st[4] == 0.0 and st[5] == 1.0 and st[10] == 0.0 and log['steps_skipped'] == 1, st
 
 
+def test_fp16_mlp_stash_overflow_skips_the_step_instead_of_poisoning_the_weights():
+    """Round 6: the scene-flow MLP's fp16 stash (implied by --act_fp16) stores the hidden activations as _Float16; one beyond
+    65504 is stashed as Inf and the weight gradients contracted against it are not finite -- before the guard, one such step
+    turned every MLP parameter into NaN for good (this fixture's seeded MLP weights put its activations next to fp16's range:
+    the second step overflows).  The MLP forward now folds max |h| into the step's forward monitor (dvd_mlp_desc.fwd_monitor =
+    slot [6] of the loss-scale state): the step is skipped for BOTH networks, every parameter stays finite, and the run says so
+    (steps_skipped in the log, a warning from the third consecutive skip on)."""
+    import warnings
+    import test_30_full_step_gpu as T30
+    import helpers
+    gd = helpers.load_golden('fullstep_midas_b1_64x96_train')
+    model, opt, batch = T30._build(gd, act_fp16=True, depth_graphs=1, depth_chunk=1)
+    batch['flow_1_2'] = batch['flow_1_2'] * 0.25
+    batch['flow_2_1'] = batch['flow_2_1'] * 0.25
+    skipped, warned = [], 0
+    for i in range(5):
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter('always')
+            log = model._train_on_batch(int(gd['epoch']), i, helpers.loader_batch(dict(batch)))
+        torch.cuda.synchronize()
+        warned += sum('activation' in str(w.message) for w in rec)
+        skipped.append(log['steps_skipped'])
+        assert bool(torch.isfinite(model._flat_sf.flat).all()) and bool(torch.isfinite(model._flat_depth.flat).all()), \
+            'step %d left non-finite parameters (state %r)' % (i, model._gscale.tolist())
+    st = model._gscale.tolist()
+    print('fp16 MLP stash overflow: steps skipped', skipped, 'state', [round(v, 1) for v in st[:11]], 'warnings', warned)
+    assert skipped[0] == 0 and skipped[-1] >= 1, skipped
+    assert st[9] >= 1.0, 'no step was skipped for an activation overflow: %r' % st
+    if st[10] >= 3.0:
+        assert warned >= 1
+
+
 # ---- the scene-flow MLP's fp16 stash ----------------------------------------------------------------------------------
 def test_mlp_fp16_stash_changes_only_the_weight_gradients():
     """dvd_mlp_desc.stash_f16: the hidden activations h_0 .. h_4 of the stash are stored as fp16 (networks/sceneflow_field.py:43-53
