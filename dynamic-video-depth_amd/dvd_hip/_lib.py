@@ -83,6 +83,10 @@ SIGNATURES = {
                                   c_void_p]),
     'dvd_mul_mask': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_void_p]),
     'dvd_scale_add': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_longlong, c_void_p]),
+    'dvd_subsample2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
+    'dvd_subsample2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
+    'dvd_depth_tail_fwd': (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
+    'dvd_depth_tail_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
     'dvd_acc_reg_workspace_bytes': (c_size_t, []),
     'dvd_acc_reg': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_void_p]),
     'dvd_adam_step': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float,

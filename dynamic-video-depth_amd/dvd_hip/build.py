@@ -64,18 +64,29 @@ def _digest(paths, flags):
     return h.hexdigest()
 
 
+def _local_includes(path, seen):
+    """csrc/ headers a source includes, transitively (the public C ABI header is left out: it changes with every new entry
+    point of ANY kernel and says nothing about the code of the units a profile is about)."""
+    import re
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), re.M):
+        h = os.path.join(CSRC, name)
+        if os.path.exists(h) and h not in seen:
+            seen.add(h)
+            _local_includes(h, seen)
+    return seen
+
+
 def source_digest(units=None):
     """sha256 (16 hex digits) over the sources a set of translation units is built from -- the .hip files named in `units`
-    (None: every unit of the library), every header of csrc/ and the C ABI header, and their flags.  A profile that bench.py
-    joins into its line (profiles/warp_loss_pmc.json, warp_loss_sq.json, mfma_roofline.json) is stamped with it by the tool that
-    writes it on the GPU box; bench.py recomputes it and says whether the profile is of the kernels it is running."""
-    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')]
-    headers.append(os.path.join(INCLUDE, 'dvd_hip.h'))
+    (None: every unit of the library), the csrc/ headers they include, and their flags.  A profile that bench.py joins into its
+    line (profiles/warp_loss_pmc.json, warp_loss_sq.json, mfma_roofline.json) is stamped with it by the tool that writes it on
+    the GPU box; bench.py recomputes it and says whether the profile is of the kernels it is running."""
     h = hashlib.sha256()
     for src, extra in SOURCES:
         if units is not None and src not in units:
             continue
-        h.update(_digest([os.path.join(CSRC, src)] + headers, COMMON + extra).encode())
+        sp = os.path.join(CSRC, src)
+        h.update(_digest([sp] + sorted(_local_includes(sp, set())), COMMON + extra).encode())
     return h.hexdigest()[:16]
 
 

@@ -197,6 +197,34 @@ class _Head1x1(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _DepthTail(torch.autograd.Function):
+    """`10000 / torch.clamp(relu(v), min=1e-2)` (third_party/MiDaS.py:192-195,240-242) as one HIP pass each way
+    (csrc/elementwise.hip dvd_depth_tail_*): the forward value is torch's (reciprocal, then x 10000), the backward autograd's formula."""
+
+    @staticmethod
+    def forward(ctx, v):
+        v = v.contiguous()
+        out = torch.empty_like(v)
+        _lib.check(_lib.load().dvd_depth_tail_fwd(_p(v), _p(out), v.numel(), _stream()), 'dvd_depth_tail_fwd')
+        ctx.save_for_backward(v)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, = ctx.saved_tensors
+        g = g.contiguous()
+        gv = torch.empty_like(v)
+        _lib.check(_lib.load().dvd_depth_tail_bwd(_p(v), _p(g), _p(gv), v.numel(), _stream()), 'dvd_depth_tail_bwd')
+        return gv
+
+
+def depth_tail(v):
+    """10000 / clamp(relu(v), 1e-2): the HIP pass for fp32 GPU tensors, the reference's ATen expression otherwise."""
+    if v.is_cuda and v.dtype == torch.float32:
+        return _DepthTail.apply(v)
+    return 10000 / torch.clamp(F.relu(v), min=1e-2)
+
+
 def head1x1(conv, x, relu_in=True):
     """conv(relu(x)) for an nn.Conv2d(C, 1, 1) on the boundary kernel (GPU tensors, C <= 64, H * W % 4 == 0)."""
     return _Head1x1.apply(x, conv.weight, conv.bias, relu_in)
@@ -429,9 +457,35 @@ def add_bounded(a, b):
     return set_amax(y, ka + kb) if (ka is not None and kb is not None) else y
 
 
+class _Subsample2(torch.autograd.Function):
+    """x[:, :, ::2, ::2] as a contiguous tensor on csrc/pool.hip (dvd_subsample2_*): one gather forward, one zero-interleaving
+    pass backward (ATen: a strided copy; a fill and a strided copy)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        y = torch.empty(N, C, (H + 1) // 2, (W + 1) // 2, device=x.device, dtype=x.dtype)
+        _lib.check(_lib.load().dvd_subsample2_fwd(_p(x), _p(y), int(_is16(x)), N * C, H, W, _stream()), 'dvd_subsample2_fwd')
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty(N, C, H, W, device=gy.device, dtype=gy.dtype)
+        _lib.check(_lib.load().dvd_subsample2_bwd(_p(gy), _p(gx), int(_is16(gy)), N * C, H, W, _stream()), 'dvd_subsample2_bwd')
+        k = known_amax(gy)
+        return gx if k is None else set_amax(gx, k)
+
+
 def _subsample(t, st):
     """t[:, :, ::st, ::st] as a contiguous tensor; max|t| stays an upper bound of the result's."""
-    y = t[:, :, ::st, ::st].contiguous()
+    if st == 2 and t.is_cuda and t.dtype in ACT_DTYPES and t.dim() == 4:
+        y = _Subsample2.apply(t)
+    else:
+        y = t[:, :, ::st, ::st].contiguous()
     k = known_amax(t)                     # the producer's bound if there is one; else reduce the (st^2 x smaller) result
     return set_amax(y, k) if k is not None else y
 

@@ -44,6 +44,49 @@ __global__ __launch_bounds__(256) void scale_add_kernel(float* __restrict__ out,
   }
 }
 
+// The tail of the MiDaS depth head, `10000 / clamp(relu(v), min=1e-2)` (third_party/MiDaS.py:192-195,240-242), in one pass each
+// way instead of ATen's clamp_min / clamp / reciprocal / mul kernels and their four backward kernels.  Forward: torch evaluates
+// `10000 / t` as reciprocal(t) * 10000 -- two roundings, an IEEE reciprocal and a multiply -- and so does this (bit-identical).
+// Backward: autograd's -(g * 10000) * r * r with r = 1 / v where the clamp passes the value on (v >= 1e-2; the ReLU in front of
+// it passes every such v), 0 elsewhere.
+__device__ __forceinline__ float depth_tail_value(float x) {
+  const float r = 1.0f / fmaxf(fmaxf(x, 0.0f), 1e-2f);      // IEEE division (this file is not built with fast-math)
+  return r * 10000.0f;
+}
+__global__ __launch_bounds__(256) void depth_tail_fwd_kernel(const float* __restrict__ v, float* __restrict__ out, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 x = reinterpret_cast<const float4*>(v)[i];
+    float4 o;
+    o.x = depth_tail_value(x.x);
+    o.y = depth_tail_value(x.y);
+    o.z = depth_tail_value(x.z);
+    o.w = depth_tail_value(x.w);
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    out[i] = depth_tail_value(v[i]);
+  }
+}
+__device__ __forceinline__ float depth_tail_grad(float x, float g) {
+  const float r = 1.0f / x;
+  return x >= 1e-2f ? -(g * 10000.0f) * r * r : 0.0f;
+}
+__global__ __launch_bounds__(256) void depth_tail_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                             float* __restrict__ gv, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 x = reinterpret_cast<const float4*>(v)[i], y = reinterpret_cast<const float4*>(g)[i];
+    reinterpret_cast<float4*>(gv)[i] =
+        make_float4(depth_tail_grad(x.x, y.x), depth_tail_grad(x.y, y.y), depth_tail_grad(x.z, y.z), depth_tail_grad(x.w, y.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    gv[i] = depth_tail_grad(v[i], g[i]);
+  }
+}
+
 // out[b, c, p] = a[b, c, p] * m[b, p]   (planar [B,C,HW] times a per-pixel mask [B,HW]; out may alias a)
 __global__ __launch_bounds__(256) void mul_mask_kernel(float* __restrict__ out, const float* __restrict__ a,
                                                        const float* __restrict__ m, int C, long long HW, long long n) {
@@ -185,6 +228,27 @@ int dvd_scale_add(float* out, const float* a, float scale, const float* scale_pt
   bytes_add(DVD_BYTES_ELEMENTWISE, 4.0 * (double)n * (b ? 3 : 2));
   hipLaunchKernelGGL(scale_add_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, static_cast<hipStream_t>(stream), out, a,
                      scale, scale_ptr, b, n);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_depth_tail_fwd(const float* v, float* depth, long long n, dvd_stream_t stream) {
+  using namespace dvd;
+  DVD_REQUIRE(v && depth && n > 0, "depth_tail_fwd: null pointer / size");
+  DVD_REQUIRE(al16(v) && al16(depth), "depth_tail_fwd: pointers must be 16-byte aligned");
+  bytes_add(DVD_BYTES_ELEMENTWISE, 8.0 * (double)n);
+  hipLaunchKernelGGL(depth_tail_fwd_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, static_cast<hipStream_t>(stream), v, depth, n);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_depth_tail_bwd(const float* v, const float* g_depth, float* g_v, long long n, dvd_stream_t stream) {
+  using namespace dvd;
+  DVD_REQUIRE(v && g_depth && g_v && n > 0, "depth_tail_bwd: null pointer / size");
+  DVD_REQUIRE(al16(v) && al16(g_depth) && al16(g_v), "depth_tail_bwd: pointers must be 16-byte aligned");
+  bytes_add(DVD_BYTES_ELEMENTWISE, 12.0 * (double)n);
+  hipLaunchKernelGGL(depth_tail_bwd_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, static_cast<hipStream_t>(stream), v, g_depth, g_v,
+                     n);
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -82,9 +82,70 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const T* __restrict
   gx[i] = s * (out_scale ? out_scale[0] : 1.0f);
 }
 
+// x[:, :, ::2, ::2] as a contiguous tensor, and its backward (zeros with gy at the even positions): the stride-2 entry of a
+// ResNeXt stage -- a strided 3x3 'same' convolution is evaluated as the stride-1 kernel's output sub-sampled, a strided 1x1
+// shortcut as the 1x1 kernel on the sub-sampled input (dvd_hip/conv.py XConv2d; third_party/midas_blocks.py:35-50 via
+// torchvision's Bottleneck).  Until round 6 ATen did both: a strided copy forward, a fill + a strided copy backward.
+template <class T>
+__global__ __launch_bounds__(256) void subsample2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                             long long total) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const long long r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const long long pl = r / Ho;
+    y[i] = x[(pl * H + 2 * oy) * W + 2 * ox];
+  }
+}
+// one thread = two horizontally adjacent input pixels (x even: the pair holds at most one gradient)
+template <class T>
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int H, int W, int Ho, int Wo,
+                                                             long long total_pairs) {
+  const int Wp = (W + 1) >> 1;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total_pairs; i += (long long)gridDim.x * 256) {
+    const int px = (int)(i % Wp);
+    const long long r = i / Wp;
+    const int y = (int)(r % H);
+    const long long pl = r / H;
+    T v = (T)0.0f;
+    if (!(y & 1)) v = gy[(pl * Ho + (y >> 1)) * Wo + px];
+    T* dst = gx + (pl * H + y) * W + 2 * px;
+    dst[0] = v;
+    if (2 * px + 1 < W) dst[1] = (T)0.0f;
+  }
+}
+
 }  // namespace dvd
 
 extern "C" {
+
+int dvd_subsample2_fwd(const void* x, void* y, int f16, long long planes, int H, int W, dvd_stream_t stream) {
+  DVD_REQUIRE(x && y && planes > 0 && H > 0 && W > 0, "subsample2 fwd: bad arguments");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long long total = planes * Ho * Wo;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  dvd::bytes_add(DVD_BYTES_POOL, (double)planes * (0.5 * H * W + (double)Ho * Wo) * (f16 ? 2 : 4));
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::subsample2_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(x), static_cast<T*>(y), H, W, Ho,
+                                         Wo, total));
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_subsample2_bwd(const void* gy, void* gx, int f16, long long planes, int H, int W, dvd_stream_t stream) {
+  DVD_REQUIRE(gy && gx && planes > 0 && H > 0 && W > 0, "subsample2 bwd: bad arguments");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const long long total = planes * H * ((W + 1) / 2);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  dvd::bytes_add(DVD_BYTES_POOL, (double)planes * ((double)H * W + (double)Ho * Wo) * (f16 ? 2 : 4));
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::subsample2_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(gy), static_cast<T*>(gx), H, W, Ho,
+                                         Wo, total));
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
 
 int dvd_maxpool3s2_fwd(const float* x, void* y, int y_f16, unsigned char* index, long long planes, int H, int W,
                        dvd_stream_t stream) {

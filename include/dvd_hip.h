@@ -245,6 +245,11 @@ int dvd_sf_mlp_bwd_dw(const dvd_mlp_desc* d, const void* stash, void* gstash, lo
  *   options/options_train.py:84-87) on a flat buffer with grad = s*grad1 + grad2. */
 int dvd_scale_add(float* out, const float* a, float scale, const float* scale_ptr, const float* b,
                   long long n, dvd_stream_t stream);
+/* The tail of the MiDaS depth head in one pass each way (ABI 7): depth = 10000 / clamp(relu(v), min = 1e-2) of
+ * third_party/MiDaS.py:192-195,240-242 -- as torch evaluates it: reciprocal, then x 10000 (bit-identical); backward
+ * g_v = -(g_depth * 10000) / v^2 where v >= 1e-2, else 0 (autograd's formula with clamp's mask).  16-byte aligned pointers, any n. */
+int dvd_depth_tail_fwd(const float* v, float* depth, long long n, dvd_stream_t stream);
+int dvd_depth_tail_bwd(const float* v, const float* g_depth, float* g_v, long long n, dvd_stream_t stream);
 /* out[b,c,p] = a[b,c,p] * mask[b,p]: `sf_1_2 *= motion_seg_1` of --use_motion_seg
  * (models/scene_flow_motion_field.py:253-254) and the matching gradient mask; out may alias a. */
 int dvd_mul_mask(float* out, const float* a, const float* mask, int B, int C, long long HW, dvd_stream_t stream);
@@ -533,6 +538,11 @@ int dvd_maxpool3s2_fwd(const float* x, void* y, int y_f16, unsigned char* index,
                        dvd_stream_t stream);
 int dvd_maxpool3s2_bwd(const void* gy, int gy_f16, const unsigned char* index, float* gx, const float* out_scale,
                        long long planes, int H, int W, dvd_stream_t stream);
+/* x[:, :, ::2, ::2] as a contiguous tensor [planes][(H + 1) / 2][(W + 1) / 2] and its backward (zeros with gy at the even
+ * positions), fp32 or _Float16 (ABI 7): the sub-sampling around the stride-2 convolutions of a ResNeXt stage's entry
+ * (third_party/midas_blocks.py:35-50 via torchvision's Bottleneck.conv2 / downsample). */
+int dvd_subsample2_fwd(const void* x, void* y, int f16, long long planes, int H, int W, dvd_stream_t stream);
+int dvd_subsample2_bwd(const void* gy, void* gx, int f16, long long planes, int H, int W, dvd_stream_t stream);
 
 #ifdef __cplusplus
 }

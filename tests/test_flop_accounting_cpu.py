@@ -54,3 +54,25 @@ def test_head_room_knob(monkeypatch):
     # a 60 GB slot next to 130 GB of stashes on a 288 GB device with 225 GB free: fits at 8 %, not with 48 GB of head room
     assert keep_slot_fits(60 * gb, 225 * gb, 288 * gb, 130 * gb, 0, 0, 150 * gb, 0.08)
     assert not keep_slot_fits(60 * gb, 225 * gb, 288 * gb, 130 * gb, 0, 0, 150 * gb, 48.0 / 288.0)
+
+
+def test_profiles_joined_by_the_bench_line_carry_a_source_digest():
+    """bench.py joins three committed profiles into its line (HBM traffic and SQ counters of the warp+loss sequence, per-class
+    kernel times); each is stamped by the tool that wrote it with dvd_hip.build.source_digest of the sources it was collected
+    from, and the line says `profile_is_of_this_binary`.  Here: the stamp exists, has the digest's form, and the warp+loss
+    profiles -- the kernel `north_star` puts a number on -- ARE of the committed sources (a kernel edit without a re-collected
+    profile fails here, not silently on the bench line)."""
+    import json
+    import os
+    import re
+    from dvd_hip import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    warp = build.source_digest(build.WARP_UNITS)
+    assert re.fullmatch(r'[0-9a-f]{16}', warp) and warp != build.source_digest(None)
+    for name in ('warp_loss_pmc.json', 'warp_loss_sq.json'):
+        rec = json.load(open(os.path.join(root, 'profiles', name)))
+        assert rec.get('source_digest') == warp, '%s was collected from other warp+loss sources (%s, now %s): re-collect it ' \
+            '(tools/gpu_visit.sh stages pmc sq)' % (name, rec.get('source_digest'), warp)
+    rec = json.load(open(os.path.join(root, 'profiles', 'mfma_roofline.json')))
+    for mode in ('fp32', 'fp16'):
+        assert re.fullmatch(r'[0-9a-f]{16}', rec[mode]['source_digest']) and rec[mode]['helpers']
