@@ -298,3 +298,31 @@ def test_cameras_outside_the_lockstep_loop_s_preconditions(case):
     cfg = _cfg_from_opt(ops, opt, False, B, H, W)
     sums, sc, g1, g2, gs = _run_hip(ops, cfg, bg, d1.cuda(), d2.cuda(), sf.cuda())
     _compare(ref, sums, sc, g1, g2, gs)
+
+
+def test_outputs_are_bitwise_reproducible_run_to_run(warp_variant):
+    """Two launches on the same inputs give the same BITS: the four sums, g_depth_1, g_sf and -- as long as no tap leaves the
+    on-chip windows -- g_depth_2 (Q31.32 integer accumulation in LDS, slabs summed in a fixed order; the strip kernel's
+    LDS-direct loads, counted waits and ring recycling included: a race there would show up here first).  Taps that do leave
+    the windows are applied with hardware fp32 atomics: g_depth_2 then only to 1e-6 of its largest element.  The direct
+    variant accumulates g_depth_2 with atomics everywhere."""
+    from dvd_hip import ops, synthetic
+    B, H, W = 3, 192, 288
+    batch = synthetic.make_batch(B, H, W, device='cuda', with_images=False)
+    d1, d2 = synthetic.make_depths(B, H, W, device='cuda')
+    sf = synthetic.make_scene_flow(B, H, W, device='cuda')
+    cams = {k: batch[k] for k in CAM_KEYS}
+    cfg = ops.warp_cfg(B, H, W)
+    for scale, exact in ((0.25, True), (1.0, False)):
+        flow = (batch['flow_1_2'] * scale).contiguous()
+        runs = []
+        for _ in range(4):
+            o = ops.warp_loss_fused(cfg, d1, d2, flow, batch['mask_2'], sf, cams)
+            torch.cuda.synchronize()
+            runs.append([t.clone() for t in o])
+        for o in runs[1:]:
+            assert torch.equal(o[0], runs[0][0]) and torch.equal(o[1], runs[0][1]) and torch.equal(o[3], runs[0][3])
+            if exact and warp_variant != 'direct':
+                assert torch.equal(o[2], runs[0][2])
+            else:
+                assert float((o[2] - runs[0][2]).abs().max()) <= 1e-6 * float(runs[0][2].abs().max())

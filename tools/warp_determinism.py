@@ -1,5 +1,11 @@
-import sys, os, torch
-sys.path.insert(0,'/root/repo/dynamic-video-depth_amd')
+"""Run-to-run reproducibility of dvd_warp_loss_fused: six launches per (shape, flow scale, kernel generation) on the same inputs,
+how many differ from the first in each output (tests/test_00::test_outputs_are_bitwise_reproducible_run_to_run is the test form)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'dynamic-video-depth_amd'))
 from dvd_hip import ops, synthetic
 CAM_KEYS = ('R_1', 'R_2', 'R_1_T', 'R_2_T', 't_1', 't_2', 'K', 'K_inv')
 def run(B,H,W,scale,variant,shape=0,n=6):
