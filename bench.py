@@ -407,7 +407,9 @@ def main():
                          'configuration; the shipped DAVIS schedule mixes 1..4: extra bench lines, not the headline)')
     ap.add_argument('--depth', choices=('midas', 'hourglass'), default='midas',
                     help="depth network: midas (BASELINE configs[1]/[2]) or the reference's default hourglass (extra bench line)")
-    ap.add_argument('--cpu_steps', type=int, default=3, help='timed oracle steps of the cpu_baseline leg (after 1 warm-up)')
+    ap.add_argument('--cpu_steps', type=int, default=2,
+                    help='timed oracle steps of the cpu_baseline leg (after 1 warm-up; ~50 s each on a 128-thread host: two keep the '
+                         'default run, which since round 6 also carries the configs4 and rccl_one_rank child lines, inside ~6 minutes)')
     ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '1')),
                     help='1 (default): replay the depth net from HIP graphs; 0: eager launches')
     ap.add_argument('--depth_chunk', type=int, default=48,

@@ -202,7 +202,8 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// FULL: the image is whole strips wide and whole steps high (W % TW == 0, H % TH == 0: 384 x 672, 768 x 1344, 192 x 384) -- no
+// FULL: the image is whole strips wide, whole steps and whole units high (W % TW == 0, H % TH == 0, H % SH == 0: 384 x 672,
+// 768 x 1344, 192 x 384) -- no
 // thread-step lies outside the image, so the lockstep walk is straight-line code: its gradient stores are unconditional, and
 // the compiler can count them when it places the wait for the next thread-step's inputs (behind CONDITIONAL stores that wait
 // is s_waitcnt vmcnt(0): the in-order counter cannot tell whether the newest operations are the loads or stores behind them).
@@ -778,7 +779,9 @@ StripPlan make_strip_plan(int B, int H, int W) {
 template <int TW, int TH, int RY, int NT, int BPC>
 static int launch_strips_shape(const WarpArgs& a, const StripPlan& p, StripArgs& sa, hipStream_t stream) {
   constexpr int lds = strip_lds_bytes(TW, TH, kSR, RY, NT);
-  const bool full = (a.W % TW) == 0 && (a.H % TH) == 0;
+  // (whole strips, whole steps AND whole units: a unit that reaches below the image has steps without pixels, which only the
+  //  instantiation with per-thread-step bounds checks skips)
+  const bool full = (a.W % TW) == 0 && (a.H % TH) == 0 && (a.H % p.SH) == 0;
   auto k = full ? warp_loss_strip_kernel<TW, TH, kSR, RY, NT, BPC, true> : warp_loss_strip_kernel<TW, TH, kSR, RY, NT, BPC, false>;
   static bool attr_set[2] = {false, false};
   if (!attr_set[full]) {

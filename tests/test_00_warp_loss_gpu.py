@@ -100,6 +100,8 @@ CASES = [
     (2, 48, 64, 1, 0, False, {'use_disp': False, 'use_disp_ratio': True}),
     (2, 48, 64, 1, 0, False, {'midas': False}),          # no depth masks
     (1, 32, 32, 1, 0, False, {'flow_mul': 2.5, 'disp_mul': 0.5}),
+    (2, 160, 192, 1, 0, False, {}),                      # whole strips and steps, but the last unit of a column reaches below the image
+    (2, 128, 192, 1, 1, False, {}),                      # whole strips, steps and units: the strip kernel's FULL instantiation
 ]
 
 
