@@ -52,7 +52,9 @@
 #define DVD_STRIP_PERSISTENT 0
 #endif
 #ifndef DVD_STRIP_PF_EARLY
-#define DVD_STRIP_PF_EARLY 1        // 1: the next thread-step's inputs are requested at the START of a thread-step (0: between its phases)
+#define DVD_STRIP_PF_EARLY 0        // 1: the next thread-step's inputs are requested at the START of a thread-step (0: between its
+                                   // phases: 186.8 against 187.8 us, median of six interleaved runs -- the extra live registers cost
+                                   // what the longer lead buys)
 #endif
 #ifndef DVD_STRIP_KO_BARRIER
 #define DVD_STRIP_KO_BARRIER 0
@@ -490,10 +492,11 @@ __global__ __launch_bounds__(NT, (BPC * NT + 255) / 256) void warp_loss_strip_ke
         In2 nxt;
         int x, y;
         const bool ok = locate(q, y0, x, y);
-        // The next thread-step's inputs are requested FIRST: a whole thread-step (~2 us) for them to arrive.  Requested between
-        // the phases (round 5's place for them) they had the backward phase only, and with twelve waves per CU the kernel
-        // ran at the rate its memory latency allowed -- its time moved one for one with the bytes of a knocked-out stream
-        // (profiles/r06_warp_strip_experiments.txt).  The scheduling barrier keeps the requests from sinking towards their use.
+        // DVD_STRIP_PF_EARLY: the next thread-step's inputs requested FIRST (a whole thread-step for them to arrive) instead of
+        // between the phases (the backward phase only).  With twelve waves per CU the kernel runs at the rate its memory
+        // latency allows -- its time moves one for one with the bytes of a knocked-out stream
+        // (profiles/r06_warp_strip_experiments.txt) -- but the longer lead did not pay: see the knob.  The scheduling
+        // barrier keeps the early requests from sinking towards their use.
         constexpr bool kEarly = DVD_STRIP_PF_EARLY && kCamRegs;
         if (kEarly) {
           nxt = fetch2(qn, yn);

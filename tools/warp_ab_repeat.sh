@@ -7,11 +7,14 @@ OUT=gpurun_out/${1:-abr}; mkdir -p $OUT
 ROOT=$(pwd); V=$ROOT/dynamic-video-depth_amd/dvd_hip/lib/variants
 LIBS="product"; for f in $V/libdvd_hip_*.so; do [ -f $f ] && LIBS="$LIBS $f"; done
 : > $OUT/ab_repeat.log
+# SHAPES="0 3": also alternate over strip shapes (csrc/warp_strip.hip kStripShapes) inside the same loop
 for r in $(seq 1 ${REPS:-5}); do
   for lib in $LIBS; do
-    if [ $lib = product ]; then e=""; else e="DVD_HIP_LIB=$lib"; fi
-    echo "== $(basename $lib)" >> $OUT/ab_repeat.log
-    env $e timeout 120 python tools/microbench_warp.py --iters 100 ${WARP_ARGS:-} 2>&1 | grep kernel >> $OUT/ab_repeat.log
+    for sh in ${SHAPES:-0}; do
+      if [ $lib = product ]; then e=""; else e="DVD_HIP_LIB=$lib"; fi
+      echo "== $(basename $lib) shape $sh" >> $OUT/ab_repeat.log
+      env $e timeout 120 python tools/microbench_warp.py --iters 100 --strip_shape $sh ${WARP_ARGS:-} 2>&1 | grep kernel >> $OUT/ab_repeat.log
+    done
   done
 done
 python - <<PY | tee $OUT/ab_repeat.txt
