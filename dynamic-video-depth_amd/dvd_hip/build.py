@@ -86,7 +86,9 @@ def source_digest(units=None):
         if units is not None and src not in units:
             continue
         sp = os.path.join(CSRC, src)
-        h.update(_digest([sp] + sorted(_local_includes(sp, set())), COMMON + extra).encode())
+        # (flags without the include paths: they are absolute, and a profile collected in one checkout must match another)
+        flags = [f for f in COMMON if not f.startswith('-I')] + extra
+        h.update(_digest([sp] + sorted(_local_includes(sp, set())), flags).encode())
     return h.hexdigest()[:16]
 
 
