@@ -48,6 +48,11 @@ c_longlong = ctypes.c_longlong
 class BnParams(ctypes.Structure):           # struct dvd_bn_params
     _fields_ = [('gamma', c_void_p), ('beta', c_void_p), ('mean', c_void_p), ('var', c_void_p), ('eps', ctypes.c_float)]
 
+class XPackItem(ctypes.Structure):          # struct dvd_xpack_item
+    _fields_ = [('w', c_void_p), ('packed', c_void_p), ('gamma', c_void_p), ('var', c_void_p), ('eps', ctypes.c_float),
+                ('Cout', c_int), ('Cin', c_int), ('KS', c_int), ('groups', c_int), ('transposed', c_int)]
+
+
 PtrArr6 = c_void_p * 6
 PtrArr5 = c_void_p * 5
 
@@ -117,7 +122,11 @@ SIGNATURES = {
                                             c_int, c_int, c_void_p]),
     'dvd_xconv_packed_bytes': (c_size_t, [c_int] * 5),
     'dvd_xconv_pack': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'dvd_xconv_pack_table_bytes': (c_size_t, [c_int]),
+    'dvd_xconv_pack_many': (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     'dvd_amax': (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p]),
+    'dvd_chansum_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'dvd_chansum': (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'dvd_xconv_fwd': (c_int, [c_void_p] * 6 + [ctypes.POINTER(BnParams), c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     'dvd_xconv_select': (c_int, [c_int]),
     'dvd_xconv_pack_scaled': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,

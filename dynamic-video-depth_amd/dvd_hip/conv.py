@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
-from .ops import _p, _stream, _workspace, amax_of, known_amax, new_scalar, set_amax
+from .ops import _p, _stream, _workspace, amax_of, chansum, known_amax, new_scalar, set_amax
 
 # Same-box A/B measurement switches (previous-generation kernels / MIOpen against the kernels in use), read ONCE at
 # import from DVD_AB="gconv32,no_bnfuse,...".  Not product configuration: every default is the fastest measured path.
@@ -31,9 +31,12 @@ from .ops import _p, _stream, _workspace, amax_of, known_amax, new_scalar, set_a
 #   no_xconv    dense convolutions on MIOpen
 #   no_alias    gradient joins of residual blocks by autograd's accumulation (ATen add) instead of the backward-data epilogue
 #   no_maskfuse the ReLU mask of a BatchNorm+ReLU site always in the site's own mask pass (never in its consumer's epilogue)
+#   no_packplan every captured graph packs its weights itself (two launches per weight tensor and graph)
+#   no_chansum  bias gradients by an ATen sum (and max|gy| by dvd_amax) instead of one dvd_chansum read
 #   rowsum      (opt-in experiment) a pre-masked site takes its per-channel sums from dvd_xwgrad1s_rowsum and max|g| from the
 #               consumer's epilogue instead of running its sum pass
 AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse',
+                         'no_chansum', 'no_packplan',
                          'rowsum')}
 for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
     if _k not in AB:
@@ -545,6 +548,142 @@ class GroupedConv3x3C8(nn.Conv2d):
 # ---------------------------------------------------------------------------------------
 # Dense stride-1 convolutions on the split-operand MFMA kernels (csrc/xconv.hip; two fp16 terms per operand, csrc/dvd_split.h)
 
+class _PackPlan(object):
+    """Every packing a captured depth-net graph needs, made by TWO launches per optimiser step (dvd_xconv_pack_many) instead
+    of two per weight tensor and per captured chunk (round 5: 964 launches, 6.3 ms of a 668 ms step).
+
+    Eager calls of xconv_packed / xconv_packed_scaled (the warm-up passes before a capture) leave a REQUEST on the weight;
+    `extend()` -- called by the model right before it opens a capture -- gives every requested packing a persistent buffer and
+    a row of the device table; under capture xconv_packed then returns that buffer and launches nothing.  The buffers hold
+    the packing of the weights' CURRENT values only after `ensure_current()`: the owner of the graphs calls it before every
+    replay (it compares version counters / the fused Adam's epoch on the host and launches only after a change).
+    Entries hold weak references: a discarded model's rows are dropped at the next extend()."""
+
+    def __init__(self):
+        self.requests = {}                    # id(weight) -> weak reference: weights with a '_dvd_pack_req' not taken yet
+        self.entries = []
+        self.items = None
+        self.table = None
+        self.key = None
+        self.dirty = False
+        self.launches = 0                     # (tests / bench read it)
+
+    def request(self, weight, kind, groups, gamma=None, var=None, eps=0.0):
+        planned = getattr(weight, '_dvd_plan', None)
+        if planned is not None and kind in planned:
+            e = planned[kind]
+            if kind != 'Ts' or (e['gamma']() is gamma and e['var']() is var and e['eps'] == float(eps)):
+                return
+        req = getattr(weight, '_dvd_pack_req', None)
+        if req is None:
+            req = {}
+            weight._dvd_pack_req = req
+        req[kind] = (int(groups), gamma, var, float(eps))
+        if id(weight) not in self.requests:
+            import weakref
+            key = id(weight)
+            self.requests[key] = weakref.ref(weight, lambda _r, key=key, reqs=self.requests: reqs.pop(key, None))
+
+    @staticmethod
+    def _ref(t):
+        import weakref
+        return weakref.ref(t) if t is not None else (lambda: None)
+
+    def extend(self):
+        """Take the pending requests (not during a capture) and bring every buffer up to date."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        lib = _lib.load()
+        import weakref
+        live = [e for e in self.entries if e['w']() is not None]
+        if len(live) != len(self.entries):
+            self.entries, self.dirty = live, True
+        for ref in list(self.requests.values()):
+            weight = ref()
+            if weight is None:
+                continue
+            req = getattr(weight, '_dvd_pack_req', None) or {}
+            planned = getattr(weight, '_dvd_plan', None)
+            if planned is None:
+                planned = {}
+                weight._dvd_plan = planned
+            Cout, Cin, KS, _ = weight.shape
+            for kind, (groups, gamma, var, eps) in req.items():
+                transposed = kind != 'F'
+                nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin * groups, KS, groups, int(transposed))
+                if nbytes == 0 or not weight.is_contiguous() or weight.dtype != torch.float32:
+                    continue
+                old = planned.get(kind)
+                if old is not None:
+                    self.entries = [e for e in self.entries if e is not old]
+                e = dict(w=weakref.ref(weight), kind=kind, groups=groups, gamma=self._ref(gamma), var=self._ref(var), eps=eps,
+                         packed=torch.empty(nbytes, device=weight.device, dtype=torch.uint8), shape=(Cout, Cin * groups, KS))
+                planned[kind] = e
+                self.entries.append(e)
+                self.dirty = True
+            weight._dvd_pack_req = None
+        self.requests.clear()
+        self.ensure_current()
+
+    @staticmethod
+    def _entry_state(e):
+        """(addresses, versions) of an entry's tensors, or None if its weight is gone."""
+        w, g, v = e['w'](), e['gamma'](), e['var']()
+        if w is None:
+            return None
+        return ((w.data_ptr(), None if g is None else g.data_ptr(), None if v is None else v.data_ptr()),
+                (w._version, None if g is None else g._version, None if v is None else v._version))
+
+    def ensure_current(self):
+        """Re-pack if any planned weight (or BatchNorm scale) changed since the last packing.  Host cost: one tuple of version
+        counters per entry; device cost: two launches after an optimiser step, none otherwise."""
+        if not self.entries:
+            return
+        from . import ops
+        states = [self._entry_state(e) for e in self.entries]
+        if any(st is None for st in states):
+            self.entries = [e for e, st in zip(self.entries, states) if st is not None]
+            states = [st for st in states if st is not None]
+            self.dirty = True
+            if not self.entries:
+                return
+        addresses = tuple(st[0] for st in states)
+        key = (ops.WEIGHT_EPOCH[0], addresses, tuple(st[1] for st in states))
+        if key == self.key and not self.dirty:
+            return
+        lib = _lib.load()
+        n = len(self.entries)
+        upload = int(self.dirty or self.items is None or self.key is None or addresses != self.key[1])
+        if upload:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('xconv pack plan: the item table changed during a graph capture (call extend() before it)')
+            items = (_lib.XPackItem * n)()
+            for i, e in enumerate(self.entries):
+                Cout, Cin, KS = e['shape']
+                wp, gp, vp = addresses[i]
+                items[i] = _lib.XPackItem(wp, e['packed'].data_ptr(), gp, vp, e['eps'], Cout, Cin, KS, e['groups'],
+                                          int(e['kind'] != 'F'))
+            self.items = items
+            self.table = torch.empty(lib.dvd_xconv_pack_table_bytes(n), device=self.entries[0]['packed'].device,
+                                     dtype=torch.uint8)
+        _lib.check(lib.dvd_xconv_pack_many(ctypes.cast(self.items, ctypes.c_void_p), n, _p(self.table),
+                                           ctypes.c_size_t(self.table.numel()), upload, _stream()), 'dvd_xconv_pack_many')
+        self.key, self.dirty = key, False
+        self.launches += 1
+
+    def lookup(self, weight, kind, gamma=None, var=None, eps=0.0):
+        planned = getattr(weight, '_dvd_plan', None)
+        e = planned.get(kind) if planned is not None else None
+        if e is None or e['w']() is not weight:
+            return None
+        if kind == 'Ts' and not (e['gamma']() is gamma and e['var']() is var and e['eps'] == float(eps)):
+            return None
+        return e['packed']
+
+
+PACK_PLAN = _PackPlan()
+
+
 def xconv_packed_scaled(weight, groups, gamma, var, eps):
     """Transposed packing with row co scaled by gamma[co] / sqrt(var[co] + eps): backward-data through a fused BatchNorm.
     Cached on the weight like xconv_packed; the key also follows gamma (optimiser steps) and the running variance."""
@@ -557,6 +696,13 @@ def xconv_packed_scaled(weight, groups, gamma, var, eps):
     lib = _lib.load()
     nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, groups, 1)
     capturing = torch.cuda.is_current_stream_capturing()
+    if not AB['no_packplan']:
+        if capturing:
+            planned = PACK_PLAN.lookup(weight, 'Ts', gamma, var, eps)
+            if planned is not None:
+                return planned
+        else:
+            PACK_PLAN.request(weight, 'Ts', groups, gamma, var, eps)
     key = (w.data_ptr(), weight._version, ops.WEIGHT_EPOCH[0], tuple(w.shape),
            None if gamma is None else (gamma.data_ptr(), gamma._version), var.data_ptr(), var._version, float(eps))
     cache = getattr(weight, '_dvd_xpack', None)
@@ -586,9 +732,16 @@ def xconv_packed(weight, transposed, groups=1):
     Cout, Cin, KS, _ = w.shape
     Cin *= groups
     lib = _lib.load()
+    if not AB['no_packplan']:
+        if torch.cuda.is_current_stream_capturing():
+            planned = PACK_PLAN.lookup(weight, 'T' if transposed else 'F')
+            if planned is not None:         # kept current by the graph's owner (PACK_PLAN.ensure_current before a replay)
+                return planned
+        else:
+            PACK_PLAN.request(weight, 'T' if transposed else 'F', groups)
     if torch.cuda.is_current_stream_capturing():
-        # HIP-graph capture: the pack launch must be PART of the graph (a replay runs no Python, and the weights
-        # change between replays), into a buffer of the graph's own pool -- never served from the cache
+        # HIP-graph capture without a plan entry: the pack launch must be PART of the graph (a replay runs no Python, and
+        # the weights change between replays), into a buffer of the graph's own pool -- never served from the cache
         nbytes = lib.dvd_xconv_packed_bytes(Cout, Cin, KS, groups, int(transposed))
         packed = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
         _lib.check(lib.dvd_xconv_pack(_p(w), _p(packed), Cout, Cin, KS, groups, int(transposed), _stream()), 'dvd_xconv_pack')
@@ -714,7 +867,11 @@ class _XConv(torch.autograd.Function):
         need = ctx.needs_input_grad
         gx = gw = gb = gr = None
         h16 = _is16(gy)
-        g_amax = amax_of(gy) if ((need[0] or need[2]) and not h16) else None   # one reduction, shared by both gradient kernels
+        want_amax = (need[0] or need[2]) and not h16
+        if has_bias and need[3] and gy.is_cuda and gy.dtype == torch.float32 and gy.dim() == 4 and not AB['no_chansum']:
+            # the bias gradient and (if nobody attached it) max|gy| from ONE read of gy (rounds 1-5: ATen sum + dvd_amax)
+            gb = chansum(gy, want_amax=want_amax and known_amax(gy) is None)
+        g_amax = amax_of(gy) if want_amax else None   # one reduction, shared by both gradient kernels
         if need[0]:
             gx_amax = _gs(3) if h16 else new_scalar(gy.device)      # fp16: the loss-scale policy's observed maximum
             gx = _xconv_run(gy, xconv_packed(weight, True, groups), Cin * groups, KS,
@@ -727,7 +884,7 @@ class _XConv(torch.autograd.Function):
                 ctx.in_site.wrote(gx, None if h16 else gx_amax)     # x is a BatchNorm+ReLU site's output: [x > 0] is already applied
         if need[2]:
             gw = xconv_wgrad(x, gy, weight.shape, relu_in, groups, x_amax=x_amax, g_amax=g_amax)
-        if has_bias and need[3]:
+        if has_bias and need[3] and gb is None:
             gb = gy.sum((0, 2, 3), dtype=torch.float32) * _gs(1) if h16 else gy.sum((0, 2, 3))
         if has_res and need[4]:
             gr = gy * (residual > 0).to(gy.dtype) if (res_relu and not res_unmasked) else gy

@@ -131,17 +131,17 @@ __global__ __launch_bounds__(64 * kWamaxWaves) void xconv_wamax4_kernel(const fl
   block_partial_max<kWamaxWaves>(mall, header);
 }
 
-__global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
-                                                         int Cin, int T, int transposed, int mtiles, int nkc, int G,
-                                                         const float* __restrict__ sc_gamma, const float* __restrict__ sc_var,
-                                                         float sc_eps, int npart) {
+__device__ __forceinline__ void xconv_pack_block(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
+                                                 int Cin, int T, int transposed, int mtiles, int nkc, int G,
+                                                 const float* __restrict__ sc_gamma, const float* __restrict__ sc_var,
+                                                 float sc_eps, int npart, unsigned block) {
   // max|A| from the partial maxima the wamax launch left in the header (one load per lane, wave maximum); block 0 publishes it
   // in header[0] for the convolution kernels
   float amax = (int)(threadIdx.x & 63) < npart ? reinterpret_cast<const float*>(packed)[kXPartial0 + (threadIdx.x & 63)] : 0.0f;
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off, kWave));
-  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(packed)[0] = amax;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (block == 0 && threadIdx.x == 0) reinterpret_cast<float*>(packed)[0] = amax;
+  const long long idx = (long long)block * 256 + threadIdx.x;
   const long long total = (long long)G * mtiles * nkc * T * 64;
   if (idx >= total) return;
   const int lane = (int)(idx & 63);
@@ -170,6 +170,76 @@ __global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict
   split8_f16(v, sw, h, l);
   packed[kXHeader + (f * 2 + 0) * 64 + lane] = h;
   packed[kXHeader + (f * 2 + 1) * 64 + lane] = l;
+}
+
+__global__ __launch_bounds__(256) void xconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ packed, int Cout,
+                                                         int Cin, int T, int transposed, int mtiles, int nkc, int G,
+                                                         const float* __restrict__ sc_gamma, const float* __restrict__ sc_var,
+                                                         float sc_eps, int npart) {
+  xconv_pack_block(w, packed, Cout, Cin, T, transposed, mtiles, nkc, G, sc_gamma, sc_var, sc_eps, npart, blockIdx.x);
+}
+
+// ---- all packings of a network in two launches (round 6: dvd_xconv_pack_many) ----------------------------------------------
+// A training step of MiDaS packs ~240 weight tensors (forward and transposed orders); one wamax + one pack launch per tensor
+// and per captured depth-net chunk were 964 launches of ~6.5 us each for 4 GB of traffic (0.67 TB/s).  The table below lists
+// every packing once; block (p, i) of the first launch takes item i's partial maximum p, block b of the second finds its item
+// by bisection of the items' first-block numbers.  Same arithmetic per element as the single-tensor kernels: the packed bytes
+// are identical.
+struct XPackDev {
+  const float* w;
+  uint4* packed;
+  const float* gamma;
+  const float* var;
+  float eps;
+  int co, ci, T, transposed, mtiles, nkc, G;      // per-group channel counts, like xconv_pack_kernel's arguments
+  int rows, row_len;                              // rows = total output channels (the BatchNorm scale's index)
+  unsigned block0;                                // first block of this item in the pack launch
+  int pad_;
+};
+constexpr int kManyPartials = 16;
+
+__global__ __launch_bounds__(64 * kWamaxWaves) void xconv_wamax_many_kernel(const XPackDev* __restrict__ table) {
+  const XPackDev it = table[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float mall = 0.0f;
+  if (it.row_len % 4 == 0 && reinterpret_cast<uintptr_t>(it.w) % 16 == 0) {
+    const int cpr = (it.row_len + 1023) / 1024, units = it.rows * cpr, n4 = it.row_len >> 2;
+    for (int unit = blockIdx.x * kWamaxWaves + wave; unit < units; unit += gridDim.x * kWamaxWaves) {
+      const int row = unit / cpr, ch = unit - row * cpr;
+      const float4* p = reinterpret_cast<const float4*>(it.w + (size_t)row * it.row_len);
+      float4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = ch * 256 + k * 64 + lane;
+        v[k] = i < n4 ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float m = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+      if (it.var) m *= fabsf((it.gamma ? it.gamma[row] : 1.0f) / sqrtf(it.var[row] + it.eps));
+      mall = fmaxf(mall, m);
+    }
+  } else {
+    for (int row = blockIdx.x * kWamaxWaves + wave; row < it.rows; row += gridDim.x * kWamaxWaves) {
+      const float* wr = it.w + (size_t)row * it.row_len;
+      float m = 0.0f;
+      for (int i = lane; i < it.row_len; i += 64) m = fmaxf(m, fabsf(wr[i]));
+      if (it.var) m *= fabsf((it.gamma ? it.gamma[row] : 1.0f) / sqrtf(it.var[row] + it.eps));
+      mall = fmaxf(mall, m);
+    }
+  }
+  block_partial_max<kWamaxWaves>(mall, reinterpret_cast<float*>(it.packed));
+}
+
+__global__ __launch_bounds__(256) void xconv_pack_many_kernel(const XPackDev* __restrict__ table, int n) {
+  int lo = 0, hi = n - 1;                         // the last item whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].block0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const XPackDev it = table[lo];
+  xconv_pack_block(it.w, it.packed, it.co, it.ci, it.T, it.transposed, it.mtiles, it.nkc, it.G, it.gamma, it.var, it.eps,
+                   kManyPartials, blockIdx.x - it.block0);
 }
 
 struct XArgs {
@@ -1064,6 +1134,59 @@ int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int K
                           const float* bn_gamma, const float* bn_var, float bn_eps, dvd_stream_t stream) {
   DVD_REQUIRE(bn_var, "xconv_pack_scaled: null variance");
   return xconv_pack_impl(w, packed, Cout, Cin, KS, groups, transposed, bn_gamma, bn_var, bn_eps, stream);
+}
+
+size_t dvd_xconv_pack_table_bytes(int n) { return n > 0 ? (size_t)n * sizeof(dvd::XPackDev) : 0; }
+
+int dvd_xconv_pack_many(const dvd_xpack_item* items, int n, void* table, size_t table_bytes, int upload, dvd_stream_t stream) {
+  DVD_REQUIRE(items && table && n > 0, "xconv_pack_many: bad arguments");
+  DVD_REQUIRE(table_bytes >= dvd_xconv_pack_table_bytes(n), "xconv_pack_many: table %zu < %zu bytes", table_bytes,
+              dvd_xconv_pack_table_bytes(n));
+  std::vector<dvd::XPackDev> host((size_t)n);
+  unsigned long long blocks = 0;
+  double bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const dvd_xpack_item& q = items[i];
+    DVD_REQUIRE(q.w && q.packed, "xconv_pack_many: item %d: null pointer", i);
+    DVD_REQUIRE(q.Cout > 0 && q.Cin > 0 && q.KS > 0 && (q.KS & 1) && q.KS <= 11 && q.groups > 0 && q.Cout % q.groups == 0 &&
+                    q.Cin % q.groups == 0,
+                "xconv_pack_many: item %d: bad shape Cout=%d Cin=%d KS=%d groups=%d", i, q.Cout, q.Cin, q.KS, q.groups);
+    DVD_REQUIRE(!q.gamma || q.var, "xconv_pack_many: item %d: BatchNorm scale without a variance", i);
+    dvd::XPackDev& d = host[(size_t)i];
+    d.w = q.w;
+    d.packed = static_cast<uint4*>(q.packed);
+    d.gamma = q.gamma;
+    d.var = q.var;
+    d.eps = q.eps;
+    d.co = q.Cout / q.groups;
+    d.ci = q.Cin / q.groups;
+    d.T = q.KS * q.KS;
+    d.transposed = q.transposed ? 1 : 0;
+    const int M = d.transposed ? d.ci : d.co, K = d.transposed ? d.co : d.ci;
+    d.mtiles = dvd::xconv_mtiles(M);
+    d.nkc = (K + 15) / 16;
+    d.G = q.groups;
+    d.rows = q.Cout;
+    d.row_len = d.ci * d.T;
+    d.block0 = (unsigned)blocks;
+    d.pad_ = 0;
+    const long long total = (long long)d.G * d.mtiles * d.nkc * d.T * 64;
+    blocks += (unsigned long long)((total + 255) / 256);
+    bytes += 8.0 * (double)q.Cout * d.ci * d.T + 16.0 * (double)total;
+  }
+  DVD_REQUIRE(blocks < (1ull << 31), "xconv_pack_many: too many blocks");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (upload) {      // (not capturable: call it outside a graph capture; replays and later calls pass upload = 0)
+    DVD_HIP_OK(hipMemcpyAsync(table, host.data(), (size_t)n * sizeof(dvd::XPackDev), hipMemcpyHostToDevice, st));
+    DVD_HIP_OK(hipStreamSynchronize(st));
+  }
+  dvd::bytes_add(DVD_BYTES_PACK, bytes);
+  const dvd::XPackDev* t = static_cast<const dvd::XPackDev*>(table);
+  hipLaunchKernelGGL(dvd::xconv_wamax_many_kernel, dim3(dvd::kManyPartials, (unsigned)n), dim3(64 * dvd::kWamaxWaves), 0, st, t);
+  DVD_LAUNCH_OK();
+  hipLaunchKernelGGL(dvd::xconv_pack_many_kernel, dim3((unsigned)blocks), dim3(256), 0, st, t, n);
+  DVD_LAUNCH_OK();
+  return DVD_OK;
 }
 
 int dvd_xconv_select(int cfg) {

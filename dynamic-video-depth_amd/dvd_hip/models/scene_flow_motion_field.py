@@ -274,6 +274,7 @@ class Model(NetInterface):
             # thread_local: calls made by other threads (the RCCL watchdog polling its events) do not invalidate
             # the capture; the step also keeps collectives out of flight while a graph is being captured
             mode = dict(capture_error_mode='thread_local')
+            conv.PACK_PLAN.extend()        # the packings the warm-up passes asked for: persistent buffers, two launches per step
             ops.begin_capture()
             f0 = ops.flop_counters()       # (bench.py roofline_mfma: the graph's algorithmic work, added at every replay)
             if kind == 'f':
@@ -364,6 +365,7 @@ class Model(NetInterface):
             mode = dict(capture_error_mode='thread_local')
             pool = torch.cuda.graph_pool_handle()
             g_f, g_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            conv.PACK_PLAN.extend()
             ops.begin_capture()
             f0 = ops.flop_counters()
             with torch.cuda.graph(g_f, pool=pool, **mode):
@@ -438,6 +440,7 @@ class Model(NetInterface):
             e = self._keep_slot(slot0 + ci, chunk, fid, reserve_bytes, others_kept) if self._use_graphs(chunk, fid) else None
             if e is not None:
                 e[2].copy_(chunk)
+                conv.PACK_PLAN.ensure_current()      # (packed weights follow the optimiser: two launches after a step)
                 e[0].replay()
                 ops.note_replay(self._graph_flops.get(id(e[0])))
                 out.append(e[3].detach().clone())
@@ -458,6 +461,7 @@ class Model(NetInterface):
                 g = self._capture_depth_graph('f', chunk, fid) if self._use_graphs(chunk, fid) else None
                 if g is not None:
                     g[1].copy_(chunk)
+                    conv.PACK_PLAN.ensure_current()      # (packed weights follow the optimiser: two launches after a step)
                     g[0].replay()
                     ops.note_replay(self._graph_flops.get(id(g[0])))
                     out.append(g[2].clone())
@@ -473,6 +477,7 @@ class Model(NetInterface):
             kept = None if slot0 is None else self._depth_graphs.get(('keep', slot0 + ci, tuple(chunk.shape), bool(self.opt.midas)))
             if kept is not None:                        # the forward of phase 1 left this chunk's graph state in its slot
                 kept[4].copy_(g_depth[b0:b0 + c])
+                conv.PACK_PLAN.ensure_current()      # (packed weights follow the optimiser: two launches after a step)
                 kept[1].replay()
                 ops.note_replay(self._graph_flops.get(id(kept[1])))
                 continue
@@ -480,6 +485,7 @@ class Model(NetInterface):
             if g is not None:
                 g[1].copy_(chunk)
                 g[3].copy_(g_depth[b0:b0 + c])
+                conv.PACK_PLAN.ensure_current()      # (packed weights follow the optimiser: two launches after a step)
                 g[0].replay()
                 ops.note_replay(self._graph_flops.get(id(g[0])))
                 continue

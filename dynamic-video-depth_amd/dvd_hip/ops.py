@@ -145,6 +145,24 @@ def amax(t):
     return out
 
 
+def chansum(t, want_amax=False):
+    """Per-channel sums of an NCHW fp32 tensor (a convolution's bias gradient) and, if want_amax, max|t| from the same read
+    (attached to t like amax_of would) -> [C] tensor."""
+    t = _dev32(t, 'tensor')
+    N, C = t.shape[0], t.shape[1]
+    HW = t.numel() // max(N * C, 1)
+    lib = _lib.load()
+    out = torch.empty(C, device=t.device, dtype=torch.float32)
+    am = new_scalar(t.device) if want_amax else None
+    nws = lib.dvd_chansum_workspace_bytes(N, C)
+    ws = torch.empty(max(nws, 4), device=t.device, dtype=torch.uint8)
+    _lib.check(lib.dvd_chansum(_p(t), N, C, ctypes.c_longlong(HW), _p(out), _p(am) if am is not None else None, _p(ws),
+                               ctypes.c_size_t(nws), _stream()), 'dvd_chansum')
+    if am is not None:
+        t._dvd_amax = (t._version, am, _capture_gen())
+    return out
+
+
 def set_amax(t, am):
     """Attach a known max|t| (or upper bound: a sub-sampled / interpolated / ReLU'd view of a bounded tensor)."""
     if am is not None:
@@ -252,7 +270,7 @@ BYTE_CLASSES = ('bnrelu_fwd', 'bnrelu_bwd', 'upsample_fwd', 'upsample_bwd', 'ama
 BYTE_CLASS_KERNELS = {
     'bnrelu_fwd': ('bnrelu_fwd_kernel',), 'bnrelu_bwd': ('bnrelu_bwd', 'bn_mask', 'bnrelu_sum'),
     'upsample_fwd': ('upsample_bilinear_fwd',), 'upsample_bwd': ('upsample_bilinear_bwd', 'upsample_bwd'),
-    'amax': ('amax_kernel',), 'pack': ('xconv_wamax', 'xconv_pack_kernel'), 'pool': ('maxpool3s2', 'subsample2_'),
+    'amax': ('amax_kernel', 'chansum_'), 'pack': ('xconv_wamax', 'xconv_pack_kernel'), 'pool': ('maxpool3s2', 'subsample2_'),
     'gconv_c8': ('gconv3x3_c8',), 'elementwise': ('mul_mask_kernel', 'scale_add_kernel', 'acc_reg_kernel', 'sum_partials_kernel',
                                                   'head1x1_', 'cast_scale_kernel'),
     'adam': ('adam_kernel',), 'geometry': ('unproject_',),

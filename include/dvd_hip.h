@@ -362,6 +362,14 @@ int dvd_upsample_bilinear_bwd(const float* gy, float* gx, long long planes, int 
  * nothing reads them on the host.  x: any 4-byte aligned address (a misaligned head is read by scalar loads). */
 int dvd_amax(const float* x, long long n, float* out, dvd_stream_t stream);
 
+/* out[c] = sum over n, p of x[n][c][p] of an NCHW fp32 tensor (HW pixels per plane) -- the bias gradient of a convolution,
+ * conv.py _XConv.backward (the reference leaves it to autograd: torch.nn.Conv2d(bias=True), third_party/midas_blocks.py) --
+ * and, when amax_out is not NULL, amax_out[0] = max(amax_out[0], max|x|) from the same read (dvd_amax's contract).
+ * Deterministic: fixed summation order.  workspace: dvd_chansum_workspace_bytes(N, C) bytes of device memory. */
+size_t dvd_chansum_workspace_bytes(int N, int C);
+int dvd_chansum(const float* x, int N, int C, long long HW, float* out, float* amax_out, void* workspace, size_t workspace_bytes,
+                dvd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Dense stride-1 "same" convolution (odd k x k up to 11, any channel counts), NCHW fp32, on the 16-bit
  * matrix cores with every fp32 operand, scaled by a power of two, split into two fp16 terms (three partial
@@ -411,6 +419,22 @@ int dvd_xconv_select(int cfg);
  * backward-data pass through a fused BatchNorm is dvd_xconv_fwd on the masked, UNSCALED output gradient. */
 int dvd_xconv_pack_scaled(const float* w, void* packed, int Cout, int Cin, int KS, int groups, int transposed,
                           const float* bn_gamma, const float* bn_var, float bn_eps, dvd_stream_t stream);
+/* All packings of a network in TWO launches (round 6).  items[i] describes one dvd_xconv_pack / dvd_xconv_pack_scaled call
+ * (var == NULL: unscaled); `packed` buffers of dvd_xconv_packed_bytes each, all distinct.  `table`: device memory of
+ * dvd_xconv_pack_table_bytes(n) that the launches read; upload != 0 (re)writes it from `items` with a blocking copy -- pass it
+ * once per item list, OUTSIDE a graph capture -- upload == 0 reuses what the last upload left (`items` must be the same list).
+ * The packed bytes are identical to n single calls.  The reference has no counterpart: nn.Conv2d consumes its fp32 weight
+ * directly (third_party/midas_blocks.py:35-50); the packing is the operand format of this library's matrix kernels. */
+typedef struct dvd_xpack_item {
+  const float* w;
+  void* packed;
+  const float* gamma;   /* may be NULL (scale 1 / sqrt(var + eps)) */
+  const float* var;     /* NULL: no BatchNorm scale */
+  float eps;
+  int Cout, Cin, KS, groups, transposed;
+} dvd_xpack_item;
+size_t dvd_xconv_pack_table_bytes(int n);
+int dvd_xconv_pack_many(const dvd_xpack_item* items, int n, void* table, size_t table_bytes, int upload, dvd_stream_t stream);
 /* After the weight-gradient kernel ran on the unscaled masked gradient (dW holds dWu [Cout][K]): scales dW in place and
  * derives the BatchNorm-gamma and convolution-bias gradients (csrc/bnrelu.hip); dbeta = per-channel sum of the masked
  * gradient (dvd_bnrelu_bwd with x = null). */

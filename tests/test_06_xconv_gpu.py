@@ -427,3 +427,79 @@ def test_heavy_tailed_operands_dynamic_range(ratio, KS):
             log_measured('hdr %s ratio %.0e k%d: bulk outputs, of their own max' % (name, ratio, KS), eb, ratio * 1.5e-11 * (Cin * KS * KS) ** 0.5 + 4e-6)
             print('%s ratio %.0e: %.2e of max, bulk %.2e of bulk max' % (name, ratio, e, eb))
             assert eb < ratio * 1.5e-11 * (Cin * KS * KS) ** 0.5 * 4 + 4e-6, (name, eb)
+
+
+@pytest.mark.parametrize('N,Cc,H,W', [(5, 7, 9, 11), (48, 64, 12, 20), (3, 300, 8, 8), (1, 2, 1, 3)])
+def test_bias_gradient_sums_and_amax_in_one_read(N, Cc, H, W):
+    """dvd_chansum: the per-channel sums of gy (a convolution's bias gradient: what autograd's sum over (0, 2, 3) of
+    torch.nn.Conv2d(bias=True) gives, third_party/midas_blocks.py:102-168) and max|gy| from the same read.
+    Tolerance: fp32 summation of N*H*W terms against float64, 2e-6 of sum|x|; the maximum is exact; bitwise run to run."""
+    from dvd_hip import ops
+    torch.manual_seed(N * 1000 + Cc)
+    x = (torch.randn(N, Cc, H, W) * 3).cuda()
+    x[N // 2, Cc // 2, H // 2, W // 2] = -77.5
+    got = ops.chansum(x, want_amax=True)
+    want = x.double().sum((0, 2, 3)).cpu()
+    scale = x.double().abs().sum((0, 2, 3)).cpu()
+    assert float(((got.double().cpu() - want).abs() / scale).max()) < 2e-6
+    assert float(ops.known_amax(x)) == 77.5
+    assert torch.equal(got, ops.chansum(x)), 'summation order depends on scheduling'
+    # a 4-byte aligned view (batch slice of odd planes) takes the scalar path
+    if N > 1:
+        v = x[1:]
+        got_v = ops.chansum(v.contiguous() if not v.is_contiguous() else v)
+        assert float(((got_v.double().cpu() - v.double().sum((0, 2, 3)).cpu()).abs() / scale).max()) < 2e-6
+
+
+def test_pack_plan_gives_the_bytes_of_single_packings_and_follows_weight_updates():
+    """dvd_xconv_pack_many (conv.PACK_PLAN: every packing of a network in two launches) against dvd_xconv_pack /
+    dvd_xconv_pack_scaled tensor by tensor: byte-identical buffers (header maximum included) for dense, grouped, 1x1, 5x5,
+    transposed, BatchNorm-scaled and 4-byte-aligned (odd row length: the stem's 27-element rows) weights; an in-place update
+    of one weight is picked up by ensure_current() with ONE more launch pair, an unchanged plan launches nothing."""
+    from dvd_hip import conv as C
+    from dvd_hip import ops
+    torch.manual_seed(5)
+    plan = C._PackPlan()
+    specs = [(64, 64, 3, 1), (256, 64, 1, 1), (48, 32, 5, 1), (64, 64, 3, 2), (32, 3, 3, 1), (40, 24, 1, 1), (128, 128, 3, 4)]
+    flat = torch.randn(sum(co * (ci // g) * k * k for co, ci, k, g in specs) + 1, device='cuda')[1:]   # 4-byte aligned views
+    weights, o = [], 0
+    for co, ci, k, g in specs:
+        n = co * (ci // g) * k * k
+        weights.append(torch.nn.Parameter(flat[o:o + n].view(co, ci // g, k, k)))
+        o += n
+    gamma, var = torch.rand(64, device='cuda') + 0.5, torch.rand(64, device='cuda') + 0.1
+    for w, (co, ci, k, g) in zip(weights, specs):
+        plan.request(w, 'F', g)
+        plan.request(w, 'T', g)
+    plan.request(weights[0], 'Ts', 1, gamma, var, 1e-5)
+    plan.extend()
+    assert plan.launches == 1 and len(plan.entries) == 2 * len(specs) + 1
+
+    def same(a, b):
+        return torch.equal(a[:4], b[:4]) and torch.equal(a[256:], b[256:])
+
+    def singles():
+        out = []
+        for w, (co, ci, k, g) in zip(weights, specs):
+            for tr in (False, True):
+                out.append((w, 'T' if tr else 'F', C.xconv_packed(w, tr, g).clone()))
+        out.append((weights[0], 'Ts', C.xconv_packed_scaled(weights[0], 1, gamma, var, 1e-5).clone()))
+        return out
+
+    for w, kind, want in singles():
+        got = plan.lookup(w, kind, gamma, var, 1e-5) if kind == 'Ts' else plan.lookup(w, kind)
+        assert got is not None and same(got, want), (tuple(w.shape), kind)
+    plan.ensure_current()
+    assert plan.launches == 1
+    with torch.no_grad():
+        weights[2].mul_(3.0)
+        weights[2][0, 0, 0, 0] = 1e3          # a new maximum: another power-of-two scale
+    plan.ensure_current()
+    assert plan.launches == 2
+    for w, kind, want in singles():
+        got = plan.lookup(w, kind, gamma, var, 1e-5) if kind == 'Ts' else plan.lookup(w, kind)
+        assert same(got, want), (tuple(w.shape), kind)
+    ops.WEIGHT_EPOCH[0] += 1                   # the fused Adam's step counter
+    plan.ensure_current()
+    assert plan.launches == 3
+    del weights[:], w, got, want
