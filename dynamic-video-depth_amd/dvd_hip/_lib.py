@@ -153,6 +153,9 @@ SIGNATURES = {
     'dvd_bnrelu_fwd_t': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_bnrelu_bwd_t': (c_int, [c_void_p] * 6 + [c_float] + [c_void_p] * 5 + [c_size_t, c_int, c_void_p, c_int, c_int, c_int,
                                                                              c_int, c_void_p, c_void_p]),
+    'dvd_bnrelu_fwd_m': (c_int, [c_void_p] * 6 + [c_float, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'dvd_bnrelu_bwd_m': (c_int, [c_void_p] * 6 + [c_float] + [c_void_p] * 5 + [c_size_t, c_int, c_void_p, c_int, c_int, c_int,
+                                                                             c_int, c_void_p, c_void_p, c_void_p]),
     'dvd_upsample_bilinear_fwd_t': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_upsample_bilinear_bwd_t': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'dvd_gconv3x3_c8_fwd_t': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -93,14 +93,19 @@ class _BnRelu(torch.autograd.Function):
             residual = residual.contiguous()
         y = torch.empty_like(x)
         lib = _lib.load()
-        _lib.check(lib.dvd_bnrelu_fwd_t(_p(x), _p(residual), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(y),
-                                        int(_is16(x)), N, C, HW, int(relu), _stream()), 'dvd_bnrelu_fwd')
+        # fp32 storage: max|y| from the same pass (the 1x1 convolution that follows takes its operand scale from it; until
+        # round 6 a dvd_amax pass over y: 18 of them per step behind the 8- and 16-per-group and the strided convolutions)
+        y_amax = None if _is16(x) else new_scalar(x.device)
+        _lib.check(lib.dvd_bnrelu_fwd_m(_p(x), _p(residual), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), _p(y),
+                                        int(_is16(x)), N, C, HW, int(relu), _p(y_amax), _stream()), 'dvd_bnrelu_fwd')
         ctx.save_for_backward(x, y if relu else None, gamma, mean, var)
         ctx.cfg = (N, C, HW, float(eps), int(relu), residual is not None)
-        return y
+        if y_amax is not None:
+            ctx.mark_non_differentiable(y_amax)
+        return y, y_amax
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _g_amax=None):
         x, y, gamma, mean, var = ctx.saved_tensors
         N, C, HW, eps, relu, has_res = ctx.cfg
         gy = gy.contiguous()
@@ -112,9 +117,17 @@ class _BnRelu(torch.autograd.Function):
         lib = _lib.load()
         ws = _workspace(lib.dvd_bnrelu_bwd_workspace_bytes(N, C, HW), x.device)
         h16 = _is16(gy)
-        _lib.check(lib.dvd_bnrelu_bwd_t(_p(gy), _p(y), _p(x), _p(gamma), _p(mean), _p(var), eps, _p(gx), _p(gr), _p(gg),
+        # fp32: max|gx| (and max|g| for the residual branch) come with the pass; the convolutions' backward found neither
+        # attached and ran a dvd_amax pass each (12 per step)
+        gx_amax = new_scalar(gy.device) if (gx is not None and not h16) else None
+        gr_amax = new_scalar(gy.device) if (gr is not None and not h16) else None
+        _lib.check(lib.dvd_bnrelu_bwd_m(_p(gy), _p(y), _p(x), _p(gamma), _p(mean), _p(var), eps, _p(gx), _p(gr), _p(gg),
                                         _p(gb), _p(ws), ctypes.c_size_t(ws.numel()), int(h16), _p(_gs(1)) if h16 else None, N, C,
-                                        HW, relu, _p(_gs(3)) if h16 else None, _stream()), 'dvd_bnrelu_bwd')
+                                        HW, relu, _p(_gs(3)) if h16 else _p(gr_amax), _p(gx_amax), _stream()), 'dvd_bnrelu_bwd')
+        if gx_amax is not None:
+            set_amax(gx, gx_amax)
+        if gr_amax is not None:
+            set_amax(gr, gr_amax)
         return gx, gr, gg, gb, None, None, None, None
 
 
@@ -127,7 +140,8 @@ def bn_eval_relu(bn, x, residual=None, relu=True):
             gamma, beta = bn.weight, bn.bias
         else:                                   # hourglass inception blocks: BatchNorm2d(affine=False)
             gamma, beta = torch.ones_like(bn.running_mean), torch.zeros_like(bn.running_mean)
-        return _BnRelu.apply(x, residual, gamma, beta, bn.running_mean, bn.running_var, bn.eps, relu)
+        y, y_amax = _BnRelu.apply(x, residual, gamma, beta, bn.running_mean, bn.running_var, bn.eps, relu)
+        return set_amax(y, y_amax)
     y = bn(x)
     if residual is not None:
         y = y + residual

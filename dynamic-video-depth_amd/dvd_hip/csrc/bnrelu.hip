@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const T* __restrict__ x
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float eps, T* __restrict__ y, int C, int HW, int chunks,
-                                                         int relu) {
+                                                         int relu, float* __restrict__ y_amax) {
   const int chunk = blockIdx.x % chunks;
   const long long pl = blockIdx.x / chunks;   // n * C + c
   const int c = (int)(pl % C);
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const T* __restrict__ x
   const float b = beta[c] - mean[c] * s;
   const long long base = pl * HW;
   const int lo = chunk * kBnChunk, hi = min(HW, lo + kBnChunk);
+  float m = 0.0f;        // max|y| of this thread (y_amax: the operand scale of the convolution that consumes y)
   if ((HW & 3) == 0) {
     for (int i = lo + threadIdx.x * 4; i < hi; i += 1024) {
       float4 v = ld4(x + base + i);
@@ -57,14 +58,18 @@ __global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const T* __restrict__ x
         v.w = fmaxf(v.w, 0.0f);
       }
       st4(y + base + i, v);
+      m = amax_acc(amax_acc(amax_acc(amax_acc(m, v.x), v.y), v.z), v.w);
     }
   } else {
     for (int i = lo + threadIdx.x; i < hi; i += 256) {
       float v = __builtin_fmaf(ldf(x + base + i), s, b);
       if (res) v += ldf(res + base + i);
-      stf(y + base + i, relu ? fmaxf(v, 0.0f) : v);
+      v = relu ? fmaxf(v, 0.0f) : v;
+      stf(y + base + i, v);
+      m = amax_acc(m, v);
     }
   }
+  if (y_amax) wave_amax_to(m, y_amax);     // (uniform; an atomic only from waves that raise the value)
 }
 
 // partial[(c * N + n) * chunks + chunk] = (sum g, sum g * (x - mean[c])) of the block
@@ -155,10 +160,11 @@ __global__ __launch_bounds__(64) void bnrelu_param_grad_kernel(const float2* __r
                                                                const float* __restrict__ var, float eps,
                                                                float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                                int C, int records, const float* __restrict__ pmax,
-                                                               float* g_amax, const float* __restrict__ out_scale) {
+                                                               float* g_amax, const float* __restrict__ out_scale,
+                                                               const float* __restrict__ gamma, float* gx_amax) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   double sg = 0.0, sgx = 0.0;
-  float m = 0.0f;
+  float m = 0.0f, mx = 0.0f;
   if (c < C) {
     for (int r = 0; r < records; ++r) {
       const float2 v = partial[(size_t)c * records + r];
@@ -170,8 +176,11 @@ __global__ __launch_bounds__(64) void bnrelu_param_grad_kernel(const float2* __r
     const double os = out_scale ? (double)out_scale[0] : 1.0;
     if (gbeta) gbeta[c] = (float)(sg * os);
     if (ggamma) ggamma[c] = (float)(sgx * os / sqrt((double)var[c] + (double)eps));
+    // max|gx| over the channel: gx = g * s with the s of bnrelu_bwd_kernel, and rounding is monotonic -- exactly |s| max|g|
+    if (gx_amax) mx = m * fabsf(gamma[c] / sqrtf(var[c] + eps));
   }
   if (g_amax) wave_amax_to(m, g_amax);      // C / 64 waves: a handful of atomics
+  if (gx_amax) wave_amax_to(mx, gx_amax);
 }
 
 // Convolution + fused eval-mode BatchNorm, backward bookkeeping of one site.  The weight-gradient kernels ran on the
@@ -215,6 +224,12 @@ int dvd_bnrelu_fwd(const float* x, const float* residual, const float* gamma, co
 
 int dvd_bnrelu_fwd_t(const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
                      const float* var, float eps, void* y, int f16, int N, int C, int HW, int relu, dvd_stream_t stream) {
+  return dvd_bnrelu_fwd_m(x, residual, gamma, beta, mean, var, eps, y, f16, N, C, HW, relu, nullptr, stream);
+}
+
+int dvd_bnrelu_fwd_m(const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
+                     const float* var, float eps, void* y, int f16, int N, int C, int HW, int relu, float* y_amax,
+                     dvd_stream_t stream) {
   DVD_REQUIRE(x && gamma && beta && mean && var && y, "bnrelu fwd: null pointer");
   DVD_REQUIRE(N > 0 && C > 0 && HW > 0, "bnrelu fwd: bad shape");
   const int chunks = (HW + dvd::kBnChunk - 1) / dvd::kBnChunk;
@@ -223,7 +238,7 @@ int dvd_bnrelu_fwd_t(const void* x, const void* residual, const float* gamma, co
   dvd::bytes_add(DVD_BYTES_BNRELU_FWD, (double)N * C * HW * (f16 ? 2 : 4) * (residual ? 3 : 2));
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::bnrelu_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
                                          static_cast<hipStream_t>(stream), static_cast<const T*>(x), static_cast<const T*>(residual),
-                                         gamma, beta, mean, var, eps, static_cast<T*>(y), C, HW, chunks, relu));
+                                         gamma, beta, mean, var, eps, static_cast<T*>(y), C, HW, chunks, relu, y_amax));
   DVD_LAUNCH_OK();
   return DVD_OK;
 }
@@ -245,6 +260,15 @@ int dvd_bnrelu_bwd_t(const void* gy, const void* y, const void* x, const float* 
                      float eps, void* gx, void* g_residual, float* g_gamma, float* g_beta, void* workspace,
                      size_t workspace_bytes, int f16, const float* out_scale, int N, int C, int HW, int relu, float* g_amax,
                      dvd_stream_t stream) {
+  return dvd_bnrelu_bwd_m(gy, y, x, gamma, mean, var, eps, gx, g_residual, g_gamma, g_beta, workspace, workspace_bytes, f16,
+                          out_scale, N, C, HW, relu, g_amax, nullptr, stream);
+}
+
+int dvd_bnrelu_bwd_m(const void* gy, const void* y, const void* x, const float* gamma, const float* mean, const float* var,
+                     float eps, void* gx, void* g_residual, float* g_gamma, float* g_beta, void* workspace,
+                     size_t workspace_bytes, int f16, const float* out_scale, int N, int C, int HW, int relu, float* g_amax,
+                     float* gx_amax, dvd_stream_t stream) {
+  DVD_REQUIRE(!gx_amax || gx, "bnrelu bwd: max|gx| without gx");
   DVD_REQUIRE(gy && gamma && mean && var && workspace, "bnrelu bwd: null pointer");
   DVD_REQUIRE(x || !g_gamma, "bnrelu bwd: the gamma gradient needs the BatchNorm input");
   DVD_REQUIRE(!relu || y, "bnrelu bwd: the ReLU mask needs the forward output");
@@ -267,15 +291,16 @@ int dvd_bnrelu_bwd_t(const void* gy, const void* y, const void* x, const float* 
   const long long blocks = (long long)C * records;
   DVD_REQUIRE(blocks < (1LL << 31), "bnrelu bwd: grid too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  float* pmax = g_amax ? reinterpret_cast<float*>(static_cast<float2*>(workspace) + (size_t)N * C * chunks) : nullptr;
+  float* pmax = (g_amax || gx_amax) ? reinterpret_cast<float*>(static_cast<float2*>(workspace) + (size_t)N * C * chunks) : nullptr;
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::bnrelu_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s,
                                          static_cast<const T*>(gy), static_cast<const T*>(y), static_cast<const T*>(x), gamma, mean,
                                          var, eps, static_cast<T*>(gx), static_cast<T*>(g_residual),
                                          static_cast<float2*>(workspace), N, C, HW, chunks, relu, pmax, npb));
   DVD_LAUNCH_OK();
-  if (g_gamma || g_beta || g_amax) {
+  if (g_gamma || g_beta || g_amax || gx_amax) {
     hipLaunchKernelGGL(dvd::bnrelu_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, s,
-                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, records, pmax, g_amax, out_scale);
+                       static_cast<const float2*>(workspace), var, eps, g_gamma, g_beta, C, records, pmax, g_amax, out_scale,
+                       gamma, gx_amax);
     DVD_LAUNCH_OK();
   }
   return DVD_OK;

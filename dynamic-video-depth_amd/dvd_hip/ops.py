@@ -6,6 +6,8 @@ stream.  They never touch tensor contents on the host and never fall back to
 PyTorch arithmetic: a tensor that is not on a GPU is an error.
 """
 import ctypes
+import os
+import sys
 
 import torch
 
@@ -136,9 +138,24 @@ def new_scalar(device):
     return out
 
 
+_AMAX_LOG = {} if os.environ.get('DVD_AMAX_LOG') else None      # developer aid: who still needs a reduction pass (printed at exit)
+if _AMAX_LOG is not None:
+    import atexit
+    import traceback
+
+    def _amax_report():
+        for k, n in sorted(_AMAX_LOG.items(), key=lambda kv: -kv[1]):
+            print('amax x%d %s' % (n, k), file=sys.stderr)
+    atexit.register(_amax_report)
+
+
 def amax(t):
     """max|t| by the reduction kernel (one read of the tensor) -> 1-element GPU tensor."""
     t = _dev32(t, 'tensor')
+    if _AMAX_LOG is not None:
+        fr = traceback.extract_stack(limit=6)[:-1]
+        key = (tuple(t.shape), ' < '.join('%s:%d' % (f.name, f.lineno) for f in reversed(fr)))
+        _AMAX_LOG[key] = _AMAX_LOG.get(key, 0) + 1
     out = new_scalar(t.device)
     if t.numel():
         _lib.check(_lib.load().dvd_amax(_p(t), ctypes.c_longlong(t.numel()), _p(out), _stream()), 'dvd_amax')

@@ -512,6 +512,16 @@ int dvd_bnrelu_bwd_t(const void* gy, const void* y, const void* x, const float* 
                      float eps, void* gx, void* g_residual, float* g_gamma, float* g_beta, void* workspace,
                      size_t workspace_bytes, int f16, const float* out_scale, int N, int C, int HW, int relu, float* g_amax,
                      dvd_stream_t stream);
+/* The same with the maxima the consuming convolutions take their operand scale from (round 6; before: a dvd_amax pass over
+ * the tensor): y_amax[0] = max(y_amax[0], max|y|); gx_amax[0] = max(gx_amax[0], max|gx|) (exact: |gamma / sqrt(var + eps)| *
+ * max|g| per channel).  NULL: not wanted.  fp32 and fp16 storage alike. */
+int dvd_bnrelu_fwd_m(const void* x, const void* residual, const float* gamma, const float* beta, const float* mean,
+                     const float* var, float eps, void* y, int f16, int N, int C, int HW, int relu, float* y_amax,
+                     dvd_stream_t stream);
+int dvd_bnrelu_bwd_m(const void* gy, const void* y, const void* x, const float* gamma, const float* mean, const float* var,
+                     float eps, void* gx, void* g_residual, float* g_gamma, float* g_beta, void* workspace,
+                     size_t workspace_bytes, int f16, const float* out_scale, int N, int C, int HW, int relu, float* g_amax,
+                     float* gx_amax, dvd_stream_t stream);
 int dvd_upsample_bilinear_fwd_t(const void* x, void* y, int f16, long long planes, int H_in, int W_in, int H_out, int W_out,
                                 int align_corners, dvd_stream_t stream);
 int dvd_upsample_bilinear_bwd_t(const void* gy, void* gx, int f16, long long planes, int H_in, int W_in, int H_out, int W_out,

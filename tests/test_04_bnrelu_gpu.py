@@ -43,7 +43,18 @@ def test_matches_aten(N, C, H, W, res, relu):
     xg = x.cuda().requires_grad_(True)
     rg = r.cuda().requires_grad_(True) if res else None
     y = bn_eval_relu(bng, xg, residual=rg, relu=relu)
+    # round 6: the pass reports max|y| (the consuming convolution's operand scale) -- exactly, not a bound
+    from dvd_hip.ops import known_amax
+    assert known_amax(y) is not None and float(known_amax(y)) == float(y.detach().abs().max())
+    seen = {}
+    y.register_hook(lambda g: None)
+    xg.register_hook(lambda g: seen.__setitem__('gx', (known_amax(g), g.detach().abs().max())))
+    if res:
+        rg.register_hook(lambda g: seen.__setitem__('gr', (known_amax(g), g.detach().abs().max())))
     y.backward(up.cuda())
+    for k, (am, true_max) in seen.items():      # ... and max|gx|, max|g_residual| ride on the gradients it hands on
+        assert am is not None and float(am) == float(true_max), k
+    assert 'gx' in seen
     got = {'y': y.detach(), 'gx': xg.grad, 'gw': bng.weight.grad, 'gb': bng.bias.grad}
     if res:
         got['gr'] = rg.grad
