@@ -82,6 +82,49 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const T* __restrict
   gx[i] = s * (out_scale ? out_scale[0] : 1.0f);
 }
 
+// Round 6: a thread owns the 2 x 2 input pixels (2 oy + {0, 1}, 2 ox + {0, 1}) -- together they are fed by the four windows
+// (oy + {0, 1}, ox + {0, 1}), whose winner bytes and gradients it loads ONCE (the pixel-per-thread kernel above loads them per
+// pixel: 9 byte + up to 9 dword loads per 2 x 2 block against 4 + 4, behind a 64-bit division per pixel; 1.2 ms per launch =
+// 0.85 TB/s).  Every pixel adds its windows in the order of the kernel above: bit-identical.
+template <class T>
+__global__ __launch_bounds__(256) void maxpool3s2_bwd2_kernel(const T* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                                              float* __restrict__ gx, int H, int W, int Ho, int Wo,
+                                                              unsigned total_blocks2, const float* __restrict__ out_scale) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;      // over (plane, oy, ox) of the 2 x 2 blocks: Hb x Wb per plane
+  if (i >= total_blocks2) return;
+  const unsigned Wb = (unsigned)(W + 1) >> 1, Hb = (unsigned)(H + 1) >> 1;
+  const unsigned ox = i % Wb, r = i / Wb, oy = r % Hb, pl = r / Hb;
+  const T* gp = gy + (size_t)pl * Ho * Wo;
+  const unsigned char* ip = idx + (size_t)pl * Ho * Wo;
+  const bool r1 = (int)oy + 1 < Ho, c1 = (int)ox + 1 < Wo;          // windows of the next output row / column exist
+  const size_t o00 = (size_t)oy * Wo + ox;
+  // (oy < Ho and ox < Wo always: Hb == Ho and Wb == Wo for this pooling geometry)
+  const int k00 = ip[o00], k01 = c1 ? ip[o00 + 1] : -1, k10 = r1 ? ip[o00 + Wo] : -1, k11 = (r1 && c1) ? ip[o00 + Wo + 1] : -1;
+  const float g00 = ldf(gp + o00), g01 = c1 ? ldf(gp + o00 + 1) : 0.0f, g10 = r1 ? ldf(gp + o00 + Wo) : 0.0f,
+              g11 = (r1 && c1) ? ldf(gp + o00 + Wo + 1) : 0.0f;
+  const float sc = out_scale ? out_scale[0] : 1.0f;
+  auto take = [](float s, int k, int tap, float g) { return k == tap ? s + g : s; };
+  // pixel (even, even): window (oy, ox) tap 4 | (even, odd): (oy, ox) tap 5, (oy, ox + 1) tap 3
+  // pixel (odd, even): (oy, ox) tap 7, (oy + 1, ox) tap 1 | (odd, odd): taps 8, 6, 2, 0 of the four windows
+  const float p00 = take(0.0f, k00, 4, g00);
+  const float p01 = take(take(0.0f, k00, 5, g00), k01, 3, g01);
+  const float p10 = take(take(0.0f, k00, 7, g00), k10, 1, g10);
+  const float p11 = take(take(take(take(0.0f, k00, 8, g00), k01, 6, g01), k10, 2, g10), k11, 0, g11);
+  float* dst = gx + ((size_t)pl * H + 2 * oy) * W + 2 * ox;
+  const bool xin = (int)(2 * ox + 1) < W, yin = (int)(2 * oy + 1) < H;
+  if (xin && !(W & 1)) {                                               // even widths: 8-byte aligned pairs
+    *reinterpret_cast<float2*>(dst) = make_float2(p00 * sc, p01 * sc);
+    if (yin) *reinterpret_cast<float2*>(dst + W) = make_float2(p10 * sc, p11 * sc);
+  } else {
+    dst[0] = p00 * sc;
+    if (xin) dst[1] = p01 * sc;
+    if (yin) {
+      dst[W] = p10 * sc;
+      if (xin) dst[W + 1] = p11 * sc;
+    }
+  }
+}
+
 // x[:, :, ::2, ::2] as a contiguous tensor, and its backward (zeros with gy at the even positions): the stride-2 entry of a
 // ResNeXt stage -- a strided 3x3 'same' convolution is evaluated as the stride-1 kernel's output sub-sampled, a strided 1x1
 // shortcut as the 1x1 kernel on the sub-sampled input (dvd_hip/conv.py XConv2d; third_party/midas_blocks.py:35-50 via
@@ -167,9 +210,16 @@ int dvd_maxpool3s2_bwd(const void* gy, int gy_f16, const unsigned char* index, f
   const long long total = planes * H * W;
   DVD_REQUIRE((total + 255) / 256 < (1LL << 31), "maxpool bwd: too large");
   dvd::bytes_add(DVD_BYTES_POOL, (double)planes * (4.0 * H * W + (double)Ho * Wo * ((gy_f16 ? 2 : 4) + 1)));
-  DVD_DISPATCH_T(gy_f16, hipLaunchKernelGGL(dvd::maxpool3s2_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                                            static_cast<hipStream_t>(stream), static_cast<const T*>(gy), index, gx, H, W, Ho, Wo,
-                                            total, out_scale));
+  const long long blocks2 = planes * Ho * Wo;            // 2 x 2 input blocks = outputs ((H + 1) / 2 == Ho for this geometry)
+  if (blocks2 < (1LL << 31) && planes * (long long)Ho < (1LL << 31)) {
+    DVD_DISPATCH_T(gy_f16, hipLaunchKernelGGL(dvd::maxpool3s2_bwd2_kernel<T>, dim3((unsigned)((blocks2 + 255) / 256)), dim3(256), 0,
+                                              static_cast<hipStream_t>(stream), static_cast<const T*>(gy), index, gx, H, W, Ho, Wo,
+                                              (unsigned)blocks2, out_scale));
+  } else {
+    DVD_DISPATCH_T(gy_f16, hipLaunchKernelGGL(dvd::maxpool3s2_bwd_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                                              static_cast<hipStream_t>(stream), static_cast<const T*>(gy), index, gx, H, W, Ho, Wo,
+                                              total, out_scale));
+  }
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

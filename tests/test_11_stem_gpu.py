@@ -56,7 +56,7 @@ def test_stem_forward_and_gradients(N, H, W):
 def test_maxpool_routes_gradients_like_aten_including_ties():
     from dvd_hip import conv as C
     torch.manual_seed(3)
-    for (N, Cc, H, W) in ((2, 4, 12, 18), (1, 3, 9, 7)):
+    for (N, Cc, H, W) in ((2, 4, 12, 18), (1, 3, 9, 7), (2, 2, 10, 9), (1, 2, 7, 12), (1, 1, 1, 1), (1, 1, 2, 3)):
         x = torch.relu(torch.randn(N, Cc, H, W))          # whole windows of zeros: the tie rule decides
         x[0, 0, :4, :6] = 1.0                              # a plateau of equal maxima
         g = torch.randn(N, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
