@@ -55,6 +55,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: 
 #ifndef DVD_XCONV_ROLL
 #define DVD_XCONV_ROLL 1
 #endif
+#ifndef DVD_XCONV_SPARE
+#define DVD_XCONV_SPARE 0     // 1: the per-tap loop stages past the last chunk unconditionally (rounds 2-5)
+#endif
 constexpr int kXHeader = 16;       // uint4 cells in front of the fragments
 
 // value of A's element as the pack kernel sees it (BatchNorm scale folded in): shared by the amax and the pack kernels
@@ -662,6 +665,8 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     // and split at the end of step kt + 1.
     auto step_one = [&](int kt, f16x8 (&bc)[TN][BT], const RawSet& rs, RawSet& ro) {
       __syncthreads();
+      // (unconditional on purpose: with block-uniform branches around the tail's spare requests and splits -- 3 of 16 chunks,
+      //  what paid in the per-tap loop below -- this loop ran 3-6 % SLOWER: the branches cost it its counted waits)
       load_a(ra, kt + 2 < nkt ? kt + 2 : kt);
       load_raw_to(ro, kt + 3 < a.nkc ? kt + 3 : a.nkc - 1);
       const u32x4* Ac = sA + ((kt + 1) & 1) * AS + al;
@@ -741,8 +746,15 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
         if (kDirect) {
           if (kc + 1 < a.nkc) stage_direct((kc + 1) & 1, kc + 1);
         } else {
+#if DVD_XCONV_SPARE
           split_write((kc + 1) & 1, kc + 1);
           load_raw(kc + 2 < a.nkc ? kc + 2 : kc);
+#else
+          // (block-uniform branches: with two chunks per tile -- the grouped layers -- the unconditional form of rounds 2-5
+          //  split one chunk in three and requested two in four for nothing)
+          if (kc + 1 < a.nkc) split_write((kc + 1) & 1, kc + 1);
+          if (kc + 2 < a.nkc) load_raw(kc + 2);
+#endif
         }
         ++kc;
       }
