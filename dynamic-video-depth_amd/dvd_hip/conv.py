@@ -33,10 +33,12 @@ from .ops import _p, _stream, _workspace, amax_of, chansum, known_amax, new_scal
 #   no_maskfuse the ReLU mask of a BatchNorm+ReLU site always in the site's own mask pass (never in its consumer's epilogue)
 #   no_packplan every captured graph packs its weights itself (two launches per weight tensor and graph)
 #   no_chansum  bias gradients by an ATen sum (and max|gy| by dvd_amax) instead of one dvd_chansum read
+#   no_s2       stride-2 3x3 convolutions as rounds 2-5 ran them: the stride-1 kernel's output sub-sampled, the gradient
+#               zero-interleaved in HBM (csrc/pool.hip) in front of the stride-1 backward-data kernel
 #   rowsum      (opt-in experiment) a pre-masked site takes its per-channel sums from dvd_xwgrad1s_rowsum and max|g| from the
 #               consumer's epilogue instead of running its sum pass
 AB = {k: False for k in ('gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse',
-                         'no_chansum', 'no_packplan',
+                         'no_chansum', 'no_packplan', 'no_s2',
                          'rowsum')}
 for _k in filter(None, _os.environ.get('DVD_AB', '').split(',')):
     if _k not in AB:
@@ -532,7 +534,10 @@ class GroupedConv3x3C16(nn.Conv2d):
         st = self.stride[0]
         if x.is_cuda and x.dtype in ACT_DTYPES and not AB['no_c16'] and (st == 1 or not AB['gconv32']):
             if not AB['gconv32']:
-                y = _xconv(x, _pair_groups_of_16(self.weight), None, None, False, False, self.groups // 2)
+                w32 = _pair_groups_of_16(self.weight)
+                if st == 2 and xconv_s2_supported(x, w32, self.groups // 2):
+                    return _xconv_s2(x, w32, None, self.groups // 2)
+                y = _xconv(x, w32, None, None, False, False, self.groups // 2)
                 # the stride-2 entry of stage 2: out[i][j] of a strided 'same' 3x3 is the stride-1 result at [s*i][s*j]
                 # (4x the needed work, still half of MIOpen's per-image im2col + GEMM + col2im path)
                 return y if st == 1 else _subsample(y, st)
@@ -779,16 +784,27 @@ def xconv_packed(weight, transposed, groups=1):
 
 
 def _xconv_run(x, packed, Cout, KS, bias=None, residual=None, mask_src=None, relu_in=False, relu_out=False,
-               res_relu=False, groups=1, bn=None, x_amax=None, y_amax=None):
+               res_relu=False, groups=1, bn=None, x_amax=None, y_amax=None, stride=1, out_hw=None):
     """bn = (gamma | None, beta | None, mean, var, eps): eval-mode BatchNorm of the output, fused into the epilogue.
     x_amax: the input's max|x| scalar (computed here if not given); y_amax: optional zeroed 1-element tensor that
-    receives max|y|."""
+    receives max|y|.  stride 2: the 3x3 / stride 2 / padding 1 forward; stride -2: its backward-data pass (x is the gradient
+    of the strided output, out_hw the full-resolution height and width), see include/dvd_hip.h."""
     N, Cin, H, W = x.shape
     h16 = _is16(x)
     if x_amax is None and not h16:
         x_amax = amax_of(x)
-    y = torch.empty(N, Cout, H, W, device=x.device, dtype=x.dtype)
     flags = int(bool(relu_in)) | (int(bool(relu_out)) << 1) | (int(bool(res_relu)) << 2)
+    if stride == 2:
+        y = torch.empty(N, Cout, (H + 1) // 2, (W + 1) // 2, device=x.device, dtype=x.dtype)
+        flags |= 8
+    elif stride == -2:
+        if ((out_hw[0] + 1) // 2, (out_hw[1] + 1) // 2) != (H, W):
+            raise RuntimeError('xconv: a %dx%d gradient is not the stride-2 image of %dx%d' % (H, W, out_hw[0], out_hw[1]))
+        H, W = int(out_hw[0]), int(out_hw[1])
+        y = torch.empty(N, Cout, H, W, device=x.device, dtype=x.dtype)
+        flags |= 16
+    else:
+        y = torch.empty(N, Cout, H, W, device=x.device, dtype=x.dtype)
     lib = _lib.load()
     bnp = None
     if bn is not None:
@@ -903,6 +919,79 @@ class _XConv(torch.autograd.Function):
         if has_res and need[4]:
             gr = gy * (residual > 0).to(gy.dtype) if (res_relu and not res_unmasked) else gy
         return gx, None, gw, gb, gr, None, None, None, None, None, None
+
+
+class _XConvS2(torch.autograd.Function):
+    """y = conv2d(x, w, bias, stride 2, padding 1) for a 3x3 kernel, dense or grouped with >= 32 channels per group
+    (torchvision's Bottleneck.conv2 at the entry of ResNeXt stages 2-4, third_party/midas_blocks.py:35-50).  Rounds 2-5 ran
+    the stride-1 kernel and sub-sampled its output (4x the products, a full-resolution round trip); now the forward stages the
+    haloed input tile as four phase planes (csrc/xconv.hip, XArgs::S2) and the backward-data kernel reads the compact
+    gradient as if it were zero-interleaved (XArgs::ZI).  The weight gradient still takes the interleaved gradient from
+    csrc/pool.hip (dvd_subsample2_bwd) into the stride-1 kernels of csrc/xwgrad3.hip."""
+
+    @staticmethod
+    def forward(ctx, x, x_amax, weight, bias, groups, in_site):
+        ctx.set_materialize_grads(False)
+        ctx.in_site = in_site if (in_site is not None and not AB['no_maskfuse']) else None
+        x = x.contiguous()
+        Cout = weight.shape[0]
+        y_amax = None if _is16(x) else new_scalar(x.device)
+        y = _xconv_run(x, xconv_packed(weight, False, groups), Cout, 3, bias=bias, groups=groups, x_amax=x_amax,
+                       y_amax=_fwd_monitor() if _is16(x) else y_amax, stride=2)
+        ctx.save_for_backward(x, x_amax)
+        ctx.wparam = weight
+        ctx.cfg = (bias is not None, groups)
+        if y_amax is not None:
+            ctx.mark_non_differentiable(y_amax)
+        return y, y_amax
+
+    @staticmethod
+    def backward(ctx, gy, _g_amax):
+        x, x_amax = ctx.saved_tensors
+        weight = ctx.wparam
+        has_bias, groups = ctx.cfg
+        if gy is None:
+            return None, None, None, None, None, None
+        gy = gy.contiguous()
+        need = ctx.needs_input_grad
+        N, Cin, H, W = x.shape
+        h16 = _is16(gy)
+        gx = gw = gb = None
+        want_amax = (need[0] or need[2]) and not h16
+        if has_bias and need[3] and gy.dtype == torch.float32 and not AB['no_chansum']:
+            gb = chansum(gy, want_amax=want_amax and known_amax(gy) is None)
+        g_amax = amax_of(gy) if want_amax else None
+        if need[0]:
+            gx_amax = _gs(3) if h16 else new_scalar(gy.device)
+            gx = _xconv_run(gy, xconv_packed(weight, True, groups), Cin, 3, mask_src=x if ctx.in_site is not None else None,
+                            groups=groups, x_amax=g_amax, y_amax=gx_amax, stride=-2, out_hw=(H, W))
+            if not h16:
+                set_amax(gx, gx_amax)
+            if ctx.in_site is not None:
+                ctx.in_site.wrote(gx, None if h16 else gx_amax)
+        if need[2]:
+            gyf = torch.empty(N, gy.shape[1], H, W, device=gy.device, dtype=gy.dtype)       # zero-interleaved gradient
+            _lib.check(_lib.load().dvd_subsample2_bwd(_p(gy), _p(gyf), int(h16), N * gy.shape[1], H, W, _stream()),
+                       'dvd_subsample2_bwd')
+            gw = xconv_wgrad(x, gyf, weight.shape, False, groups, x_amax=x_amax, g_amax=g_amax)
+        if has_bias and need[3] and gb is None:
+            gb = gy.sum((0, 2, 3), dtype=torch.float32) * _gs(1) if h16 else gy.sum((0, 2, 3))
+        return gx, None, gw, gb, None, None
+
+
+def xconv_s2_supported(x, weight, groups):
+    """3x3 / stride 2 / padding 1 on the strided forms of csrc/xconv.hip: whole 16-channel chunks per group (the
+    buffer-addressed main loop), grouped layers with at least 32 channels per group."""
+    cpg = weight.shape[1]
+    return (x.is_cuda and x.dtype in ACT_DTYPES and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3) and
+            cpg % 16 == 0 and (weight.shape[0] // groups) % 16 == 0 and (groups == 1 or cpg >= 32) and
+            not AB['no_xconv'] and not AB['no_s2'])
+
+
+def _xconv_s2(x, weight, bias, groups=1):
+    x_amax = None if _is16(x) else amax_of(x)
+    y, y_amax = _XConvS2.apply(x, x_amax, weight, bias, groups, getattr(x, '_dvd_site', None))
+    return set_amax(y, y_amax)
 
 
 def _xconv(x, weight, bias, residual, relu_in, res_relu, groups=1, alias=False, res_unmasked=False):
@@ -1161,6 +1250,8 @@ class XConv2d(nn.Conv2d):
         if (x.is_cuda and x.dtype in ACT_DTYPES and k == (3, 3) and st[0] == st[1] and st[0] > 1 and
                 tuple(self.padding) == (1, 1) and tuple(self.dilation) == (1, 1) and
                 (self.groups == 1 or self.in_channels // self.groups >= 32) and not AB['no_xconv']):
+            if st[0] == 2 and xconv_s2_supported(x, self.weight, self.groups):
+                return _xconv_s2(x, self.weight, self.bias, self.groups)
             # out[i][j] of a stride-s 'same' 3x3 convolution is out1[s*i][s*j] of the stride-1 one
             y = _xconv(x, self.weight, self.bias, None, False, False, self.groups)
             return _subsample(y, st[0])

@@ -266,6 +266,14 @@ struct XArgs {
   int nkc, npos, nfi;     // nfi: B staging items per thread (FI == 0 kernels loop over them at run time)
   int relu_in, relu_out, res_relu;
   int vec_out;            // 1x1 kernels: positions are pixels in runs of 8 and every pointer is 16-byte aligned (wide epilogue)
+  // Strided 3x3 convolutions (round 6; stride 1: Hi = H, Wi = W, S2 = ZI = 0).  H x W are always the OUTPUT's dimensions.
+  //   S2 > 0  stride-2 forward: the input is Hi x Wi = (about) 2H x 2W; the haloed (2 TR + 1) x (2 TC + 1) input tile is staged
+  //           as FOUR phase planes of S2 cells, plane (row parity, column parity), pitch P = TC + 1, so that tap (ky, kx) of
+  //           output q = r * P + c is the cell q + ((ky & 1) * 2 + (kx & 1)) * S2 + (ky >> 1) * P + (kx >> 1): a constant
+  //           offset per tap, as at stride 1
+  //   ZI      backward-data of a stride-2 convolution: the input IS the Hi x Wi gradient of the strided output, staged as if it
+  //           were zero-interleaved to H x W (v[2i][2j] = g[i][j]) -- the interleaved tensor never exists in HBM
+  int Hi, Wi, S2, ZI;
 };
 
 // One block = WM x WN waves, each wave TM x TN tiles of 32 x 32; A and B double buffered in LDS, one barrier per
@@ -311,8 +319,9 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   const int grp = blockIdx.y / a.mbpg;                 // group of a grouped convolution (0 for dense)
   const int mt0 = (blockIdx.y - grp * a.mbpg) * MT;
   const int n = blockIdx.z;
-  const size_t plane = (size_t)a.H * a.W;
-  const TX* xn = static_cast<const TX*>(a.x) + ((size_t)n * a.G + grp) * a.Cin * plane;
+  const size_t plane = (size_t)a.H * a.W;                // output plane
+  const size_t planeI = (size_t)a.Hi * a.Wi;             // input plane (differs for the strided forms only)
+  const TX* xn = static_cast<const TX*>(a.x) + ((size_t)n * a.G + grp) * a.Cin * planeI;
   const int npos = a.npos, P = a.P, T = a.T, KS = a.KS;
   const int nkt = a.nkc * T;
 
@@ -320,6 +329,32 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   //      every staging step unconditionally (no divergent branches around loads: hipcc would serialise them
   //      with vmcnt(0) waits and park the staging registers in scratch): items beyond the tile load a valid
   //      dummy address and store to the spare cell npos - 1 of the first plane.
+  // staged item p of the haloed tile -> element offset in the input plane (go; ok = inside the image), LDS cell (lp)
+  auto locate = [&](int p, bool live, int& go, bool& ok, int& lp) {
+    if (a.S2) {                                        // block-uniform: stride-2 forward, phase planes
+      const int PI = 2 * a.TC + 1;
+      const int rr = p / PI, cc = p - rr * PI;
+      const int row = 2 * r0 - 1 + rr, col = 2 * c0 - 1 + cc;
+      ok = live && row >= 0 && row < a.Hi && col >= 0 && col < a.Wi;
+      go = ok ? (row * a.Wi + col) : 0;
+      lp = ((rr & 1) * 2 + (cc & 1)) * a.S2 + (rr >> 1) * P + (cc >> 1);
+      return;
+    }
+    const int rr = p / P, cc = p - rr * P;
+    const int row = r0 - a.pad + rr, col = c0 - a.pad + cc;
+    ok = live && row >= 0 && row < a.H && col >= 0 && col < a.W;
+    if (a.ZI) {                                        // virtual zero-interleaved input: only (even, even) cells exist
+      ok = ok && !((row | col) & 1);
+      go = ok ? ((row >> 1) * a.Wi + (col >> 1)) : 0;
+    } else {
+      go = ok ? (row * a.W + col) : 0;
+    }
+    lp = p;
+  };
+  // LDS offset of tap (ky, kx) relative to the centre-less origin of the tile
+  auto tapoff = [&](int ky, int kx) {
+    return a.S2 ? ((ky & 1) * 2 + (kx & 1)) * a.S2 + (ky >> 1) * P + (kx >> 1) : ky * P + kx;
+  };
   int goff[FI], lidx[FI], cig8[FI];
   bool gok[FI];
 #pragma unroll
@@ -327,21 +362,19 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
     const int item = it * NT + tid;
     const int cig = item >= a.NV ? 1 : 0;
     const int p = item - cig * a.NV;
-    const int rr = p / P, cc = p - rr * P;
-    const int row = r0 - a.pad + rr, col = c0 - a.pad + cc;
     const bool live = item < 2 * a.NV;
-    gok[it] = live && row >= 0 && row < a.H && col >= 0 && col < a.W;
-    goff[it] = gok[it] ? (row * a.W + col) : 0;
-    lidx[it] = live ? (cig * npos + p) : (npos - 1);
+    int lp;
+    locate(p, live, goff[it], gok[it], lp);
+    lidx[it] = live ? (cig * npos + lp) : (npos - 1);
     cig8[it] = live ? cig * 8 : 0;
   }
   // FAST: byte offset of channel (0 | 8) of the item's position from the image's base, or an offset beyond the buffer
-  const int planeB = (int)plane * XB;
+  const int planeB = (int)planeI * XB;
   const float sx = IN16 ? 1.0f : pow2_scale(a.x_amax[0]);         // power-of-two operand scales (csrc/dvd_split.h)
   const float sw = pow2_scale(reinterpret_cast<const float*>(a.wp)[0]);
   int voff[FI];
 #pragma unroll
-  for (int it = 0; it < FI; ++it) voff[it] = gok[it] ? (goff[it] + cig8[it] * (int)plane) * XB : (int)0x80000000;
+  for (int it = 0; it < FI; ++it) voff[it] = gok[it] ? (goff[it] + cig8[it] * (int)planeI) * XB : (int)0x80000000;
   const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(
       uniform_ptr(const_cast<TX*>(xn)), 0, FAST ? a.Cin * planeB : 0, 0x00020000);
   typedef RawT RawSet[FI][8];
@@ -381,7 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int ch = (ch0 + e) < a.Cin ? (ch0 + e) : (a.Cin - 1);
-        raw[it][e] = xn[(size_t)ch * plane + goff[it]];
+        raw[it][e] = xn[(size_t)ch * planeI + goff[it]];
       }
     }
     }
@@ -428,15 +461,14 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       const int item = it * NT + tid;
       const int cig = item >= a.NV ? 1 : 0;
       const int p = item - cig * a.NV;
-      const int rr = p / P, cc = p - rr * P;
-      const int row = r0 - a.pad + rr, col = c0 - a.pad + cc;
       const bool live = item < 2 * a.NV;
-      const bool ok = live && row >= 0 && row < a.H && col >= 0 && col < a.W;
-      const int go = ok ? (row * a.W + col) : 0;
+      int go, lp;
+      bool ok;
+      locate(p, live, go, ok, lp);
       const int ch0 = kc * 16 + (live ? cig * 8 : 0);
-      const int li = live ? (cig * npos + p) : (npos - 1);
+      const int li = live ? (cig * npos + lp) : (npos - 1);
       if constexpr (IN16) {
-        const int vo = ok ? (go + cig * 8 * (int)plane) * XB : (int)0x80000000;
+        const int vo = ok ? (go + cig * 8 * (int)planeI) * XB : (int)0x80000000;
         const int s0 = kc * 16 * planeB;
         unsigned short r16[8];
 #pragma unroll
@@ -446,7 +478,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       }
       float v[8];
       if (FAST) {
-        const int vo = ok ? (go + cig * 8 * (int)plane) * 4 : (int)0x80000000;
+        const int vo = ok ? (go + cig * 8 * (int)planeI) * 4 : (int)0x80000000;
         const int s0 = kc * 16 * planeB;
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -459,7 +491,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int ch = (ch0 + e) < a.Cin ? (ch0 + e) : (a.Cin - 1);
-          v[e] = (float)xn[(size_t)ch * plane + go];
+          v[e] = (float)xn[(size_t)ch * planeI + go];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -619,7 +651,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
       __syncthreads();
       load_a(ra, kt + 2 < nkt ? kt + 2 : kt);
       const u32x4* Ac = sA + ((kt + 1) & 1) * AS + al;
-      const u32x4* Bc = sB + (nc & 1) * 2 * BT * npos + bl + ny * P + nx;      // (past the last step: in range, never used)
+      const u32x4* Bc = sB + (nc & 1) * 2 * BT * npos + bl + tapoff(ny, nx);      // (past the last step: in range, never used)
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -730,7 +762,7 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   auto step = [&](int kt, ARegs& rn) {             // rn holds A(kt + 1) (two-set scheme)
     __syncthreads();
     Frag f;
-    read_frags(f, kt & 1, kc, ky * P + kx);
+    read_frags(f, kt & 1, kc, tapoff(ky, kx));
     if (kSingleA) {
       load_a(rn, kt + 1 < nkt ? kt + 1 : kt);
       __builtin_amdgcn_sched_barrier(0);             // keep the request above the MFMAs (the scheduler sinks it to its use)
@@ -1059,6 +1091,38 @@ static bool pick_tile(int H, int W, int KS, const XCfg& c, XTile& best) {
   return pick_tile_budget(H, W, KS, c, best, kXLdsBudget) || pick_tile_budget(H, W, KS, c, best, 156 * 1024);
 }
 
+// Stride-2 forward (XArgs::S2): TR x TC OUTPUTS per block in a pitch of P = TC + 1, four phase planes of (TR + 1) * P cells.
+static bool pick_tile_s2_budget(int Ho, int Wo, const XCfg& c, XTile& best, int& S2, int budget) {
+  const int NQ = c.NQ(), NT = c.NT();
+  double best_eff = -1.0;
+  for (int nct = 1; nct <= Wo; ++nct) {
+    const int TC = (Wo + nct - 1) / nct, P = TC + 1;
+    if (P > NQ) continue;
+    const int ntc = (Wo + TC - 1) / TC;
+    int trmax = NQ / P;
+    if (trmax > Ho) trmax = Ho;
+    const int ntr = (Ho + trmax - 1) / trmax;
+    const int TR = (Ho + ntr - 1) / ntr;
+    const int s2 = (TR + 1) * P;
+    const int npos = 3 * s2 + NQ + 1;                     // + the spare cell of the staging code
+    const int NV = (2 * TR + 1) * (2 * TC + 1);
+    const int FI = (2 * NV + NT - 1) / NT;
+    if (xconv_lds(c, npos) <= (size_t)budget && FI <= 4 * kXMaxFIDirect) {
+      const double eff = (double)Ho * Wo / ((double)ntr * ntc * NQ) - 1e-6 * nct;
+      if (eff > best_eff) {
+        best_eff = eff;
+        best = {TR, TC, P, ntr, ntc, NV, npos, FI, xconv_lds(c, npos)};
+        S2 = s2;
+      }
+    }
+    if (TC <= 4) break;
+  }
+  return best_eff > -1.0;
+}
+static bool pick_tile_s2(int Ho, int Wo, const XCfg& c, XTile& best, int& S2) {
+  return pick_tile_s2_budget(Ho, Wo, c, best, S2, kXLdsBudget) || pick_tile_s2_budget(Ho, Wo, c, best, S2, 156 * 1024);
+}
+
 template <int TM, int TN, int WM, int WN, bool FAST, bool B1 = false, bool IN16 = false, bool OUT16 = false>
 static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t s) {
   auto go = [&](auto kern) -> int {
@@ -1067,7 +1131,8 @@ static int launch_fi(const XArgs& a, int FI, dim3 grid, size_t lds, hipStream_t 
     DVD_LAUNCH_OK();
     return DVD_OK;
   };
-  const double flops = 2.0 * a.N * (double)a.G * a.Cout * a.Cin * a.T * (double)a.H * a.W;      // (a.Cin / a.Cout: per group)
+  // (a.Cin / a.Cout: per group; ZI: three of four staged cells are structural zeros -- the NEEDED work is counted)
+  const double flops = 2.0 * a.N * (double)a.G * a.Cout * a.Cin * a.T * (double)a.H * a.W * (a.ZI ? 0.25 : 1.0);
   if constexpr (TM >= 4 && !B1 && FAST && DVD_XCONV_ROLL != 0) {
     if (a.T == 1 && FI == 1 && g_xcfg != 6) {
       flops_add(DVD_FLOP_XCONV_1X1_WIDE, flops);
@@ -1221,14 +1286,23 @@ static int xconv_fwd_impl(const void* x, const float* x_amax, const void* packed
   DVD_REQUIRE((long long)H * W * (long long)(Cin_total > Cout_total ? Cin_total : Cout_total) < (1ll << 31),
               "xconv: image too large for 32-bit offsets");
   DVD_REQUIRE(in16 || !out16, "xconv: fp32 input with fp16 output is not a configuration of this kernel");
+  // flags bit 3: stride-2 forward (x is [N, Cin, H, W], y [N, Cout, (H + 1) / 2, (W + 1) / 2]); bit 4: backward-data of a
+  // stride-2 convolution (x is the [N, Cin, (H + 1) / 2, (W + 1) / 2] gradient of the strided output, y [N, Cout, H, W])
+  const int s2 = (flags >> 3) & 1, zi = (flags >> 4) & 1;
+  DVD_REQUIRE(!(s2 && zi), "xconv: stride-2 forward and stride-2 backward-data are different launches");
+  DVD_REQUIRE(!(s2 || zi) || KS == 3, "xconv: the strided forms exist for 3x3 kernels (got %d)", KS);
+  const int Hq = (H + 1) / 2, Wq = (W + 1) / 2;
   const int Cin = Cin_total / groups, Cout = Cout_total / groups;
   // buffer-addressed main loop: whole 16-channel chunks, 31-bit byte offsets inside one image's input channels and
   // inside the packed weights of one block row
   const bool fast = (Cin % 16 == 0) && ((long long)Cin * H * W * 4 < (1ll << 31)) &&
                     ((long long)8 * ((Cin + 15) / 16) * KS * KS * 2048 < (1ll << 31)) && dvd::g_xcfg != 4;
   DVD_REQUIRE(fast || !in16, "xconv: fp16 activations need input channels in multiples of 16 (got %d per group)", Cin);
-  dvd::XCfg c = dvd::pick_cfg(fast ? Cout : (Cout < 128 ? Cout : 128), KS);
+  DVD_REQUIRE(!(s2 || zi) || fast, "xconv: the strided forms need input channels in multiples of 16 (got %d per group)", Cin);
+  // (stride 2: four input cells per output -- blocks of at most 128 channels, fp32 activations on ONE activation stage)
+  dvd::XCfg c = dvd::pick_cfg((fast && !s2) ? Cout : (Cout < 128 ? Cout : 128), KS);
   if (!fast) c.b1 = false;   // the wide shapes exist as FAST kernels only
+  if (s2) c.b1 = true;
   if (in16) c.b1 = false;
   c.in16 = in16 != 0;
   int Hh = H, Ww = W;
@@ -1237,8 +1311,15 @@ static int xconv_fwd_impl(const void* x, const float* x_amax, const void* packed
     Ww = H * W;
   }
   dvd::XTile t;
-  if (c.b1 && !dvd::pick_tile(Hh, Ww, KS, c, t)) c.b1 = false;     // (large kernels: the haloed tile needs more LDS)
-  DVD_REQUIRE(dvd::pick_tile(Hh, Ww, KS, c, t), "xconv: no tile of a %dx%d image with a %dx%d kernel fits the LDS", H, W, KS, KS);
+  int S2 = 0;
+  if (s2) {
+    Hh = Hq;
+    Ww = Wq;
+    DVD_REQUIRE(dvd::pick_tile_s2(Hh, Ww, c, t, S2), "xconv: no stride-2 tile of a %dx%d image fits the LDS", H, W);
+  } else {
+    if (c.b1 && !dvd::pick_tile(Hh, Ww, KS, c, t)) c.b1 = false;     // (large kernels: the haloed tile needs more LDS)
+    DVD_REQUIRE(dvd::pick_tile(Hh, Ww, KS, c, t), "xconv: no tile of a %dx%d image with a %dx%d kernel fits the LDS", H, W, KS, KS);
+  }
   dvd::XArgs a;
   a.x = x;
   a.wp = static_cast<const uint4*>(packed);
@@ -1259,6 +1340,7 @@ static int xconv_fwd_impl(const void* x, const float* x_amax, const void* packed
   a.KS = KS; a.pad = KS / 2; a.T = KS * KS;
   a.TR = t.TR; a.TC = t.TC; a.P = t.P; a.ntr = t.ntr; a.ntc = t.ntc; a.NV = t.NV;
   a.nkc = (Cin + 15) / 16; a.npos = t.npos; a.nfi = t.FI;
+  a.Hi = s2 ? H : (zi ? Hq : Hh); a.Wi = s2 ? W : (zi ? Wq : Ww); a.S2 = S2; a.ZI = zi;
   a.relu_in = flags & 1; a.relu_out = (flags >> 1) & 1; a.res_relu = (flags >> 2) & 1;
   const int mblocks = (Cout + c.blockM() - 1) / c.blockM();
   a.mbpg = mblocks;
@@ -1281,6 +1363,8 @@ static int xconv_fwd_impl(const void* x, const float* x_amax, const void* packed
     if (c.TM == 4 && c.WN == 4) DVD_XGO(4, 2, 2, 4);
     if (c.TM == 4) DVD_XGO(4, 2, 2, 2);
     if (c.WM == 2 && c.b1) return dvd::launch_fi<2, 2, 2, 2, true, true>(a, t.FI, grid, lds, s);
+    if (c.TM == 2 && c.WM == 1 && c.b1) return dvd::launch_fi<2, 2, 1, 4, true, true>(a, t.FI, grid, lds, s);     // (stride 2 only)
+    if (c.TM == 1 && c.b1) return dvd::launch_fi<1, 2, 1, 4, true, true>(a, t.FI, grid, lds, s);
     if (c.WM == 2) DVD_XGO(2, 2, 2, 2);
     if (c.TM == 2) DVD_XGO(2, 2, 1, 4);
     DVD_XGO(1, 2, 1, 4);

@@ -386,7 +386,14 @@ int dvd_chansum(const float* x, int N, int C, long long HW, float* out, float* a
  *   flags bit0: act_in = ReLU on the input as it is staged (conv(relu(x)) of ResidualConvUnit),
  *         bit1: act_out = ReLU, bit2: res' = relu(residual) instead of residual;
  *   bias [Cout], residual / mask_src [N,Cout,H,W] may be NULL.  mask_src is the ReLU mask of the
- *   backward-data pass (gx = dgrad(gy) * [x > 0]). */
+ *   backward-data pass (gx = dgrad(gy) * [x > 0]).
+ *   Stride 2 (3x3 kernels, nn.Conv2d(.., 3, stride=2, padding=1): torchvision's Bottleneck.conv2 at the entry of ResNeXt
+ *   stages 2-4, reached through third_party/midas_blocks.py:35-50).  H x W are the dimensions of the FULL-resolution tensor:
+ *         bit3: stride-2 forward -- x is [N,Cin,H,W], y (and residual / mask_src) [N,Cout,(H+1)/2,(W+1)/2]; the haloed input
+ *               tile is staged in LDS as four phase planes, every tap stays one constant LDS offset;
+ *         bit4: backward-data of that convolution -- x is the gradient [N,Cin,(H+1)/2,(W+1)/2] of the strided output (Cin =
+ *               the convolution's output channels, weights packed transposed), y [N,Cout,H,W]; the kernel stages the
+ *               gradient AS IF zero-interleaved (v[2i][2j] = g[i][j]): the interleaved tensor is never written to HBM. */
 /* Channel counts are totals; groups > 1 = grouped convolution with weight [Cout][Cin / groups][k][k] (nn.Conv2d's
  * layout): the 64-channels-per-group 3x3 convolutions of ResNeXt stage 4 run here with groups = 32. */
 size_t dvd_xconv_packed_bytes(int Cout, int Cin, int KS, int groups, int transposed);

@@ -207,6 +207,10 @@ GROUPED = [
     (1, 2048, 32, 12, 21, 2),        # its stride-2 entry
     (1, 1024, 32, 13, 23, 2),        # stage 3's stride-2 entry (32 per group), odd image
     (2, 96, 3, 9, 14, 1),            # group counts / sizes that are multiples of nothing much
+    (1, 64, 2, 24, 41, 2),           # stride 2 on the strided kernels (round 6): even x odd image, one tile
+    (2, 128, 2, 50, 90, 2),          # ... several tiles per image (64 per group: 64-channel blocks), ragged last tile row
+    (1, 64, 2, 1, 7, 2),             # ... a one-row image
+    (1, 256, 1, 21, 30, 2),          # ... dense: 128-channel blocks, two per image
 ]
 
 
@@ -261,6 +265,44 @@ def test_sixteen_per_group_module_incl_stride_two(stride):
     assert _err(y.detach(), want.detach()) < TOL
     assert _err(xg.grad, xd.grad) < TOL
     assert _err(mg.weight.grad, wd.grad) < 2e-5
+
+
+def test_stride_two_is_the_subsampled_stride_one_result():
+    """The strided kernels (csrc/xconv.hip XArgs::S2 / ZI, conv._XConvS2) against rounds 2-5's form of the same convolution:
+    the stride-1 kernel's output sub-sampled, the gradient zero-interleaved in HBM.  Same products, same split operands (the
+    tensor-wide scales are shared), another accumulation order per output: 2e-6 of the largest element; the module with a
+    bias, in front of a BatchNorm+ReLU site's input (the mask hand-over of conv._Site)."""
+    from dvd_hip import conv as C
+    torch.manual_seed(5)
+    N, Cc, G, H, W = 2, 128, 4, 26, 45
+    mod = C.XConv2d(Cc, Cc, 3, stride=2, padding=1, groups=G, bias=True).cuda()
+    x = torch.randn(N, Cc, H, W, device='cuda')
+    gy = torch.randn(N, Cc, (H + 1) // 2, (W + 1) // 2, device='cuda')
+    outs = []
+    for off in (False, True):
+        C.AB['no_s2'] = off
+        try:
+            xg = x.clone().requires_grad_(True)
+            mod.zero_grad()
+            y = mod(xg)
+            names = set()
+
+            def walk(fn, depth=0):
+                if fn is None or depth > 4:
+                    return
+                names.add(type(fn).__name__)
+                for n, _ in fn.next_functions:
+                    walk(n, depth + 1)
+            walk(y.grad_fn)
+            assert any('XConvS2' in n for n in names) == (not off), names
+            y.backward(gy)
+            outs.append((y.detach().clone(), xg.grad.clone(), mod.weight.grad.clone(), mod.bias.grad.clone()))
+        finally:
+            C.AB['no_s2'] = False
+    for name, a, b in zip(('y', 'gx', 'gw', 'gb'), outs[0], outs[1]):
+        e = float((a - b).abs().max() / b.abs().max())
+        print('%s: native vs sub-sampled stride 1: %.2e of max' % (name, e))
+        assert e < 2e-6, name
 
 
 def test_fused_input_relu_residual_and_its_backward():

@@ -162,6 +162,37 @@ def test_conv_fp16_activations_forward_input_and_weight_gradient(N, Cin, Cout, H
     assert float(st[3]) >= 0.99 * float(xg.grad.float().abs().max())
 
 
+@pytest.mark.parametrize('N,Cc,G,H,W', [(2, 128, 4, 26, 45), (1, 128, 2, 50, 90), (1, 64, 4, 13, 22), (1, 256, 1, 21, 30)])
+def test_stride_two_conv_fp16_activations(N, Cc, G, H, W):
+    """The 3x3 / stride 2 convolutions at the entries of ResNeXt stages 2-4 (torchvision Bottleneck.conv2 through
+    third_party/midas_blocks.py:35-50) on the strided kernels with fp16 activations (csrc/xconv.hip XArgs::S2 / ZI, IN16):
+    forward, input gradient and weight gradient against float64; 16 per group through conv.GroupedConv3x3C16."""
+    from dvd_hip import conv as C
+    torch.manual_seed(Cc + G + H)
+    st = _state()
+    if Cc // G == 16:
+        mod = C.GroupedConv3x3C16(Cc, stride=2)
+    else:
+        mod = C.XConv2d(Cc, Cc, 3, stride=2, padding=1, groups=G, bias=False)
+    x32, x16 = _h(torch.randn(N, Cc, H, W))
+    g32, g16 = _h(torch.randn(N, Cc, (H + 1) // 2, (W + 1) // 2))
+    xd = x32.double().requires_grad_(True)
+    wd = mod.weight.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, stride=2, padding=1, groups=G)
+    yd.backward(g32.double())
+    mod = mod.cuda()
+    xg = x16.requires_grad_(True)
+    y = mod(xg)
+    assert y.dtype == torch.float16 and y.shape == yd.shape
+    assert 'XConvS2' in type(y.grad_fn).__name__ or any('XConvS2' in type(n).__name__ for n, _ in y.grad_fn.next_functions)
+    y.backward(g16)
+    tag = 'a16 stride-2 conv %s' % ((N, Cc, G, H, W),)
+    _chk(tag + ' y', y.detach(), yd.detach(), 1.01 * H_EPS, 4e-6)
+    _chk(tag + ' gx', xg.grad, xd.grad, 1.01 * H_EPS, 4e-6)
+    _chk(tag + ' gw', mod.weight.grad, wd.grad, 0.0, 2e-5)
+    assert float(st[3]) >= 0.99 * float(xg.grad.float().abs().max())
+
+
 def test_conv_bn_relu_fused_fp16():
     """conv + eval-mode BatchNorm + residual + ReLU in one launch, fp16 in / out, and its backward through the masked pass."""
     from dvd_hip import conv as C
