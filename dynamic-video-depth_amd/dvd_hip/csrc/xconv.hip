@@ -58,6 +58,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: 
 #ifndef DVD_XCONV_SPARE
 #define DVD_XCONV_SPARE 0     // 1: the per-tap loop stages past the last chunk unconditionally (rounds 2-5)
 #endif
+#ifndef DVD_XCONV_DIRECT_BATCH
+#define DVD_XCONV_DIRECT_BATCH 4   // direct staging (k >= 5, stride 2): items whose loads are in flight together (1: rounds 2-5)
+#endif
 constexpr int kXHeader = 16;       // uint4 cells in front of the fragments
 
 // value of A's element as the pack kernel sees it (BatchNorm scale folded in): shared by the amax and the pack kernels
@@ -457,6 +460,50 @@ __global__ __launch_bounds__(64 * WM * WN, B1 ? 3 : 2) void xconv_kernel(const X
   // direct staging (kDirect): load, split and store item by item, nothing kept in registers across the MFMAs
   auto stage_direct = [&](int buf, int kc) {
     u32x4* dst = sB + (B1 ? 0 : buf * 2 * BT * npos);
+    if constexpr (FAST && DVD_XCONV_DIRECT_BATCH > 1) {
+      // items in batches of U: the 8 U loads of a batch are in flight together (one item at a time exposed one memory round
+      // trip per item: 9 per chunk for a stride-2 tile, up to 16 for the hourglass's 11x11 branches).  Items past the tile
+      // (the last batch's spare slots) are not live: an out-of-range offset, the spare LDS cell.
+      constexpr int U = DVD_XCONV_DIRECT_BATCH;
+      const int s0 = kc * 16 * planeB;
+      for (int it0 = 0; it0 < a.nfi; it0 += U) {
+        int vo[U], li[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int item = (it0 + u) * NT + tid;
+          const int cig = item >= a.NV ? 1 : 0;
+          const bool live = item < 2 * a.NV;
+          int go, lp;
+          bool ok;
+          locate(item - cig * a.NV, live, go, ok, lp);
+          vo[u] = ok ? (go + cig * 8 * (int)planeI) * XB : (int)0x80000000;
+          li[u] = live ? (cig * npos + lp) : (npos - 1);
+        }
+        RawT r[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if constexpr (IN16) r[u][e] = __builtin_amdgcn_raw_buffer_load_b16(srdB, vo[u], s0 + e * planeB, 0);
+            else r[u][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdB, vo[u], s0 + e * planeB, 0));
+          }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if constexpr (IN16) {
+            dst[li[u]] = cell16(r[u]);
+          } else {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = a.relu_in ? fmaxf(r[u][e], 0.0f) : r[u][e];
+            uint4 h, l;
+            split8_f16(v, sx, h, l);
+            dst[li[u]] = (u32x4){h.x, h.y, h.z, h.w};
+            dst[2 * npos + li[u]] = (u32x4){l.x, l.y, l.z, l.w};
+          }
+        }
+      }
+      return;
+    }
     for (int it = 0; it < a.nfi; ++it) {
       const int item = it * NT + tid;
       const int cig = item >= a.NV ? 1 : 0;
