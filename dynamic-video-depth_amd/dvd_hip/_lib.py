@@ -90,6 +90,8 @@ SIGNATURES = {
     'dvd_scale_add': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_longlong, c_void_p]),
     'dvd_subsample2_fwd': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
     'dvd_subsample2_bwd': (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
+    'dvd_avgpool_fwd': (c_int, [c_void_p, c_void_p, c_int, c_longlong] + [c_int] * 5 + [c_void_p]),
+    'dvd_avgpool_bwd': (c_int, [c_void_p, c_void_p, c_int, c_longlong] + [c_int] * 5 + [c_void_p]),
     'dvd_depth_tail_fwd': (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
     'dvd_depth_tail_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
     'dvd_acc_reg_workspace_bytes': (c_size_t, []),

@@ -509,6 +509,46 @@ def _subsample(t, st):
     return set_amax(y, k) if k is not None else y
 
 
+class _AvgPool(torch.autograd.Function):
+    """F.avg_pool2d(x, k, stride, pad) with PyTorch's defaults on csrc/pool.hip (dvd_avgpool_*; ATen's arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, x, k, st, pad):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        Ho, Wo = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+        y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=x.dtype)
+        _lib.check(_lib.load().dvd_avgpool_fwd(_p(x), _p(y), int(_is16(x)), N * C, H, W, k, st, pad, _stream()), 'dvd_avgpool_fwd')
+        ctx.cfg = (N, C, H, W, k, st, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W, k, st, pad = ctx.cfg
+        gy = gy.contiguous()
+        gx = torch.empty(N, C, H, W, device=gy.device, dtype=gy.dtype)
+        _lib.check(_lib.load().dvd_avgpool_bwd(_p(gy), _p(gx), int(_is16(gy)), N * C, H, W, k, st, pad, _stream()), 'dvd_avgpool_bwd')
+        kg = known_amax(gy)                   # at most ceil(k / st)^2 windows of weight 1 / k^2 hold a pixel: |gx| <= max|gy|
+        return (gx if kg is None else set_amax(gx, kg)), None, None, None
+
+
+class AvgPool2d(nn.AvgPool2d):
+    """Drop-in nn.AvgPool2d: GPU fp32 / fp16 tensors of the default configuration (floor mode, count_include_pad, square
+    window, 2 * padding <= kernel) run on csrc/pool.hip -- the hourglass's AvgPool2d(2) (third_party/hourglass.py:60-158) and
+    FCNUnet's AvgPool2d(3, 2, 1) (networks/FCNUnet.py:64); everything else, and CPU tensors, take ATen."""
+
+    def forward(self, x):
+        def one(v):
+            return v if isinstance(v, int) else (v[0] if v[0] == v[1] else None)
+        k, st, pad = one(self.kernel_size), one(self.stride), one(self.padding)
+        if (x.is_cuda and x.dtype in ACT_DTYPES and x.dim() == 4 and None not in (k, st, pad) and not self.ceil_mode and
+                self.count_include_pad and self.divisor_override is None and 1 <= k <= 7 and 2 * pad <= k):
+            y = _AvgPool.apply(x, k, st, pad)
+            kx = known_amax(x)                # an average of inputs (and padding zeros) never exceeds the largest magnitude
+            return y if kx is None else set_amax(y, kx)
+        return super().forward(x)
+
+
 def _pair_groups_of_16(weight):
     """[C,16,3,3] (16 channels per group) -> the equivalent [C,32,3,3] with groups paired into blocks of 32
     channels and zeros off the 16x16 diagonal blocks (exact: the extra products are with 0.0)."""

@@ -158,6 +158,58 @@ __global__ __launch_bounds__(256) void subsample2_bwd_kernel(const T* __restrict
   }
 }
 
+// nn.AvgPool2d(k, stride, padding) with PyTorch's defaults (count_include_pad: every window is divided by k * k, floor mode):
+// AvgPool2d(2) = the hourglass's down-sampling (third_party/hourglass.py:60-158 `nn.AvgPool2d(2)` in front of every lower level)
+// and AvgPool2d(3, 2, 1) = FCNUnet's (networks/FCNUnet.py:64, --use_cnn).  Until round 6 both ran on ATen
+// (avg_pool2d_out_cuda_frame / avg_pool2d_backward_out_cuda_frame: 2.2 + 1.2 % of the hourglass step,
+// profiles/r04_bench_kernel_trace_hourglass.txt).  Arithmetic as ATen's: the window is summed row by row in fp32 and divided
+// by k * k (a division, not a reciprocal: 1 / 9 is not exact); backward adds gy / (k * k) of the windows that contain the
+// pixel in (row, column) order of the windows.  One thread per output (forward) / input (backward) pixel.
+template <class T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int Ho, int Wo,
+                                                          int k, int st, int pad, long long total) {
+  const float div = (float)(k * k);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const long long r = i / Wo;
+    const int oy = (int)(r % Ho);
+    const T* xp = x + (r / Ho) * H * W;
+    const int y0 = oy * st - pad, x0 = ox * st - pad;
+    float sum = 0.0f;
+    for (int dy = 0; dy < k; ++dy) {
+      const int yy = y0 + dy;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int xx = x0 + dx;
+        if (xx >= 0 && xx < W) sum += (float)xp[yy * W + xx];
+      }
+    }
+    y[i] = (T)(sum / div);
+  }
+}
+template <class T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int H, int W, int Ho, int Wo,
+                                                          int k, int st, int pad, long long total) {
+  const float div = (float)(k * k);
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ix = (int)(i % W);
+    const long long r = i / W;
+    const int iy = (int)(r % H);
+    const T* gp = gy + (r / H) * Ho * Wo;
+    // windows oy with oy * st - pad <= iy < oy * st - pad + k
+    int oy0 = (iy + pad - k + st) / st, ox0 = (ix + pad - k + st) / st;        // ceil((iy + pad - k + 1) / st) for a numerator >= -st + 1
+    if (iy + pad - k + 1 <= 0) oy0 = 0;
+    if (ix + pad - k + 1 <= 0) ox0 = 0;
+    int oy1 = (iy + pad) / st, ox1 = (ix + pad) / st;
+    if (oy1 > Ho - 1) oy1 = Ho - 1;
+    if (ox1 > Wo - 1) ox1 = Wo - 1;
+    float sum = 0.0f;
+    for (int oy = oy0; oy <= oy1; ++oy)
+      for (int ox = ox0; ox <= ox1; ++ox) sum += (float)gp[oy * Wo + ox] / div;
+    gx[i] = (T)sum;
+  }
+}
+
 }  // namespace dvd
 
 extern "C" {
@@ -186,6 +238,40 @@ int dvd_subsample2_bwd(const void* gy, void* gx, int f16, long long planes, int 
   DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::subsample2_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
                                          static_cast<hipStream_t>(stream), static_cast<const T*>(gy), static_cast<T*>(gx), H, W, Ho,
                                          Wo, total));
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_avgpool_fwd(const void* x, void* y, int f16, long long planes, int H, int W, int k, int stride, int pad,
+                    dvd_stream_t stream) {
+  DVD_REQUIRE(x && y && planes > 0 && H > 0 && W > 0, "avgpool fwd: bad arguments");
+  DVD_REQUIRE(k >= 1 && k <= 7 && stride >= 1 && pad >= 0 && 2 * pad <= k, "avgpool fwd: kernel %d stride %d padding %d", k, stride, pad);
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  DVD_REQUIRE(Ho > 0 && Wo > 0, "avgpool fwd: a %dx%d image is smaller than the window", H, W);
+  const long long total = planes * Ho * Wo;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 32768) blocks = 32768;
+  dvd::bytes_add(DVD_BYTES_POOL, (double)planes * ((double)H * W + (double)Ho * Wo) * (f16 ? 2 : 4));
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::avgpool_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(x), static_cast<T*>(y), H, W, Ho,
+                                         Wo, k, stride, pad, total));
+  DVD_LAUNCH_OK();
+  return DVD_OK;
+}
+
+int dvd_avgpool_bwd(const void* gy, void* gx, int f16, long long planes, int H, int W, int k, int stride, int pad,
+                    dvd_stream_t stream) {
+  DVD_REQUIRE(gy && gx && planes > 0 && H > 0 && W > 0, "avgpool bwd: bad arguments");
+  DVD_REQUIRE(k >= 1 && k <= 7 && stride >= 1 && pad >= 0 && 2 * pad <= k, "avgpool bwd: kernel %d stride %d padding %d", k, stride, pad);
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  DVD_REQUIRE(Ho > 0 && Wo > 0, "avgpool bwd: a %dx%d image is smaller than the window", H, W);
+  const long long total = planes * H * W;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 32768) blocks = 32768;
+  dvd::bytes_add(DVD_BYTES_POOL, (double)planes * ((double)H * W + (double)Ho * Wo) * (f16 ? 2 : 4));
+  DVD_DISPATCH_T(f16, hipLaunchKernelGGL(dvd::avgpool_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
+                                         static_cast<hipStream_t>(stream), static_cast<const T*>(gy), static_cast<T*>(gx), H, W, Ho,
+                                         Wo, k, stride, pad, total));
   DVD_LAUNCH_OK();
   return DVD_OK;
 }

@@ -10,15 +10,16 @@ so checkpoints interchange.
 GPU fp32 tensors: every convolution runs on csrc/xconv.hip / csrc/xwgrad3.hip (`conv._xconv`: forward, backward-data and
 backward-weight).  The kernels pad with zeros, the network pads by REFLECTION, so a block reflects its input explicitly
 (ATen reflection_pad2d: an HBM copy) and takes the interior of the zero-padded "same" convolution of the padded tensor -- which
-is the valid convolution the reference computes.  AvgPool2d(3, 2, 1), the channel concatenations and LeakyReLU stay ATen
-elementwise / copy kernels; the x2 bilinear up-sampling (align_corners=True) is csrc/upsample.hip.  CPU tensors take the ATen
+is the valid convolution the reference computes.  AvgPool2d(3, 2, 1) is csrc/pool.hip (round 6: `conv.AvgPool2d`), the x2
+bilinear up-sampling (align_corners=True) csrc/upsample.hip; the channel concatenations and LeakyReLU stay ATen elementwise /
+copy kernels.  CPU tensors take the ATen
 modules, i.e. the reference's own arithmetic (the oracle / golden generator instantiate this class on the CPU).
 """
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..conv import _xconv, upsample_bilinear2x
+from ..conv import AvgPool2d, _xconv, upsample_bilinear2x
 
 
 class Conv2dBlock(nn.Module):
@@ -61,7 +62,7 @@ class FCNUnet(nn.Module):
                 cs.get('pad_type', 'reflect') != 'reflect' or cs.get('stride', 1) != 1):
             raise NotImplementedError('FCNUnet: the configuration of models/scene_flow_motion_field.py:102-105 is implemented '
                                       '(double_conv blocks, avgpool, reflect padding, lrelu, no norm)')
-        self.down_sample = nn.AvgPool2d(kernel_size=3, stride=2, padding=1)
+        self.down_sample = AvgPool2d(kernel_size=3, stride=2, padding=1)      # (nn.AvgPool2d on csrc/pool.hip for GPU tensors)
         self.upsample = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
         self.n_down = n_down
         self.down_conv, self.up_conv = [], []

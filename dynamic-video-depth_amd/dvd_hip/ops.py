@@ -287,7 +287,7 @@ BYTE_CLASSES = ('bnrelu_fwd', 'bnrelu_bwd', 'upsample_fwd', 'upsample_bwd', 'ama
 BYTE_CLASS_KERNELS = {
     'bnrelu_fwd': ('bnrelu_fwd_kernel',), 'bnrelu_bwd': ('bnrelu_bwd', 'bn_mask', 'bnrelu_sum'),
     'upsample_fwd': ('upsample_bilinear_fwd',), 'upsample_bwd': ('upsample_bilinear_bwd', 'upsample_bwd'),
-    'amax': ('amax_kernel', 'chansum_'), 'pack': ('xconv_wamax', 'xconv_pack_kernel'), 'pool': ('maxpool3s2', 'subsample2_'),
+    'amax': ('amax_kernel', 'chansum_'), 'pack': ('xconv_wamax', 'xconv_pack_kernel'), 'pool': ('maxpool3s2', 'subsample2_', 'avgpool_'),
     'gconv_c8': ('gconv3x3_c8',), 'elementwise': ('mul_mask_kernel', 'scale_add_kernel', 'acc_reg_kernel', 'sum_partials_kernel',
                                                   'head1x1_', 'cast_scale_kernel'),
     'adam': ('adam_kernel',), 'geometry': ('unproject_',),

@@ -584,6 +584,14 @@ int dvd_maxpool3s2_bwd(const void* gy, int gy_f16, const unsigned char* index, f
  * (third_party/midas_blocks.py:35-50 via torchvision's Bottleneck.conv2 / downsample). */
 int dvd_subsample2_fwd(const void* x, void* y, int f16, long long planes, int H, int W, dvd_stream_t stream);
 int dvd_subsample2_bwd(const void* gy, void* gx, int f16, long long planes, int H, int W, dvd_stream_t stream);
+/* nn.AvgPool2d(k, stride, pad) with PyTorch's defaults (count_include_pad, floor mode) on [planes, H, W] tensors, fp32 or fp16
+ * (f16 != 0): AvgPool2d(2) of the hourglass (third_party/hourglass.py:60-158), AvgPool2d(3, 2, 1) of FCNUnet
+ * (networks/FCNUnet.py:64); ATen's arithmetic (fp32 window sum / (k * k); backward: gy / (k * k) summed over the windows that
+ * hold the pixel).  y / gy are [planes, (H + 2 pad - k) / stride + 1, (W + 2 pad - k) / stride + 1]. */
+int dvd_avgpool_fwd(const void* x, void* y, int f16, long long planes, int H, int W, int k, int stride, int pad,
+                    dvd_stream_t stream);
+int dvd_avgpool_bwd(const void* gy, void* gx, int f16, long long planes, int H, int W, int k, int stride, int pad,
+                    dvd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -75,3 +75,38 @@ def test_subsample2_equals_strided_slicing_forward_and_backward(shape, dtype):
     ya.backward(go)
     yb.backward(go)
     assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('k,st,pad', [(2, 2, 0), (3, 2, 1)])
+@pytest.mark.parametrize('shape', [(2, 5, 12, 20), (1, 3, 7, 9), (3, 2, 2, 2), (2, 4, 24, 43), (1, 2, 33, 64)])
+def test_avgpool_equals_aten_forward_and_backward(shape, k, st, pad, dtype):
+    """conv.AvgPool2d on csrc/pool.hip (dvd_avgpool_*) against nn.AvgPool2d on the same GPU tensors: the hourglass's
+    AvgPool2d(2) (third_party/hourglass.py:60-158) and FCNUnet's AvgPool2d(3, 2, 1) (networks/FCNUnet.py:64), odd sizes (floor mode
+    drops the last row / column of a 2x2 pool) included.  ATen's arithmetic is reproduced: fp32 bit for bit in the forward
+    (same summation order, one division), one fp32 ulp in the backward of overlapping windows (ATen's order over the windows
+    is its own); fp16 storage: the fp32 result rounded once."""
+    from dvd_hip import conv as C
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g).to(dtype).cuda()
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    ya = C.AvgPool2d(k, st, pad)(a)
+    assert type(ya.grad_fn).__name__.startswith('_AvgPool')
+    yb = torch.nn.AvgPool2d(k, st, pad)(b)
+    assert ya.shape == yb.shape and ya.dtype == yb.dtype
+    tol = 1e-3 if dtype == torch.float16 else 2e-7
+    if dtype == torch.float32:
+        assert torch.equal(ya, yb)
+    else:
+        assert float((ya.float() - yb.float()).abs().max()) <= tol * float(yb.float().abs().max())
+    go = torch.randn(yb.shape, generator=g).to(dtype).cuda()
+    ya.backward(go)
+    yb.backward(go)
+    assert float((a.grad.float() - b.grad.float()).abs().max()) <= tol * float(b.grad.float().abs().max())
+    # against float64 on the CPU (the definition)
+    xd = x.double().cpu().requires_grad_(True)
+    yd = torch.nn.functional.avg_pool2d(xd, k, st, pad)
+    yd.backward(go.double().cpu())
+    assert float((ya.detach().double().cpu() - yd.detach()).abs().max()) <= (2e-3 if dtype == torch.float16 else 1e-6) * float(yd.abs().max())
+    assert float((a.grad.double().cpu() - xd.grad).abs().max()) <= (2e-3 if dtype == torch.float16 else 1e-6) * float(xd.grad.abs().max())

@@ -124,7 +124,7 @@ def test_grouped_conv_modules_on_cpu_are_plain_convolutions():
         assert torch.equal(m(x), ref(x))
     # the A/B switches are exactly these, and none is on by default (DVD_AB is an experimenter's tool, not a configuration)
     assert set(C.AB) == {'gconv32', 'no_c16', 'no_xwgrad3', 'no_xwgrad', 'no_bnfuse', 'no_xconv', 'no_alias', 'no_maskfuse',
-                         'no_chansum', 'no_packplan', 'rowsum'} and not any(C.AB.values())
+                         'no_chansum', 'no_packplan', 'no_s2', 'rowsum'} and not any(C.AB.values())
 
 
 def test_site_handover_detects_a_modified_or_replaced_gradient():
