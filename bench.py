@@ -412,9 +412,11 @@ def main():
                          'default run, which since round 6 also carries the configs4 and rccl_one_rank child lines, inside ~6 minutes)')
     ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '1')),
                     help='1 (default): replay the depth net from HIP graphs; 0: eager launches')
-    ap.add_argument('--depth_chunk', type=int, default=48,
-                    help='images per depth-net forward/backward chunk = per kept-activation graph slot (48: two slots per step; '
-                         '16 / 24 / 48 measured 0.840 / 0.843 / 0.851 iters/s on one box)')
+    ap.add_argument('--depth_chunk', type=int, default=None,
+                    help='images per depth-net forward/backward chunk = per kept-activation graph slot.  Default 48 (two slots per '
+                         '48-pair step; 16 / 24 / 48 measured 0.840 / 0.843 / 0.851 iters/s on one box); --config 4 with more than 32 '
+                         'pairs: 16 -- a slot of 48 images at 768x1344 is 112 GB and needs as much again free for the recompute graph of '
+                         'a chunk that is not kept, so none fits; three 38 GB slots do (64 pairs: 3.07 -> 2.93 s per step)')
     ap.add_argument('--act_fp16', action='store_true',
                     help='fp16 ACTIVATION storage in the depth net (fp32 parameters / accumulation / loss sums): the arithmetic of '
                          'BASELINE configs[4] at the headline image size -- an extra bench line, not the headline')
@@ -429,6 +431,9 @@ def main():
                     help="hbm (default, the contract's `value`): inputs resident in HBM before the timed region; host: every "
                          "step's batch starts in host memory and goes through the pinned double-buffered feeder "
                          "(dvd_hip.datasets.davis_sequence.DeviceFeeder), so the PCIe copy is inside the timed region")
+    ap.add_argument('--mlp_recompute', type=int, default=1, choices=(0, 1),
+                    help='A/B of the scene-flow MLP schedule when the stashes of the whole batch do not fit (configs[4] at 64 pairs): '
+                         '1 = recompute schedule (round 6), 0 = late normaliser (rounds 1-5); see Model.add_arguments')
     ap.add_argument('--no_extras', action='store_true',
                     help='only the headline measurement: without the configs4 and rccl_one_rank sub-records the default N = 1 run '
                          'adds from child processes of this script')
@@ -444,6 +449,10 @@ def main():
         a.act_fp16 = True
         if a.pairs == PAIRS:
             a.pairs = PAIRS_CFG4
+        if a.depth_chunk is None and a.pairs > 32:
+            a.depth_chunk = 16
+    if a.depth_chunk is None:
+        a.depth_chunk = 48
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(a.gpus)
 
@@ -478,7 +487,7 @@ def main():
         if hip.hipMalloc(ctypes.byref(ballast), ctypes.c_size_t(nbytes)) != 0:
             raise SystemExit('DVD_RESERVE_GB: hipMalloc of %d bytes failed' % nbytes)
     opt = make_opt(global_rank=rank, depth_chunk=min(a.depth_chunk, a.pairs), depth_graphs=bool(a.depth_graphs),
-                   midas=a.depth == 'midas', act_fp16=bool(a.act_fp16))
+                   midas=a.depth == 'midas', act_fp16=bool(a.act_fp16), mlp_recompute=int(a.mlp_recompute))
     model = build_model(opt, device, seed=0)
     batch = synthetic.make_batch(a.pairs, H, W, gap=a.gap, seed=1234, rank=rank, device=device)
     epoch = opt.warm_sf + 1            # non-warm phase

@@ -115,6 +115,11 @@ class Model(NetInterface):
         parser.add_argument('--mlp_whole_batch_gb', type=float, default=160.0,
                             help='HBM ceiling for keeping the forward stashes of the whole batch alive so that the '
                                  'warp+loss kernel runs as ONE launch (falls back to one launch per chunk)')
+        parser.add_argument('--mlp_recompute', type=int, default=1,
+                            help='when the forward stashes of the whole batch do not fit --mlp_whole_batch_gb: 1 = one stash-free '
+                                 'forward over all pairs, ONE warp+loss launch, then per chunk the stashed forward again + the '
+                                 'merged backward (3 forward + 2 dX + 2 dW passes per pair at gap 1); 0 = the late-normaliser '
+                                 'schedule of rounds 1-5 (one warp+loss launch per chunk, 3 + 3 + 3 passes)')
         parser.add_argument('--depth_chunk', type=int, default=48,
                             help='images per depth-net forward/backward chunk = per kept-activation graph slot (48: the '
                                  'configuration bench.py measures; two slots per 48-pair step)')
@@ -572,8 +577,15 @@ class Model(NetInterface):
                 mlp_need = B * HW * self._cnn_bytes_per_px() * (steps + (1 if do_reg else 0)) + 24 * B * HW * 4
             else:
                 stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
-                mlp_need = min(B * steps * stash + Bc0 * (gstash + (stash if (do_reg and steps == 1) else 0)),
-                               float(getattr(opt, 'mlp_whole_batch_gb', 160.0)) * 2 ** 30) + 24 * B * HW * 4
+                # what phase 2 will allocate: the stashes of the whole batch if they fit --mlp_whole_batch_gb, else those of
+                # ONE chunk (late-normaliser / recompute schedules).  (Rounds 1-5 reserved min(whole batch, the ceiling) in
+                # the chunked case too: 160 GB for 48 GB of stashes at BASELINE configs[4]'s 64 pairs, and not one depth-net
+                # slot was kept there.)
+                if Bc0 >= B or self._whole_batch_fits(B, Bc0, HW, steps, do_reg):
+                    mlp_need = B * steps * stash + min(Bc0, B) * (gstash + (stash if (do_reg and steps == 1) else 0))
+                else:
+                    mlp_need = Bc0 * (stash * max(steps, 2 if do_reg else 1) + gstash)
+                mlp_need += 24 * B * HW * 4
             depth_1 = self._depths_keep(inp.img_1, fid1, 0, mlp_need, 2 * n_slots)
             depth_2 = self._depths_keep(inp.img_2, fid2, n_slots, mlp_need, 2 * n_slots)
             self._trim_keep_slots(dev, mlp_need)
@@ -623,7 +635,15 @@ class Model(NetInterface):
                     kept = self._depth_graphs.get(('keep', s0 + ci, tuple(chunk.shape), bool(opt.midas)))
                     if kept is None and self._graph_key('fb', chunk) not in self._depth_graphs:
                         may_capture = True
-        late, n_global, capturing = parallel.agree_on_step_plan(dev, not (whole or Bc >= B), B, may_capture)
+        # Round 6: when the forward stashes of the whole batch do NOT fit (BASELINE configs[4]: 64 pairs at 768 x 1344 = 211 GB of
+        # stashes), the late-normaliser schedule below costs 3 forward + 3 dX + 3 dW passes per pair and Euler step -- the
+        # regulariser cannot share the main path's backward while the normaliser is unknown.  The RECOMPUTE schedule runs the
+        # Euler chain once WITHOUT stashes for every pair (the cheapest form of the forward kernel), one warp+loss launch over
+        # the whole batch, and then per chunk the stashed forward again + the merged backward: 3 forward + 2 dX + 2 dW at
+        # gap 1 (2k + k + k instead of (k + 2) x 3 at gap k), same arithmetic as the whole-batch schedule (the recomputed
+        # evaluations are bit-identical: the forward kernel is deterministic).  --mlp_recompute 0 restores the late schedule.
+        recompute = Bc < B and not whole and bool(int(getattr(opt, 'mlp_recompute', 1)))
+        late, n_global, capturing = parallel.agree_on_step_plan(dev, not (whole or Bc >= B or recompute), B, may_capture)
         early_norm = not late
         reg_coef = opt.acc_mul / (3.0 * n_global * HW + 1e-6)
         chunks = [(b0, min(B, b0 + Bc)) for b0 in range(0, B, Bc)]
@@ -634,21 +654,24 @@ class Model(NetInterface):
         def cams_of(b0, b1):
             return {kk: getattr(inp, kk)[b0:b1] for kk in CAM_KEYS}
 
-        def mlp_forward_chunk(b0, b1, keep_first=None):
+        def mlp_forward_chunk(b0, b1, keep_first=None, acc=None, with_stash=True):
             """Euler integration of the scene flow over `steps` frames (:360-367).  keep_first: also
-            return sf_0 and q = P1 + sf_0 of the first evaluation (the regulariser's sf_0, see below)."""
+            return sf_0 and q = P1 + sf_0 of the first evaluation (the regulariser's sf_0, see below).
+            acc: the tensor the integrated flow is accumulated into (default: this chunk of sf_all); with_stash=False: no
+            activation stashes (the first pass of the recompute schedule)."""
             ts = inp.time_stamp_1[b0:b1] if opt.time_dependent else None
             n_pix = (b1 - b0) * HW
             stashes, p_cur, first = [], P1_all[b0:b1], None
+            acc = sf_all[b0:b1] if acc is None else acc
             for i in range(steps):
-                st = mlp.new_stash(n_pix)
+                st = mlp.new_stash(n_pix) if with_stash else None
                 want_next = i + 1 < steps or (keep_first and i == 0)
                 p_next = torch.empty_like(p_cur) if want_next else None
                 # the regulariser's two evaluations ARE Euler evaluations 0 and 1 (see merged_backward_chunk): keep their
                 # outputs (evaluation 0's only when it is not the accumulated flow itself)
                 sf_i = torch.empty_like(p_cur) if (keep_first and i < 2 and steps > 1) else None
                 mlp.forward(p_cur, ts, t_offset=i * time_step, out_scale=inv_div, sf_out=sf_i, p_next=p_next,
-                            acc=sf_all[b0:b1], stash=st)
+                            acc=acc, stash=st)
                 if keep_first and i == 0:
                     first = [sf_i, p_next, None]    # sf_i is None when steps == 1: sf_0 is the accumulated flow itself
                 if keep_first and i == 1:
@@ -759,7 +782,21 @@ class Model(NetInterface):
             ops.unproject_backward(g_P, True, cams['R_1'], cams['K_inv'], out=g_d1_main[b0:b1], accumulate=True)
 
         gst = mlp.new_gstash(min(Bc, B) * HW)
-        if early_norm:
+        if early_norm and recompute and Bc < B and not whole:
+            for b0, b1 in chunks:
+                mlp_forward_chunk(b0, b1, with_stash=False)
+            warp(0, B)
+            parallel.all_reduce_sum_(sums[:4])
+            scalars = ops.loss_finalize(cfg_all, sums)
+            inv = scalars[0:1]
+            ops.scale_add(g_d1_main, g_d1_main, scale_ptr=inv)
+            for b0, b1 in chunks:
+                # the same evaluations again, stashed; their flow goes to a scratch accumulator (sf_all already holds it)
+                st, first = mlp_forward_chunk(b0, b1, keep_first=bool(do_reg), acc=torch.zeros_like(sf_all[b0:b1]))
+                merged_backward_chunk(b0, b1, st, first, gst, inv)
+                del st[:], first
+            parallel.all_reduce_sum_(sums[4:])
+        elif early_norm:
             kept = [mlp_forward_chunk(b0, b1, keep_first=bool(do_reg)) for b0, b1 in chunks]
             warp(0, B)
             # the batch-global normaliser is known before the MLP backward: all-reduce the four loss sums

@@ -123,20 +123,27 @@ def test_two_steps_run_and_change_the_loss():
     assert model._flat_sf.step_count == 2 and model._flat_depth.step_count == 2
 
 
-@pytest.mark.parametrize('whole_gb', [160.0, 0.0])
-def test_pair_chunking_is_invisible(whole_gb):
-    """A stash budget that forces one pair per MLP chunk gives the same step, both when the
+@pytest.mark.parametrize('name', ['fullstep_hourglass_b2_32x48_train', 'fullstep_hourglass_b2_32x48_mseg_gap2'])
+@pytest.mark.parametrize('whole_gb,recompute', [(160.0, 1), (0.0, 1), (0.0, 0)])
+def test_pair_chunking_is_invisible(whole_gb, recompute, name):
+    """A stash budget that forces one pair per MLP chunk gives the same step: when the
     warp+loss kernel still runs once over the whole batch (forward stashes of all chunks kept
-    alive) and when it runs once per chunk."""
-    gd = helpers.load_golden('fullstep_hourglass_b2_32x48_train')
+    alive), when the stashes of the whole batch do not fit and the Euler chain is evaluated twice (stash-free over the
+    batch, stashed again per chunk: the recompute schedule of round 6), and when warp+loss runs once per chunk with the
+    late normaliser (rounds 1-5).  Also at frame gap 2 with --use_motion_seg (two Euler evaluations, the regulariser's
+    second evaluation shared with the chain's)."""
+    gd = helpers.load_golden(name)
     m1, _, batch = _build(gd)
-    m2, _, _ = _build(gd, mlp_stash_gb=1e-6, depth_chunk=1, mlp_whole_batch_gb=whole_gb)
-    a = m1._train_on_batch(6, 0, helpers.loader_batch(batch))
-    b = m2._train_on_batch(6, 0, helpers.loader_batch({k: v.clone() if torch.is_tensor(v) else v for k, v in batch.items()}))
+    m2, _, _ = _build(gd, mlp_stash_gb=1e-6, depth_chunk=1, mlp_whole_batch_gb=whole_gb, mlp_recompute=recompute)
+    ep = int(gd['epoch'])
+    a = m1._train_on_batch(ep, 0, helpers.loader_batch(batch))
+    b = m2._train_on_batch(ep, 0, helpers.loader_batch({k: v.clone() if torch.is_tensor(v) else v for k, v in batch.items()}))
     for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
         np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-9, err_msg=k)
     ga, gb = m1._flat_sf.grad, m2._flat_sf.grad
     assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max())
+    da, db = m1._flat_depth.grad, m2._flat_depth.grad          # the depth net's gradient goes through the same schedules
+    assert float((da - db).abs().max()) <= 1e-4 * float(da.abs().max())
 
 
 def _dp_worker(rank, world, port, name, q, mode='fixture'):
@@ -164,7 +171,7 @@ def _dp_worker(rank, world, port, name, q, mode='fixture'):
         gd = H.load_golden(name)
         over = dict(global_rank=rank)
         if mode != 'fixture' and rank == 0:
-            over.update(mlp_stash_gb=1e-6, depth_chunk=1, mlp_whole_batch_gb=0.0)
+            over.update(mlp_stash_gb=1e-6, depth_chunk=1, mlp_whole_batch_gb=0.0, mlp_recompute=0)
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             model, opt, batch = _build(gd, **over)

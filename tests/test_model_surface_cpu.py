@@ -18,7 +18,7 @@ EXPECTED_FLAGS = {
     'acc_mul', 'si_mul', 'cos_mul', 'warm_mul', 'interp_steps', 'warm_sf', 'n_freq_xyz', 'n_freq_t', 'sf_mag_div',
     'one_way', 'weight_steps', 'static', 'motion_seg_hard', 'warm_static', 'use_disp', 'use_disp_ratio',
     'time_dependent', 'use_cnn', 'use_embedding', 'use_motion_seg', 'warm_reg', 'midas'}
-OWN_FLAGS = {'mlp_stash_gb', 'mlp_whole_batch_gb', 'depth_chunk', 'depth_graphs', 'grad_buckets', 'depth_keep_gb', 'act_fp16', 'mlp_stash_fp16',
+OWN_FLAGS = {'mlp_stash_gb', 'mlp_whole_batch_gb', 'mlp_recompute', 'depth_chunk', 'depth_graphs', 'grad_buckets', 'depth_keep_gb', 'act_fp16', 'mlp_stash_fp16',
              'max_act_overflow_skips'}
 
 
