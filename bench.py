@@ -434,6 +434,9 @@ def main():
     ap.add_argument('--mlp_recompute', type=int, default=1, choices=(0, 1),
                     help='A/B of the scene-flow MLP schedule when the stashes of the whole batch do not fit (configs[4] at 64 pairs): '
                          '1 = recompute schedule (round 6), 0 = late normaliser (rounds 1-5); see Model.add_arguments')
+    ap.add_argument('--depth_keep_gb', type=float, default=None,
+                    help='HBM budget of the kept depth-net activation slots (Model.add_arguments: 150); every slot is still '
+                         'subject to the free-memory test of keep_slot_fits')
     ap.add_argument('--no_extras', action='store_true',
                     help='only the headline measurement: without the configs4 and rccl_one_rank sub-records the default N = 1 run '
                          'adds from child processes of this script')
@@ -451,6 +454,8 @@ def main():
             a.pairs = PAIRS_CFG4
         if a.depth_chunk is None and a.pairs > 32:
             a.depth_chunk = 16
+            if a.depth_keep_gb is None:
+                a.depth_keep_gb = 160.0        # four 38 GB slots of 16 images (the model's default budget, 150 GB, stops at three)
     if a.depth_chunk is None:
         a.depth_chunk = 48
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -488,6 +493,8 @@ def main():
             raise SystemExit('DVD_RESERVE_GB: hipMalloc of %d bytes failed' % nbytes)
     opt = make_opt(global_rank=rank, depth_chunk=min(a.depth_chunk, a.pairs), depth_graphs=bool(a.depth_graphs),
                    midas=a.depth == 'midas', act_fp16=bool(a.act_fp16), mlp_recompute=int(a.mlp_recompute))
+    if a.depth_keep_gb is not None:
+        opt.depth_keep_gb = float(a.depth_keep_gb)
     model = build_model(opt, device, seed=0)
     batch = synthetic.make_batch(a.pairs, H, W, gap=a.gap, seed=1234, rank=rank, device=device)
     epoch = opt.warm_sf + 1            # non-warm phase
