@@ -18,6 +18,10 @@
 #   ranks   8-GPU readiness on one GPU: DVD_RESERVE_GB ballast lines (gap 1 / gap 2 / hourglass), 8 ranks over gloo,
 #           one rank over RCCL with the collectives forced (bench.py --rccl_one_rank)
 #   wtrace  per-kernel durations of the warp+loss launch sequence (tools/warp_trace.sh)
+#   s2      the stride-2 3x3 convolutions (native strided kernels vs DVD_AB=no_s2) and the hourglass's k x k branches, fp32 / fp16
+#   gaps    GPU idle time inside a steady step (rocprofv3 --kernel-trace of bench.py -> tools/step_gaps.py)
+#   hgtrace per-step kernel times of the hourglass line (two step counts, differenced)
+#   sched   BASELINE configs[4] at 64 pairs and frame gap 4: the recompute schedule against the late-normaliser one
 set -u
 OUT=gpurun_out/${TAG:-visit}; mkdir -p $OUT
 STAGES=${STAGES:-"tests bench extras trace pmc sq micro"}
@@ -142,6 +146,30 @@ if has ranks; then
   runr reserve24_gap2 DVD_RESERVE_GB=24 python bench.py --no_cpu_baseline --no_extras --gap 2
   runr reserve24_hourglass DVD_RESERVE_GB=24 python bench.py --no_cpu_baseline --no_extras --depth hourglass
   runr gloo8 DVD_DIST_BACKEND=gloo python bench.py --gpus 8 --pairs 2 --no_cpu_baseline --steps 2
+fi
+if has s2; then
+  timeout 300 python tools/microbench_s2.py > $OUT/s2_fp32.jsonl 2> $OUT/s2_fp32.err; cut -c1-260 $OUT/s2_fp32.jsonl
+  XCONV_FP16=1 timeout 300 python tools/microbench_s2.py > $OUT/s2_fp16.jsonl 2> $OUT/s2_fp16.err; cut -c1-260 $OUT/s2_fp16.jsonl
+  timeout 300 python tools/microbench_kxk.py > $OUT/kxk.jsonl 2> $OUT/kxk.err; cut -c1-200 $OUT/kxk.jsonl
+fi
+if has gaps; then
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/gaps_tr -o b -- \
+      python $ROOT/bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_extras > $ROOT/$OUT/gaps_tr.log 2>&1 )
+  python tools/step_gaps.py "$(find /tmp/gaps_tr -name '*kernel_trace.csv' | head -1)" 30 > $OUT/step_gaps.txt 2>&1; head -8 $OUT/step_gaps.txt
+fi
+if has hgtrace; then
+  for n in 2 5; do
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/hg_tr$n -o b -- \
+        python $ROOT/bench.py --depth hourglass --steps $n --warmup 1 --no_cpu_baseline --no_extras > $ROOT/$OUT/hg_tr$n.log 2>&1 )
+    cp "$(find /tmp/hg_tr$n -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats_hourglass_$n.csv
+  done
+fi
+if has sched; then
+  run() { name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; tail -1 $OUT/bench_$name.json | cut -c1-230; }
+  run cfg4_p64 --config 4 --pairs 64 --steps 2 --cfg4_parity none --no_extras --no_cpu_baseline
+  run cfg4_p64_late --config 4 --pairs 64 --steps 2 --cfg4_parity none --no_extras --no_cpu_baseline --mlp_recompute 0
+  run gap4 --gap 4 --no_cpu_baseline --steps 2
+  run gap4_late --gap 4 --no_cpu_baseline --steps 2 --mlp_recompute 0
 fi
 if has wtrace; then
   bash tools/warp_trace.sh ${TAG:-visit}/wtrace | tail -5
