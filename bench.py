@@ -414,7 +414,8 @@ def main():
                     help='1 (default): replay the depth net from HIP graphs; 0: eager launches')
     ap.add_argument('--depth_chunk', type=int, default=None,
                     help='images per depth-net forward/backward chunk = per kept-activation graph slot.  Default 48 (two slots per '
-                         '48-pair step; 16 / 24 / 48 measured 0.840 / 0.843 / 0.851 iters/s on one box); --config 4 with more than 32 '
+                         '48-pair step; 16 / 24 / 48 measured 0.840 / 0.843 / 0.851 iters/s on one box), 16 for the hourglass, 24 at frame '
+                         'gaps 2-3 (smaller slots where not every slot fits beside the MLP stashes); --config 4 with more than 32 '
                          'pairs: 16 -- a slot of 48 images at 768x1344 is 112 GB and needs as much again free for the recompute graph of '
                          'a chunk that is not kept, so none fits; three 38 GB slots do (64 pairs: 3.07 -> 2.93 s per step)')
     ap.add_argument('--act_fp16', action='store_true',
@@ -457,7 +458,11 @@ def main():
             if a.depth_keep_gb is None:
                 a.depth_keep_gb = 160.0        # four 38 GB slots of 16 images (the model's default budget, 150 GB, stops at three)
     if a.depth_chunk is None:
-        a.depth_chunk = 48
+        # (hourglass: a 48-image slot is 77 GB -- one of two fits beside the MLP's stashes; five of six 16-image slots do:
+        #  1.183 -> 1.12 s per step)
+        #  frame gaps 2-3 keep two Euler stashes of the whole batch (156 GB): three of four 24-image MiDaS slots fit, one of two
+        #  48-image ones -- 1.289 -> 1.334 iters/s at gap 2; gap 1 and gap >= 4 (recompute schedule) keep every 48-image slot)
+        a.depth_chunk = 16 if a.depth == 'hourglass' else (24 if a.gap in (2, 3) else 48)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(a.gpus)
 

@@ -339,7 +339,10 @@ class Model(NetInterface):
         budget = float(getattr(self.opt, 'depth_keep_gb', 150.0)) * 2 ** 30
         # room that must stay free: the MLP stashes of phase 2 + 8 % head room + (unless this is the last slot of a step
         # whose other slots are all kept) the pool of the forward+backward recompute graph a non-kept chunk will need
-        spare = 0 if last_and_all_kept else est
+        # (the recompute graph of a non-kept chunk frees its activations as its backward proceeds: its pool measures 0.26-0.31
+        #  of a kept slot's -- 8.0 vs 25.6 GB for 16 hourglass images, 9.7 vs 37.9 GB for 16 MiDaS images at 768x1344 -- so half
+        #  the slot's estimate is room enough; rounds 4-5 asked for all of it and kept one slot fewer)
+        spare = 0 if last_and_all_kept else est // 2
         if os.environ.get('DVD_KEEP_DEBUG'):
             print('keep slot %d: est %.1f GB, free %.1f, reserve %.1f + %.1f + spare %.1f, kept so far %.1f, pools %.1f' % (
                 slot, est / 2 ** 30, free / 2 ** 30, reserve_bytes / 2 ** 30,
