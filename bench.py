@@ -415,7 +415,7 @@ def main():
     ap.add_argument('--depth_chunk', type=int, default=None,
                     help='images per depth-net forward/backward chunk = per kept-activation graph slot.  Default 48 (two slots per '
                          '48-pair step; 16 / 24 / 48 measured 0.840 / 0.843 / 0.851 iters/s on one box), 16 for the hourglass, 24 at frame '
-                         'gaps 2-3 (smaller slots where not every slot fits beside the MLP stashes); --config 4 with more than 32 '
+                         'gaps 2-3 (smaller slots where not every slot fits beside the MLP stashes); --config 4 with more than 24 '
                          'pairs: 16 -- a slot of 48 images at 768x1344 is 112 GB and needs as much again free for the recompute graph of '
                          'a chunk that is not kept, so none fits; three 38 GB slots do (64 pairs: 3.07 -> 2.93 s per step)')
     ap.add_argument('--act_fp16', action='store_true',
@@ -453,7 +453,7 @@ def main():
         a.act_fp16 = True
         if a.pairs == PAIRS:
             a.pairs = PAIRS_CFG4
-        if a.depth_chunk is None and a.pairs > 32:
+        if a.depth_chunk is None and a.pairs > 24:
             a.depth_chunk = 16
             if a.depth_keep_gb is None:
                 a.depth_keep_gb = 160.0        # four 38 GB slots of 16 images (the model's default budget, 150 GB, stops at three)
