@@ -412,12 +412,12 @@ def main():
                          'default run, which since round 6 also carries the configs4 and rccl_one_rank child lines, inside ~6 minutes)')
     ap.add_argument('--depth_graphs', type=int, default=int(os.environ.get('DVD_DEPTH_GRAPHS', '1')),
                     help='1 (default): replay the depth net from HIP graphs; 0: eager launches')
-    ap.add_argument('--depth_chunk', type=int, default=None,
-                    help='images per depth-net forward/backward chunk = per kept-activation graph slot.  Default 48 (two slots per '
-                         '48-pair step; 16 / 24 / 48 measured 0.840 / 0.843 / 0.851 iters/s on one box), 16 for the hourglass, 24 at frame '
-                         'gaps 2-3 (smaller slots where not every slot fits beside the MLP stashes); --config 4 with more than 24 '
-                         'pairs: 16 -- a slot of 48 images at 768x1344 is 112 GB and needs as much again free for the recompute graph of '
-                         'a chunk that is not kept, so none fits; three 38 GB slots do (64 pairs: 3.07 -> 2.93 s per step)')
+    ap.add_argument('--depth_chunk', type=int, default=0,
+                    help='images per depth-net forward/backward chunk = per kept-activation graph slot.  0 (default): the model '
+                         'chooses at its first step (Model --depth_chunk 0: the largest of 48 / 24 / 16 for which every slot fits beside '
+                         'the MLP stashes, else 16) -- 48 on the headline line (two slots, both kept), 16 for the hourglass (six of six '
+                         '26 GB slots kept; one of two 77 GB ones at 48: 0.845 -> 0.929 iters/s), at frame gap 2 and for --config 4 above '
+                         '24 pairs; the line reports it as depth_chunk')
     ap.add_argument('--act_fp16', action='store_true',
                     help='fp16 ACTIVATION storage in the depth net (fp32 parameters / accumulation / loss sums): the arithmetic of '
                          'BASELINE configs[4] at the headline image size -- an extra bench line, not the headline')
@@ -453,16 +453,8 @@ def main():
         a.act_fp16 = True
         if a.pairs == PAIRS:
             a.pairs = PAIRS_CFG4
-        if a.depth_chunk is None and a.pairs > 24:
-            a.depth_chunk = 16
-            if a.depth_keep_gb is None:
-                a.depth_keep_gb = 160.0        # four 38 GB slots of 16 images (the model's default budget, 150 GB, stops at three)
-    if a.depth_chunk is None:
-        # (hourglass: a 48-image slot is 77 GB -- one of two fits beside the MLP's stashes; five of six 16-image slots do:
-        #  1.183 -> 1.12 s per step)
-        #  frame gaps 2-3 keep two Euler stashes of the whole batch (156 GB): three of four 24-image MiDaS slots fit, one of two
-        #  48-image ones -- 1.289 -> 1.334 iters/s at gap 2; gap 1 and gap >= 4 (recompute schedule) keep every 48-image slot)
-        a.depth_chunk = 16 if a.depth == 'hourglass' else (24 if a.gap in (2, 3) else 48)
+        if a.pairs > 24 and a.depth_keep_gb is None:
+            a.depth_keep_gb = 160.0        # four 38 GB slots of 16 images (the model's default budget, 150 GB, stops at three)
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         relaunch_under_torchrun(a.gpus)
 
@@ -496,7 +488,7 @@ def main():
         nbytes = int(float(os.environ['DVD_RESERVE_GB']) * 2 ** 30)
         if hip.hipMalloc(ctypes.byref(ballast), ctypes.c_size_t(nbytes)) != 0:
             raise SystemExit('DVD_RESERVE_GB: hipMalloc of %d bytes failed' % nbytes)
-    opt = make_opt(global_rank=rank, depth_chunk=min(a.depth_chunk, a.pairs), depth_graphs=bool(a.depth_graphs),
+    opt = make_opt(global_rank=rank, depth_chunk=min(a.depth_chunk, a.pairs), depth_graphs=bool(a.depth_graphs),     # (0 = auto)
                    midas=a.depth == 'midas', act_fp16=bool(a.act_fp16), mlp_recompute=int(a.mlp_recompute))
     if a.depth_keep_gb is not None:
         opt.depth_keep_gb = float(a.depth_keep_gb)
@@ -584,6 +576,9 @@ def main():
         'hbm_peak_allocated_GB': torch.cuda.max_memory_allocated(device) / 2 ** 30,
         'hbm_peak_reserved_GB': torch.cuda.max_memory_reserved(device) / 2 ** 30,
         'hbm_graph_pools_GB': getattr(model, '_pool_bytes', 0) / 2 ** 30,      # kept depth-net activations + graph temporaries
+        'depth_chunk': model._chunk(),                                          # images per kept slot (--depth_chunk 0: the model's choice)
+        'depth_slots_kept': '%d of %d' % (sum(1 for k, v in model._depth_graphs.items() if k[0] == 'keep' and v is not None),
+                                          sum(1 for k in model._depth_graphs if k[0] == 'keep')),
         'last_loss': log['loss'],
         # BatchNorm+ReLU sites of the depth net's captured backward passes: how many found their ReLU mask already applied by
         # the consuming convolution's epilogue (conv._Site) and how many ran their own mask pass

@@ -121,8 +121,9 @@ class Model(NetInterface):
                                  'merged backward (3 forward + 2 dX + 2 dW passes per pair at gap 1); 0 = the late-normaliser '
                                  'schedule of rounds 1-5 (one warp+loss launch per chunk, 3 + 3 + 3 passes)')
         parser.add_argument('--depth_chunk', type=int, default=48,
-                            help='images per depth-net forward/backward chunk = per kept-activation graph slot (48: the '
-                                 'configuration bench.py measures; two slots per 48-pair step)')
+                            help='images per depth-net forward/backward chunk = per kept-activation graph slot (48: two slots per '
+                                 '48-pair step).  0 = chosen at the first training step: the largest of 48 / 24 / 16 for which every '
+                                 'slot is expected to fit beside the MLP stashes, else 16 (what bench.py runs with)')
         parser.add_argument('--depth_graphs', type=int, default=1,
                             help='1 (default): capture the depth net per chunk shape in HIP graphs (forward, forward+backward) '
                                  'and replay them: one launch per chunk instead of ~2 000, so the step does not depend on '
@@ -194,6 +195,7 @@ class Model(NetInterface):
         self._graph_flops = {}          # id(CUDAGraph) -> algorithmic work per kernel class, counted at its capture
         self._keep_bytes = 0         # HBM held by kept-activation graph slots
         self._keep_per_px = 0.0      # measured bytes per image pixel of a captured slot
+        self._auto_chunk = None      # --depth_chunk 0: images per slot, chosen at the first training step that keeps slots
         self._pool_bytes = 0         # HBM reserved by the private pools of all captured graphs
         self._keep_denied = {}       # slot key -> step at which it was last denied / trimmed (retried 16 steps later)
         self._step_no = 0
@@ -333,8 +335,7 @@ class Model(NetInterface):
         # bytes a slot will hold: measured on the slots captured so far (per image and pixel), a-priori figure (MiDaS with
         # fused epilogues: ~4.1 KB per pixel, ~2.2 KB with fp16 activations) for the first one, + packed weights
         n_px = chunk.shape[0] * chunk.shape[2] * chunk.shape[3]
-        apriori = 2400.0 if self._gscale is not None else 4400.0        # fp16 activation storage halves the kept state
-        est = int(n_px * max(apriori, self._keep_per_px) + 1.5 * 2 ** 30)
+        est = int(n_px * self._slot_bytes_per_px() + 1.5 * 2 ** 30)
         free, total = self._free_hbm(chunk.device)
         budget = float(getattr(self.opt, 'depth_keep_gb', 150.0)) * 2 ** 30
         # room that must stay free: the MLP stashes of phase 2 + 8 % head room + (unless this is the last slot of a step
@@ -436,10 +437,52 @@ class Model(NetInterface):
             gc.collect()
             free, total = self._free_hbm(device)
 
+    def _chunk(self):
+        """Images per depth-net chunk: --depth_chunk, or (0 = auto) what _pick_depth_chunk chose at the first training step."""
+        c = int(getattr(self.opt, 'depth_chunk', 48))
+        return max(1, c if c > 0 else int(self._auto_chunk or 48))
+
+    def _slot_bytes_per_px(self):
+        """Autograd state a kept slot holds per image pixel: measured on the slots captured so far, else an a-priori figure
+        (as measured in round 6: MiDaS with fused epilogues 4.8 KB -- 55.8 GB per 48 images at 384x672 --, 2.5 KB with fp16
+        activations, the hourglass 6.7 KB; rounds 4-5 assumed 4.4 / 2.4 KB)."""
+        apriori = (2500.0 if self._gscale is not None else 4900.0) if self.opt.midas else 6700.0
+        return max(apriori, self._keep_per_px)
+
+    def _pick_depth_chunk(self, B, HW, mlp_need, device):
+        """--depth_chunk 0: the largest of 48 / 24 / 16 images per slot for which EVERY slot of the step is expected to fit
+        beside phase 2's allocations (then nothing is recomputed, and larger launches are a little faster: 16 / 24 / 48
+        measured 0.840 / 0.843 / 0.851 iters/s); if no size fits, the finest -- slots are kept one by one, so smaller slots
+        keep more of the batch (hourglass at 384x672: one of two 48-image slots, or all six 16-image ones)."""
+        free, total = self._free_hbm(device)
+        budget = float(getattr(self.opt, 'depth_keep_gb', 150.0)) * 2 ** 30
+        avail = min(budget, free - mlp_need - head_room_fraction(parallel.world_size(), total) * total)
+        per_img = HW * self._slot_bytes_per_px()
+        for c in (48, 24, 16):
+            cc = min(c, B)
+            if 2 * B * per_img + 2 * (-(-B // cc)) * 1.5 * 2 ** 30 <= avail:
+                return cc
+        return min(16, B)
+
+    def _phase2_bytes(self, B, HW, steps, do_reg):
+        """What phase 2 will allocate (the room phase 1 leaves free): the MLP stashes of the whole batch if they fit
+        --mlp_whole_batch_gb, else those of ONE chunk (late-normaliser / recompute schedules).  (Rounds 1-5 reserved
+        min(whole batch, the ceiling) in the chunked case too: 160 GB for 48 GB of stashes at BASELINE configs[4]'s 64 pairs,
+        and not one depth-net slot was kept there.)"""
+        Bc0 = self._pairs_per_chunk(B, HW, steps, do_reg)
+        if self._mlp is None:        # --use_cnn: autograd state of the U-Net, per pixel and evaluation (measured)
+            return B * HW * self._cnn_bytes_per_px() * (steps + (1 if do_reg else 0)) + 24 * B * HW * 4
+        stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
+        if Bc0 >= B or self._whole_batch_fits(B, Bc0, HW, steps, do_reg):
+            need = B * steps * stash + min(Bc0, B) * (gstash + (stash if (do_reg and steps == 1) else 0))
+        else:
+            need = Bc0 * (stash * max(steps, 2 if do_reg else 1) + gstash)
+        return need + 24 * B * HW * 4
+
     def _depths_keep(self, img, frame_ids, slot0, reserve_bytes, n_slots_total):
         """Depth maps of phase 1 with the autograd state of as many chunks as fit kept for phase 3."""
         out = []
-        c = max(1, int(self.opt.depth_chunk))
+        c = self._chunk()
         for ci, b0 in enumerate(range(0, img.shape[0], c)):
             fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
             chunk = img[b0:b0 + c]
@@ -461,7 +504,7 @@ class Model(NetInterface):
 
     def _depths_nograd(self, img, frame_ids):
         out = []
-        c = max(1, int(self.opt.depth_chunk))
+        c = self._chunk()
         with torch.no_grad():
             for b0 in range(0, img.shape[0], c):
                 fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
@@ -478,7 +521,7 @@ class Model(NetInterface):
         return torch.cat(out, 0).contiguous()
 
     def _depth_backward(self, img, frame_ids, g_depth, slot0=None):
-        c = max(1, int(self.opt.depth_chunk))
+        c = self._chunk()
         for ci, b0 in enumerate(range(0, img.shape[0], c)):
             fid = frame_ids[b0:b0 + c] if frame_ids is not None else None
             chunk = img[b0:b0 + c]
@@ -570,25 +613,16 @@ class Model(NetInterface):
         # ---- phase 1: depth maps; the autograd state of as many chunks as fit stays alive for phase 3 (kept slots),
         #      the rest is a no-graph forward that phase 3 recomputes
         do_reg = opt.interp_steps > 0 and (not warm or opt.warm_reg) and opt.acc_mul > 0
-        n_slots = -(-B // max(1, int(opt.depth_chunk)))
-        if warm or not getattr(opt, 'depth_graphs', 1) or float(getattr(opt, 'depth_keep_gb', 150.0)) <= 0:
+        keeping = not (warm or not getattr(opt, 'depth_graphs', 1) or float(getattr(opt, 'depth_keep_gb', 150.0)) <= 0)
+        if keeping and int(opt.depth_chunk) <= 0 and self._auto_chunk is None:
+            # decided ONCE, at the first training step that keeps slots (graphs and slots are per chunk shape)
+            self._auto_chunk = self._pick_depth_chunk(B, HW, self._phase2_bytes(B, HW, steps, do_reg), dev)
+        n_slots = -(-B // self._chunk())
+        if not keeping:
             depth_1 = self._depths_nograd(inp.img_1, fid1)
             depth_2 = self._depths_nograd(inp.img_2, fid2)
         else:
-            Bc0 = self._pairs_per_chunk(B, HW, steps, do_reg)
-            if self._mlp is None:        # --use_cnn: autograd state of the U-Net, per pixel and evaluation (measured, below)
-                mlp_need = B * HW * self._cnn_bytes_per_px() * (steps + (1 if do_reg else 0)) + 24 * B * HW * 4
-            else:
-                stash, gstash = self._mlp.stash_floats(HW) * 4, self._mlp.gstash_floats(HW) * 4
-                # what phase 2 will allocate: the stashes of the whole batch if they fit --mlp_whole_batch_gb, else those of
-                # ONE chunk (late-normaliser / recompute schedules).  (Rounds 1-5 reserved min(whole batch, the ceiling) in
-                # the chunked case too: 160 GB for 48 GB of stashes at BASELINE configs[4]'s 64 pairs, and not one depth-net
-                # slot was kept there.)
-                if Bc0 >= B or self._whole_batch_fits(B, Bc0, HW, steps, do_reg):
-                    mlp_need = B * steps * stash + min(Bc0, B) * (gstash + (stash if (do_reg and steps == 1) else 0))
-                else:
-                    mlp_need = Bc0 * (stash * max(steps, 2 if do_reg else 1) + gstash)
-                mlp_need += 24 * B * HW * 4
+            mlp_need = self._phase2_bytes(B, HW, steps, do_reg)
             depth_1 = self._depths_keep(inp.img_1, fid1, 0, mlp_need, 2 * n_slots)
             depth_2 = self._depths_keep(inp.img_2, fid2, n_slots, mlp_need, 2 * n_slots)
             self._trim_keep_slots(dev, mlp_need)
@@ -631,7 +665,7 @@ class Model(NetInterface):
         # over the REAL chunk list of both image sets (a ragged last chunk has its own slot / graph keys)
         may_capture = False
         if not warm and getattr(opt, 'depth_graphs', 1):
-            cw = max(1, int(opt.depth_chunk))
+            cw = self._chunk()
             for s0, img in ((0, inp.img_1), (n_slots, inp.img_2)):
                 for ci, b0 in enumerate(range(0, B, cw)):
                     chunk = img[b0:b0 + cw]

@@ -171,12 +171,14 @@ def _dp_worker(rank, world, port, name, q, mode='fixture'):
         gd = H.load_golden(name)
         over = dict(global_rank=rank)
         if mode != 'fixture' and rank == 0:
-            over.update(mlp_stash_gb=1e-6, depth_chunk=1, mlp_whole_batch_gb=0.0, mlp_recompute=0)
+            # rank 0's budget forces one MLP chunk per pair: the late-normaliser schedule (mixed_plan, mixed_gap), or -- the
+            # default since round 6 -- the recompute schedule, which keeps the early normaliser ('mixed_recompute')
+            over.update(mlp_stash_gb=1e-6, depth_chunk=1, mlp_whole_batch_gb=0.0, mlp_recompute=int(mode == 'mixed_recompute'))
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             model, opt, batch = _build(gd, **over)
         B = int(gd['B'])
-        if mode == 'mixed_plan':
+        if mode in ('mixed_plan', 'mixed_recompute'):
             B = 4
             batch = synthetic.make_batch(B, int(gd['H']), int(gd['W']), gap=1, seed=4242)
         if mode == 'mixed_gap':
@@ -226,6 +228,28 @@ def test_ranks_with_different_local_plans_issue_the_same_collectives():
     torch.cuda.synchronize()
     ref_g = model._flat_sf.grad.cpu().numpy()
     res = _run_two_ranks(name, 'mixed_plan')
+    for rank, log, sf, depth, g in res:
+        for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
+            np.testing.assert_allclose(log[k], ref[k], rtol=1e-5, atol=1e-9, err_msg='rank %d %s' % (rank, k))
+        assert np.abs(g - ref_g).max() <= 2e-4 * np.abs(ref_g).max()
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_on_the_recompute_schedule_next_to_a_whole_batch_rank():
+    """Rank 0's stash budget holds one pair, so it evaluates the Euler chain twice (stash-free over its pairs, stashed again
+    per chunk: the recompute schedule) while rank 1 keeps the stashes of its whole shard; both reduce the loss sums BEFORE
+    their backward passes (early normaliser on every rank), and the step equals the single-process step on the 4-pair batch."""
+    from dvd_hip import synthetic
+    name = 'fullstep_hourglass_b2_32x48_train'
+    gd = helpers.load_golden(name)
+    model, opt, _ = _build(gd)
+    batch = synthetic.make_batch(4, int(gd['H']), int(gd['W']), gap=1, seed=4242)
+    ref = model._train_on_batch(int(gd['epoch']), 0, helpers.loader_batch(batch))
+    torch.cuda.synchronize()
+    ref_g = model._flat_sf.grad.cpu().numpy()
+    res = _run_two_ranks(name, 'mixed_recompute')
     for rank, log, sf, depth, g in res:
         for k in ('loss', 'flow_loss_1_2', 'disp_loss_1_2', 'sf_loss', 'acc_reg'):
             np.testing.assert_allclose(log[k], ref[k], rtol=1e-5, atol=1e-9, err_msg='rank %d %s' % (rank, k))

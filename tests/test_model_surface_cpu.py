@@ -90,6 +90,31 @@ def test_attribute_contract_after_construction():
         assert torch.equal(ref(x), mc.net_sceneflow(x))              # CPU tensors: the reference's own ATen arithmetic
 
 
+def test_automatic_depth_chunk_choice():
+    """Model --depth_chunk 0 (what bench.py runs with): the largest of 48 / 24 / 16 images per slot for which every slot of the
+    step fits beside phase 2's allocations, else 16 -- with the free memory / phase-2 figures of the round-6 bench lines
+    (DVD_KEEP_DEBUG logs): the headline line keeps two 48-image slots, the hourglass, frame gap 2 and configs[4] above 24 pairs
+    take 16-image slots, configs[4] at 24 pairs one slot per image set."""
+    from types import SimpleNamespace
+    from dvd_hip.models.scene_flow_motion_field import Model
+    G = 2 ** 30
+
+    def pick(B, HW, mlp_need_gb, free_gb, midas=True, fp16=False, budget=150.0, measured=0.0):
+        fake = SimpleNamespace(opt=SimpleNamespace(depth_keep_gb=budget, midas=midas), _gscale=object() if fp16 else None,
+                               _keep_per_px=measured, _free_hbm=lambda dev: (free_gb * G, 288 * G))
+        fake._slot_bytes_per_px = lambda: Model._slot_bytes_per_px(fake)
+        return Model._pick_depth_chunk(fake, B, HW, mlp_need_gb * G, None)
+    hw, hw4 = 384 * 672, 768 * 1344
+    assert pick(48, hw, 109.2, 286.4) == 48                              # headline: 96 images x 1.06 GB + two pools fit
+    assert pick(48, hw, 109.2, 286.4, midas=False) == 16                 # hourglass: 6.2 KB per pixel, 154 GB for 96 images
+    assert pick(48, hw, 155.6, 284.9) == 16                              # gap 2: two Euler stashes of the whole batch
+    assert pick(48, hw, 63.4, 284.9) == 48                               # gap 4: the recompute schedule reserves one chunk
+    assert pick(64, hw4, 62.5, 281.9, fp16=True, budget=160.0) == 16     # configs[4] at 64 pairs
+    assert pick(32, hw4, 145.1, 283.8, fp16=True, budget=160.0) == 16    # ... at 32 pairs
+    assert pick(24, hw4, 100.0, 284.0, fp16=True) == 24                  # ... at 24 pairs: one slot per image set
+    assert pick(2, 32 * 48, 0.1, 280.0) == 2                             # tiny batches: one slot per image set
+
+
 def test_kept_activation_slot_planning_arithmetic():
     """models.scene_flow_motion_field.keep_slot_fits with the numbers of the bench (288 GB device, MLP stashes 130 GB):
     two 58 GB slots fit, a third does not; with 82 GB slots (no BatchNorm fusion) only the first fits; the
