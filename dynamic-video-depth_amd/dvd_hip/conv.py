@@ -1280,8 +1280,9 @@ def xconv2d(conv, x, relu_in=False, residual=None, res_relu=False, alias=False, 
 class XConv2d(nn.Conv2d):
     """Drop-in nn.Conv2d (same parameters / state_dict keys) whose stride-1 'same' case (dense, or grouped 3x3 with
     at least 32 channels per group) runs on the HIP kernels; a strided 1x1 convolution without padding (the ResNeXt
-    down-sampling shortcut) is the 1x1 kernel on the sub-sampled input, a strided 3x3 'same' convolution is the
-    stride-1 kernel's output sub-sampled.  Anything else, and CPU tensors, take ATen."""
+    down-sampling shortcut) is the 1x1 kernel on the sub-sampled input, a stride-2 3x3 'same' convolution runs on the strided
+    forms of the kernel (_XConvS2, round 6; other strides, and DVD_AB=no_s2: the stride-1 kernel's output sub-sampled).
+    Anything else, and CPU tensors, take ATen."""
 
     def forward(self, x):
         if xconv_supported(self, x):
