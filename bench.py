@@ -280,7 +280,7 @@ def _valu_issue(pixels_per_launch):
         return None
 
 
-def _roofline_mfma(f0, f1, steps, dt, world, act_fp16):
+def _roofline_mfma(f0, f1, steps, dt, world, act_fp16, r0=None, r1=None):
     """Matrix-pipe roofline of the step (the kernels that own ~85 % of it): the algorithmic work the timed steps EXECUTED per
     kernel class -- counted by the library at launch / graph-capture time and at every graph replay (dvd_flop_counters,
     ops.executed_flops) -- over the timed wall clock, as fp32-equivalent TFLOP/s, as issued fp16 MFMA TFLOP/s (x products per
@@ -300,6 +300,14 @@ def _roofline_mfma(f0, f1, steps, dt, world, act_fp16):
            'products_per_mac': {k: prod[k] for k in per_step if per_step[k]},
            'note': 'step-wide: all matrix-kernel work of a step over the WHOLE step time (per GPU; the other ~15 % of the step '
                    'is memory-bound helper kernels); achieved = issued fp16 MFMA rate = sum(work x products per MAC) / time'}
+    if r0 is not None and r1 is not None:
+        # the part of that work that is RE-computation (ops.RECOMPUTED: depth-net forwards of chunks whose autograd state was not
+        # kept, the stash-free Euler chain of the MLP's recompute schedule) is executed, not needed
+        rec_step = {k: (r1[k] - r0[k]) / steps for k in per_step}
+        needed = {k: per_step[k] - rec_step[k] for k in per_step}
+        out['recomputed_TFLOP_per_step'] = sum(rec_step.values()) / 1e12
+        out['needed_TFLOP_per_step'] = sum(needed.values()) / 1e12
+        out['frac_of_needed_work'] = sum(needed[k] * prod[k] for k in needed) / s_per_step / 1e12 / MFMA_PEAK_TFLOPS
     path = os.path.join(ROOT, 'profiles', 'mfma_roofline.json')
     try:
         rec = json.load(open(path))
@@ -521,12 +529,12 @@ def main():
         torch.cuda.synchronize()
         wt.on = True
         from dvd_hip import ops as _ops
-        flops0 = _ops.executed_flops()
+        flops0, rec0 = _ops.executed_flops(), dict(_ops.RECOMPUTED)
         t0 = time.time()
         for i in range(a.steps):
             log = one_step(a.warmup + i)
         torch.cuda.synchronize()
-        flops1 = _ops.executed_flops()
+        flops1, rec1 = _ops.executed_flops(), dict(_ops.RECOMPUTED)
         if parallel.is_distributed():
             torch.distributed.barrier()
         dt = time.time() - t0
@@ -617,7 +625,7 @@ def main():
                            # this kernel: wave instructions x 64 lanes / pixels, and the time they take at 100 % issue
                            # (256 CUs x 64 lanes per clock at the measured 2.16 GHz)
                            'valu_issue': _valu_issue(warp['pixels_per_launch'])}
-    out['roofline_mfma'] = _roofline_mfma(flops0, flops1, a.steps, dt, world, a.act_fp16)
+    out['roofline_mfma'] = _roofline_mfma(flops0, flops1, a.steps, dt, world, a.act_fp16, rec0, rec1)
     out['roofline_helpers'] = _roofline_helpers(flops0, flops1, a.steps, a.act_fp16)
     if rccl_one is not None:
         out['rccl_one_rank'] = dict(rccl_one, comm_hbm_GB=rccl_one['comm_hbm_bytes'] / 2 ** 30, collectives_forced=True)

@@ -496,7 +496,8 @@ class Model(NetInterface):
                 ops.note_replay(self._graph_flops.get(id(e[0])))
                 out.append(e[3].detach().clone())
             else:
-                out.append(self._depths_nograd(chunk, fid))
+                with ops.counting_recomputed():      # phase 3 runs this chunk's forward again (forward+backward graph)
+                    out.append(self._depths_nograd(chunk, fid))
         return torch.cat(out, 0).contiguous()
 
     def _use_graphs(self, img, frame_ids):
@@ -619,8 +620,11 @@ class Model(NetInterface):
             self._auto_chunk = self._pick_depth_chunk(B, HW, self._phase2_bytes(B, HW, steps, do_reg), dev)
         n_slots = -(-B // self._chunk())
         if not keeping:
-            depth_1 = self._depths_nograd(inp.img_1, fid1)
-            depth_2 = self._depths_nograd(inp.img_2, fid2)
+            import contextlib
+            # (non-warm steps without kept slots: phase 3 recomputes every chunk's forward; a warm-up step has no depth-net backward)
+            with (contextlib.nullcontext() if warm else ops.counting_recomputed()):
+                depth_1 = self._depths_nograd(inp.img_1, fid1)
+                depth_2 = self._depths_nograd(inp.img_2, fid2)
         else:
             mlp_need = self._phase2_bytes(B, HW, steps, do_reg)
             depth_1 = self._depths_keep(inp.img_1, fid1, 0, mlp_need, 2 * n_slots)
@@ -820,8 +824,9 @@ class Model(NetInterface):
 
         gst = mlp.new_gstash(min(Bc, B) * HW)
         if early_norm and recompute and Bc < B and not whole:
-            for b0, b1 in chunks:
-                mlp_forward_chunk(b0, b1, with_stash=False)
+            with ops.counting_recomputed():          # the stashed evaluations below are the ones the backward needs
+                for b0, b1 in chunks:
+                    mlp_forward_chunk(b0, b1, with_stash=False)
             warp(0, B)
             parallel.all_reduce_sum_(sums[:4])
             scalars = ops.loss_finalize(cfg_all, sums)

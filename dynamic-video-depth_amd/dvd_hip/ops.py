@@ -315,6 +315,27 @@ def flop_counters(reset=False):
 REPLAYED = {k: 0.0 for k in ALL_CLASSES}
 
 
+# work that is a RE-computation (round 6; SURVEY 8d: "recompute is not counted"): the no-graph depth-net forward of a chunk whose
+# autograd state is not kept (phase 3 runs that forward again inside its forward+backward graph) and the stash-free Euler
+# chain of the scene-flow MLP's recompute schedule.  Included in executed_flops(); bench.py reports the step's work with and
+# without it (roofline_mfma.needed_TFLOP_per_step, frac_of_needed_work).
+RECOMPUTED = {k: 0.0 for k in ALL_CLASSES}
+
+
+class counting_recomputed(object):
+    """with ops.counting_recomputed(): ...   -- everything launched / replayed inside is a re-computation."""
+
+    def __enter__(self):
+        self.before = executed_flops()
+        return self
+
+    def __exit__(self, *exc):
+        now = executed_flops()
+        for k in ALL_CLASSES:
+            RECOMPUTED[k] += now[k] - self.before[k]
+        return False
+
+
 def flops_since(snapshot):
     now = flop_counters()
     return {k: now[k] - snapshot.get(k, 0.0) for k in ALL_CLASSES}

@@ -42,6 +42,24 @@ def test_counters_read_reset_and_replay_bookkeeping():
     assert ops.flops_since(ops.flop_counters()) == {k: 0.0 for k in ops.ALL_CLASSES}
 
 
+def test_recomputed_work_is_counted_apart():
+    """ops.counting_recomputed(): the work launched or replayed inside the context is executed AND recorded as a re-computation
+    (bench.py: roofline_mfma.needed_TFLOP_per_step = executed - recomputed; SURVEY 8d does not count recompute); nested and
+    repeated regions add up, work outside is untouched."""
+    r0, e0 = dict(ops.RECOMPUTED), ops.executed_flops()
+    ops.note_replay({'xconv_wide': 3.0e9})                               # needed work
+    with ops.counting_recomputed():
+        ops.note_replay({'xconv_wide': 1.0e9, 'mlp_fwd': 2.0e9})         # a chunk's forward / a stash-free MLP pass, again
+    with ops.counting_recomputed():
+        ops.note_replay({'mlp_fwd': 0.5e9})
+    e1 = ops.executed_flops()
+    rec = {k: ops.RECOMPUTED[k] - r0[k] for k in r0}
+    exe = {k: e1[k] - e0[k] for k in e1}
+    assert rec['xconv_wide'] == 1.0e9 and rec['mlp_fwd'] == 2.5e9 and sum(rec.values()) == 3.5e9
+    assert exe['xconv_wide'] == 4.0e9 and exe['mlp_fwd'] == 2.5e9
+    assert sum(exe.values()) - sum(rec.values()) == 3.0e9
+
+
 def test_head_room_knob(monkeypatch):
     from dvd_hip.models.scene_flow_motion_field import head_room_fraction, keep_slot_fits
     monkeypatch.delenv('DVD_HEAD_ROOM_GB', raising=False)
